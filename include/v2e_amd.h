@@ -1,0 +1,203 @@
+/*
+ * v2e_amd.h -- C ABI of libv2e_amd.so, the MI355X (gfx950) implementation of the
+ * v2e hot path.  Plain pointers and sizes only; no torch types.  Every device
+ * pointer is memory owned by the caller (PyTorch-ROCm tensors in the Python host);
+ * the library allocates only its private scratch at create().
+ *
+ * All functions return 0 on success or a negative V2E_E* code; nothing throws
+ * across the boundary.  Unless stated otherwise a call only enqueues work on the
+ * given hipStream_t (passed as void*) and returns.
+ *
+ * Reference interfaces replaced (paths relative to the SensorsINI/v2e tree):
+ *   v2ecore/emulator.py:439-511   EventEmulator._init            -> v2e_emu_init_state
+ *   v2ecore/emulator.py:656-775   generate_events, front half    -> v2e_emu_count
+ *     (lin_log emulator_utils.py:18-45, rescale_intensity_frame :48-54,
+ *      low_pass_filter :57-109, subtract_leak_current :114-134,
+ *      compute_event_map :137-173, generate_shot_noise :297-351)
+ *   v2ecore/emulator.py:791-942   iteration loop, refractory, event list,
+ *      shot-noise events, base update (get_event_list_from_coords :1024-1059)
+ *                                                                -> v2e_emu_emit
+ *   v2ecore/emulator.py:867-869   randperm shuffle               -> v2e_emu_permute
+ *   v2ecore/model.py:10-226       UNet / down / up               -> v2e_unet_forward
+ *   v2ecore/model.py:229-300      backWarp                       -> v2e_slomo_prep / _fuse
+ *   v2ecore/slomo.py:404-433      per-t blend, warps, fusion     -> v2e_slomo_prep / _fuse
+ */
+#ifndef V2E_AMD_H
+#define V2E_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2E_OK 0
+#define V2E_EINVAL (-22)
+#define V2E_ENOMEM (-12)
+#define V2E_EHIP (-5)      /* a HIP runtime call failed; see v2e_last_error() */
+#define V2E_ENODEV (-19)
+#define V2E_EOVERFLOW (-75)
+
+/* frame element types accepted by the emulator (emulator.py:663 converts all to f64) */
+#define V2E_DT_U8 0
+#define V2E_DT_F32 1
+#define V2E_DT_F64 2
+
+#define V2E_RNG_TAPE 0   /* random numbers / timestamps / permutations supplied by host */
+#define V2E_RNG_PHILOX 1 /* counter-based Philox4x32-10 in-kernel (include/v2e_detmath.h) */
+
+/* record flags */
+#define V2E_FLAG_EVENTS_DROPPED 1u /* event buffer capacity exceeded; counts are still exact */
+#define V2E_FLAG_ITERS_CLAMPED 2u  /* max events per pixel exceeded max_iters: frame NOT emitted */
+
+/*
+ * DVS model parameters, read at every call (the reference reads plain attributes
+ * lazily, so callers may change them between frames, e.g. set_dvs_params()).
+ * Scalars that the reference computes in Python doubles stay doubles here.
+ */
+typedef struct v2e_emu_params {
+    int32_t f64_state;      /* 1: lp/base planes are double (cutoff_hz > 0), 0: float   */
+    int32_t scalar_thres;   /* 1: sigma_thres == 0, thresholds are Python floats        */
+    int32_t rng_mode;       /* V2E_RNG_TAPE / V2E_RNG_PHILOX                            */
+    int32_t shuffle;        /* philox mode: apply the keyed bijection per iteration     */
+    double pos_thres_nominal, neg_thres_nominal;
+    double pos_thres_scalar, neg_thres_scalar; /* used when scalar_thres                */
+    double sigma_thres;
+    double cutoff_hz;
+    double leak_rate_hz;
+    double leak_jitter_fraction;
+    double noise_rate_cov_decades;
+    double refractory_period_s;
+    double shot_noise_rate_hz;
+    double shot_noise_inten_factor; /* emulator.py:210, 0.25 */
+    float pos_pre_scalar, neg_pre_scalar; /* nominal/thres when scalar_thres (host torch.div) */
+    uint64_t seed;          /* philox key */
+} v2e_emu_params;
+
+/* Per-(frame, clip) result record, written on device. */
+typedef struct v2e_frame_rec {
+    int32_t max_events;  /* max_num_events_any_pixel (emulator.py:773) */
+    uint32_t flags;
+    uint32_t n_signal;   /* signal events after refractory filtering   */
+    uint32_t n_events;   /* signal + shot                              */
+    uint32_t n_on, n_off;/* totals incl. shot (emulator.py:1038-1040)  */
+    uint64_t ev_offset;  /* first row of this frame in the clip's event region */
+} v2e_frame_rec;
+
+typedef struct v2e_emu v2e_emu;
+
+const char *v2e_last_error(void);
+int v2e_version(void);
+
+/*
+ * H, W: sensor size; n_clips: independent pixel arrays advanced in lock-step by one
+ * launch (state planes are [n_clips][npx_pad], npx_pad = v2e_emu_npx_pad(H,W));
+ * max_iters: cap on events per pixel per frame (hist scratch is sized by it).
+ */
+int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu **out);
+int v2e_emu_destroy(v2e_emu *h);
+int64_t v2e_emu_npx_pad(int H, int W);
+
+/* Device pointers to the persistent per-pixel state (caller-owned, [n_clips][npx_pad]).
+ * lp/base are double planes when params.f64_state else float planes. */
+int v2e_emu_bind_state(v2e_emu *h, void *lp, void *base, float *ts_mem,
+                       float *pos_thres, float *neg_thres, float *noise_rate);
+
+/*
+ * First frame (emulator.py:681-717 + _init :439-511).  frame: [n_clips][H*W] of
+ * `dtype`.  Tape mode: thres_pos/thres_neg hold the torch.normal draws (pre-clamp)
+ * and noise_rate the final exp() values (or NULL when unused); Philox mode: pass
+ * NULL and they are generated in-kernel.
+ */
+int v2e_emu_init_state(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype,
+                       double t_frame, const float *thres_pos, const float *thres_neg,
+                       const float *noise_rate, void *stream);
+
+/*
+ * Front half of one time step for all clips: photoreceptor, IIR, leak, event
+ * counts, shot-noise decisions, global max.  leak_randn/shot_rand: [n_clips][npx_pad]
+ * host-drawn tapes (tape mode) or NULL (Philox).  frame_idx: Philox counter word and
+ * record slot (rec slot = frame_idx % ring).  t_prev/t_frame: per-clip host arrays.
+ */
+int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype,
+                  const double *t_prev, const double *t_frame, uint32_t frame_idx,
+                  const float *leak_randn, const float *shot_rand, void *stream);
+
+/* Blocking: copy the per-clip records of `frame_idx` to host (syncs the stream). */
+int v2e_emu_read_rec(v2e_emu *h, uint32_t frame_idx, v2e_frame_rec *recs_host, void *stream);
+
+/*
+ * Back half: refractory filter, per-(iteration,polarity) compaction into the dense
+ * [N,4] float32 (t,x,y,p) list in reference order (emulator.py:810-923), base/ts_mem
+ * update (:936-942).  ts_table: device [n_clips][n_ts] float32 timestamps
+ * (torch.linspace drawn by the host, tape mode) or NULL for the in-kernel formula.
+ * events: device [n_clips][cap][4] float32.  ev_offset0: per-clip host array of
+ * the row at which this frame's events start (NULL: continue after previous frame).
+ */
+int v2e_emu_emit(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx,
+                 const float *ts_table, int n_ts, float *events, uint64_t cap,
+                 const uint64_t *ev_offset0, void *stream);
+
+/* Blocking: per-iteration (on_i, off_i) totals of the last emitted frame,
+ * host array [n_clips][2*(max_events+1)]; the last pair is the shot-noise pair. */
+int v2e_emu_read_iter_counts(v2e_emu *h, uint32_t frame_idx, int n_iters, uint32_t *counts_host,
+                             void *stream);
+
+/* out[dst0 + j] = in[src0 + idx[j]], j < n   (events_curr_iter[idx], emulator.py:869) */
+int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const int32_t *idx,
+                    uint64_t row0, uint64_t n, void *stream);
+
+/*
+ * Philox-mode, fully device-resident multi-frame run: frames [n_frames][n_clips][H*W],
+ * t_prev/t_frame host arrays [n_frames][n_clips].  Records for frame f go to
+ * recs_dev[f][clip] (device, caller-owned).  No host synchronisation inside.
+ * use_graph: capture the launch sequence into a hipGraph (cached per shape).
+ */
+int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames,
+                const double *t_prev, const double *t_frame, uint32_t frame_idx0, float *events,
+                uint64_t cap, v2e_frame_rec *recs_dev, int use_graph, void *stream);
+
+/* ------------------------------------------------------------- SuperSloMo */
+
+/* one 2-D convolution layer of the UNet (model.py: nn.Conv2d + leaky_relu 0.1) */
+typedef struct v2e_conv_desc {
+    const float *weight; /* device, pre-packed [Cin][k][k][Cout] (v2e_pack_conv_weight) */
+    const float *bias;   /* device [Cout] */
+    int32_t cin, cout, ksize;
+} v2e_conv_desc;
+
+/* repack torch [Cout][Cin][k][k] -> [Cin][k][k][Cout] on device */
+int v2e_pack_conv_weight(const float *w_oihw, float *w_packed, int cout, int cin, int k, void *stream);
+
+/*
+ * y = leaky_relu(conv2d(cat(x0, x1), W) + b, 0.1), stride 1, zero pad (k-1)/2, NCHW f32.
+ * x1 may be NULL (c1 = 0).  pre: 0 none, 1 avg_pool2d(x0,2) fused on load (x0 is
+ * [N][c0][2H][2W]), 2 bilinear x2 upsample (align_corners=False) fused on load
+ * (x0 is [N][c0][H/2][W/2]).
+ */
+int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre,
+                     const v2e_conv_desc *conv, float *y, int n, int h, int w, void *stream);
+
+/* 23-conv UNet forward (model.py:198-226).  convs: 23 descriptors in forward order;
+ * workspace: device scratch of v2e_unet_workspace_bytes(n,h,w) bytes. */
+int64_t v2e_unet_workspace_bytes(int n, int h, int w, int cin);
+int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *convs, int cout, float *y,
+                     int n, int h, int w, void *workspace, void *stream);
+
+/*
+ * slomo.py:405-419 for `n_t` time points of one batch: flow blend, two backWarps and
+ * assembly of the 12-channel interpolation input
+ * [I0,I1,F01(2),F10(2),Ft1(2),Ft0(2),g1,g0] -> x12 [n_t*b][12][h][w].
+ * flow: flow-UNet output [b][4][h][w]; t: host array [n_t].
+ */
+int v2e_slomo_prep(const float *i0, const float *i1, const float *flow, const float *t, int n_t,
+                   int b, int h, int w, float *x12, void *stream);
+
+/* slomo.py:421-433: refine flows, visibility, two backWarps, fusion -> out [n_t*b][1][h][w] */
+int v2e_slomo_fuse(const float *i0, const float *i1, const float *x12, const float *intrp,
+                   const float *t, int n_t, int b, int h, int w, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2E_AMD_H */

@@ -1,0 +1,229 @@
+/*
+ * v2e_detmath.h -- counter-based RNG (Philox4x32-10) and *deterministic* f32 math
+ * shared verbatim by the gfx950 HIP kernels (v2e_amd/csrc) and the CPU oracle
+ * (oracle/emu_oracle.c).
+ *
+ * Why this exists: the reference draws its per-pixel noise from torch's global
+ * generators (v2ecore/emulator.py:459-471, 501-505; emulator_utils.py:122-124,
+ * 338-341).  A GPU kernel cannot replay MT19937, so "philox mode" defines its own
+ * counter-based streams.  To make device and host produce the SAME bits, every
+ * function below uses only IEEE-exact operations (+, -, *, /, fmaf, sqrtf, rintf,
+ * floorf and integer ops) -- no libm/ocml transcendental whose rounding differs
+ * between glibc and the device library.  Compile with -ffp-contract=off on both
+ * sides; all fusion is spelled fmaf().
+ *
+ * Plain C99; under hipcc the functions become __host__ __device__.
+ */
+#ifndef V2E_DETMATH_H
+#define V2E_DETMATH_H
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define V2E_HD __host__ __device__ static inline
+#else
+#define V2E_HD static inline
+#endif
+
+/* ------------------------------------------------------------------ Philox */
+#define V2E_PHILOX_M0 0xD2511F53u
+#define V2E_PHILOX_M1 0xCD9E8D57u
+#define V2E_PHILOX_W0 0x9E3779B9u
+#define V2E_PHILOX_W1 0xBB67AE85u
+
+/* Philox4x32-10 (Salmon et al., SC'11).  ctr[4] in, out[4] out. */
+V2E_HD void v2e_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                           uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)V2E_PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)V2E_PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += V2E_PHILOX_W0; k1 += V2E_PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Stream ids (counter word 2). */
+#define V2E_STREAM_FRAME 0u /* per (pixel, frame): [0],[1] leak normal, [2] shot uniform */
+#define V2E_STREAM_THRES 1u /* per pixel: [0],[1] pos-threshold normal, [2],[3] neg-threshold normal */
+#define V2E_STREAM_RATE  2u /* per pixel: [0],[1] noise-rate normal */
+#define V2E_STREAM_PERM  3u /* per (frame, iteration): shuffle key */
+
+/* 24-bit uniform in [0,1): same granularity as torch's f32 uniform. */
+V2E_HD float v2e_u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+/* 24-bit uniform in (0,1]. */
+V2E_HD float v2e_u01_open0(uint32_t x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-08f; }
+
+V2E_HD uint32_t v2e_f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+V2E_HD float v2e_u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+
+/* ------------------------------------------------------- deterministic math */
+
+/* ln(x) for normal positive x.  ~1.5 ulp; deterministic. */
+V2E_HD float v2e_det_logf(float x)
+{
+    uint32_t ux = v2e_f2u(x);
+    /* normalise mantissa to [sqrt(1/2), sqrt(2)) */
+    int32_t e = (int32_t)(ux >> 23) - 127;
+    uint32_t mbits = (ux & 0x007FFFFFu) | 0x3F800000u;
+    float m = v2e_u2f(mbits);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    /* 2*atanh(s) = 2s(1 + z/3 + z^2/5 + z^3/7 + z^4/9) , |s| <= 0.1716 */
+    float p = 0.2222222222f;
+    p = fmaf(p, z, 0.2857142857f);
+    p = fmaf(p, z, 0.4f);
+    p = fmaf(p, z, 0.6666666667f);
+    p = fmaf(p, z, 2.0f);
+    float lm = p * s;
+    float fe = (float)e;
+    /* ln2 split: hi has 12 trailing zero bits so fe*hi is exact for |e|<=127+ */
+    float r = fmaf(fe, 1.42860677e-06f, lm);
+    return fmaf(fe, 0.693145752f, r);
+}
+
+/* sin/cos of 2*pi*u for u in [0,1).  deterministic, ~1e-7 abs. */
+V2E_HD void v2e_det_sincos2pi(float u, float *sn, float *cs)
+{
+    float a = u * 4.0f;                 /* exact */
+    float kf = floorf(a + 0.5f);
+    float r = a - kf;                   /* exact, in [-0.5, 0.5] */
+    float t = r * 1.57079632679f;       /* quadrant angle in [-pi/4, pi/4] */
+    float t2 = t * t;
+    float sp = -1.9515295891e-4f;
+    sp = fmaf(sp, t2, 8.3321608736e-3f);
+    sp = fmaf(sp, t2, -1.6666654611e-1f);
+    float s0 = fmaf(sp * t2, t, t);
+    float cp = 2.443315711809948e-5f;
+    cp = fmaf(cp, t2, -1.388731625493765e-3f);
+    cp = fmaf(cp, t2, 4.166664568298827e-2f);
+    float c0 = fmaf(cp, t2 * t2, fmaf(-0.5f, t2, 1.0f));
+    int k = ((int)kf) & 3;
+    float s, c;
+    if (k == 0)      { s = s0;  c = c0; }
+    else if (k == 1) { s = c0;  c = -s0; }
+    else if (k == 2) { s = -s0; c = -c0; }
+    else             { s = -c0; c = s0; }
+    *sn = s; *cs = c;
+}
+
+/* exp(x), |x| < 80.  deterministic, ~1 ulp. */
+V2E_HD float v2e_det_expf(float x)
+{
+    float n = rintf(x * 1.44269504089f);
+    float r = fmaf(-n, 0.693145752f, x);
+    r = fmaf(-n, 1.42860677e-06f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float y = fmaf(p * r, r, r) + 1.0f;
+    int32_t ni = (int32_t)n;
+    /* scale by 2^n in two steps to stay in range */
+    int32_t h = ni / 2;
+    float s1 = v2e_u2f((uint32_t)(h + 127) << 23);
+    float s2 = v2e_u2f((uint32_t)(ni - h + 127) << 23);
+    return y * s1 * s2;
+}
+
+/* Standard normal from two Philox words (Box-Muller, cosine branch). */
+V2E_HD float v2e_normal(uint32_t a, uint32_t b)
+{
+    float u1 = v2e_u01_open0(a);
+    float u2 = v2e_u01(b);
+    float rad = sqrtf(-2.0f * v2e_det_logf(u1));
+    float s, c;
+    v2e_det_sincos2pi(u2, &s, &c);
+    return rad * c;
+}
+
+/* Per-(pixel,frame) draws: leak jitter normal and shot-noise uniform. */
+V2E_HD void v2e_draw_frame(uint64_t seed, uint32_t clip, uint32_t frame, uint32_t pixel,
+                           float *leak_randn, float *shot_u)
+{
+    uint32_t o[4];
+    v2e_philox4x32(pixel, frame, V2E_STREAM_FRAME, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    *leak_randn = v2e_normal(o[0], o[1]);
+    *shot_u = v2e_u01(o[2]);
+}
+
+/* Per-pixel first-frame draws (emulator.py:459-471, 501-505 in philox mode). */
+V2E_HD void v2e_draw_init(uint64_t seed, uint32_t clip, uint32_t pixel,
+                          float *n_pos, float *n_neg, float *n_rate)
+{
+    uint32_t o[4];
+    v2e_philox4x32(pixel, 0u, V2E_STREAM_THRES, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    *n_pos = v2e_normal(o[0], o[1]);
+    *n_neg = v2e_normal(o[2], o[3]);
+    v2e_philox4x32(pixel, 0u, V2E_STREAM_RATE, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    *n_rate = v2e_normal(o[0], o[1]);
+}
+
+/* ------------------------------------------------ keyed bijection (shuffle) */
+/*
+ * Philox-mode replacement for `idx = torch.randperm(n_i)` (emulator.py:868):
+ * a keyed Feistel bijection on [0,n) with cycle walking (the construction used by
+ * thrust::shuffle).  sigma(c) is the OUTPUT position of the event whose canonical
+ * (ON-row-major-then-OFF-row-major) index is c, i.e. reference idx[sigma(c)] = c.
+ */
+V2E_HD uint32_t v2e_mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+typedef struct { uint32_t k[4]; uint32_t lbits, rbits, lmask, rmask; uint32_t n; } v2e_perm_t;
+
+V2E_HD void v2e_perm_init(v2e_perm_t *p, uint64_t seed, uint32_t clip, uint32_t frame,
+                          uint32_t iter, uint32_t n)
+{
+    v2e_philox4x32(iter, frame, V2E_STREAM_PERM, clip, (uint32_t)seed, (uint32_t)(seed >> 32), p->k);
+    uint32_t bits = 2;
+    while (bits < 32 && (1u << bits) < n) ++bits;
+    p->rbits = bits >> 1;
+    p->lbits = bits - p->rbits;
+    p->lmask = (1u << p->lbits) - 1u;
+    p->rmask = (1u << p->rbits) - 1u;
+    p->n = n;
+}
+
+V2E_HD uint32_t v2e_perm_apply(const v2e_perm_t *p, uint32_t c)
+{
+    uint32_t x = c;
+    do {
+        uint32_t l = x >> p->rbits, r = x & p->rmask;   /* l: lbits, r: rbits */
+        for (int round = 0; round < 4; ++round) {
+            /* unbalanced Feistel: alternate which half is hashed */
+            if ((round & 1) == 0) l = (l ^ v2e_mix32(r + p->k[round])) & p->lmask;
+            else                  r = (r ^ v2e_mix32(l + p->k[round])) & p->rmask;
+        }
+        x = (l << p->rbits) | r;
+    } while (x >= p->n);
+    return x;
+}
+
+/* ------------------------------------------------------- timestamp formula */
+/*
+ * In-kernel stand-in for torch.linspace(start, end, n, dtype=float32)
+ * (emulator.py:793-796) used when no host timestamp table is supplied.  It is the
+ * scalar form of ATen's symmetric fill (RangeFactoriesKernel.cpp) with the
+ * multiply-add fused, which is what the AVX2/AVX-512 builds of that kernel
+ * compute for n below one unrolled vector step.  start/end/step are f32.
+ */
+V2E_HD float v2e_ts_formula(uint32_t i, uint32_t n, float start, float end, float step)
+{
+    if (n <= 1u) return start;
+    if (i < n / 2u) return fmaf(step, (float)i, start);
+    return fmaf(-step, (float)(n - 1u - i), end);
+}
+
+#endif /* V2E_DETMATH_H */

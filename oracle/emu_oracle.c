@@ -1,0 +1,449 @@
+/*
+ * emu_oracle.c -- CPU restatement of the reference DVS pixel model.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product package (v2e_amd/) links,
+ * imports or calls this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and only as the checker / reported baseline.
+ *
+ * Restates, op for op and dtype for dtype, the arithmetic of
+ *   v2ecore/emulator.py:439-511   (_init)
+ *   v2ecore/emulator.py:656-775   (generate_events, front half)
+ *   v2ecore/emulator.py:791-942   (iteration loop, refractory, shot noise, base update)
+ *   v2ecore/emulator.py:1024-1059 (get_event_list_from_coords)
+ *   v2ecore/emulator_utils.py:18-173, 297-351
+ * whose arithmetic lives in torch (un-pinned third-party dependency: setup.py:44
+ * bare 'torch'; run here against torch 2.10.0 CPU kernels).  The reference ships no
+ * golden vectors, so this oracle is pinned against outputs of
+ * the reference itself executed in-process: tests/golden/make_golden.py and
+ * tests/test_oracle_vs_reference.py.
+ *
+ * Build: oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/v2e_amd.h"
+#include "../include/v2e_detmath.h"
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* (1./20) * math.log(20) evaluated by CPython/glibc (emulator_utils.py:34) */
+static const double LINLOG_F = 0x1.32c352f8fe941p-3; /* 0.14978661367769955 */
+
+/* emulator_utils.py:30-45 */
+static float lin_log(double x)
+{
+    double y = (x <= 20.0) ? x * LINLOG_F : log(x);
+    y = rint(y * 1e8) / 1e8; /* torch.round: half to even */
+    return (float)y;
+}
+
+/* c10::div_floor_floating (torch.div(..., rounding_mode='floor'), emulator_utils.py:154-157) */
+static double div_floor_d(double a, double b)
+{
+    if (b == 0) return a / b;
+    double mod = fmod(a, b);
+    double div = (a - mod) / b;
+    if (mod != 0 && ((b < 0) != (mod < 0))) div -= 1.0;
+    double fd;
+    if (div != 0) {
+        fd = floor(div);
+        if (div - fd > 0.5) fd += 1.0;
+    } else {
+        fd = copysign(0.0, a / b);
+    }
+    return fd;
+}
+static float div_floor_f(float a, float b)
+{
+    if (b == 0) return a / b;
+    float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0 && ((b < 0) != (mod < 0))) div -= 1.0f;
+    float fd;
+    if (div != 0) {
+        fd = floorf(div);
+        if (div - fd > 0.5f) fd += 1.0f;
+    } else {
+        fd = copysignf(0.0f, a / b);
+    }
+    return fd;
+}
+
+/* ---------------------------------------------------------------- RNG taps */
+EXPORT void v2e_oracle_philox_frame(uint64_t seed, uint32_t clip, uint32_t frame, int64_t npx,
+                                    float *leak_randn, float *shot_u)
+{
+    for (int64_t p = 0; p < npx; ++p) {
+        float a, b;
+        v2e_draw_frame(seed, clip, frame, (uint32_t)p, &a, &b);
+        if (leak_randn) leak_randn[p] = a;
+        if (shot_u) shot_u[p] = b;
+    }
+}
+
+EXPORT void v2e_oracle_philox_init(uint64_t seed, uint32_t clip, int64_t npx, float *n_pos,
+                                   float *n_neg, float *n_rate)
+{
+    for (int64_t p = 0; p < npx; ++p) {
+        float a, b, c;
+        v2e_draw_init(seed, clip, (uint32_t)p, &a, &b, &c);
+        if (n_pos) n_pos[p] = a;
+        if (n_neg) n_neg[p] = b;
+        if (n_rate) n_rate[p] = c;
+    }
+}
+
+/* idx with idx[sigma(c)] = c, i.e. what `torch.randperm` must return for the
+ * reference's `events[idx]` to equal the philox-mode order. */
+EXPORT void v2e_oracle_perm_idx(uint64_t seed, uint32_t clip, uint32_t frame, uint32_t iter,
+                                uint32_t n, int64_t *idx)
+{
+    v2e_perm_t pm;
+    v2e_perm_init(&pm, seed, clip, frame, iter, n);
+    for (uint32_t c = 0; c < n; ++c) idx[v2e_perm_apply(&pm, c)] = (int64_t)c;
+}
+
+EXPORT void v2e_oracle_ts(double t_prev, double t_frame, int32_t n, float *ts)
+{
+    double dt = t_frame - t_prev;
+    double ts_step = dt / (double)n;
+    float start = (float)(t_prev + ts_step), end = (float)t_frame;
+    float step = (n > 1) ? (end - start) / (float)(n - 1) : 0.0f;
+    for (int32_t i = 0; i < n; ++i) ts[i] = v2e_ts_formula((uint32_t)i, (uint32_t)n, start, end, step);
+}
+
+EXPORT float v2e_oracle_det_logf(float x) { return v2e_det_logf(x); }
+EXPORT float v2e_oracle_det_expf(float x) { return v2e_det_expf(x); }
+EXPORT float v2e_oracle_normal(uint32_t a, uint32_t b) { return v2e_normal(a, b); }
+
+/* ------------------------------------------------------------- first frame */
+/*
+ * emulator.py:681-717 and _init :439-511.  frame: float64 [H*W].
+ * Tape mode: thres_pos/thres_neg = torch.normal draws (pre-clamp), noise_rate =
+ * exp() already applied by torch; Philox mode: all three NULL.
+ */
+EXPORT int v2e_oracle_init_state(const v2e_emu_params *P, int H, int W, const double *frame,
+                                 double t_frame, uint32_t clip, const float *thres_pos_tape,
+                                 const float *thres_neg_tape, const float *noise_rate_tape,
+                                 void *lp_v, void *base_v, float *ts_mem, float *pos_thres,
+                                 float *neg_thres, float *noise_rate)
+{
+    int64_t npx = (int64_t)H * W;
+    double delta_time = t_frame - 0.0; /* t_previous starts at 0 (emulator.py:171) */
+    double tau = (P->cutoff_hz > 0) ? 1.0 / (M_PI * 2 * P->cutoff_hz) : 0.0;
+    double dt_over_tau = (P->cutoff_hz > 0) ? delta_time / tau : 0.0;
+    float ln10cov = (float)(log(10.0) * P->noise_rate_cov_decades);
+    for (int64_t p = 0; p < npx; ++p) {
+        double x = frame[p];
+        float L = lin_log(x);
+        if (P->f64_state) {
+            double inten01 = (x + 20.0) / 275.0;
+            double eps = inten01 * dt_over_tau;
+            if (eps > 1.0) eps = 1.0;
+            double lp = (1.0 - eps) * (double)L + eps * (double)L; /* lp initialised to L */
+            ((double *)lp_v)[p] = lp;
+            ((double *)base_v)[p] = lp;
+        } else {
+            ((float *)lp_v)[p] = L;
+            ((float *)base_v)[p] = L;
+        }
+        if (!P->scalar_thres) {
+            float tp, tn;
+            if (P->rng_mode == V2E_RNG_PHILOX) {
+                float a, b, c;
+                v2e_draw_init(P->seed, clip, (uint32_t)p, &a, &b, &c);
+                tp = a * (float)P->sigma_thres + (float)P->pos_thres_scalar;
+                tn = b * (float)P->sigma_thres + (float)P->neg_thres_scalar;
+            } else {
+                tp = thres_pos_tape[p];
+                tn = thres_neg_tape[p];
+            }
+            pos_thres[p] = tp < 0.01f ? 0.01f : tp; /* torch.clamp(min=0.01), :466,472 */
+            neg_thres[p] = tn < 0.01f ? 0.01f : tn;
+        } else {
+            pos_thres[p] = (float)P->pos_thres_scalar;
+            neg_thres[p] = (float)P->neg_thres_scalar;
+        }
+        if (P->leak_rate_hz > 0) {
+            if (P->rng_mode == V2E_RNG_PHILOX) {
+                float a, b, c;
+                v2e_draw_init(P->seed, clip, (uint32_t)p, &a, &b, &c);
+                noise_rate[p] = v2e_det_expf(ln10cov * c);
+            } else {
+                noise_rate[p] = noise_rate_tape[p];
+            }
+        }
+        if (P->refractory_period_s > 0) ts_mem[p] = 0.0f - (float)P->refractory_period_s;
+    }
+    return 0;
+}
+
+/* -------------------------------------------------------------- front half */
+/*
+ * emulator.py:656-775 for one frame.  Outputs integer count maps (int32, exact
+ * parity objects), shot-noise decisions and M = max_num_events_any_pixel.
+ */
+EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double *frame,
+                            double t_prev, double t_frame, uint32_t frame_idx, uint32_t clip,
+                            const float *leak_randn, const float *shot_rand, void *lp_v,
+                            void *base_v, const float *pos_thres, const float *neg_thres,
+                            const float *noise_rate, int32_t *pos_cnt, int32_t *neg_cnt,
+                            uint8_t *shot_on, uint8_t *shot_off, int32_t *M_out)
+{
+    int64_t npx = (int64_t)H * W;
+    double delta_time = t_frame - t_prev;
+    double tau = (P->cutoff_hz > 0) ? 1.0 / (M_PI * 2 * P->cutoff_hz) : 0.0;
+    double dt_over_tau = (P->cutoff_hz > 0) ? delta_time / tau : 0.0;
+    int use_inten = (P->cutoff_hz > 0) || (P->shot_noise_rate_hz > 0);
+    int do_leak = P->leak_rate_hz > 0;
+    int do_shot = P->shot_noise_rate_hz > 0;
+    float leak_hz = (float)P->leak_rate_hz, jit = (float)P->leak_jitter_fraction;
+    float dt_f = (float)delta_time;
+    double shot_base = (P->shot_noise_rate_hz / 2) * delta_time;
+    double inten_slope = P->shot_noise_inten_factor - 1;
+    float pos_nom_f = (float)P->pos_thres_nominal, neg_nom_f = (float)P->neg_thres_nominal;
+    int32_t M = 0;
+    for (int64_t p = 0; p < npx; ++p) {
+        double x = frame[p];
+        float L = lin_log(x);
+        double inten01 = use_inten ? (x + 20.0) / 275.0 : 0.0;
+        float r = 0.0f, u = 0.0f;
+        if (P->rng_mode == V2E_RNG_PHILOX) {
+            if (do_leak || do_shot) v2e_draw_frame(P->seed, clip, frame_idx, (uint32_t)p, &r, &u);
+        } else {
+            if (do_leak) r = leak_randn[p];
+            if (do_shot && shot_rand) u = shot_rand[p];
+        }
+        float delta_leak = 0.0f;
+        if (do_leak) {
+            /* emulator_utils.py:126-129, all float32 */
+            float rate = (leak_hz * noise_rate[p]) * (1.0f - jit * r);
+            delta_leak = (dt_f * rate) * pos_thres[p];
+        }
+        int32_t pc, nc;
+        if (P->f64_state) {
+            double *lp = (double *)lp_v, *base = (double *)base_v;
+            double eps = inten01 * dt_over_tau;
+            if (eps > 1.0) eps = 1.0;
+            double lpn = (1.0 - eps) * lp[p] + eps * (double)L;
+            lp[p] = lpn;
+            double b = base[p];
+            if (do_leak) b = b - (double)delta_leak;
+            base[p] = b;
+            double diff = (lpn + (double)0.0f) - b;
+            double pf = diff > 0 ? diff : 0.0, nf = (-diff) > 0 ? -diff : 0.0;
+            double tp = P->scalar_thres ? P->pos_thres_scalar : (double)pos_thres[p];
+            double tn = P->scalar_thres ? P->neg_thres_scalar : (double)neg_thres[p];
+            pc = (int32_t)div_floor_d(pf, tp);
+            nc = (int32_t)div_floor_d(nf, tn);
+        } else {
+            float *lp = (float *)lp_v, *base = (float *)base_v;
+            lp[p] = L;
+            float b = base[p];
+            if (do_leak) b = b - delta_leak;
+            base[p] = b;
+            float diff = (L + 0.0f) - b;
+            float pf = diff > 0 ? diff : 0.0f, nf = (-diff) > 0 ? -diff : 0.0f;
+            pc = (int32_t)div_floor_f(pf, pos_thres[p]);
+            nc = (int32_t)div_floor_f(nf, neg_thres[p]);
+        }
+        pos_cnt[p] = pc;
+        neg_cnt[p] = nc;
+        if (pc > M) M = pc;
+        if (nc > M) M = nc;
+        uint8_t so = 0, sf = 0;
+        if (do_shot && (shot_rand || P->rng_mode == V2E_RNG_PHILOX)) {
+            /* emulator_utils.py:326-349 */
+            double F = shot_base * (inten_slope * inten01 + 1);
+            float ppre = P->scalar_thres ? P->pos_pre_scalar : pos_nom_f / pos_thres[p];
+            float npre = P->scalar_thres ? P->neg_pre_scalar : neg_nom_f / neg_thres[p];
+            double on_thr = 1 - F * (double)ppre;
+            double off_thr = F * (double)npre;
+            so = (double)u > on_thr;
+            sf = (double)u < off_thr;
+        }
+        shot_on[p] = so;
+        shot_off[p] = sf;
+    }
+    *M_out = M;
+    return 0;
+}
+
+/* emulator_utils.py:326-349 as its own pass (tape mode draws `rand` AFTER the
+ * per-iteration randperms, emulator.py:868 then :906, so the host cannot supply it
+ * to the front half). */
+EXPORT int v2e_oracle_shot(const v2e_emu_params *P, int H, int W, const double *frame,
+                           double t_prev, double t_frame, const float *shot_rand,
+                           const float *pos_thres, const float *neg_thres, uint8_t *shot_on,
+                           uint8_t *shot_off)
+{
+    int64_t npx = (int64_t)H * W;
+    double delta_time = t_frame - t_prev;
+    double shot_base = (P->shot_noise_rate_hz / 2) * delta_time;
+    double inten_slope = P->shot_noise_inten_factor - 1;
+    float pos_nom_f = (float)P->pos_thres_nominal, neg_nom_f = (float)P->neg_thres_nominal;
+    for (int64_t p = 0; p < npx; ++p) {
+        double inten01 = (frame[p] + 20.0) / 275.0;
+        double F = shot_base * (inten_slope * inten01 + 1);
+        float ppre = P->scalar_thres ? P->pos_pre_scalar : pos_nom_f / pos_thres[p];
+        float npre = P->scalar_thres ? P->neg_pre_scalar : neg_nom_f / neg_thres[p];
+        double on_thr = 1 - F * (double)ppre;
+        double off_thr = F * (double)npre;
+        float u = shot_rand[p];
+        shot_on[p] = (double)u > on_thr;
+        shot_off[p] = (double)u < off_thr;
+    }
+    return 0;
+}
+
+/* --------------------------------------------------------------- back half */
+/*
+ * emulator.py:791-942.  ts_table: host-drawn torch.linspace (tape mode) or NULL.
+ * events: [cap][4] float32 in reference order *before* the randperm shuffle of each
+ * iteration block in tape mode (the caller applies events[idx] exactly like
+ * emulator.py:868-869), or already shuffled by the keyed bijection in Philox mode
+ * with P->shuffle.  iter_counts: [(M+1)][2] = per-iteration (on, off) and the final
+ * shot pair.
+ */
+EXPORT int v2e_oracle_emit(const v2e_emu_params *P, int H, int W, double t_prev, double t_frame,
+                           uint32_t frame_idx, uint32_t clip, const float *ts_table, int n_ts,
+                           const int32_t *pos_cnt, const int32_t *neg_cnt, const uint8_t *shot_on,
+                           const uint8_t *shot_off, int32_t M, const void *lp_v, void *base_v,
+                           float *ts_mem, const float *pos_thres, const float *neg_thres,
+                           float *events, uint64_t cap, uint32_t *iter_counts, v2e_frame_rec *rec,
+                           int dry_run)
+{
+    int64_t npx = (int64_t)H * W;
+    double delta_time = t_frame - t_prev;
+    int32_t n = M > 0 ? M : 1;
+    float *ts_mem_copy = NULL;
+    if (dry_run) { /* count-only pass: no state mutation, no event writes */
+        cap = 0;
+        if (P->refractory_period_s > 0) {
+            ts_mem_copy = (float *)malloc(sizeof(float) * (size_t)npx);
+            memcpy(ts_mem_copy, ts_mem, sizeof(float) * (size_t)npx);
+            ts_mem = ts_mem_copy;
+        }
+    }
+    double ts_step = delta_time / (double)n;
+    float *ts = (float *)malloc(sizeof(float) * (size_t)n);
+    if (ts_table) {
+        if (n_ts < n) { free(ts); return V2E_EINVAL; }
+        memcpy(ts, ts_table, sizeof(float) * (size_t)n);
+    } else {
+        v2e_oracle_ts(t_prev, t_frame, n, ts);
+    }
+    int use_refr = P->refractory_period_s > ts_step; /* emulator.py:830 */
+    float refr_f = (float)P->refractory_period_s;
+    int32_t *fpos = (int32_t *)calloc((size_t)npx, sizeof(int32_t));
+    int32_t *fneg = (int32_t *)calloc((size_t)npx, sizeof(int32_t));
+    uint8_t *pcord = (uint8_t *)malloc((size_t)npx), *ncord = (uint8_t *)malloc((size_t)npx);
+    uint64_t ne = 0;
+    uint32_t n_on = 0, n_off = 0, flags = 0;
+    for (int32_t i = 0; i < M; ++i) {
+        float tsi = ts[i];
+        uint32_t on_i = 0, off_i = 0;
+        for (int64_t p = 0; p < npx; ++p) {
+            uint8_t pc = pos_cnt[p] >= i + 1, nc = neg_cnt[p] >= i + 1;
+            if (use_refr) {
+                float pt = (pc ? 1.0f : 0.0f) * tsi - ts_mem[p];
+                float nt = (nc ? 1.0f : 0.0f) * tsi - ts_mem[p];
+                pc = pt > refr_f;
+                nc = nt > refr_f;
+                if (pc) ts_mem[p] = tsi;
+                if (nc) ts_mem[p] = tsi;
+            }
+            pcord[p] = pc;
+            ncord[p] = nc;
+            fpos[p] += pc;
+            fneg[p] += nc;
+            on_i += pc;
+            off_i += nc;
+        }
+        iter_counts[2 * i] = on_i;
+        iter_counts[2 * i + 1] = off_i;
+        uint32_t n_i = on_i + off_i;
+        v2e_perm_t pm;
+        int shuf = (P->rng_mode == V2E_RNG_PHILOX) && P->shuffle && n_i > 0;
+        if (shuf) v2e_perm_init(&pm, P->seed, clip, frame_idx, (uint32_t)i, n_i);
+        uint32_t c = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint8_t *cord = pass == 0 ? pcord : ncord;
+            for (int64_t p = 0; p < npx; ++p) {
+                if (!cord[p]) continue;
+                uint64_t row = ne + (shuf ? v2e_perm_apply(&pm, c) : c);
+                ++c;
+                if (row < cap) {
+                    float *e = events + 4 * row;
+                    e[0] = tsi;
+                    e[1] = (float)(p % W);
+                    e[2] = (float)(p / W);
+                    e[3] = pass == 0 ? 1.0f : -1.0f;
+                } else {
+                    flags |= V2E_FLAG_EVENTS_DROPPED;
+                }
+            }
+        }
+        ne += n_i;
+        n_on += on_i;
+        n_off += off_i;
+    }
+    uint32_t n_signal = (uint32_t)ne;
+    uint32_t s_on = 0, s_off = 0;
+    if (P->shot_noise_rate_hz > 0) {
+        float tl = ts[n - 1];
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint8_t *cord = pass == 0 ? shot_on : shot_off;
+            for (int64_t p = 0; p < npx; ++p) {
+                if (!cord[p]) continue;
+                if (ne < cap) {
+                    float *e = events + 4 * ne;
+                    e[0] = tl;
+                    e[1] = (float)(p % W);
+                    e[2] = (float)(p / W);
+                    e[3] = pass == 0 ? 1.0f : -1.0f;
+                } else {
+                    flags |= V2E_FLAG_EVENTS_DROPPED;
+                }
+                ++ne;
+                if (pass == 0) ++s_on; else ++s_off;
+            }
+        }
+    }
+    iter_counts[2 * M] = s_on;
+    iter_counts[2 * M + 1] = s_off;
+    /* emulator.py:936-942 */
+    for (int64_t p = 0; p < npx && !dry_run; ++p) {
+        float dp = (float)fpos[p] * pos_thres[p];
+        float dn = (float)fneg[p] * neg_thres[p];
+        if (P->f64_state) {
+            double *base = (double *)base_v;
+            const double *lp = (const double *)lp_v;
+            double b = base[p];
+            b = b + (double)dp;
+            b = b - (double)dn;
+            if (P->shot_noise_rate_hz > 0 && (shot_on[p] || shot_off[p])) b = lp[p];
+            base[p] = b;
+        } else {
+            float *base = (float *)base_v;
+            const float *lp = (const float *)lp_v;
+            float b = base[p];
+            b = b + dp;
+            b = b - dn;
+            if (P->shot_noise_rate_hz > 0 && (shot_on[p] || shot_off[p])) b = lp[p];
+            base[p] = b;
+        }
+    }
+    rec->max_events = M;
+    rec->flags = dry_run ? 0 : flags;
+    rec->n_signal = n_signal;
+    rec->n_events = (uint32_t)ne;
+    rec->n_on = n_on + s_on;
+    rec->n_off = n_off + s_off;
+    rec->ev_offset = 0;
+    free(ts); free(fpos); free(fneg); free(pcord); free(ncord); free(ts_mem_copy);
+    return 0;
+}

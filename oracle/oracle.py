@@ -1,0 +1,338 @@
+"""Python driver of the CPU oracle (oracle/emu_oracle.c, oracle/slomo_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package v2e_amd/.
+
+`OracleEmulator` restates EventEmulator.generate_events (v2ecore/emulator.py:619-1022)
+around the C passes, including the reference's RNG call order:
+frame 0: normal, normal, randn; frame k: randn, randperm per non-empty iteration,
+rand.  Random numbers come from a *tape source*: `TorchTape` draws from torch's
+global CPU generator exactly like the reference; `RecordedTape` replays stored
+draws; `PhiloxTape` is None (in-"kernel" Philox, include/v2e_detmath.h).
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libv2e_oracle.so")
+
+import sys
+sys.path.insert(0, os.path.dirname(_HERE))
+from v2e_amd._capi import EmuParams, FrameRec, RNG_TAPE, RNG_PHILOX  # noqa: E402  (struct layouts only)
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.isfile(_LIB):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.v2e_oracle_det_logf.restype = C.c_float
+        _lib.v2e_oracle_det_logf.argtypes = [C.c_float]
+        _lib.v2e_oracle_det_expf.restype = C.c_float
+        _lib.v2e_oracle_det_expf.argtypes = [C.c_float]
+        _lib.v2e_oracle_normal.restype = C.c_float
+        _lib.v2e_oracle_normal.argtypes = [C.c_uint32, C.c_uint32]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ tapes
+class TorchTape:
+    """Live draws from torch's global CPU generator, same calls as the reference."""
+
+    def normal(self, mean, std, shape):
+        import torch
+        return torch.normal(mean, std, size=shape, dtype=torch.float32).numpy()
+
+    def randn(self, shape):
+        import torch
+        return torch.randn(shape, dtype=torch.float32).numpy()
+
+    def rand(self, shape):
+        import torch
+        return torch.rand(size=shape, dtype=torch.float32).numpy()
+
+    def randperm(self, n, frame=None, it=None):
+        import torch
+        return torch.randperm(n).numpy()
+
+    def linspace(self, start, end, n):
+        import torch
+        return torch.linspace(start=start, end=end, steps=n, dtype=torch.float32).numpy()
+
+    def exp_noise_rate(self, cov, randn):
+        import torch
+        return torch.exp(math.log(10) * cov * torch.from_numpy(randn)).numpy()
+
+
+class RecordedTape:
+    """Replays a list of (kind, array) draws recorded from a reference run."""
+
+    def __init__(self, items):
+        self.items = list(items)
+        self.pos = 0
+
+    def _next(self, kind):
+        k, a = self.items[self.pos]
+        assert k == kind, "tape out of order: want %s got %s at %d" % (kind, k, self.pos)
+        self.pos += 1
+        return a
+
+    def normal(self, mean, std, shape):
+        return self._next("normal").reshape(shape)
+
+    def randn(self, shape):
+        return self._next("randn").reshape(shape)
+
+    def rand(self, shape):
+        return self._next("rand").reshape(shape)
+
+    def randperm(self, n, frame=None, it=None):
+        a = self._next("randperm")
+        assert a.shape[0] == n
+        return a
+
+    def linspace(self, start, end, n):
+        a = self._next("linspace")
+        assert a.shape[0] == n
+        return a
+
+    def exp_noise_rate(self, cov, randn):
+        return self._next("noise_rate").reshape(randn.shape)
+
+
+def philox_frame(seed, clip, frame, npx):
+    a = np.empty(npx, np.float32)
+    b = np.empty(npx, np.float32)
+    lib().v2e_oracle_philox_frame(C.c_uint64(seed), C.c_uint32(clip), C.c_uint32(frame),
+                                  C.c_int64(npx), _p(a), _p(b))
+    return a, b
+
+
+def philox_init(seed, clip, npx):
+    a = np.empty(npx, np.float32)
+    b = np.empty(npx, np.float32)
+    c = np.empty(npx, np.float32)
+    lib().v2e_oracle_philox_init(C.c_uint64(seed), C.c_uint32(clip), C.c_int64(npx), _p(a), _p(b), _p(c))
+    return a, b, c
+
+
+def perm_idx(seed, clip, frame, it, n):
+    idx = np.empty(n, np.int64)
+    lib().v2e_oracle_perm_idx(C.c_uint64(seed), C.c_uint32(clip), C.c_uint32(frame), C.c_uint32(it),
+                              C.c_uint32(n), _p(idx))
+    return idx
+
+
+def ts_formula(t_prev, t_frame, n):
+    ts = np.empty(n, np.float32)
+    lib().v2e_oracle_ts(C.c_double(t_prev), C.c_double(t_frame), C.c_int32(n), _p(ts))
+    return ts
+
+
+# --------------------------------------------------------------- emulator
+class OracleEmulator:
+    """CPU restatement of v2ecore.emulator.EventEmulator (hot path only)."""
+
+    def __init__(self, pos_thres=0.2, neg_thres=0.2, sigma_thres=0.03, cutoff_hz=0.0,
+                 leak_rate_hz=0.1, refractory_period_s=0.0, shot_noise_rate_hz=0.0,
+                 leak_jitter_fraction=0.1, noise_rate_cov_decades=0.1, seed=0,
+                 rng_mode="tape", tape=None, shuffle=True, clip=0):
+        self.pos_thres = pos_thres
+        self.neg_thres = neg_thres
+        self.pos_thres_nominal = pos_thres
+        self.neg_thres_nominal = neg_thres
+        self.sigma_thres = sigma_thres
+        self.cutoff_hz = cutoff_hz
+        self.leak_rate_hz = leak_rate_hz
+        self.refractory_period_s = refractory_period_s
+        self.shot_noise_rate_hz = shot_noise_rate_hz
+        self.leak_jitter_fraction = leak_jitter_fraction
+        self.noise_rate_cov_decades = noise_rate_cov_decades
+        self.SHOT_NOISE_INTEN_FACTOR = 0.25
+        self.seed = seed
+        self.rng_mode = rng_mode
+        self.shuffle = shuffle
+        self.clip = clip
+        if rng_mode == "tape":
+            if tape is None:
+                tape = TorchTape()
+                if seed != 0:  # emulator.py:221-224
+                    import torch, random
+                    torch.manual_seed(seed)
+                    np.random.seed(seed)
+                    random.seed(seed)
+        self.tape = tape
+        self.t_previous = 0
+        self.frame_counter = 0
+        self.num_events_total = self.num_events_on = self.num_events_off = 0
+        self.base_log_frame = None
+        self.lp_log_frame = None
+        self.timestamp_mem = None
+        self.noise_rate_array = None
+        self.last = {}
+
+    def set_dvs_params(self, model):  # emulator.py:513-535
+        if model == "clean":
+            self.pos_thres = self.neg_thres = 0.2
+            self.sigma_thres = 0.02
+            self.cutoff_hz = 0
+            self.leak_rate_hz = 0
+            self.leak_jitter_fraction = 0
+            self.noise_rate_cov_decades = 0
+            self.shot_noise_rate_hz = 0
+            self.refractory_period_s = 0
+        elif model == "noisy":
+            self.pos_thres = self.neg_thres = 0.2
+            self.sigma_thres = 0.05
+            self.cutoff_hz = 30
+            self.leak_rate_hz = 0.1
+            self.shot_noise_rate_hz = 5.0
+            self.refractory_period_s = 0
+            self.leak_jitter_fraction = 0.1
+            self.noise_rate_cov_decades = 0.1
+
+    def _params(self):
+        P = EmuParams()
+        P.f64_state = 1 if self.cutoff_hz > 0 else 0
+        P.scalar_thres = 0 if self.sigma_thres > 0 else 1
+        P.rng_mode = RNG_PHILOX if self.rng_mode == "philox" else RNG_TAPE
+        P.shuffle = 1 if self.shuffle else 0
+        P.pos_thres_nominal = self.pos_thres_nominal
+        P.neg_thres_nominal = self.neg_thres_nominal
+        P.pos_thres_scalar = self._pos_scalar
+        P.neg_thres_scalar = self._neg_scalar
+        P.sigma_thres = self.sigma_thres
+        P.cutoff_hz = self.cutoff_hz
+        P.leak_rate_hz = self.leak_rate_hz
+        P.leak_jitter_fraction = self.leak_jitter_fraction
+        P.noise_rate_cov_decades = self.noise_rate_cov_decades
+        P.refractory_period_s = self.refractory_period_s
+        P.shot_noise_rate_hz = self.shot_noise_rate_hz
+        P.shot_noise_inten_factor = self.SHOT_NOISE_INTEN_FACTOR
+        if P.scalar_thres:
+            import torch
+            P.pos_pre_scalar = float(torch.div(self.pos_thres_nominal, self._pos_scalar))
+            P.neg_pre_scalar = float(torch.div(self.neg_thres_nominal, self._neg_scalar))
+        P.seed = self.seed
+        return P
+
+    def generate_events(self, new_frame, t_frame):
+        L = lib()
+        frame = np.ascontiguousarray(np.asarray(new_frame), dtype=np.float64)
+        H, W = frame.shape
+        npx = H * W
+        self.frame_counter += 1
+        if t_frame < self.t_previous:
+            raise ValueError("this frame time={} must be later than previous frame time={}".format(
+                t_frame, self.t_previous))
+        t_prev = float(self.t_previous)
+        t_frame = float(t_frame)
+        philox = self.rng_mode == "philox"
+        if self.base_log_frame is None:
+            self._pos_scalar = float(self.pos_thres)
+            self._neg_scalar = float(self.neg_thres)
+            P = self._params()
+            sdt = np.float64 if P.f64_state else np.float32
+            self.lp_log_frame = np.zeros((H, W), sdt)
+            self.base_log_frame = np.zeros((H, W), sdt)
+            self.timestamp_mem = np.zeros((H, W), np.float32)
+            self.pos_thres_arr = np.zeros((H, W), np.float32)
+            self.neg_thres_arr = np.zeros((H, W), np.float32)
+            self.noise_rate_array = np.zeros((H, W), np.float32)
+            tp = tn = nr = None
+            if not philox:
+                if self.sigma_thres > 0:
+                    tp = np.ascontiguousarray(self.tape.normal(self.pos_thres, self.sigma_thres, (H, W)))
+                    tn = np.ascontiguousarray(self.tape.normal(self.neg_thres, self.sigma_thres, (H, W)))
+                if self.leak_rate_hz > 0:
+                    r = np.ascontiguousarray(self.tape.randn((H, W)))
+                    nr = np.ascontiguousarray(self.tape.exp_noise_rate(self.noise_rate_cov_decades, r))
+            rc = L.v2e_oracle_init_state(C.byref(P), H, W, _p(frame), C.c_double(t_frame),
+                                         C.c_uint32(self.clip), _p(tp), _p(tn), _p(nr),
+                                         _p(self.lp_log_frame), _p(self.base_log_frame),
+                                         _p(self.timestamp_mem), _p(self.pos_thres_arr),
+                                         _p(self.neg_thres_arr), _p(self.noise_rate_array))
+            assert rc == 0
+            return None  # t_previous intentionally NOT advanced (emulator.py:717)
+
+        P = self._params()
+        fidx = self.frame_counter - 1
+        pos_cnt = np.zeros((H, W), np.int32)
+        neg_cnt = np.zeros((H, W), np.int32)
+        shot_on = np.zeros((H, W), np.uint8)
+        shot_off = np.zeros((H, W), np.uint8)
+        M = C.c_int32(0)
+        leak = None
+        if not philox and self.leak_rate_hz > 0:
+            leak = np.ascontiguousarray(self.tape.randn((H, W)))
+        rc = L.v2e_oracle_count(C.byref(P), H, W, _p(frame), C.c_double(t_prev), C.c_double(t_frame),
+                                C.c_uint32(fidx), C.c_uint32(self.clip), _p(leak), None,
+                                _p(self.lp_log_frame), _p(self.base_log_frame), _p(self.pos_thres_arr),
+                                _p(self.neg_thres_arr), _p(self.noise_rate_array), _p(pos_cnt),
+                                _p(neg_cnt), _p(shot_on), _p(shot_off), C.byref(M))
+        assert rc == 0
+        M = M.value
+        n = M if M > 0 else 1
+        ts = None
+        if not philox:
+            ts_step = (t_frame - t_prev) / n
+            ts = np.ascontiguousarray(self.tape.linspace(t_prev + ts_step, t_frame, n))
+        cap = int(pos_cnt.sum() + neg_cnt.sum()) + 2 * npx + 1
+        events = np.zeros((cap, 4), np.float32)
+        itc = np.zeros(2 * (M + 1), np.uint32)
+        rec = FrameRec()
+        perms = []
+
+        def emit(dry):
+            rc = L.v2e_oracle_emit(C.byref(P), H, W, C.c_double(t_prev), C.c_double(t_frame),
+                                   C.c_uint32(fidx), C.c_uint32(self.clip), _p(ts), n, _p(pos_cnt),
+                                   _p(neg_cnt), _p(shot_on), _p(shot_off), C.c_int32(M),
+                                   _p(self.lp_log_frame), _p(self.base_log_frame),
+                                   _p(self.timestamp_mem), _p(self.pos_thres_arr),
+                                   _p(self.neg_thres_arr), _p(events), C.c_uint64(cap), _p(itc),
+                                   C.byref(rec), C.c_int(1 if dry else 0))
+            assert rc == 0
+
+        if not philox:
+            emit(True)  # per-iteration totals -> randperm sizes, then rand for shot noise
+            for i in range(M):
+                n_i = int(itc[2 * i]) + int(itc[2 * i + 1])
+                perms.append(self.tape.randperm(n_i, fidx, i) if n_i > 0 else None)
+            if self.shot_noise_rate_hz > 0:
+                u = np.ascontiguousarray(self.tape.rand((H, W)))
+                rc = L.v2e_oracle_shot(C.byref(P), H, W, _p(frame), C.c_double(t_prev),
+                                       C.c_double(t_frame), _p(u), _p(self.pos_thres_arr),
+                                       _p(self.neg_thres_arr), _p(shot_on), _p(shot_off))
+                assert rc == 0
+        emit(False)
+        ne = rec.n_events
+        events = events[:ne]
+        if not philox:
+            row = 0
+            for i in range(M):
+                n_i = int(itc[2 * i]) + int(itc[2 * i + 1])
+                if n_i > 0:
+                    events[row:row + n_i] = events[row:row + n_i][perms[i]]  # emulator.py:869
+                row += n_i
+        self.num_events_total += ne
+        self.num_events_on += rec.n_on
+        self.num_events_off += rec.n_off
+        self.last = dict(pos_cnt=pos_cnt, neg_cnt=neg_cnt, M=M, ts=ts, iter_counts=itc.copy(),
+                         shot_on=shot_on, shot_off=shot_off)
+        self.t_previous = t_frame
+        return events if ne > 0 else None
