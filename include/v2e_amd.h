@@ -16,7 +16,7 @@
  *      compute_event_map :137-173, generate_shot_noise :297-351)
  *   v2ecore/emulator.py:791-942   iteration loop, refractory, event list,
  *      shot-noise events, base update (get_event_list_from_coords :1024-1059)
- *                                                                -> v2e_emu_emit
+ *                                                                -> v2e_emu_rank + v2e_emu_emit
  *   v2ecore/emulator.py:867-869   randperm shuffle               -> v2e_emu_permute
  *   v2ecore/model.py:10-226       UNet / down / up               -> v2e_unet_forward
  *   v2ecore/model.py:229-300      backWarp                       -> v2e_slomo_prep / _fuse
@@ -126,13 +126,30 @@ int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dt
 /* Blocking: copy the per-clip records of `frame_idx` to host (syncs the stream). */
 int v2e_emu_read_rec(v2e_emu *h, uint32_t frame_idx, v2e_frame_rec *recs_host, void *stream);
 
+/* Shot-noise decisions as their own pass (tape mode only: the reference draws `rand`
+ * after the per-iteration randperms, emulator.py:868 then :906 / emulator_utils.py:338). */
+int v2e_emu_shot(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype,
+                 uint32_t frame_idx, const float *shot_rand, void *stream);
+
+/* Grow the per-iteration scratch if max_events exceeds the create()-time max_iters
+ * (blocking; frame-at-a-time API only, after v2e_emu_read_rec). */
+int v2e_emu_reserve_iters(v2e_emu *h, int max_events, void *stream);
+
 /*
- * Back half: refractory filter, per-(iteration,polarity) compaction into the dense
- * [N,4] float32 (t,x,y,p) list in reference order (emulator.py:810-923), base/ts_mem
- * update (:936-942).  ts_table: device [n_clips][n_ts] float32 timestamps
- * (torch.linspace drawn by the host, tape mode) or NULL for the in-kernel formula.
- * events: device [n_clips][cap][4] float32.  ev_offset0: per-clip host array of
- * the row at which this frame's events start (NULL: continue after previous frame).
+ * Back half, step 1: refractory filter (emulator.py:830-846) and per-(iteration,
+ * polarity) histograms + exclusive scan; no state is modified.  ts_table: device
+ * [n_clips][n_ts] float32 timestamps (torch.linspace drawn by the host, tape mode)
+ * or NULL for the in-kernel formula.  Totals are readable with
+ * v2e_emu_read_iter_counts afterwards.
+ */
+int v2e_emu_rank(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, const float *ts_table,
+                 int n_ts, void *stream);
+
+/*
+ * Back half, step 2 (after v2e_emu_rank): dense [N,4] float32 (t,x,y,p) list in
+ * reference order (emulator.py:861-923), base/ts_mem update (:936-942), record.
+ * events: device [n_clips][cap][4] float32.  ev_offset0: per-clip host array of the
+ * row at which this frame's events start (NULL: continue after the previous frame).
  */
 int v2e_emu_emit(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx,
                  const float *ts_table, int n_ts, float *events, uint64_t cap,

@@ -1,0 +1,44 @@
+"""CPU: the oracle (oracle/emu_oracle.c) against the golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  Bit-exact: integer and float32 event
+rows, final float64/float32 state planes."""
+import numpy as np
+import pytest
+
+from fixtures import PHILOX_FIXTURES, TAPE_FIXTURES, PhiloxFixture, TapeFixture, events_equal, sha
+
+
+@pytest.mark.parametrize("name", TAPE_FIXTURES)
+def test_oracle_replays_reference_tape(name, oracle_lib):
+    fx = TapeFixture(name)
+    emu = oracle_lib.OracleEmulator(seed=0, rng_mode="tape", tape=oracle_lib.RecordedTape(fx.items), **fx.kw)
+    if fx.preset:
+        emu.set_dvs_params(fx.preset)
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        ev = emu.generate_events(f, float(t))
+        assert events_equal(ev, fx.events[k]), "frame %d differs" % k
+    assert emu.tape.pos == len(fx.items), "tape not fully consumed"
+    assert emu.base_log_frame.dtype == fx.base_final.dtype
+    assert np.array_equal(emu.base_log_frame, fx.base_final)
+    assert np.array_equal(emu.lp_log_frame, fx.lp_final)
+    if fx.ts_mem_final is not None:
+        assert np.array_equal(emu.timestamp_mem, fx.ts_mem_final)
+    assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
+@pytest.mark.parametrize("name", PHILOX_FIXTURES)
+def test_oracle_philox_matches_reference_with_philox_source(name, oracle_lib):
+    fx = PhiloxFixture(name)
+    emu = oracle_lib.OracleEmulator(seed=fx.seed, rng_mode="philox", **fx.kw)
+    if fx.preset:
+        emu.set_dvs_params(fx.preset)
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        ev = emu.generate_events(f, float(t))
+        n = 0 if ev is None else len(ev)
+        assert n == fx.n_events[k], "frame %d: %d events, reference %d" % (k, n, fx.n_events[k])
+        if n:
+            assert sha(ev) == fx.ev_sha[k], "frame %d event digest differs" % k
+    assert sha(emu.base_log_frame) == fx.base_sha
+    assert sha(emu.lp_log_frame) == fx.lp_sha
+    if fx.ts_mem_sha:
+        assert sha(emu.timestamp_mem) == fx.ts_mem_sha
+    assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)

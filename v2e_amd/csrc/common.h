@@ -1,0 +1,28 @@
+// common.h -- error plumbing shared by the gfx950 translation units of libv2e_amd.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/v2e_amd.h"
+
+void v2e_set_error(const char *fmt, ...);
+
+#define V2E_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            v2e_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return V2E_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+#define V2E_REQUIRE(cond, msg)                                       \
+    do {                                                             \
+        if (!(cond)) {                                               \
+            v2e_set_error("%s:%d %s", __FILE__, __LINE__, msg);      \
+            return V2E_EINVAL;                                       \
+        }                                                            \
+    } while (0)
+
+static inline int v2e_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,956 @@
+// emu.hip -- DVS pixel model (EventEmulator.generate_events) for gfx950 / MI355X.
+//
+// What is computed, and where it comes from in the reference (SensorsINI/v2e):
+//   k_init   first-frame state           v2ecore/emulator.py:681-717, _init :439-511
+//   k_count  lin-log photoreceptor, intensity-dependent IIR low-pass, leak, ON/OFF
+//            event counts, shot-noise decisions, global max
+//                                        emulator.py:656-775, emulator_utils.py:18-173,297-351
+//   k_shot   shot-noise decisions as a separate pass (tape mode draw order)
+//   k_rank   refractory filter + per-wave (iteration,polarity) histograms
+//                                        emulator.py:810-850
+//   k_scan   exclusive scan of the histograms over waves (one workgroup per key)
+//   k_emit   dense (t,x,y,p) list in reference order, shuffle, base/ts_mem update
+//                                        emulator.py:861-870, 906-942, 1024-1059
+//
+// Layout: one thread per pixel, row-major, so a wave64 touches 64 consecutive x
+// (256/512-byte fully coalesced requests per plane).  Per-pixel state is SoA, one
+// plane per field, [n_clips][npx_pad].  Compaction is deterministic: a wave ranks its
+// events with __ballot/__popcll, k_scan turns per-wave counts into row offsets, so the
+// output order is exactly the reference's nonzero() order -- no atomic cursors.
+//
+// Numerics: every floating-point step reproduces the reference's dtype and operation
+// order; this file must be compiled with -ffp-contract=off.
+#include "common.h"
+#include "../../include/v2e_detmath.h"
+
+#include <cstdarg>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVE = 64;
+constexpr int RING = 64;        // record / control ring for the frame-at-a-time API
+constexpr int SCAN_BLOCKS = 64; // workgroups of k_scan per clip
+
+// packed per-pixel scratch word written by k_count
+constexpr uint32_t CNT_MASK = 0x00FFFFFFu;
+constexpr uint32_t CNT_NEG = 1u << 24;
+constexpr uint32_t CNT_SHOT_ON = 1u << 25;
+constexpr uint32_t CNT_SHOT_OFF = 1u << 26;
+
+struct FrameCtl {
+    double t_prev, t_frame;
+};
+
+// (1./20)*math.log(20) as evaluated by CPython (emulator_utils.py:34)
+__device__ constexpr double LINLOG_F = 0x1.32c352f8fe941p-3;
+
+struct KArgs {
+    int W, npx, nwaves, nkeys_cap, max_iters;
+    long long npx_pad;
+    int scalar_thres, rng_mode, shuffle;
+    int do_leak, do_shot, use_inten, has_cutoff, has_refr;
+    double cutoff_two_pi; // math.pi*2*cutoff_hz
+    double pos_div, neg_div;
+    float pos_nom_f, neg_nom_f, pos_pre_scalar, neg_pre_scalar;
+    float leak_hz_f, jit_f;
+    float sigma_f, pos_mean_f, neg_mean_f, ln10cov_f;
+    double shot_half_rate, inten_slope;
+    double refr;
+    float refr_f;
+    unsigned long long seed;
+    // state planes
+    void *lp, *base;
+    float *ts_mem, *pos_thres, *neg_thres, *noise_rate;
+    // scratch
+    uint32_t *cnt;
+    uint32_t *hist; // [n_clips][nkeys_cap][nwaves]
+    uint32_t *tot;  // [n_clips][nkeys_cap]
+};
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ float lin_log(double x)
+{
+    double y = (x <= 20.0) ? x * LINLOG_F : log(x);
+    y = rint(y * 1e8) / 1e8;
+    return (float)y;
+}
+
+// c10::div_floor_floating
+template <typename R> __device__ __forceinline__ R div_floor(R a, R b)
+{
+    if (b == (R)0) return a / b;
+    R mod = fmod(a, b);
+    R div = (a - mod) / b;
+    if (mod != (R)0 && ((b < (R)0) != (mod < (R)0))) div -= (R)1;
+    R fd;
+    if (div != (R)0) {
+        fd = floor(div);
+        if (div - fd > (R)0.5) fd += (R)1;
+    } else {
+        fd = copysign((R)0, a / b);
+    }
+    return fd;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// exclusive prefix sum across the 64 lanes
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane)
+{
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += t;
+    }
+    return inc - v;
+}
+
+// shot-noise decision, emulator_utils.py:326-349 (float64 compare of a float32 draw)
+__device__ __forceinline__ uint32_t shot_bits(const KArgs &a, double inten01, double shot_base,
+                                              float thp, float thn, float u)
+{
+    double F = shot_base * (a.inten_slope * inten01 + 1);
+    float ppre = a.scalar_thres ? a.pos_pre_scalar : a.pos_nom_f / thp;
+    float npre = a.scalar_thres ? a.neg_pre_scalar : a.neg_nom_f / thn;
+    double on_thr = 1 - F * (double)ppre;
+    double off_thr = F * (double)npre;
+    uint32_t b = 0;
+    if ((double)u > on_thr) b |= CNT_SHOT_ON;
+    if ((double)u < off_thr) b |= CNT_SHOT_OFF;
+    return b;
+}
+
+// timestamps of the n iterations of one frame (emulator.py:791-796)
+struct TsGen {
+    const float *tab;
+    float start, end, step;
+    uint32_t n;
+    __device__ __forceinline__ TsGen(const FrameCtl &c, int n_, const float *tab_) : tab(tab_), n((uint32_t)n_)
+    {
+        double dt = c.t_frame - c.t_prev;
+        double ts_step = dt / (double)n_;
+        start = (float)(c.t_prev + ts_step);
+        end = (float)c.t_frame;
+        step = (n_ > 1) ? (end - start) / (float)(n_ - 1) : 0.0f;
+    }
+    __device__ __forceinline__ float operator()(int i) const
+    {
+        return tab ? tab[i] : v2e_ts_formula((uint32_t)i, n, start, end, step);
+    }
+};
+
+// ------------------------------------------------------------------ k_init
+template <typename R, typename FT>
+__global__ __launch_bounds__(BLOCK) void k_init(KArgs a, const FT *__restrict__ frame, double t_frame,
+                                                const float *__restrict__ tp_tape,
+                                                const float *__restrict__ tn_tape,
+                                                const float *__restrict__ nr_tape)
+{
+    const int clip = blockIdx.y;
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= a.npx) return;
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const size_t fp = (size_t)clip * a.npx + p;
+    double x = (double)frame[fp];
+    float L = lin_log(x);
+    R lp;
+    if (a.has_cutoff) {
+        double delta_time = t_frame - 0.0;
+        double tau = 1.0 / a.cutoff_two_pi;
+        double dt_over_tau = delta_time / tau;
+        double inten01 = (x + 20.0) / 275.0;
+        double eps = inten01 * dt_over_tau;
+        if (eps > 1.0) eps = 1.0;
+        lp = (R)((1.0 - eps) * (double)L + eps * (double)L);
+    } else {
+        lp = (R)L;
+    }
+    ((R *)a.lp)[sp] = lp;
+    ((R *)a.base)[sp] = lp;
+    float n_pos = 0.f, n_neg = 0.f, n_rate = 0.f;
+    if (a.rng_mode == V2E_RNG_PHILOX)
+        v2e_draw_init(a.seed, (uint32_t)clip, (uint32_t)p, &n_pos, &n_neg, &n_rate);
+    float tp, tn;
+    if (!a.scalar_thres) {
+        if (a.rng_mode == V2E_RNG_PHILOX) {
+            tp = n_pos * a.sigma_f + a.pos_mean_f;
+            tn = n_neg * a.sigma_f + a.neg_mean_f;
+        } else {
+            tp = tp_tape[fp];
+            tn = tn_tape[fp];
+        }
+        tp = tp < 0.01f ? 0.01f : tp;
+        tn = tn < 0.01f ? 0.01f : tn;
+    } else {
+        tp = a.pos_mean_f;
+        tn = a.neg_mean_f;
+    }
+    a.pos_thres[sp] = tp;
+    a.neg_thres[sp] = tn;
+    if (a.do_leak)
+        a.noise_rate[sp] = (a.rng_mode == V2E_RNG_PHILOX) ? v2e_det_expf(a.ln10cov_f * n_rate) : nr_tape[fp];
+    if (a.has_refr) a.ts_mem[sp] = 0.0f - a.refr_f;
+}
+
+// ----------------------------------------------------------------- k_count
+template <typename R, typename FT>
+__global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__ frame,
+                                                 const FrameCtl *__restrict__ ctl,
+                                                 const uint32_t *__restrict__ fidx_base, uint32_t fidx_off,
+                                                 const float *__restrict__ leak_tape,
+                                                 const float *__restrict__ shot_tape, v2e_frame_rec *rec)
+{
+    __shared__ int smax[BLOCK / WAVE];
+    const int clip = blockIdx.y;
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    const FrameCtl c = ctl[clip];
+    const uint32_t frame_idx = (fidx_base ? *fidx_base : 0u) + fidx_off;
+    int m = 0;
+    if (p < a.npx) {
+        const size_t sp = (size_t)clip * a.npx_pad + p;
+        const size_t fp = (size_t)clip * a.npx + p;
+        const double delta_time = c.t_frame - c.t_prev;
+        double x = (double)frame[fp];
+        float L = lin_log(x);
+        double inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
+        float r = 0.f, u = 0.f;
+        const bool shot_here = a.do_shot && (a.rng_mode == V2E_RNG_PHILOX || shot_tape != nullptr);
+        if (a.rng_mode == V2E_RNG_PHILOX) {
+            if (a.do_leak || a.do_shot)
+                v2e_draw_frame(a.seed, (uint32_t)clip, frame_idx, (uint32_t)p, &r, &u);
+        } else {
+            if (a.do_leak) r = leak_tape[fp];
+            if (shot_here) u = shot_tape[fp];
+        }
+        const float thp = a.pos_thres[sp], thn = a.neg_thres[sp];
+        float delta_leak = 0.f;
+        if (a.do_leak) { // emulator_utils.py:126-129, float32 left to right
+            float rate = (a.leak_hz_f * a.noise_rate[sp]) * (1.0f - a.jit_f * r);
+            delta_leak = ((float)delta_time * rate) * thp;
+        }
+        R lpn;
+        if (a.has_cutoff) { // R == double
+            double tau = 1.0 / a.cutoff_two_pi;
+            double dt_over_tau = delta_time / tau;
+            double eps = inten01 * dt_over_tau;
+            if (eps > 1.0) eps = 1.0;
+            lpn = (R)((1.0 - eps) * (double)((R *)a.lp)[sp] + eps * (double)L);
+        } else {
+            lpn = (R)L;
+        }
+        ((R *)a.lp)[sp] = lpn;
+        R b = ((R *)a.base)[sp];
+        if (a.do_leak) {
+            b = b - (R)delta_leak;
+            ((R *)a.base)[sp] = b;
+        }
+        R diff = (lpn + (R)0.0f) - b;
+        R pf = diff > (R)0 ? diff : (R)0;
+        R nf = (-diff) > (R)0 ? -diff : (R)0;
+        R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;
+        R tnd = a.scalar_thres ? (R)a.neg_div : (R)thn;
+        int pc = (int)div_floor<R>(pf, tpd);
+        int nc = (int)div_floor<R>(nf, tnd);
+        uint32_t w = 0;
+        if (pc > 0) w = (uint32_t)pc & CNT_MASK;
+        else if (nc > 0) w = ((uint32_t)nc & CNT_MASK) | CNT_NEG;
+        if (shot_here) {
+            double shot_base = a.shot_half_rate * delta_time;
+            w |= shot_bits(a, inten01, shot_base, thp, thn, u);
+        }
+        a.cnt[sp] = w;
+        m = pc > nc ? pc : nc;
+    }
+    m = wave_max_i32(m);
+    if ((threadIdx.x & (WAVE - 1)) == 0) smax[threadIdx.x / WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int bm = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+        if (bm > 0) atomicMax(&rec[clip].max_events, bm);
+    }
+}
+
+// ------------------------------------------------------------------ k_shot
+template <typename FT>
+__global__ __launch_bounds__(BLOCK) void k_shot(KArgs a, const FT *__restrict__ frame,
+                                                const FrameCtl *__restrict__ ctl,
+                                                const float *__restrict__ shot_tape)
+{
+    const int clip = blockIdx.y;
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= a.npx) return;
+    const FrameCtl c = ctl[clip];
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const size_t fp = (size_t)clip * a.npx + p;
+    double x = (double)frame[fp];
+    double inten01 = (x + 20.0) / 275.0;
+    double shot_base = a.shot_half_rate * (c.t_frame - c.t_prev);
+    uint32_t w = a.cnt[sp] & ~(CNT_SHOT_ON | CNT_SHOT_OFF);
+    w |= shot_bits(a, inten01, shot_base, a.pos_thres[sp], a.neg_thres[sp], shot_tape[fp]);
+    a.cnt[sp] = w;
+}
+
+// ------------------------------------------------------------------ k_rank
+// One wave = 64 consecutive pixels.  For every iteration i < M the wave counts its
+// surviving ON and OFF events (keys 2i, 2i+1); keys 2M, 2M+1 are the shot pair.
+__global__ __launch_bounds__(BLOCK) void k_rank(KArgs a, const FrameCtl *__restrict__ ctl,
+                                                const v2e_frame_rec *__restrict__ rec,
+                                                const float *__restrict__ ts_tab, int n_ts)
+{
+    const int clip = blockIdx.y;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = (blockIdx.x * BLOCK + threadIdx.x) / WAVE;
+    if (w >= a.nwaves) return;
+    const int p = w * WAVE + lane;
+    const int M = rec[clip].max_events;
+    if (M > a.max_iters) return;
+    const int n = M > 0 ? M : 1;
+    const FrameCtl c = ctl[clip];
+    const TsGen tg(c, n, ts_tab ? ts_tab + (size_t)clip * n_ts : nullptr);
+    const bool use_refr = a.has_refr && (a.refr > (c.t_frame - c.t_prev) / (double)n);
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const uint32_t cw = p < a.npx ? a.cnt[sp] : 0u;
+    const int mag = (int)(cw & CNT_MASK);
+    const bool neg = (cw & CNT_NEG) != 0;
+    float tsm = (use_refr && p < a.npx) ? a.ts_mem[sp] : 0.f;
+    uint32_t *hrow = a.hist + (size_t)clip * a.nkeys_cap * a.nwaves;
+    bool alive = true; // some lane of the wave still has a candidate at this iteration
+    for (int kb = 0; kb < 2 * M; kb += WAVE) {
+        uint32_t mine = 0;
+        const int i0 = kb >> 1;
+        for (int ii = 0; ii < WAVE / 2 && i0 + ii < M && alive; ++ii) {
+            const int i = i0 + ii;
+            const bool cand = mag > i;
+            if (__ballot(cand) == 0ull) { alive = false; break; }
+            bool pass = cand;
+            if (use_refr) {
+                const float t = tg(i);
+                const float pt = (cand ? 1.0f : 0.0f) * t - tsm;
+                pass = pt > a.refr_f;
+                if (pass) tsm = t;
+            }
+            const unsigned long long bo = __ballot(pass && !neg);
+            const unsigned long long bf = __ballot(pass && neg);
+            if (lane == 2 * ii) mine = (uint32_t)__popcll(bo);
+            if (lane == 2 * ii + 1) mine = (uint32_t)__popcll(bf);
+        }
+        const int key = kb + lane;
+        if (key < 2 * M) hrow[(size_t)key * a.nwaves + w] = mine;
+    }
+    const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
+    const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+    if (lane == 0) hrow[(size_t)(2 * M) * a.nwaves + w] = (uint32_t)__popcll(so);
+    if (lane == 1) hrow[(size_t)(2 * M + 1) * a.nwaves + w] = (uint32_t)__popcll(sf);
+}
+
+// ------------------------------------------------------------------ k_scan
+// One workgroup per key: in-place exclusive scan over the per-wave counts, total to tot[].
+__global__ __launch_bounds__(BLOCK) void k_scan(KArgs a, const v2e_frame_rec *__restrict__ rec)
+{
+    __shared__ uint32_t wsum[BLOCK / WAVE];
+    const int clip = blockIdx.y;
+    const int M = rec[clip].max_events;
+    if (M > a.max_iters) return;
+    const int nkeys = 2 * M + 2;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+    const int ipt = (a.nwaves + BLOCK - 1) / BLOCK;
+    for (int key = blockIdx.x; key < nkeys; key += gridDim.x) {
+        uint32_t *row = a.hist + ((size_t)clip * a.nkeys_cap + key) * a.nwaves;
+        const int b = tid * ipt, e = min(b + ipt, a.nwaves);
+        uint32_t s = 0;
+        for (int j = b; j < e; ++j) s += row[j];
+        const uint32_t ex = wave_excl_scan_u32(s, lane);
+        if (lane == WAVE - 1) wsum[wid] = ex + s;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < BLOCK / WAVE; ++q) {
+            if (q < wid) wbase += wsum[q];
+            total += wsum[q];
+        }
+        uint32_t run = wbase + ex;
+        for (int j = b; j < e; ++j) {
+            const uint32_t v = row[j];
+            row[j] = run;
+            run += v;
+        }
+        if (tid == 0) a.tot[(size_t)clip * a.nkeys_cap + key] = total;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ k_emit
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_emit(KArgs a, const FrameCtl *__restrict__ ctl, v2e_frame_rec *rec,
+                                                const v2e_frame_rec *__restrict__ rec_prev,
+                                                const unsigned long long *__restrict__ ev_offset0,
+                                                const uint32_t *__restrict__ fidx_base, uint32_t fidx_off,
+                                                const float *__restrict__ ts_tab, int n_ts,
+                                                float4 *__restrict__ events, unsigned long long cap)
+{
+    const int clip = blockIdx.y;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = (blockIdx.x * BLOCK + threadIdx.x) / WAVE;
+    if (w >= a.nwaves) return;
+    const int p = w * WAVE + lane;
+    const uint32_t frame_idx = (fidx_base ? *fidx_base : 0u) + fidx_off;
+    const int M = rec[clip].max_events;
+    unsigned long long ev0 = 0;
+    if (ev_offset0) ev0 = ev_offset0[clip];
+    else if (rec_prev) ev0 = rec_prev[clip].ev_offset + rec_prev[clip].n_events;
+    if (M > a.max_iters) {
+        if (w == 0 && lane == 0) {
+            rec[clip].flags |= V2E_FLAG_ITERS_CLAMPED;
+            rec[clip].ev_offset = ev0;
+        }
+        return;
+    }
+    const int n = M > 0 ? M : 1;
+    const FrameCtl c = ctl[clip];
+    const TsGen tg(c, n, ts_tab ? ts_tab + (size_t)clip * n_ts : nullptr);
+    const bool use_refr = a.has_refr && (a.refr > (c.t_frame - c.t_prev) / (double)n);
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const bool valid = p < a.npx;
+    const uint32_t cw = valid ? a.cnt[sp] : 0u;
+    const int mag = (int)(cw & CNT_MASK);
+    const bool neg = (cw & CNT_NEG) != 0;
+    float tsm = (use_refr && valid) ? a.ts_mem[sp] : 0.f;
+    const uint32_t *hrow = a.hist + (size_t)clip * a.nkeys_cap * a.nwaves;
+    const uint32_t *trow = a.tot + (size_t)clip * a.nkeys_cap;
+    float4 *ev = events + (size_t)clip * cap;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float fx = (float)(p % a.W), fy = (float)(p / a.W);
+    const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
+    uint32_t carry = 0;          // events of all earlier iterations (whole frame)
+    uint32_t sum_on = 0, sum_off = 0;
+    int fcount = 0;              // this pixel's surviving events
+    bool dropped = false;
+    bool alive = true;
+    for (int kb = 0; kb < 2 * M; kb += WAVE) {
+        const int key = kb + lane;
+        const uint32_t t_k = key < 2 * M ? trow[key] : 0u;
+        const uint32_t o_k = key < 2 * M ? hrow[(size_t)key * a.nwaves + w] : 0u;
+        const uint32_t kb_k = carry + wave_excl_scan_u32(t_k, lane);
+        const uint32_t chunk_total = wave_sum_u32(t_k);
+        sum_on += wave_sum_u32((lane & 1) ? 0u : t_k);
+        sum_off += wave_sum_u32((lane & 1) ? t_k : 0u);
+        const int i0 = kb >> 1;
+        for (int ii = 0; ii < WAVE / 2 && i0 + ii < M && alive; ++ii) {
+            const int i = i0 + ii;
+            const bool cand = mag > i;
+            if (__ballot(cand) == 0ull) { alive = false; break; }
+            const float t = tg(i);
+            bool pass = cand;
+            if (use_refr) {
+                const float pt = (cand ? 1.0f : 0.0f) * t - tsm;
+                pass = pt > a.refr_f;
+                if (pass) tsm = t;
+            }
+            const unsigned long long bo = __ballot(pass && !neg);
+            const unsigned long long bf = __ballot(pass && neg);
+            if ((bo | bf) == 0ull) continue;
+            const uint32_t it_base = __shfl(kb_k, 2 * ii, WAVE);
+            const uint32_t tot_on = __shfl(t_k, 2 * ii, WAVE);
+            const uint32_t tot_off = __shfl(t_k, 2 * ii + 1, WAVE);
+            const uint32_t off_on = __shfl(o_k, 2 * ii, WAVE);
+            const uint32_t off_off = __shfl(o_k, 2 * ii + 1, WAVE);
+            if (pass) {
+                uint32_t cidx = neg ? tot_on + off_off + (uint32_t)__popcll(bf & lt)
+                                    : off_on + (uint32_t)__popcll(bo & lt);
+                if (shuf) {
+                    v2e_perm_t pm;
+                    v2e_perm_init(&pm, a.seed, (uint32_t)clip, frame_idx, (uint32_t)i, tot_on + tot_off);
+                    cidx = v2e_perm_apply(&pm, cidx);
+                }
+                const unsigned long long row = ev0 + it_base + cidx;
+                if (row < cap) ev[row] = make_float4(t, fx, fy, neg ? -1.0f : 1.0f);
+                else dropped = true;
+                ++fcount;
+            }
+        }
+        carry += chunk_total;
+    }
+    // shot-noise events: after all signal events, ON block then OFF block, ts[-1], unshuffled
+    const uint32_t son_tot = trow[2 * M], soff_tot = trow[2 * M + 1];
+    if (a.do_shot) {
+        const bool s_on = (cw & CNT_SHOT_ON) != 0, s_off = (cw & CNT_SHOT_OFF) != 0;
+        const unsigned long long so = __ballot(s_on), sf = __ballot(s_off);
+        if (so | sf) {
+            const float tl = tg(n - 1);
+            if (s_on) {
+                const unsigned long long row = ev0 + carry + hrow[(size_t)(2 * M) * a.nwaves + w] + (uint32_t)__popcll(so & lt);
+                if (row < cap) ev[row] = make_float4(tl, fx, fy, 1.0f);
+                else dropped = true;
+            }
+            if (s_off) {
+                const unsigned long long row = ev0 + carry + son_tot + hrow[(size_t)(2 * M + 1) * a.nwaves + w] + (uint32_t)__popcll(sf & lt);
+                if (row < cap) ev[row] = make_float4(tl, fx, fy, -1.0f);
+                else dropped = true;
+            }
+        }
+    }
+    // emulator.py:936-942
+    if (valid) {
+        const bool shot = a.do_shot && (cw & (CNT_SHOT_ON | CNT_SHOT_OFF));
+        if (fcount > 0 || shot) {
+            R b = ((R *)a.base)[sp];
+            const float dp = (float)(neg ? 0 : fcount) * a.pos_thres[sp];
+            const float dn = (float)(neg ? fcount : 0) * a.neg_thres[sp];
+            b = b + (R)dp;
+            b = b - (R)dn;
+            if (shot) b = ((R *)a.lp)[sp];
+            ((R *)a.base)[sp] = b;
+        }
+        if (use_refr && fcount > 0) a.ts_mem[sp] = tsm;
+    }
+    if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
+    if (w == 0 && lane == 0) {
+        rec[clip].n_signal = carry;
+        rec[clip].n_events = carry + (a.do_shot ? son_tot + soff_tot : 0u);
+        rec[clip].n_on = sum_on + (a.do_shot ? son_tot : 0u);
+        rec[clip].n_off = sum_off + (a.do_shot ? soff_tot : 0u);
+        rec[clip].ev_offset = ev0;
+    }
+}
+
+// out[row0 + j] = in[row0 + idx[j]]  (events_curr_iter[idx], emulator.py:869)
+__global__ __launch_bounds__(BLOCK) void k_permute(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                   const int32_t *__restrict__ idx, unsigned long long row0,
+                                                   unsigned long long n)
+{
+    const unsigned long long j = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (j < n) out[row0 + j] = in[row0 + (unsigned long long)idx[j]];
+}
+
+} // namespace
+
+// =================================================================== host side
+struct v2e_emu {
+    int H, W, n_clips, max_iters, device;
+    int npx, nwaves, nkeys_cap;
+    long long npx_pad;
+    void *lp = nullptr, *base = nullptr;
+    float *ts_mem = nullptr, *pos_thres = nullptr, *neg_thres = nullptr, *noise_rate = nullptr;
+    uint32_t *cnt = nullptr, *hist = nullptr, *tot = nullptr;
+    v2e_frame_rec *rec_ring = nullptr; // [RING][n_clips]
+    FrameCtl *ctl_ring = nullptr;      // [RING][n_clips]
+    FrameCtl *ctl_host = nullptr;      // pinned staging [RING][n_clips]
+    unsigned long long *off_dev = nullptr, *off_host = nullptr; // [n_clips] explicit event offsets
+    // multi-frame run
+    FrameCtl *run_ctl = nullptr;       // device [run_cap][n_clips]
+    FrameCtl *run_ctl_host = nullptr;  // pinned
+    int run_cap = 0;
+    uint32_t *run_fidx = nullptr;      // device: frame_idx0 of the current run
+    uint32_t *run_fidx_host = nullptr; // pinned
+    hipGraphExec_t graph = nullptr;
+    std::vector<unsigned char> graph_key;
+};
+
+static thread_local char g_err[512] = "";
+
+void v2e_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
+{
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    a.W = h->W; a.npx = h->npx; a.nwaves = h->nwaves; a.nkeys_cap = h->nkeys_cap; a.max_iters = h->max_iters;
+    a.npx_pad = h->npx_pad;
+    a.scalar_thres = p->scalar_thres; a.rng_mode = p->rng_mode; a.shuffle = p->shuffle;
+    a.do_leak = p->leak_rate_hz > 0; a.do_shot = p->shot_noise_rate_hz > 0;
+    a.has_cutoff = p->cutoff_hz > 0; a.has_refr = p->refractory_period_s > 0;
+    a.use_inten = a.has_cutoff || a.do_shot;
+    a.cutoff_two_pi = M_PI * 2 * p->cutoff_hz;
+    a.pos_div = p->pos_thres_scalar; a.neg_div = p->neg_thres_scalar;
+    a.pos_nom_f = (float)p->pos_thres_nominal; a.neg_nom_f = (float)p->neg_thres_nominal;
+    a.pos_pre_scalar = p->pos_pre_scalar; a.neg_pre_scalar = p->neg_pre_scalar;
+    a.leak_hz_f = (float)p->leak_rate_hz; a.jit_f = (float)p->leak_jitter_fraction;
+    a.sigma_f = (float)p->sigma_thres;
+    a.pos_mean_f = (float)p->pos_thres_scalar; a.neg_mean_f = (float)p->neg_thres_scalar;
+    a.ln10cov_f = (float)(log(10.0) * p->noise_rate_cov_decades);
+    a.shot_half_rate = p->shot_noise_rate_hz / 2;
+    a.inten_slope = p->shot_noise_inten_factor - 1;
+    a.refr = p->refractory_period_s; a.refr_f = (float)p->refractory_period_s;
+    a.seed = p->seed;
+    a.lp = h->lp; a.base = h->base; a.ts_mem = h->ts_mem;
+    a.pos_thres = h->pos_thres; a.neg_thres = h->neg_thres; a.noise_rate = h->noise_rate;
+    a.cnt = h->cnt; a.hist = h->hist; a.tot = h->tot;
+    return a;
+}
+
+static int check_params(const v2e_emu *h, const v2e_emu_params *p)
+{
+    V2E_REQUIRE(h && p, "null handle/params");
+    V2E_REQUIRE(h->lp && h->base && h->pos_thres && h->neg_thres, "state not bound (v2e_emu_bind_state)");
+    V2E_REQUIRE((p->f64_state != 0) == (p->cutoff_hz > 0), "f64_state must equal (cutoff_hz > 0)");
+    V2E_REQUIRE(!(p->leak_rate_hz > 0) || h->noise_rate, "leak enabled but noise_rate plane not bound");
+    V2E_REQUIRE(!(p->refractory_period_s > 0) || h->ts_mem, "refractory enabled but ts_mem plane not bound");
+    return 0;
+}
+
+extern "C" {
+
+const char *v2e_last_error(void) { return g_err; }
+int v2e_version(void) { return 100; }
+
+int64_t v2e_emu_npx_pad(int H, int W)
+{
+    int64_t npx = (int64_t)H * W;
+    return (npx + 255) / 256 * 256;
+}
+
+static int alloc_iter_scratch(v2e_emu *h, int max_iters)
+{
+    if (h->hist) { V2E_HIP(hipFree(h->hist)); h->hist = nullptr; }
+    if (h->tot) { V2E_HIP(hipFree(h->tot)); h->tot = nullptr; }
+    h->max_iters = max_iters;
+    h->nkeys_cap = 2 * max_iters + 2;
+    V2E_HIP(hipMalloc(&h->hist, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap * h->nwaves));
+    V2E_HIP(hipMalloc(&h->tot, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap));
+    if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+    return 0;
+}
+
+int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu **out)
+{
+    V2E_REQUIRE(out && H > 0 && W > 0 && n_clips > 0 && max_iters > 0, "bad create args");
+    V2E_REQUIRE((int64_t)H * W < (1ll << 31) - 256, "sensor too large");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        v2e_set_error("no HIP device visible");
+        return V2E_ENODEV;
+    }
+    V2E_REQUIRE(device >= 0 && device < ndev, "bad device index");
+    V2E_HIP(hipSetDevice(device));
+    v2e_emu *h = new v2e_emu();
+    h->H = H; h->W = W; h->n_clips = n_clips; h->device = device;
+    h->npx = H * W;
+    h->npx_pad = v2e_emu_npx_pad(H, W);
+    h->nwaves = (h->npx + WAVE - 1) / WAVE;
+    V2E_HIP(hipMalloc(&h->cnt, sizeof(uint32_t) * (size_t)n_clips * h->npx_pad));
+    int rc = alloc_iter_scratch(h, max_iters);
+    if (rc) return rc;
+    V2E_HIP(hipMalloc(&h->rec_ring, sizeof(v2e_frame_rec) * RING * n_clips));
+    V2E_HIP(hipMemset(h->rec_ring, 0, sizeof(v2e_frame_rec) * RING * n_clips));
+    V2E_HIP(hipMalloc(&h->ctl_ring, sizeof(FrameCtl) * RING * n_clips));
+    V2E_HIP(hipHostMalloc(&h->ctl_host, sizeof(FrameCtl) * RING * n_clips));
+    V2E_HIP(hipMalloc(&h->off_dev, sizeof(unsigned long long) * n_clips));
+    V2E_HIP(hipHostMalloc(&h->off_host, sizeof(unsigned long long) * n_clips));
+    V2E_HIP(hipMalloc(&h->run_fidx, sizeof(uint32_t)));
+    V2E_HIP(hipHostMalloc(&h->run_fidx_host, sizeof(uint32_t)));
+    *out = h;
+    return 0;
+}
+
+int v2e_emu_destroy(v2e_emu *h)
+{
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    if (h->graph) hipGraphExecDestroy(h->graph);
+    hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
+    if (h->ctl_host) hipHostFree(h->ctl_host);
+    hipFree(h->off_dev);
+    if (h->off_host) hipHostFree(h->off_host);
+    if (h->run_ctl) hipFree(h->run_ctl);
+    if (h->run_ctl_host) hipHostFree(h->run_ctl_host);
+    hipFree(h->run_fidx);
+    if (h->run_fidx_host) hipHostFree(h->run_fidx_host);
+    delete h;
+    return 0;
+}
+
+int v2e_emu_bind_state(v2e_emu *h, void *lp, void *base, float *ts_mem, float *pos_thres, float *neg_thres,
+                       float *noise_rate)
+{
+    V2E_REQUIRE(h && lp && base && pos_thres && neg_thres, "bind_state: null plane");
+    h->lp = lp; h->base = base; h->ts_mem = ts_mem;
+    h->pos_thres = pos_thres; h->neg_thres = neg_thres; h->noise_rate = noise_rate;
+    if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+    return 0;
+}
+
+#define DISPATCH_FT(dtype, ...)                                          \
+    switch (dtype) {                                                     \
+    case V2E_DT_U8: { typedef uint8_t FT; __VA_ARGS__; } break;          \
+    case V2E_DT_F32: { typedef float FT; __VA_ARGS__; } break;           \
+    case V2E_DT_F64: { typedef double FT; __VA_ARGS__; } break;          \
+    default: v2e_set_error("bad frame dtype %d", dtype); return V2E_EINVAL; \
+    }
+
+int v2e_emu_init_state(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, double t_frame,
+                       const float *thres_pos, const float *thres_neg, const float *noise_rate, void *stream)
+{
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    V2E_REQUIRE(frame, "null frame");
+    if (p->rng_mode == V2E_RNG_TAPE) {
+        V2E_REQUIRE(p->scalar_thres || (thres_pos && thres_neg), "tape mode needs threshold draws");
+        V2E_REQUIRE(!(p->leak_rate_hz > 0) || noise_rate, "tape mode needs noise_rate values");
+    }
+    V2E_HIP(hipSetDevice(h->device));
+    KArgs a = make_kargs(h, p);
+    dim3 grid(v2e_cdiv(h->npx, BLOCK), h->n_clips);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_FT(dtype, {
+        if (p->f64_state) k_init<double, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, t_frame, thres_pos, thres_neg, noise_rate);
+        else k_init<float, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, t_frame, thres_pos, thres_neg, noise_rate);
+    });
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+static int stage_ctl(v2e_emu *h, uint32_t frame_idx, const double *t_prev, const double *t_frame, hipStream_t s)
+{
+    const int slot = frame_idx % RING;
+    FrameCtl *hc = h->ctl_host + (size_t)slot * h->n_clips;
+    for (int c = 0; c < h->n_clips; ++c) { hc[c].t_prev = t_prev[c]; hc[c].t_frame = t_frame[c]; }
+    V2E_HIP(hipMemcpyAsync(h->ctl_ring + (size_t)slot * h->n_clips, hc, sizeof(FrameCtl) * h->n_clips,
+                           hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+static int launch_count(v2e_emu *h, const KArgs &a, int f64_state, const void *frame, int dtype, const FrameCtl *ctl,
+                        const uint32_t *fidx_base, uint32_t fidx_off, const float *leak, const float *shot,
+                        v2e_frame_rec *rec, hipStream_t s)
+{
+    dim3 grid(v2e_cdiv(h->npx, BLOCK), h->n_clips);
+    DISPATCH_FT(dtype, {
+        if (f64_state) k_count<double, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, fidx_base, fidx_off, leak, shot, rec);
+        else k_count<float, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, fidx_base, fidx_off, leak, shot, rec);
+    });
+    return 0;
+}
+
+int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, const double *t_prev,
+                  const double *t_frame, uint32_t frame_idx, const float *leak_randn, const float *shot_rand,
+                  void *stream)
+{
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    V2E_REQUIRE(frame && t_prev && t_frame, "null frame/time");
+    if (p->rng_mode == V2E_RNG_TAPE) V2E_REQUIRE(!(p->leak_rate_hz > 0) || leak_randn, "tape mode needs leak_randn");
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = stage_ctl(h, frame_idx, t_prev, t_frame, s);
+    if (rc) return rc;
+    const int slot = frame_idx % RING;
+    v2e_frame_rec *rec = h->rec_ring + (size_t)slot * h->n_clips;
+    V2E_HIP(hipMemsetAsync(rec, 0, sizeof(v2e_frame_rec) * h->n_clips, s));
+    KArgs a = make_kargs(h, p);
+    rc = launch_count(h, a, p->f64_state, frame, dtype, h->ctl_ring + (size_t)slot * h->n_clips, nullptr, frame_idx,
+                      leak_randn, shot_rand, rec, s);
+    if (rc) return rc;
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_emu_shot(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, uint32_t frame_idx,
+                 const float *shot_rand, void *stream)
+{
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    V2E_REQUIRE(frame && shot_rand, "null frame/shot_rand");
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int slot = frame_idx % RING;
+    KArgs a = make_kargs(h, p);
+    dim3 grid(v2e_cdiv(h->npx, BLOCK), h->n_clips);
+    DISPATCH_FT(dtype, { k_shot<FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, h->ctl_ring + (size_t)slot * h->n_clips, shot_rand); });
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_emu_read_rec(v2e_emu *h, uint32_t frame_idx, v2e_frame_rec *recs_host, void *stream)
+{
+    V2E_REQUIRE(h && recs_host, "null");
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int slot = frame_idx % RING;
+    V2E_HIP(hipMemcpyAsync(recs_host, h->rec_ring + (size_t)slot * h->n_clips, sizeof(v2e_frame_rec) * h->n_clips,
+                           hipMemcpyDeviceToHost, s));
+    V2E_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int v2e_emu_reserve_iters(v2e_emu *h, int max_events, void *stream)
+{
+    V2E_REQUIRE(h, "null");
+    if (max_events <= h->max_iters) return 0;
+    V2E_HIP(hipSetDevice(h->device));
+    V2E_HIP(hipStreamSynchronize((hipStream_t)stream));
+    int want = h->max_iters;
+    while (want < max_events) want *= 2;
+    return alloc_iter_scratch(h, want);
+}
+
+int v2e_emu_rank(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, const float *ts_table, int n_ts,
+                 void *stream)
+{
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int slot = frame_idx % RING;
+    KArgs a = make_kargs(h, p);
+    const FrameCtl *ctl = h->ctl_ring + (size_t)slot * h->n_clips;
+    v2e_frame_rec *rec = h->rec_ring + (size_t)slot * h->n_clips;
+    dim3 grid(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), h->n_clips);
+    k_rank<<<grid, BLOCK, 0, s>>>(a, ctl, rec, ts_table, n_ts);
+    k_scan<<<dim3(SCAN_BLOCKS, h->n_clips), BLOCK, 0, s>>>(a, rec);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_emu_emit(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, const float *ts_table, int n_ts,
+                 float *events, uint64_t cap, const uint64_t *ev_offset0, void *stream)
+{
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    V2E_REQUIRE(events || cap == 0, "null events");
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int slot = frame_idx % RING;
+    KArgs a = make_kargs(h, p);
+    const FrameCtl *ctl = h->ctl_ring + (size_t)slot * h->n_clips;
+    v2e_frame_rec *rec = h->rec_ring + (size_t)slot * h->n_clips;
+    unsigned long long *d_off = nullptr;
+    if (ev_offset0) { // host array -> pinned staging -> device (frame-at-a-time API syncs every frame)
+        for (int c = 0; c < h->n_clips; ++c) h->off_host[c] = ev_offset0[c];
+        d_off = h->off_dev;
+        V2E_HIP(hipMemcpyAsync(d_off, h->off_host, sizeof(unsigned long long) * h->n_clips, hipMemcpyHostToDevice, s));
+    }
+    const v2e_frame_rec *rec_prev = h->rec_ring + (size_t)((frame_idx + RING - 1) % RING) * h->n_clips;
+    dim3 grid(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), h->n_clips);
+    if (p->f64_state) k_emit<double><<<grid, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, d_off, nullptr, frame_idx, ts_table, n_ts, (float4 *)events, cap);
+    else k_emit<float><<<grid, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, d_off, nullptr, frame_idx, ts_table, n_ts, (float4 *)events, cap);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_emu_read_iter_counts(v2e_emu *h, uint32_t frame_idx, int n_iters, uint32_t *counts_host, void *stream)
+{
+    (void)frame_idx;
+    V2E_REQUIRE(h && counts_host && n_iters >= 0 && n_iters <= h->max_iters, "bad read_iter_counts args");
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int nk = 2 * (n_iters + 1);
+    for (int c = 0; c < h->n_clips; ++c)
+        V2E_HIP(hipMemcpyAsync(counts_host + (size_t)c * nk, h->tot + (size_t)c * h->nkeys_cap, sizeof(uint32_t) * nk,
+                               hipMemcpyDeviceToHost, s));
+    V2E_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const int32_t *idx, uint64_t row0,
+                    uint64_t n, void *stream)
+{
+    V2E_REQUIRE(h && events_in && events_out && idx, "null");
+    if (n == 0) return 0;
+    V2E_HIP(hipSetDevice(h->device));
+    k_permute<<<v2e_cdiv((int64_t)n, BLOCK), BLOCK, 0, (hipStream_t)stream>>>((const float4 *)events_in, (float4 *)events_out,
+                                                                              idx, row0, n);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+// Enqueue the whole multi-frame sequence on stream s (no host sync).
+static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
+                       float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s)
+{
+    const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
+    V2E_HIP(hipMemsetAsync(recs, 0, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
+    dim3 gridw(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), h->n_clips);
+    for (int f = 0; f < n_frames; ++f) {
+        const void *fr = (const char *)frames + (size_t)f * h->n_clips * h->npx * esz;
+        const FrameCtl *ctl = h->run_ctl + (size_t)f * h->n_clips;
+        v2e_frame_rec *rec = recs + (size_t)f * h->n_clips;
+        const v2e_frame_rec *rec_prev = f > 0 ? rec - h->n_clips : nullptr;
+        int rc = launch_count(h, a, p->f64_state, fr, dtype, ctl, h->run_fidx, (uint32_t)f, nullptr, nullptr, rec, s);
+        if (rc) return rc;
+        k_rank<<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, 0);
+        k_scan<<<dim3(SCAN_BLOCKS, h->n_clips), BLOCK, 0, s>>>(a, rec);
+        if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, nullptr, h->run_fidx, (uint32_t)f, nullptr, 0, (float4 *)events, cap);
+        else k_emit<float><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, nullptr, h->run_fidx, (uint32_t)f, nullptr, 0, (float4 *)events, cap);
+    }
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames, const double *t_prev,
+                const double *t_frame, uint32_t frame_idx0, float *events, uint64_t cap, v2e_frame_rec *recs_dev,
+                int use_graph, void *stream)
+{
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    V2E_REQUIRE(p->rng_mode == V2E_RNG_PHILOX, "v2e_emu_run is the device-resident Philox path");
+    V2E_REQUIRE(frames && t_prev && t_frame && events && recs_dev && n_frames > 0, "bad run args");
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n_frames > h->run_cap) {
+        V2E_HIP(hipStreamSynchronize(s));
+        if (h->run_ctl) V2E_HIP(hipFree(h->run_ctl));
+        if (h->run_ctl_host) V2E_HIP(hipHostFree(h->run_ctl_host));
+        h->run_cap = n_frames;
+        V2E_HIP(hipMalloc(&h->run_ctl, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
+        V2E_HIP(hipHostMalloc(&h->run_ctl_host, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
+        if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+    } else {
+        // the pinned staging buffers are reused: make sure the previous upload finished
+        V2E_HIP(hipStreamSynchronize(s));
+    }
+    const size_t nct = (size_t)n_frames * h->n_clips;
+    for (size_t i = 0; i < nct; ++i) { h->run_ctl_host[i].t_prev = t_prev[i]; h->run_ctl_host[i].t_frame = t_frame[i]; }
+    *h->run_fidx_host = frame_idx0;
+    V2E_HIP(hipMemcpyAsync(h->run_ctl, h->run_ctl_host, sizeof(FrameCtl) * nct, hipMemcpyHostToDevice, s));
+    V2E_HIP(hipMemcpyAsync(h->run_fidx, h->run_fidx_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    KArgs a = make_kargs(h, p);
+    if (!use_graph) return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s);
+
+    // graph path: everything baked into the graph is part of the cache key
+    std::vector<unsigned char> key;
+    auto push = [&key](const void *ptr, size_t n) { const unsigned char *b = (const unsigned char *)ptr; key.insert(key.end(), b, b + n); };
+    push(&a, sizeof(a)); push(&frames, sizeof(frames)); push(&dtype, sizeof(dtype)); push(&n_frames, sizeof(n_frames));
+    push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
+    int f64 = p->f64_state; push(&f64, sizeof(f64));
+    if (!h->graph || key != h->graph_key) {
+        if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
+        hipStream_t cs;
+        V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(cs, &g);
+        hipStreamDestroy(cs);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        V2E_HIP(e);
+        V2E_HIP(hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0));
+        V2E_HIP(hipGraphDestroy(g));
+        h->graph_key = key;
+    }
+    V2E_HIP(hipGraphLaunch(h->graph, s));
+    return 0;
+}
+
+} // extern "C"

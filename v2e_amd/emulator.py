@@ -1,0 +1,533 @@
+"""Drop-in `EventEmulator` running the DVS pixel model on MI355X HIP kernels.
+
+Mirrors the public surface of the reference class (v2ecore/emulator.py:35-1059):
+same constructor signature (:86-117), `generate_events(new_frame, t_frame)` (:619),
+`set_dvs_params` (:513), `reset` (:558), `prepare_storage` (:374), `cleanup` (:402),
+the counters `num_events_total/on/off`, `t_previous`, and the class attributes that
+v2ecore/v2e_args.py:209,216 reads.
+
+Random numbers come in two modes, selected with the extra keyword
+`rng_mode` (or env V2E_AMD_RNG):
+  "tape"   (default) the host issues exactly the reference's torch calls in the
+           reference's order from torch's global CPU generator -- normal, normal, randn
+           on the first frame; randn, one randperm per non-empty iteration, rand on every
+           later frame, plus torch.linspace for the timestamps -- and hands the values to
+           the kernels.  Event-for-event identical to the reference torch-CPU path under
+           the same seed.
+  "philox" counter-based Philox4x32-10 inside the kernels, timestamps and the
+           per-iteration shuffle computed on device; no host round trip except the final
+           copy of the event list.  `generate_events_batch` keeps a whole clip on device.
+
+The reference's research-only pixel variants are not part of the hot path and raise
+NotImplementedError here: photoreceptor_noise, CSDVS (cs_lambda_pixels), SCIDVS,
+hdr, show_dvs_model_state, record_single_pixel_states.
+"""
+import atexit
+import logging
+import math
+import os
+import random
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import EmuParams, RNG_PHILOX, RNG_TAPE
+from .engine import EmuEngine
+
+logger = logging.getLogger(__name__)
+
+
+class _TorchTape:
+    """The reference's own random draws, issued on the host (tape mode)."""
+
+    def normal(self, mean, std, shape):
+        return torch.normal(mean, std, size=shape, dtype=torch.float32)  # emulator.py:460-471
+
+    def randn(self, shape):
+        return torch.randn(shape, dtype=torch.float32)  # emulator.py:501, emulator_utils.py:122
+
+    def rand(self, shape):
+        return torch.rand(size=shape, dtype=torch.float32)  # emulator_utils.py:338
+
+    def randperm(self, n, frame=None, it=None):
+        return torch.randperm(n)  # emulator.py:868
+
+    def linspace(self, start, end, n):
+        return torch.linspace(start=start, end=end, steps=n, dtype=torch.float32)  # emulator.py:793
+
+    def exp_noise_rate(self, cov, randn):
+        return torch.exp(math.log(10) * cov * randn)  # emulator.py:504-505
+
+
+def _as_f32_tensor(a):
+    return a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+class EventEmulator(object):
+    """compute events based on the input frame (MI355X implementation)."""
+
+    # class attributes read by v2ecore/v2e_args.py (emulator.py:41-56)
+    l255 = np.log(255)
+    gr = (0, 255)
+    lg = (0, l255)
+    slg = (-l255 / 8, l255 / 8)
+    MODEL_STATES = {'new_frame': gr, 'log_new_frame': lg, 'lp_log_frame': lg, 'scidvs_highpass': slg,
+                    'photoreceptor_noise_arr': slg, 'cs_surround_frame': lg, 'c_minus_s_frame': slg,
+                    'base_log_frame': slg, 'diff_frame': slg}
+    MAX_CHANGE_TO_TERMINATE_EULER_SURROUND_STEPPING = 1e-5
+    SINGLE_PIXEL_STATES_FILENAME = 'pixel-states.dat'
+    SINGLE_PIXEL_MAX_SAMPLES = 10000
+    SCIDVS_GAIN = 2
+    SCIDVS_TAU_S = .01
+    SCIDVS_TAU_COV = 0.5
+
+    def __init__(
+            self,
+            pos_thres: float = 0.2,
+            neg_thres: float = 0.2,
+            sigma_thres: float = 0.03,
+            cutoff_hz: float = 0.0,
+            leak_rate_hz: float = 0.1,
+            refractory_period_s: float = 0.0,
+            shot_noise_rate_hz: float = 0.0,
+            photoreceptor_noise: bool = False,
+            leak_jitter_fraction: float = 0.1,
+            noise_rate_cov_decades: float = 0.1,
+            seed: int = 0,
+            output_folder: str = None,
+            dvs_h5: str = None,
+            dvs_aedat2: str = None,
+            dvs_aedat4: str = None,
+            dvs_text: str = None,
+            show_dvs_model_state: str = None,
+            save_dvs_model_state: bool = False,
+            output_width: int = None,
+            output_height: int = None,
+            device: str = "cuda",
+            cs_lambda_pixels: float = None,
+            cs_tau_p_ms: float = None,
+            hdr: bool = False,
+            scidvs: bool = False,
+            record_single_pixel_states=None,
+            label_signal_noise=False,
+            *,
+            rng_mode: Optional[str] = None,
+            shuffle: bool = True,
+            tape=None,
+            max_iters: int = 64,
+    ):
+        unsupported = []
+        if photoreceptor_noise: unsupported.append("photoreceptor_noise")
+        if cs_lambda_pixels is not None: unsupported.append("cs_lambda_pixels (CSDVS)")
+        if scidvs: unsupported.append("scidvs")
+        if hdr: unsupported.append("hdr")
+        if show_dvs_model_state is not None: unsupported.append("show_dvs_model_state")
+        if record_single_pixel_states is not None: unsupported.append("record_single_pixel_states")
+        if unsupported:
+            raise NotImplementedError(
+                "v2e_amd.EventEmulator implements the v2e hot path only; not available: " + ", ".join(unsupported))
+
+        self.no_events_warning_count = 0
+        logger.info("ON/OFF log_e temporal contrast thresholds: {} / {} +/- {}".format(
+            pos_thres, neg_thres, sigma_thres))
+        self.reset()
+        self.t_previous = 0
+        self.device = device
+
+        self.sigma_thres = sigma_thres
+        self.pos_thres = pos_thres
+        self.neg_thres = neg_thres
+        self.pos_thres_nominal = pos_thres
+        self.neg_thres_nominal = neg_thres
+        self.cutoff_hz = cutoff_hz
+        self.leak_rate_hz = leak_rate_hz
+        self.refractory_period_s = refractory_period_s
+        self.shot_noise_rate_hz = shot_noise_rate_hz
+        self.photoreceptor_noise = False
+        self.leak_jitter_fraction = leak_jitter_fraction
+        self.noise_rate_cov_decades = noise_rate_cov_decades
+        self.SHOT_NOISE_INTEN_FACTOR = 0.25
+        self.output_folder = output_folder
+        self.output_width = output_width
+        self.output_height = output_height
+        self.show_dvs_model_state = None
+        self.save_dvs_model_state = save_dvs_model_state
+        self.label_signal_noise = label_signal_noise
+        self.log_input = False
+        self.scidvs = False
+        self.csdvs_enabled = False
+        self.seed = seed
+
+        self.rng_mode = (rng_mode or os.environ.get("V2E_AMD_RNG", "tape")).lower()
+        if self.rng_mode not in ("tape", "philox"):
+            raise ValueError("rng_mode must be 'tape' or 'philox', got %r" % (self.rng_mode,))
+        self.shuffle = bool(shuffle)
+        self._tape = tape if tape is not None else _TorchTape()
+        self._max_iters = max_iters
+        if seed != 0:  # emulator.py:221-224
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            random.seed(seed)
+
+        # event file writers are outside the hot path: pass through to the reference's own
+        # writer classes when they are importable (emulator.py:312-346)
+        self.dvs_h5 = self.dvs_aedat2 = self.dvs_aedat4 = self.dvs_text = None
+        self.dvs_h5_dataset = self.frame_h5_dataset = self.frame_ts_dataset = self.frame_ev_idx_dataset = None
+        self._open_writers(dvs_h5, dvs_aedat2, dvs_aedat4, dvs_text)
+
+        self._engine: Optional[EmuEngine] = None
+        self._thres_scalar = None
+        atexit.register(self.cleanup)
+
+    # ------------------------------------------------------------- plumbing
+    def _open_writers(self, dvs_h5, dvs_aedat2, dvs_aedat4, dvs_text):
+        if not (dvs_h5 or dvs_aedat2 or dvs_aedat4 or dvs_text):
+            return
+        try:
+            from v2ecore.v2e_utils import checkAddSuffix
+            if dvs_h5:
+                import h5py
+                path = checkAddSuffix(os.path.join(self.output_folder, dvs_h5), '.h5')
+                self.dvs_h5 = h5py.File(path, "w")
+                self.dvs_h5_dataset = self.dvs_h5.create_dataset(
+                    name="events", shape=(0, 4), maxshape=(None, 4), dtype="uint32", compression="gzip")
+            if dvs_aedat2:
+                from v2ecore.output.aedat2_output import AEDat2Output
+                path = checkAddSuffix(os.path.join(self.output_folder, dvs_aedat2), '.aedat')
+                self.dvs_aedat2 = AEDat2Output(path, output_width=self.output_width,
+                                               output_height=self.output_height,
+                                               label_signal_noise=self.label_signal_noise)
+            if dvs_aedat4:
+                from v2ecore.output.aedat4_output import AEDat4Output
+                path = checkAddSuffix(os.path.join(self.output_folder, dvs_aedat4), '.aedat4')
+                self.dvs_aedat4 = AEDat4Output(path)
+            if dvs_text:
+                from v2ecore.output.ae_text_output import DVSTextOutput
+                path = checkAddSuffix(os.path.join(self.output_folder, dvs_text), '.txt')
+                self.dvs_text = DVSTextOutput(path, label_signal_noise=self.label_signal_noise)
+        except ImportError as e:
+            raise NotImplementedError(
+                "event file output (dvs_h5/dvs_aedat2/dvs_aedat4/dvs_text) is delegated to the reference's "
+                "writer classes, which are not importable here: %s" % e)
+
+    def prepare_storage(self, n_frames, frame_ts):  # emulator.py:374-400
+        if self.dvs_h5:
+            self.frame_h5_dataset = self.dvs_h5.create_dataset(
+                name="frame", shape=(n_frames, self.output_height, self.output_width), dtype="uint8",
+                compression="gzip")
+            frame_ts_arr = np.array(frame_ts, dtype=np.float32) * 1e6
+            self.frame_ts_dataset = self.dvs_h5.create_dataset(
+                name="frame_ts", shape=(n_frames,), data=frame_ts_arr.astype(np.uint32), dtype="uint32",
+                compression="gzip")
+            self.frame_ev_idx_dataset = self.dvs_h5.create_dataset(
+                name="frame_idx", shape=(n_frames,), dtype="uint64", compression="gzip")
+        else:
+            self.frame_h5_dataset = self.frame_ts_dataset = self.frame_ev_idx_dataset = None
+
+    def cleanup(self):  # emulator.py:402-429
+        for w in ("dvs_h5", "dvs_aedat2", "dvs_aedat4", "dvs_text"):
+            o = getattr(self, w, None)
+            if o is not None:
+                try:
+                    o.close()
+                except Exception:
+                    pass
+                setattr(self, w, None)
+
+    def set_dvs_params(self, model: str):  # emulator.py:513-556
+        if model == 'clean':
+            self.pos_thres = 0.2
+            self.neg_thres = 0.2
+            self.sigma_thres = 0.02
+            self.cutoff_hz = 0
+            self.leak_rate_hz = 0
+            self.leak_jitter_fraction = 0
+            self.noise_rate_cov_decades = 0
+            self.shot_noise_rate_hz = 0
+            self.refractory_period_s = 0
+        elif model == 'noisy':
+            self.pos_thres = 0.2
+            self.neg_thres = 0.2
+            self.sigma_thres = 0.05
+            self.cutoff_hz = 30
+            self.leak_rate_hz = 0.1
+            self.shot_noise_rate_hz = 5.0
+            self.refractory_period_s = 0
+            self.leak_jitter_fraction = 0.1
+            self.noise_rate_cov_decades = 0.1
+        else:
+            logger.warning("dvs_params {} not known: Using commandline assigned options".format(model))
+
+    def reset(self):  # emulator.py:558-578
+        self.num_events_total = 0
+        self.num_events_on = 0
+        self.num_events_off = 0
+        self.new_frame = None
+        self.log_new_frame = None
+        self.lp_log_frame = None
+        self.base_log_frame = None
+        self.diff_frame = None
+        self.frame_counter = 0
+        self.timestamp_mem = None
+        self.noise_rate_array = None
+        self._initialized = False
+
+    # ------------------------------------------------------------- parameters
+    def _params(self) -> EmuParams:
+        """Snapshot the (mutable) attributes into the C struct, every call."""
+        P = EmuParams()
+        P.f64_state = 1 if self.cutoff_hz > 0 else 0
+        P.scalar_thres = 1 if self._thres_scalar is not None and self._thres_is_scalar else 0
+        P.rng_mode = RNG_PHILOX if self.rng_mode == "philox" else RNG_TAPE
+        P.shuffle = 1 if self.shuffle else 0
+        P.pos_thres_nominal = float(self.pos_thres_nominal)
+        P.neg_thres_nominal = float(self.neg_thres_nominal)
+        P.pos_thres_scalar, P.neg_thres_scalar = self._thres_scalar
+        P.sigma_thres = float(self.sigma_thres)
+        P.cutoff_hz = float(self.cutoff_hz)
+        P.leak_rate_hz = float(self.leak_rate_hz)
+        P.leak_jitter_fraction = float(self.leak_jitter_fraction)
+        P.noise_rate_cov_decades = float(self.noise_rate_cov_decades)
+        P.refractory_period_s = float(self.refractory_period_s)
+        P.shot_noise_rate_hz = float(self.shot_noise_rate_hz)
+        P.shot_noise_inten_factor = float(self.SHOT_NOISE_INTEN_FACTOR)
+        if P.scalar_thres:  # emulator.py:475-478 with Python-float thresholds
+            P.pos_pre_scalar = float(torch.div(self.pos_thres_nominal, P.pos_thres_scalar))
+            P.neg_pre_scalar = float(torch.div(self.neg_thres_nominal, P.neg_thres_scalar))
+        P.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
+        return P
+
+    def _ensure_engine(self, H, W):
+        if self._engine is None or (self._engine.H, self._engine.W) != (H, W):
+            self._engine = EmuEngine(H, W, n_clips=1, device=self.device, max_iters=self._max_iters)
+        return self._engine
+
+    # ------------------------------------------------------------- first frame
+    def _first_frame(self, frame_dev, H, W, t_frame):
+        """emulator.py:681-717 + _init :439-511."""
+        eng = self._ensure_engine(H, W)
+        # thresholds are scalars (Python floats) until _init draws them; remember the
+        # values current at this moment (set_dvs_params may have changed them)
+        self._thres_scalar = (float(self.pos_thres), float(self.neg_thres))
+        self._thres_is_scalar = not (self.sigma_thres > 0)
+        eng.alloc_state(self.cutoff_hz > 0)
+        P = self._params()
+        tp = tn = nr = None
+        if self.rng_mode == "tape":
+            dev = eng.device
+            if self.sigma_thres > 0:
+                tp = _as_f32_tensor(self._tape.normal(self.pos_thres, self.sigma_thres, (H, W))).to(dev)
+                tn = _as_f32_tensor(self._tape.normal(self.neg_thres, self.sigma_thres, (H, W))).to(dev)
+            if self.leak_rate_hz > 0:
+                r = _as_f32_tensor(self._tape.randn((H, W)))
+                nr = _as_f32_tensor(self._tape.exp_noise_rate(self.noise_rate_cov_decades, r)).to(dev)
+        eng.init_state(P, frame_dev, t_frame, tp, tn, nr)
+        # public state attributes, as [H,W] device views
+        self.lp_log_frame = eng.plane(eng.lp)
+        self.base_log_frame = eng.plane(eng.base)
+        if self.sigma_thres > 0:
+            self.pos_thres = eng.plane(eng.pos_thres)
+            self.neg_thres = eng.plane(eng.neg_thres)
+        if self.leak_rate_hz > 0:
+            self.noise_rate_array = eng.plane(eng.noise_rate)
+        if self.refractory_period_s > 0:
+            self.timestamp_mem = eng.plane(eng.ts_mem)
+        self._initialized = True
+
+    # ------------------------------------------------------------- hot path
+    def generate_events(self, new_frame, t_frame):
+        """Compute events in new frame (emulator.py:619-1022).
+
+        new_frame: np.ndarray or torch tensor [height, width]; t_frame: seconds.
+        Returns np.ndarray [N,4] float32 rows [t, x, y, p(+1/-1)] or None.
+        """
+        if self.frame_h5_dataset is not None:
+            self.frame_h5_dataset[self.frame_counter] = np.asarray(new_frame).astype(np.uint8)
+        self.frame_counter += 1
+        if t_frame < self.t_previous:
+            raise ValueError("this frame time={} must be later than previous frame time={}".format(
+                t_frame, self.t_previous))
+        shape = tuple(new_frame.shape)
+        if len(shape) != 2:
+            raise ValueError("new_frame must be [height, width], got shape %r" % (shape,))
+        H, W = shape
+        eng = self._ensure_engine(H, W)
+        frame_dev = eng.to_device_frame(new_frame)
+
+        if not self._initialized:
+            self._first_frame(frame_dev, H, W, float(t_frame))
+            return None  # t_previous intentionally not advanced (emulator.py:717)
+
+        t_prev = float(self.t_previous)
+        t_frame = float(t_frame)
+        fidx = self.frame_counter - 1
+        P = self._params()
+        if bool(P.f64_state) != eng.f64_state:
+            raise ValueError("cutoff_hz changed sign after the first frame: the state dtype "
+                             "(float64 iff cutoff_hz > 0) is fixed by the first frame")
+        tape = self.rng_mode == "tape"
+        dev = eng.device
+
+        leak = None
+        if tape and self.leak_rate_hz > 0:
+            leak = _as_f32_tensor(self._tape.randn((H, W))).to(dev)
+        eng.count(P, frame_dev, [t_prev], [t_frame], fidx, leak_randn=leak)
+        rec = eng.read_rec(fidx)[0]
+        M = int(rec.max_events)
+        if M > 100:
+            logger.warning(f'Too many events generated for this frame: num_iter={M}>100 events')
+        eng.reserve_iters(M)
+        n = M if M > 0 else 1
+        ts_dev = None
+        if tape:
+            ts_step = (t_frame - t_prev) / n
+            ts = self._tape.linspace(t_prev + ts_step, t_frame, n)
+            ts_dev = _as_f32_tensor(ts).to(dev).view(1, n)
+        if M == 0 and self.no_events_warning_count < 100:
+            logger.warning(f'no signal events generated for frame #{self.frame_counter:,} at t={t_frame:.4f}s')
+            self.no_events_warning_count += 1
+
+        eng.rank(P, fidx, ts_dev)
+        itc = eng.read_iter_counts(fidx, M)[0]  # [M+1][2]; last row = shot pair
+        perms = []
+        if tape:
+            for i in range(M):
+                n_i = int(itc[i, 0]) + int(itc[i, 1])
+                perms.append(self._tape.randperm(n_i, fidx, i) if n_i > 0 else None)
+            if self.shot_noise_rate_hz > 0:
+                u = _as_f32_tensor(self._tape.rand((H, W))).to(dev)
+                eng.shot(P, frame_dev, fidx, u)
+                eng.rank(P, fidx, ts_dev)
+                itc = eng.read_iter_counts(fidx, M)[0]
+        n_events = int(itc.sum())
+        n_on = int(itc[:, 0].sum())
+        n_off = int(itc[:, 1].sum())
+        n_signal = int(itc[:M].sum())
+
+        events = None
+        ev = eng.event_buffer(max(n_events, 1))
+        eng.emit(P, fidx, ev, ts_dev, ev_offset0=[0])
+        if tape and n_signal > 0:
+            if eng._events_tmp is None or eng._events_tmp.shape != ev.shape:
+                eng._events_tmp = torch.empty_like(ev)
+            out = eng._events_tmp
+            row = 0
+            any_perm = False
+            for i in range(M):
+                n_i = int(itc[i, 0]) + int(itc[i, 1])
+                if n_i > 0:
+                    idx = perms[i]
+                    idx = idx if torch.is_tensor(idx) else torch.from_numpy(np.ascontiguousarray(idx))
+                    idx_dev = idx.to(torch.int32).to(dev)
+                    eng.permute(ev, out, idx_dev, row, n_i)  # events_curr_iter[idx], emulator.py:869
+                    any_perm = True
+                row += n_i
+            if any_perm:
+                if n_events > n_signal:
+                    out[0, n_signal:n_events] = ev[0, n_signal:n_events]
+                eng._events, eng._events_tmp = out, ev
+                ev = out
+        if n_events > 0:
+            events = ev[0, :n_events].cpu().numpy()
+
+        self.num_events_on += n_on
+        self.num_events_off += n_off
+        self.num_events_total += n_events
+
+        if events is not None:
+            self._write_events(events, n_signal)
+        if self.frame_ev_idx_dataset is not None:
+            self.frame_ev_idx_dataset[self.frame_counter - 1] = self.dvs_h5_dataset.shape[0]
+        self.t_previous = t_frame
+        return events
+
+    def _write_events(self, events, n_signal):
+        """emulator.py:953-977 (file sinks; not part of the hot path)."""
+        label = None
+        if self.label_signal_noise:
+            label = np.zeros(len(events), dtype=bool)
+            label[:n_signal] = True
+        if self.dvs_h5 is not None:
+            temp = np.array(events, dtype=np.float32)
+            temp[:, 0] = temp[:, 0] * 1e6
+            temp[temp[:, 3] == -1, 3] = 0
+            temp = temp.astype(np.uint32)
+            self.dvs_h5_dataset.resize(self.dvs_h5_dataset.shape[0] + temp.shape[0], axis=0)
+            self.dvs_h5_dataset[-temp.shape[0]:] = temp
+        if self.dvs_aedat2 is not None:
+            self.dvs_aedat2.appendEvents(events, signnoise_label=label)
+        if self.dvs_aedat4 is not None:
+            self.dvs_aedat4.appendEvents(events, signnoise_label=label)
+        if self.dvs_text is not None:
+            if self.label_signal_noise:
+                self.dvs_text.appendEvents(events, signnoise_label=label)
+            else:
+                self.dvs_text.appendEvents(events)
+
+    # ------------------------------------------------------------- device-resident clip
+    def generate_events_batch(self, frames, t_frames, return_device=False, use_graph=True, cap=None):
+        """Philox mode: run a whole clip [F,H,W] with timestamps t_frames[F] on device.
+
+        Equivalent to calling generate_events once per frame (same events, same order) but
+        with no host synchronisation between frames.  Returns (events, counts): events is
+        an [N,4] float32 array (or device tensor) of all frames' events concatenated,
+        counts[f] the number of events of frame f (0 for the very first frame).
+        """
+        if self.rng_mode != "philox":
+            raise ValueError("generate_events_batch needs rng_mode='philox' (tape mode needs the host per frame)")
+        if isinstance(frames, np.ndarray):
+            if frames.dtype not in (np.uint8, np.float32, np.float64):
+                frames = frames.astype(np.float64)
+        F = int(frames.shape[0])
+        H, W = int(frames.shape[1]), int(frames.shape[2])
+        t_frames = [float(t) for t in t_frames]
+        if len(t_frames) != F:
+            raise ValueError("need one timestamp per frame")
+        eng = self._ensure_engine(H, W)
+        frames_dev = eng.to_device_frame(frames)
+        counts = np.zeros(F, dtype=np.int64)
+        start = 0
+        if not self._initialized:
+            if t_frames[0] < self.t_previous:
+                raise ValueError("frame time must not decrease")
+            self.frame_counter += 1
+            self._first_frame(frames_dev[0], H, W, t_frames[0])
+            start = 1
+        nrun = F - start
+        if nrun <= 0:
+            empty = torch.empty((0, 4), dtype=torch.float32, device=eng.device)
+            return (empty if return_device else None), counts
+        t_prev = []
+        tp = float(self.t_previous)
+        for f in range(start, F):
+            if t_frames[f] < tp:
+                raise ValueError("this frame time={} must be later than previous frame time={}".format(
+                    t_frames[f], tp))
+            t_prev.append(tp)
+            tp = t_frames[f]
+        P = self._params()
+        if cap is None:
+            cap = max(4 * H * W, 1 << 16) * min(nrun, 64)
+        ev = eng.event_buffer(cap)
+        recs = eng.alloc_recs(nrun)
+        eng.run(P, frames_dev[start:], t_prev, t_frames[start:], self.frame_counter, ev, recs, use_graph=use_graph)
+        r = eng.recs_to_numpy(recs)[:, 0]
+        if (r["flags"] & _capi.FLAG_ITERS_CLAMPED).any():
+            raise _capi.V2EAmdError("a pixel produced more than max_iters=%d events in one frame; "
+                                    "construct with a larger max_iters" % eng.max_iters)
+        if (r["flags"] & _capi.FLAG_EVENTS_DROPPED).any():
+            raise _capi.V2EAmdError("event buffer capacity %d exceeded (needed %d); pass a larger cap" % (
+                ev.shape[1], int(r["n_events"].sum())))
+        counts[start:] = r["n_events"]
+        total = int(r["n_events"].sum())
+        self.frame_counter += nrun
+        self.num_events_total += total
+        self.num_events_on += int(r["n_on"].sum())
+        self.num_events_off += int(r["n_off"].sum())
+        self.t_previous = t_frames[-1]
+        out = ev[0, :total]
+        if return_device:
+            return out, counts
+        return (out.cpu().numpy() if total > 0 else None), counts

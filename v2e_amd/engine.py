@@ -1,0 +1,193 @@
+"""Thin torch-facing wrapper of the emulator C ABI (include/v2e_amd.h).
+
+PyTorch is plumbing here: it owns the HBM allocations (state planes, frame and event
+buffers) and the HIP stream; all arithmetic happens in libv2e_amd.so.  `EmuEngine`
+advances `n_clips` independent pixel arrays in lock-step; the drop-in
+`EventEmulator` (v2e_amd/emulator.py) uses n_clips = 1.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import EmuParams, FrameRec, check
+
+_DT = {torch.uint8: _capi.DT_U8, torch.float32: _capi.DT_F32, torch.float64: _capi.DT_F64}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dbl_array(vals):
+    arr = (C.c_double * len(vals))(*[float(v) for v in vals])
+    return arr
+
+
+class EmuEngine:
+    """Device state + kernels of `n_clips` DVS pixel arrays of size H x W."""
+
+    def __init__(self, H, W, n_clips=1, device="cuda", max_iters=64):
+        self.H, self.W, self.n_clips = int(H), int(W), int(n_clips)
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise _capi.V2EAmdError(
+                "v2e_amd needs a ROCm GPU (device=%r, torch.cuda.is_available()=%s); "
+                "there is no CPU fallback" % (device, torch.cuda.is_available()))
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = _capi.lib()
+        self.max_iters = int(max_iters)
+        self.npx = self.H * self.W
+        self.npx_pad = int(self.lib.v2e_emu_npx_pad(self.H, self.W))
+        h = C.c_void_p()
+        check(self.lib.v2e_emu_create(self.H, self.W, self.n_clips, int(max_iters), self.device.index,
+                                      C.byref(h)), "v2e_emu_create")
+        self._h = h
+        self.f64_state = None
+        self.lp = self.base = self.ts_mem = self.pos_thres = self.neg_thres = self.noise_rate = None
+        self._events = None
+        self._events_tmp = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.v2e_emu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------ state
+    def alloc_state(self, f64_state):
+        """(Re)allocate the per-pixel planes [n_clips][npx_pad] and bind them."""
+        self.f64_state = bool(f64_state)
+        sd = torch.float64 if self.f64_state else torch.float32
+        shp = (self.n_clips, self.npx_pad)
+        dev = self.device
+        self.lp = torch.zeros(shp, dtype=sd, device=dev)
+        self.base = torch.zeros(shp, dtype=sd, device=dev)
+        self.ts_mem = torch.zeros(shp, dtype=torch.float32, device=dev)
+        self.pos_thres = torch.zeros(shp, dtype=torch.float32, device=dev)
+        self.neg_thres = torch.zeros(shp, dtype=torch.float32, device=dev)
+        self.noise_rate = torch.zeros(shp, dtype=torch.float32, device=dev)
+        check(self.lib.v2e_emu_bind_state(self._h, _ptr(self.lp), _ptr(self.base), _ptr(self.ts_mem),
+                                          _ptr(self.pos_thres), _ptr(self.neg_thres),
+                                          _ptr(self.noise_rate)), "v2e_emu_bind_state")
+
+    def plane(self, t, clip=0):
+        """[H,W] view of a state plane."""
+        return t[clip, :self.npx].view(self.H, self.W)
+
+    # ----------------------------------------------------------- frames
+    def to_device_frame(self, frame):
+        """np.ndarray / torch tensor [n_clips?,H,W] -> contiguous device tensor u8/f32/f64.
+
+        Anything that is not uint8/float32/float64 is converted to float64 on the way,
+        which is what `torch.tensor(new_frame, dtype=torch.float64)` (emulator.py:663) does.
+        """
+        if isinstance(frame, np.ndarray):
+            if frame.dtype not in (np.uint8, np.float32, np.float64):
+                frame = frame.astype(np.float64)
+            t = torch.from_numpy(np.ascontiguousarray(frame))
+        elif torch.is_tensor(frame):
+            t = frame
+            if t.dtype not in _DT:
+                t = t.to(torch.float64)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(frame, dtype=np.float64)))
+        t = t.to(self.device, non_blocking=True).contiguous()
+        return t
+
+    def _check_frame(self, t, lead):
+        if t.numel() != lead * self.npx:
+            raise ValueError("frame has %d elements, expected %d x %d x %d" % (t.numel(), lead, self.H, self.W))
+
+    # ------------------------------------------------------------ calls
+    def init_state(self, P, frame_dev, t_frame, thres_pos=None, thres_neg=None, noise_rate=None):
+        self._check_frame(frame_dev, self.n_clips)
+        check(self.lib.v2e_emu_init_state(self._h, C.byref(P), _ptr(frame_dev), _DT[frame_dev.dtype],
+                                          float(t_frame), _ptr(thres_pos), _ptr(thres_neg), _ptr(noise_rate),
+                                          self.stream), "v2e_emu_init_state")
+
+    def count(self, P, frame_dev, t_prev, t_frame, frame_idx, leak_randn=None, shot_rand=None):
+        self._check_frame(frame_dev, self.n_clips)
+        check(self.lib.v2e_emu_count(self._h, C.byref(P), _ptr(frame_dev), _DT[frame_dev.dtype],
+                                     _dbl_array(t_prev), _dbl_array(t_frame), int(frame_idx),
+                                     _ptr(leak_randn), _ptr(shot_rand), self.stream), "v2e_emu_count")
+
+    def shot(self, P, frame_dev, frame_idx, shot_rand):
+        check(self.lib.v2e_emu_shot(self._h, C.byref(P), _ptr(frame_dev), _DT[frame_dev.dtype],
+                                    int(frame_idx), _ptr(shot_rand), self.stream), "v2e_emu_shot")
+
+    def read_rec(self, frame_idx):
+        recs = (FrameRec * self.n_clips)()
+        check(self.lib.v2e_emu_read_rec(self._h, int(frame_idx), recs, self.stream), "v2e_emu_read_rec")
+        return recs
+
+    def reserve_iters(self, max_events):
+        check(self.lib.v2e_emu_reserve_iters(self._h, int(max_events), self.stream), "v2e_emu_reserve_iters")
+
+    def rank(self, P, frame_idx, ts_table=None):
+        n_ts = 0 if ts_table is None else int(ts_table.shape[-1])
+        check(self.lib.v2e_emu_rank(self._h, C.byref(P), int(frame_idx), _ptr(ts_table), n_ts, self.stream),
+              "v2e_emu_rank")
+
+    def read_iter_counts(self, frame_idx, n_iters):
+        nk = 2 * (n_iters + 1)
+        out = (C.c_uint32 * (nk * self.n_clips))()
+        check(self.lib.v2e_emu_read_iter_counts(self._h, int(frame_idx), int(n_iters), out, self.stream),
+              "v2e_emu_read_iter_counts")
+        return np.frombuffer(out, dtype=np.uint32).reshape(self.n_clips, n_iters + 1, 2).copy()
+
+    def event_buffer(self, cap):
+        """Device [n_clips][cap][4] float32 buffer, grown geometrically."""
+        if self._events is None or self._events.shape[1] < cap:
+            ncap = max(int(cap), 1024)
+            if self._events is not None:
+                ncap = max(ncap, 2 * self._events.shape[1])
+            self._events = torch.empty((self.n_clips, ncap, 4), dtype=torch.float32, device=self.device)
+            self._events_tmp = None
+        return self._events
+
+    def emit(self, P, frame_idx, events, ts_table=None, ev_offset0=None):
+        n_ts = 0 if ts_table is None else int(ts_table.shape[-1])
+        off = None
+        if ev_offset0 is not None:
+            off = (C.c_uint64 * self.n_clips)(*[int(v) for v in ev_offset0])
+        check(self.lib.v2e_emu_emit(self._h, C.byref(P), int(frame_idx), _ptr(ts_table), n_ts, _ptr(events),
+                                    int(events.shape[1]), off, self.stream), "v2e_emu_emit")
+
+    def permute(self, events_in, events_out, idx_dev, row0, n):
+        check(self.lib.v2e_emu_permute(self._h, _ptr(events_in), _ptr(events_out), _ptr(idx_dev), int(row0),
+                                       int(n), self.stream), "v2e_emu_permute")
+
+    def run(self, P, frames_dev, t_prev, t_frame, frame_idx0, events, recs_dev, use_graph=True):
+        """Device-resident Philox run over frames_dev [F][n_clips][H*W]; no host sync."""
+        F = int(frames_dev.shape[0])
+        self._check_frame(frames_dev, F * self.n_clips)
+        tp = np.ascontiguousarray(np.asarray(t_prev, dtype=np.float64).reshape(F * self.n_clips))
+        tf = np.ascontiguousarray(np.asarray(t_frame, dtype=np.float64).reshape(F * self.n_clips))
+        check(self.lib.v2e_emu_run(self._h, C.byref(P), _ptr(frames_dev), _DT[frames_dev.dtype], F,
+                                   tp.ctypes.data_as(C.POINTER(C.c_double)),
+                                   tf.ctypes.data_as(C.POINTER(C.c_double)), int(frame_idx0), _ptr(events),
+                                   int(events.shape[1]), _ptr(recs_dev), 1 if use_graph else 0, self.stream),
+              "v2e_emu_run")
+
+    def alloc_recs(self, n_frames):
+        """Device record array [F][n_clips] (struct v2e_frame_rec = 32 bytes)."""
+        return torch.zeros((n_frames, self.n_clips, C.sizeof(FrameRec)), dtype=torch.uint8, device=self.device)
+
+    @staticmethod
+    def recs_to_numpy(recs_dev):
+        dt = np.dtype([("max_events", "<i4"), ("flags", "<u4"), ("n_signal", "<u4"), ("n_events", "<u4"),
+                       ("n_on", "<u4"), ("n_off", "<u4"), ("ev_offset", "<u8")])
+        a = recs_dev.cpu().numpy()
+        return a.view(dt).reshape(a.shape[0], a.shape[1])
