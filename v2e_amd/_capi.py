@@ -85,6 +85,8 @@ SIGNATURES = {
     "v2e_emu_permute": (_i, [_vp, _vp, _vp, _vp, _u64, _u64, _vp]),
     "v2e_emu_run": (_i, [_vp, _PP, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d), _u32, _vp, _u64,
                          _vp, _i, _vp]),
+    "v2e_emu_last_profile": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),
+                                  C.POINTER(_i)]),
     "v2e_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_conv2d_lrelu": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(ConvDesc), _vp, _i, _i, _i, _vp]),
     "v2e_unet_workspace_bytes": (_i64, [_i, _i, _i, _i]),

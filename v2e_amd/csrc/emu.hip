@@ -560,6 +560,8 @@ struct v2e_emu {
     uint32_t *run_fidx_host = nullptr; // pinned
     hipGraphExec_t graph = nullptr;
     std::vector<unsigned char> graph_key;
+    double prof_ms[4] = {0, 0, 0, 0}; // count, rank, scan, emit (use_graph == 2)
+    int prof_launches = 0;
 };
 
 static thread_local char g_err[512] = "";
@@ -877,8 +879,9 @@ int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const
 
 // Enqueue the whole multi-frame sequence on stream s (no host sync).
 static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
-                       float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s)
+                       float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, hipEvent_t *evs = nullptr)
 {
+#define V2E_MARK(i) do { if (evs) V2E_HIP(hipEventRecord(evs[(i)], s)); } while (0)
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
     V2E_HIP(hipMemsetAsync(recs, 0, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
     dim3 gridw(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), h->n_clips);
@@ -887,13 +890,19 @@ static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, cons
         const FrameCtl *ctl = h->run_ctl + (size_t)f * h->n_clips;
         v2e_frame_rec *rec = recs + (size_t)f * h->n_clips;
         const v2e_frame_rec *rec_prev = f > 0 ? rec - h->n_clips : nullptr;
+        V2E_MARK(4 * f + 0);
         int rc = launch_count(h, a, p->f64_state, fr, dtype, ctl, h->run_fidx, (uint32_t)f, nullptr, nullptr, rec, s);
         if (rc) return rc;
+        V2E_MARK(4 * f + 1);
         k_rank<<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, 0);
+        V2E_MARK(4 * f + 2);
         k_scan<<<dim3(SCAN_BLOCKS, h->n_clips), BLOCK, 0, s>>>(a, rec);
+        V2E_MARK(4 * f + 3);
         if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, nullptr, h->run_fidx, (uint32_t)f, nullptr, 0, (float4 *)events, cap);
         else k_emit<float><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, nullptr, h->run_fidx, (uint32_t)f, nullptr, 0, (float4 *)events, cap);
     }
+    V2E_MARK(4 * n_frames);
+#undef V2E_MARK
     V2E_HIP(hipGetLastError());
     return 0;
 }
@@ -927,6 +936,24 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     V2E_HIP(hipMemcpyAsync(h->run_fidx, h->run_fidx_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     KArgs a = make_kargs(h, p);
     if (!use_graph) return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s);
+    if (use_graph == 2) { // instrumented: hipEvents between the kernels (bench.py roofline leg); blocking
+        const int ne = 4 * n_frames + 1;
+        std::vector<hipEvent_t> evs(ne);
+        for (int i = 0; i < ne; ++i) V2E_HIP(hipEventCreate(&evs[i]));
+        rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, evs.data());
+        if (rc == 0) {
+            V2E_HIP(hipStreamSynchronize(s));
+            for (int k = 0; k < 4; ++k) h->prof_ms[k] = 0.0;
+            for (int i = 0; i < ne - 1; ++i) {
+                float ms = 0.f;
+                V2E_HIP(hipEventElapsedTime(&ms, evs[i], evs[i + 1]));
+                h->prof_ms[i & 3] += ms;
+            }
+            h->prof_launches = n_frames;
+        }
+        for (int i = 0; i < ne; ++i) hipEventDestroy(evs[i]);
+        return rc;
+    }
 
     // graph path: everything baked into the graph is part of the cache key
     std::vector<unsigned char> key;
@@ -950,6 +977,14 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         h->graph_key = key;
     }
     V2E_HIP(hipGraphLaunch(h->graph, s));
+    return 0;
+}
+
+int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *ms_scan, double *ms_emit, int *launches)
+{
+    V2E_REQUIRE(h && ms_count && ms_rank && ms_scan && ms_emit && launches, "null");
+    *ms_count = h->prof_ms[0]; *ms_rank = h->prof_ms[1]; *ms_scan = h->prof_ms[2]; *ms_emit = h->prof_ms[3];
+    *launches = h->prof_launches;
     return 0;
 }
 

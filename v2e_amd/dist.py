@@ -1,0 +1,105 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+The hot path shards over *clips*: each clip owns its pixel state, so clips are
+independent units and the compute needs no collective.  The one
+exchange step BASELINE.json names is the all-gather(v) of the ranks' event streams, which
+`EventStreamGatherer` runs on a side stream so that it overlaps the next step's kernels.
+xGMI is point-to-point, so the payload is kept as one large message per rank per step
+(a 300-frame step is ~10 M events = ~170 MB per rank) rather than one per frame.
+"""
+import torch
+import torch.distributed as dist
+
+
+def clips_of_rank(n_clips, world, rank):
+    """clip c runs on rank c mod world (round-robin; clips are independent)."""
+    return [c for c in range(n_clips) if c % world == rank]
+
+
+class EventStreamGatherer:
+    """all-gather(v) of per-rank event lists [n_r,4] float32 -> every rank gets all of them.
+
+    submit(ev, n) snapshots the first n rows of `ev` (device tensor) into a staging buffer and
+    enqueues, on a side stream: MAX-all-reduce of n, all-gather of the counts, all-gather of the
+    row-padded payload.  result() returns (list of per-rank [n_r,4] views in rank order) of the
+    most recent completed submit.  On CPU tensors (gloo, tests) everything runs inline.
+    """
+
+    def __init__(self, device, world, group=None):
+        self.device = torch.device(device)
+        self.world = world
+        self.group = group
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(self.device) if self.cuda else None
+        self.staging = [None, None]
+        self.flip = 0
+        self.done_evt = [None, None]
+        self.out = None
+        self.counts = None
+        self.nmax = 0
+        self.bytes_gathered = 0
+
+    def _ensure(self, slot, rows):
+        s = self.staging[slot]
+        if s is None or s.shape[0] < rows:
+            self.staging[slot] = torch.empty((max(rows, 1), 4), dtype=torch.float32, device=self.device)
+        return self.staging[slot]
+
+    def submit(self, ev, n):
+        slot = self.flip
+        self.flip ^= 1
+        n = int(n)
+        nt = torch.tensor([n], dtype=torch.int64, device=self.device)
+        if self.cuda:
+            main = torch.cuda.current_stream(self.device)
+            if self.done_evt[slot] is not None:
+                main.wait_event(self.done_evt[slot])  # previous gather out of this staging slot
+            ready = torch.cuda.Event()
+            with torch.cuda.stream(self.side):
+                nmax_t = nt.clone()
+                dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX, group=self.group)
+            nmax = int(nmax_t.item())  # small host sync; the previous payload gather is already enqueued
+            st = self._ensure(slot, nmax)
+            st[:n].copy_(ev[:n], non_blocking=True)
+            ready.record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                self._collect(st, nt, nmax)
+                self.done_evt[slot] = torch.cuda.Event()
+                self.done_evt[slot].record(self.side)
+        else:
+            nmax_t = nt.clone()
+            dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX, group=self.group)
+            nmax = int(nmax_t.item())
+            st = self._ensure(slot, nmax)
+            st[:n].copy_(ev[:n])
+            self._collect(st, nt, nmax)
+
+    def _collect(self, st, nt, nmax):
+        counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        out = self.out
+        if out is None or out.shape[0] < self.world * max(nmax, 1):
+            out = torch.empty((self.world * max(nmax, 1), 4), dtype=torch.float32, device=self.device)
+        payload = st[:max(nmax, 1)]
+        if self.cuda:
+            dist.all_gather_into_tensor(counts, nt, group=self.group)
+            dist.all_gather_into_tensor(out[:self.world * max(nmax, 1)], payload, group=self.group)
+        else:
+            cl = [torch.zeros_like(nt) for _ in range(self.world)]
+            dist.all_gather(cl, nt, group=self.group)
+            counts = torch.cat(cl)
+            pl = [torch.empty_like(payload) for _ in range(self.world)]
+            dist.all_gather(pl, payload.contiguous(), group=self.group)
+            out = torch.cat(pl)
+        self.out, self.counts, self.nmax = out, counts, max(nmax, 1)
+        self.bytes_gathered += self.world * max(nmax, 1) * 16
+
+    def wait(self):
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+    def result(self):
+        """Per-rank event lists of the last submit, in rank order (call wait() first)."""
+        self.wait()
+        c = self.counts.cpu().tolist()
+        return [self.out[r * self.nmax: r * self.nmax + c[r]] for r in range(self.world)]

@@ -512,7 +512,7 @@ class EventEmulator(object):
             cap = max(4 * H * W, 1 << 16) * min(nrun, 64)
         ev = eng.event_buffer(cap)
         recs = eng.alloc_recs(nrun)
-        eng.run(P, frames_dev[start:], t_prev, t_frames[start:], self.frame_counter, ev, recs, use_graph=use_graph)
+        eng.run(P, frames_dev[start:], t_prev, t_frames[start:], self.frame_counter, ev, recs, use_graph=int(use_graph))
         r = eng.recs_to_numpy(recs)[:, 0]
         if (r["flags"] & _capi.FLAG_ITERS_CLAMPED).any():
             raise _capi.V2EAmdError("a pixel produced more than max_iters=%d events in one frame; "

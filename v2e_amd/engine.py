@@ -178,12 +178,26 @@ class EmuEngine:
         check(self.lib.v2e_emu_run(self._h, C.byref(P), _ptr(frames_dev), _DT[frames_dev.dtype], F,
                                    tp.ctypes.data_as(C.POINTER(C.c_double)),
                                    tf.ctypes.data_as(C.POINTER(C.c_double)), int(frame_idx0), _ptr(events),
-                                   int(events.shape[1]), _ptr(recs_dev), 1 if use_graph else 0, self.stream),
+                                   int(events.shape[1]), _ptr(recs_dev), int(use_graph), self.stream),
               "v2e_emu_run")
 
+    def last_profile(self):
+        """(ms_count, ms_rank, ms_scan, ms_emit, launches) of the last run(use_graph=2)."""
+        v = [C.c_double() for _ in range(4)]
+        n = C.c_int()
+        check(self.lib.v2e_emu_last_profile(self._h, *[C.byref(x) for x in v], C.byref(n)), "v2e_emu_last_profile")
+        return dict(count=v[0].value, rank=v[1].value, scan=v[2].value, emit=v[3].value, launches=n.value)
+
     def alloc_recs(self, n_frames):
-        """Device record array [F][n_clips] (struct v2e_frame_rec = 32 bytes)."""
-        return torch.zeros((n_frames, self.n_clips, C.sizeof(FrameRec)), dtype=torch.uint8, device=self.device)
+        """Device record array [F][n_clips] (struct v2e_frame_rec = 32 bytes), cached per F so that
+        the hipGraph of run() (which bakes the pointer in) stays valid across calls."""
+        cache = self.__dict__.setdefault("_recs_cache", {})
+        if n_frames not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[n_frames] = torch.zeros((n_frames, self.n_clips, C.sizeof(FrameRec)), dtype=torch.uint8,
+                                          device=self.device)
+        return cache[n_frames]
 
     @staticmethod
     def recs_to_numpy(recs_dev):
