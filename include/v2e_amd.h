@@ -211,14 +211,15 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *convs, int co
  * slomo.py:405-419 for `n_t` time points of one batch: flow blend, two backWarps and
  * assembly of the 12-channel interpolation input
  * [I0,I1,F01(2),F10(2),Ft1(2),Ft0(2),g1,g0] -> x12 [n_t*b][12][h][w].
- * flow: flow-UNet output [b][4][h][w]; t: host array [n_t].
+ * flow: flow-UNet output [b][4][h][w]; tcoef: DEVICE array [n_t][6] float32 =
+ * {fCoeff[0..3], wCoeff[0..1]} of slomo.py:406-407,429, evaluated by the host in doubles.
  */
-int v2e_slomo_prep(const float *i0, const float *i1, const float *flow, const float *t, int n_t,
+int v2e_slomo_prep(const float *i0, const float *i1, const float *flow, const float *tcoef, int n_t,
                    int b, int h, int w, float *x12, void *stream);
 
 /* slomo.py:421-433: refine flows, visibility, two backWarps, fusion -> out [n_t*b][1][h][w] */
 int v2e_slomo_fuse(const float *i0, const float *i1, const float *x12, const float *intrp,
-                   const float *t, int n_t, int b, int h, int w, float *out, void *stream);
+                   const float *tcoef, int n_t, int b, int h, int w, float *out, void *stream);
 
 #ifdef __cplusplus
 }

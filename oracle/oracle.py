@@ -336,3 +336,90 @@ class OracleEmulator:
                          shot_on=shot_on, shot_off=shot_off)
         self.t_previous = t_frame
         return events if ne > 0 else None
+
+
+# ----------------------------------------------------------------- SuperSloMo
+UNET_LAYERS = (["conv1", "conv2"] + ["down%d.conv%d" % (d, c) for d in range(1, 6) for c in (1, 2)] +
+               ["up%d.conv%d" % (u, c) for u in range(1, 6) for c in (1, 2)] + ["conv3"])
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def conv2d_lrelu(x, w, b):
+    """leaky_relu(conv2d(x, w, b, padding=(k-1)//2), 0.1); x [n,cin,h,w], w [cout,cin,k,k]."""
+    x, w, b = _f32(x), _f32(w), _f32(b)
+    n, cin, h, wd = x.shape
+    cout, _, k, _ = w.shape
+    y = np.empty((n, cout, h, wd), np.float32)
+    lib().v2e_oracle_conv2d_lrelu(_p(x), n, cin, h, wd, _p(w), _p(b), cout, k, _p(y))
+    return y
+
+
+def avgpool2(x):
+    x = _f32(x)
+    n, c, h, w = x.shape
+    y = np.empty((n, c, h // 2, w // 2), np.float32)
+    lib().v2e_oracle_avgpool2(_p(x), n * c, h, w, _p(y))
+    return y
+
+
+def upsample2(x):
+    x = _f32(x)
+    n, c, h, w = x.shape
+    y = np.empty((n, c, 2 * h, 2 * w), np.float32)
+    lib().v2e_oracle_upsample2(_p(x), n * c, h, w, _p(y))
+    return y
+
+
+def unet_forward(x, sd):
+    """model.UNet.forward with state dict `sd` (numpy arrays, torch key names)."""
+    x = _f32(x)
+    n, cin, h, w = x.shape
+    ws = [_f32(sd[k + ".weight"]) for k in UNET_LAYERS]
+    bs = [_f32(sd[k + ".bias"]) for k in UNET_LAYERS]
+    meta = np.array([[wt.shape[1], wt.shape[0], wt.shape[2]] for wt in ws], np.int32)
+    cout = ws[-1].shape[0]
+    wp = (C.c_void_p * 23)(*[wt.ctypes.data for wt in ws])
+    bp = (C.c_void_p * 23)(*[bt.ctypes.data for bt in bs])
+    y = np.empty((n, cout, h, w), np.float32)
+    rc = lib().v2e_oracle_unet_forward(_p(x), n, cin, h, w, wp, bp, _p(meta), _p(y))
+    assert rc == 0
+    return y
+
+
+def time_coefficients(ts):
+    rows = []
+    for t in ts:
+        t = float(t)
+        temp = -t * (1 - t)
+        rows.append([temp, t * t, (1 - t) * (1 - t), temp, 1 - t, t])
+    return np.asarray(rows, dtype=np.float64).astype(np.float32)
+
+
+def slomo_prep(I0, I1, flow, ts):
+    I0, I1, flow = _f32(I0), _f32(I1), _f32(flow)
+    b, _, h, w = I0.shape
+    coef = time_coefficients(ts)
+    x12 = np.empty((len(ts) * b, 12, h, w), np.float32)
+    lib().v2e_oracle_slomo_prep(_p(I0), _p(I1), _p(flow), _p(coef), len(ts), b, h, w, _p(x12))
+    return x12
+
+
+def slomo_fuse(I0, I1, x12, intrp, ts):
+    I0, I1, x12, intrp = _f32(I0), _f32(I1), _f32(x12), _f32(intrp)
+    b, _, h, w = I0.shape
+    coef = time_coefficients(ts)
+    out = np.empty((len(ts) * b, 1, h, w), np.float32)
+    lib().v2e_oracle_slomo_fuse(_p(I0), _p(I1), _p(x12), _p(intrp), _p(coef), len(ts), b, h, w, _p(out))
+    return out.reshape(len(ts), b, 1, h, w)
+
+
+def slomo_interpolate(I0, I1, ts, flow_sd, interp_sd):
+    """slomo.py:343, 404-433 on numpy arrays; returns dict(flow, x12, intrp, Ft)."""
+    flow = unet_forward(np.concatenate((I0, I1), axis=1), flow_sd)
+    x12 = slomo_prep(I0, I1, flow, ts)
+    intrp = unet_forward(x12, interp_sd)
+    Ft = slomo_fuse(I0, I1, x12, intrp, ts)
+    return dict(flow=flow, x12=x12, intrp=intrp, Ft=Ft)

@@ -91,8 +91,8 @@ SIGNATURES = {
     "v2e_conv2d_lrelu": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(ConvDesc), _vp, _i, _i, _i, _vp]),
     "v2e_unet_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "v2e_unet_forward": (_i, [_vp, _i, C.POINTER(ConvDesc), _i, _vp, _i, _i, _i, _vp, _vp]),
-    "v2e_slomo_prep": (_i, [_vp, _vp, _vp, C.POINTER(C.c_float), _i, _i, _i, _i, _vp, _vp]),
-    "v2e_slomo_fuse": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_float), _i, _i, _i, _i, _vp, _vp]),
+    "v2e_slomo_prep": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "v2e_slomo_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

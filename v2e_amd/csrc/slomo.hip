@@ -1,10 +1,428 @@
-// placeholder translation unit; real kernels follow
+// slomo.hip -- SuperSloMo frame interpolation (two UNets + backWarp + fusion) for gfx950.
+//
+// Reference (SensorsINI/v2e): v2ecore/model.py:10-226 (UNet/down/up), :229-300 (backWarp),
+// v2ecore/slomo.py:338-345 (flow UNet), :404-433 (per-t blend, 4 warps, interp UNet, fusion).
+//
+// Convolutions are implicit GEMMs on the exact-f32 matrix cores:
+//   D[co][pixel] += W[co][k] * X[k][pixel],  k = (ci, ky, kx)
+// with v_mfma_f32_32x32x2_f32 (A = 32 output channels x 2 k, B = 2 k x 32 pixels).  The pixel
+// axis is the MFMA column axis, so every accumulator register is 32 consecutive x of one
+// output channel: NCHW stores are 128-byte coalesced.  The f32 MFMA is bit-identical to an
+// fmaf chain in k order, and the k order here is fixed (ci-chunk, ky, kx, ci-pair), so results
+// are deterministic run to run; parity with torch-CPU (different summation order) is checked
+// at 1e-5 * max(1,|y|).
+//
+// Per workgroup: WP waves; each wave owns CT x PT tiles of 32 channels x 32 pixels.  Per
+// ci-chunk the input patch (with halo, zero padding, and optionally the preceding
+// avg_pool2d / bilinear x2 upsample / channel concat applied on the fly) and the weight
+// slice are staged in LDS; both operand reads are then `lane base + immediate` ds_read_b32
+// over 32 consecutive dwords per half-wave (conflict-free).
 #include "common.h"
-extern "C" {
-int v2e_pack_conv_weight(const float *, float *, int, int, int, void *) { v2e_set_error("slomo not built"); return V2E_EINVAL; }
-int v2e_conv2d_lrelu(const float *, int, const float *, int, int, const v2e_conv_desc *, float *, int, int, int, void *) { v2e_set_error("slomo not built"); return V2E_EINVAL; }
-int64_t v2e_unet_workspace_bytes(int, int, int, int) { return 0; }
-int v2e_unet_forward(const float *, int, const v2e_conv_desc *, int, float *, int, int, int, void *, void *) { v2e_set_error("slomo not built"); return V2E_EINVAL; }
-int v2e_slomo_prep(const float *, const float *, const float *, const float *, int, int, int, int, float *, void *) { v2e_set_error("slomo not built"); return V2E_EINVAL; }
-int v2e_slomo_fuse(const float *, const float *, const float *, const float *, const float *, int, int, int, int, float *, void *) { v2e_set_error("slomo not built"); return V2E_EINVAL; }
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float *x0, *x1; // x1: second concat source or nullptr
+    int c0, c1;           // channels of x0 / x1
+    const float *w;       // packed [Cin][KS][KS][Cout]
+    const float *bias;
+    float *y;
+    int n, h, w_, cin, cout;
+    int tiles_x, tiles_y;
+};
+
+// element fetch with the producer op fused: PRE 0 plain, 1 avg_pool2d(2) of a [2H][2W] source,
+// 2 bilinear x2 upsample (align_corners=False) of a [H/2][W/2] source.
+template <int PRE>
+__device__ __forceinline__ float fetch(const ConvArgs &a, int n, int c, int gy, int gx)
+{
+    const float *src;
+    int cs, C;
+    if (c < a.c0) { src = a.x0; cs = c; C = a.c0; }
+    else { src = a.x1; cs = c - a.c0; C = a.c1; }
+    if (PRE == 0) {
+        return src[(((size_t)n * C + cs) * a.h + gy) * a.w_ + gx];
+    } else if (PRE == 1) { // F.avg_pool2d(x, 2): (((a+b)+c)+d) / 4
+        const int sw = 2 * a.w_;
+        const float *p = src + (((size_t)n * C + cs) * (2 * a.h) + 2 * gy) * sw + 2 * gx;
+        return (((p[0] + p[1]) + p[sw]) + p[sw + 1]) * 0.25f;
+    } else { // F.interpolate(scale_factor=2, mode='bilinear', align_corners=False)
+        const int sh = a.h >> 1, sw = a.w_ >> 1;
+        float ry = ((float)gy + 0.5f) * 0.5f - 0.5f;
+        float rx = ((float)gx + 0.5f) * 0.5f - 0.5f;
+        ry = ry < 0.f ? 0.f : ry;
+        rx = rx < 0.f ? 0.f : rx;
+        const int y0 = (int)ry, x0 = (int)rx;
+        const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+        const float ly = ry - (float)y0, lx = rx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float *p = src + ((size_t)n * C + cs) * sh * sw;
+        return hy * (hx * p[y0 * sw + x0] + lx * p[y0 * sw + x1]) + ly * (hx * p[y1 * sw + x0] + lx * p[y1 * sw + x1]);
+    }
 }
+
+template <int KS, int CI_T, int CT, int PT, int WP, int TW, int PRE>
+__global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
+{
+    constexpr int NT = WP * 64;
+    constexpr int PAD = KS / 2;
+    constexpr int NPX = WP * PT * 32;
+    constexpr int TH = NPX / TW;
+    constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+    constexpr int COT = CT * 32;
+    constexpr int KK = KS * KS;
+    constexpr int PATCH = CI_T * PH * PW;
+    constexpr int WTS = CI_T * KK * COT;
+    static_assert(NPX % TW == 0, "tile");
+    static_assert(CI_T % 2 == 0, "ci pairs");
+    __shared__ float smem[PATCH + WTS];
+    float *sp = smem, *sw = smem + PATCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hsel = lane >> 5, l31 = lane & 31;
+    int bx = blockIdx.x;
+    const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+    const int ty_i = bx % a.tiles_y;
+    const int n = bx / a.tiles_y;
+    const int oy0 = ty_i * TH, ox0 = tx_i * TW;
+    const int cobase = blockIdx.y * COT;
+
+    int bofs[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int m = (wave * PT + pt) * 32 + l31;
+        bofs[pt] = (hsel * PH + m / TW) * PW + (m % TW);
+    }
+    const int aofs = hsel * KK * COT + l31;
+
+    f32x16 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+
+    for (int cb = 0; cb < a.cin; cb += CI_T) {
+        __syncthreads();
+        for (int idx = tid; idx < PATCH; idx += NT) {
+            const int ci = idx / (PH * PW);
+            const int r = idx - ci * (PH * PW);
+            const int py = r / PW, px = r - py * PW;
+            const int gy = oy0 + py - PAD, gx = ox0 + px - PAD;
+            const int c = cb + ci;
+            float v = 0.f;
+            if (c < a.cin && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_) v = fetch<PRE>(a, n, c, gy, gx);
+            sp[idx] = v;
+        }
+        for (int idx = tid; idx < WTS; idx += NT) {
+            const int kk = idx / COT, co = idx - kk * COT;
+            const int ci = kk / KK;
+            const int gco = cobase + co;
+            float v = 0.f;
+            if (cb + ci < a.cin && gco < a.cout) v = a.w[((size_t)cb * KK + kk) * a.cout + gco];
+            sw[idx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+                for (int cp = 0; cp < CI_T / 2; ++cp) {
+                    const int koff_w = ((cp * 2) * KK + ky * KS + kx) * COT;
+                    const int koff_p = (cp * 2) * PH * PW + ky * PW + kx;
+                    float av[CT], bv[PT];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) av[ct] = sw[aofs + koff_w + ct * 32];
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) bv[pt] = sp[bofs[pt] + koff_p];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[pt], acc[ct][pt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // epilogue: bias + leaky_relu(0.1); register r of lane: channel (r&3)+8(r>>2)+4*hsel, pixel l31
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int m = (wave * PT + pt) * 32 + l31;
+        const int oy = oy0 + m / TW, ox = ox0 + (m % TW);
+        const bool pok = oy < a.h && ox < a.w_;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = cobase + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (pok && ch < a.cout) {
+                    float v = acc[ct][pt][r] + a.bias[ch];
+                    v = v > 0.f ? v : v * 0.1f;
+                    a.y[(((size_t)n * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void k_pack_weight(const float *__restrict__ w, float *__restrict__ wp, int cout, int cin, int kk)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)cout * cin * kk;
+    if (i >= total) return;
+    // wp[(ci*kk + k)*cout + co] = w[(co*cin + ci)*kk + k]
+    const int co = (int)(i % cout);
+    const size_t r = i / cout;
+    const int k = (int)(r % kk);
+    const int ci = (int)(r / kk);
+    wp[i] = w[((size_t)co * cin + ci) * kk + k];
+}
+
+// torch.nn.functional.grid_sample(img, grid) as used by backWarp (model.py:289-299):
+// bilinear, zeros padding, align_corners=False.  x,y already include the flow.
+__device__ __forceinline__ float warp_sample(const float *__restrict__ img, int h, int w, float x, float y)
+{
+    // model.py:294-295: range -1..1, same float32 operation sequence
+    float gx = 2.f * (x / (float)w - 0.5f);
+    float gy = 2.f * (y / (float)h - 0.5f);
+    // grid_sampler unnormalize, align_corners=False: ((g + 1) * size - 1) / 2
+    float ix = ((gx + 1.f) * (float)w - 1.f) / 2.f;
+    float iy = ((gy + 1.f) * (float)h - 1.f) / 2.f;
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    float tx = ix - fx0, ty = iy - fy0;
+    // weights as in ATen grid_sampler_2d: nw = (x1-ix)*(y1-iy) ...
+    float wx1 = tx, wx0 = 1.f - tx, wy1 = ty, wy0 = 1.f - ty;
+    float nw = wx0 * wy0, ne = wx1 * wy0, sw_ = wx0 * wy1, se = wx1 * wy1;
+    float out = 0.f;
+    if (y0 >= 0 && y0 < h) {
+        if (x0 >= 0 && x0 < w) out += img[y0 * w + x0] * nw;
+        if (x1 >= 0 && x1 < w) out += img[y0 * w + x1] * ne;
+    }
+    if (y1 >= 0 && y1 < h) {
+        if (x0 >= 0 && x0 < w) out += img[y1 * w + x0] * sw_;
+        if (x1 >= 0 && x1 < w) out += img[y1 * w + x1] * se;
+    }
+    return out;
+}
+
+// slomo.py:405-419: x12[(ti*b+bi)] = [I0, I1, F01(2), F10(2), Ft1(2), Ft0(2), g(I1,Ft1), g(I0,Ft0)]
+__global__ __launch_bounds__(256) void k_prep(const float *__restrict__ i0, const float *__restrict__ i1,
+                                              const float *__restrict__ flow, const float *__restrict__ coef, int n_t,
+                                              int b, int h, int w, float *__restrict__ x12)
+{
+    const int hw = h * w;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y; // ti*b + bi
+    if (p >= hw) return;
+    const int ti = s / b, bi = s - ti * b;
+    // fCoeff of slomo.py:406-407, evaluated by the host in Python doubles and rounded to float32
+    const float c00 = coef[ti * 6 + 0], c01 = coef[ti * 6 + 1], c10 = coef[ti * 6 + 2], c11 = coef[ti * 6 + 3];
+    const float *fl = flow + (size_t)bi * 4 * hw;
+    const float f01x = fl[p], f01y = fl[hw + p], f10x = fl[2 * hw + p], f10y = fl[3 * hw + p];
+    const float ft0x = c00 * f01x + c01 * f10x, ft0y = c00 * f01y + c01 * f10y;
+    const float ft1x = c10 * f01x + c11 * f10x, ft1y = c10 * f01y + c11 * f10y;
+    const int py = p / w, px = p - py * w;
+    const float *im0 = i0 + (size_t)bi * hw, *im1 = i1 + (size_t)bi * hw;
+    const float g0 = warp_sample(im0, h, w, (float)px + ft0x, (float)py + ft0y);
+    const float g1 = warp_sample(im1, h, w, (float)px + ft1x, (float)py + ft1y);
+    float *o = x12 + (size_t)s * 12 * hw + p;
+    o[0] = im0[p];
+    o[hw] = im1[p];
+    o[2 * hw] = f01x; o[3 * hw] = f01y;
+    o[4 * hw] = f10x; o[5 * hw] = f10y;
+    o[6 * hw] = ft1x; o[7 * hw] = ft1y;
+    o[8 * hw] = ft0x; o[9 * hw] = ft0y;
+    o[10 * hw] = g1;
+    o[11 * hw] = g0;
+}
+
+// slomo.py:421-433
+__global__ __launch_bounds__(256) void k_fuse(const float *__restrict__ i0, const float *__restrict__ i1,
+                                              const float *__restrict__ x12, const float *__restrict__ intrp,
+                                              const float *__restrict__ coef, int n_t, int b, int h, int w,
+                                              float *__restrict__ out)
+{
+    const int hw = h * w;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (p >= hw) return;
+    const int ti = s / b, bi = s - ti * b;
+    const float *x = x12 + (size_t)s * 12 * hw + p;
+    const float *q = intrp + (size_t)s * 5 * hw + p;
+    const float ft0x = q[0] + x[8 * hw], ft0y = q[hw] + x[9 * hw];
+    const float ft1x = q[2 * hw] + x[6 * hw], ft1y = q[3 * hw] + x[7 * hw];
+    const float v0 = 1.f / (1.f + expf(-q[4 * hw])); // torch.sigmoid
+    const float v1 = 1.f - v0;
+    const int py = p / w, px = p - py * w;
+    const float g0 = warp_sample(i0 + (size_t)bi * hw, h, w, (float)px + ft0x, (float)py + ft0y);
+    const float g1 = warp_sample(i1 + (size_t)bi * hw, h, w, (float)px + ft1x, (float)py + ft1y);
+    const float w0 = coef[ti * 6 + 4], w1 = coef[ti * 6 + 5]; // wCoeff = [1 - t, t]
+    out[(size_t)s * hw + p] = (w0 * v0 * g0 + w1 * v1 * g1) / (w0 * v0 + w1 * v1);
+}
+
+// ---------------------------------------------------------------- dispatch
+template <int KS, int CI_T, int CT, int PT, int WP, int TW, int PRE>
+static void launch_conv(const ConvArgs &a0, hipStream_t s)
+{
+    ConvArgs a = a0;
+    constexpr int TH = WP * PT * 32 / TW;
+    a.tiles_x = (a.w_ + TW - 1) / TW;
+    a.tiles_y = (a.h + TH - 1) / TH;
+    dim3 grid((unsigned)(a.n * a.tiles_x * a.tiles_y), (unsigned)((a.cout + CT * 32 - 1) / (CT * 32)));
+    k_conv<KS, CI_T, CT, PT, WP, TW, PRE><<<grid, WP * 64, 0, s>>>(a);
+}
+
+template <int KS, int CI_T, int CT, int PRE>
+static void launch_conv_tw(const ConvArgs &a, hipStream_t s)
+{
+    if (a.w_ % 32 == 0 || (a.w_ % 16 != 0 && a.w_ % 8 != 0)) launch_conv<KS, CI_T, CT, 2, 4, 32, PRE>(a, s);
+    else if (a.w_ % 16 == 0) launch_conv<KS, CI_T, CT, 2, 4, 16, PRE>(a, s);
+    else launch_conv<KS, CI_T, CT, 2, 4, 8, PRE>(a, s);
+}
+
+static int conv_dispatch(const ConvArgs &a, int ks, int pre, hipStream_t s)
+{
+    // wide channel tile only when it still leaves enough workgroups to fill 256 CUs
+    const long px_tiles = (long)a.n * ((a.h * a.w_ + 255) / 256);
+    const bool wide = a.cout >= 64 && px_tiles * (a.cout / 64) >= 512;
+    if (ks == 7) {
+        if (pre != 0) return V2E_EINVAL;
+        if (a.cin % 4 == 0) launch_conv<7, 4, 1, 2, 4, 32, 0>(a, s);
+        else launch_conv<7, 2, 1, 2, 4, 32, 0>(a, s);
+    } else if (ks == 5) {
+        if (pre == 2) return V2E_EINVAL;
+        if (wide) { if (pre) launch_conv<5, 4, 2, 2, 4, 32, 1>(a, s); else launch_conv<5, 4, 2, 2, 4, 32, 0>(a, s); }
+        else { if (pre) launch_conv<5, 4, 1, 2, 4, 32, 1>(a, s); else launch_conv<5, 4, 1, 2, 4, 32, 0>(a, s); }
+    } else if (ks == 3) {
+        if (wide) {
+            if (pre == 0) launch_conv_tw<3, 8, 2, 0>(a, s);
+            else if (pre == 1) launch_conv_tw<3, 8, 2, 1>(a, s);
+            else launch_conv_tw<3, 8, 2, 2>(a, s);
+        } else {
+            if (pre == 0) launch_conv_tw<3, 8, 1, 0>(a, s);
+            else if (pre == 1) launch_conv_tw<3, 8, 1, 1>(a, s);
+            else launch_conv_tw<3, 8, 1, 2>(a, s);
+        }
+    } else {
+        return V2E_EINVAL;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int v2e_pack_conv_weight(const float *w_oihw, float *w_packed, int cout, int cin, int k, void *stream)
+{
+    V2E_REQUIRE(w_oihw && w_packed && cout > 0 && cin > 0 && k > 0, "bad pack args");
+    const size_t total = (size_t)cout * cin * k * k;
+    k_pack_weight<<<v2e_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, w_packed, cout, cin, k * k);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, const v2e_conv_desc *conv, float *y,
+                     int n, int h, int w, void *stream)
+{
+    V2E_REQUIRE(x0 && conv && conv->weight && conv->bias && y, "null conv arg");
+    V2E_REQUIRE(c0 + c1 == conv->cin && (c1 == 0 || x1), "channel split does not match the layer");
+    V2E_REQUIRE(pre == 0 || c1 == 0, "fused pool/upsample takes a single source");
+    V2E_REQUIRE(pre != 2 || (h % 2 == 0 && w % 2 == 0), "upsample target must be even");
+    V2E_REQUIRE(conv->cin % 2 == 0, "cin must be even");
+    ConvArgs a;
+    a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1;
+    a.w = conv->weight; a.bias = conv->bias; a.y = y;
+    a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout;
+    a.tiles_x = a.tiles_y = 0;
+    int rc = conv_dispatch(a, conv->ksize, pre, (hipStream_t)stream);
+    if (rc) { v2e_set_error("unsupported conv: k=%d pre=%d", conv->ksize, pre); return rc; }
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+// workspace layout (floats): s1 s2 s3 s4 s5 | tA tB   (model.py:198-226)
+int64_t v2e_unet_workspace_bytes(int n, int h, int w, int cin)
+{
+    (void)cin;
+    const int64_t hw = (int64_t)h * w;
+    // s1 32hw, s2 16hw, s3 8hw, s4 4hw, s5 2hw, two temporaries of 32hw
+    return (int64_t)n * hw * (32 + 16 + 8 + 4 + 2 + 32 + 32) * (int64_t)sizeof(float);
+}
+
+int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout, float *y, int n, int h, int w,
+                     void *workspace, void *stream)
+{
+    V2E_REQUIRE(x && cv && y && workspace, "null unet arg");
+    V2E_REQUIRE(h % 32 == 0 && w % 32 == 0, "UNet input must be a multiple of 32 (dataloader.py:122-123)");
+    V2E_REQUIRE(cv[0].cin == cin && cv[22].cout == cout, "descriptor list does not match cin/cout");
+    const int64_t hw = (int64_t)h * w;
+    float *ws = (float *)workspace;
+    float *s1 = ws; float *s2 = s1 + n * hw * 32; float *s3 = s2 + n * hw * 16; float *s4 = s3 + n * hw * 8;
+    float *s5 = s4 + n * hw * 4; float *tA = s5 + n * hw * 2; float *tB = tA + n * hw * 32;
+    int rc;
+#define CONV(X0, C0, X1, C1, PRE, IDX, Y, HH, WW)                                              \
+    do {                                                                                        \
+        rc = v2e_conv2d_lrelu((X0), (C0), (X1), (C1), (PRE), &cv[(IDX)], (Y), n, (HH), (WW), stream); \
+        if (rc) return rc;                                                                      \
+    } while (0)
+    // conv1, conv2
+    CONV(x, cin, nullptr, 0, 0, 0, tA, h, w);
+    CONV(tA, 32, nullptr, 0, 0, 1, s1, h, w);
+    // down1..down5: avg_pool2d fused into the first conv of each block
+    CONV(s1, 32, nullptr, 0, 1, 2, tA, h / 2, w / 2);
+    CONV(tA, 64, nullptr, 0, 0, 3, s2, h / 2, w / 2);
+    CONV(s2, 64, nullptr, 0, 1, 4, tA, h / 4, w / 4);
+    CONV(tA, 128, nullptr, 0, 0, 5, s3, h / 4, w / 4);
+    CONV(s3, 128, nullptr, 0, 1, 6, tA, h / 8, w / 8);
+    CONV(tA, 256, nullptr, 0, 0, 7, s4, h / 8, w / 8);
+    CONV(s4, 256, nullptr, 0, 1, 8, tA, h / 16, w / 16);
+    CONV(tA, 512, nullptr, 0, 0, 9, s5, h / 16, w / 16);
+    CONV(s5, 512, nullptr, 0, 1, 10, tA, h / 32, w / 32);
+    CONV(tA, 512, nullptr, 0, 0, 11, tB, h / 32, w / 32);
+    // up1..up5: bilinear x2 fused into conv1, skip concat fused into conv2 (x first, skip second)
+    CONV(tB, 512, nullptr, 0, 2, 12, tA, h / 16, w / 16);
+    CONV(tA, 512, s5, 512, 0, 13, tB, h / 16, w / 16);
+    CONV(tB, 512, nullptr, 0, 2, 14, tA, h / 8, w / 8);
+    CONV(tA, 256, s4, 256, 0, 15, tB, h / 8, w / 8);
+    CONV(tB, 256, nullptr, 0, 2, 16, tA, h / 4, w / 4);
+    CONV(tA, 128, s3, 128, 0, 17, tB, h / 4, w / 4);
+    CONV(tB, 128, nullptr, 0, 2, 18, tA, h / 2, w / 2);
+    CONV(tA, 64, s2, 64, 0, 19, tB, h / 2, w / 2);
+    CONV(tB, 64, nullptr, 0, 2, 20, tA, h, w);
+    CONV(tA, 32, s1, 32, 0, 21, tB, h, w);
+    // conv3 (+ leaky relu, model.py:225)
+    CONV(tB, 32, nullptr, 0, 0, 22, y, h, w);
+#undef CONV
+    return 0;
+}
+
+int v2e_slomo_prep(const float *i0, const float *i1, const float *flow, const float *tcoef, int n_t, int b, int h, int w,
+                   float *x12, void *stream)
+{
+    const float *t = tcoef;
+    V2E_REQUIRE(i0 && i1 && flow && t && x12 && n_t > 0 && b > 0, "bad prep args");
+    dim3 grid(v2e_cdiv((int64_t)h * w, 256), n_t * b);
+    k_prep<<<grid, 256, 0, (hipStream_t)stream>>>(i0, i1, flow, t, n_t, b, h, w, x12);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_slomo_fuse(const float *i0, const float *i1, const float *x12, const float *intrp, const float *tcoef, int n_t,
+                   int b, int h, int w, float *out, void *stream)
+{
+    const float *t = tcoef;
+    V2E_REQUIRE(i0 && i1 && x12 && intrp && t && out && n_t > 0 && b > 0, "bad fuse args");
+    dim3 grid(v2e_cdiv((int64_t)h * w, 256), n_t * b);
+    k_fuse<<<grid, 256, 0, (hipStream_t)stream>>>(i0, i1, x12, intrp, t, n_t, b, h, w, out);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+} // extern "C"

@@ -1,3 +1,281 @@
-"""placeholder, replaced below"""
+"""Drop-in `SuperSloMo` running the interpolation network on MI355X HIP kernels.
+
+Mirrors v2ecore/slomo.py: constructor signature (:44-54), `interpolate(source_frame_path,
+output_folder, frame_size) -> (interpTimes, avgUpsampling)` writing `<idx>.png` (:231-495),
+`get_interpolated_timestamps` (:540-564), `cleanup`.  The two UNets, the backWarp
+grid-sample, the flow blends and the fusion (slomo.py:338-345, 404-433; model.py:10-300) run
+in libv2e_amd.so (f32 MFMA implicit-GEMM convolutions); PyTorch only owns the buffers.
+
+Differences from the reference, all at the edges of the hot path:
+  * all `upsampling_factor` time points of a batch go through the interpolation UNet as one
+    batch (n_t * B samples) instead of a Python loop -- same arithmetic per sample;
+  * the AVI/preview writers (slomo.py:288-303, 447-490) are not implemented
+    (`video_path`/`preview` raise NotImplementedError);
+  * host-side pre/post-processing (PIL LANCZOS / BILINEAR resize, PNG files) is kept as is.
+"""
+import atexit
+import glob
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import ConvDesc, check
+
+logger = logging.getLogger(__name__)
+
+# forward order of the 23 convolutions of model.UNet (model.py:184-196, 198-226)
+UNET_LAYERS = (["conv1", "conv2"] + ["down%d.conv%d" % (d, c) for d in range(1, 6) for c in (1, 2)] +
+               ["up%d.conv%d" % (u, c) for u in range(1, 6) for c in (1, 2)] + ["conv3"])
+
+
+def _ptr(t):
+    import ctypes as C
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipUNet:
+    """One UNet's weights, repacked [Cin][k][k][Cout] in HBM, and its forward pass."""
+
+    def __init__(self, state_dict, cin, cout, device):
+        import ctypes as C
+        self.lib = _capi.lib()
+        self.device = torch.device(device)
+        self.cin, self.cout = cin, cout
+        self._keep = []
+        descs = (ConvDesc * 23)()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        for i, name in enumerate(UNET_LAYERS):
+            w = state_dict[name + ".weight"].detach().to(self.device, torch.float32).contiguous()
+            b = state_dict[name + ".bias"].detach().to(self.device, torch.float32).contiguous()
+            co, ci, kh, kw = w.shape
+            assert kh == kw
+            wp = torch.empty((ci, kh, kw, co), dtype=torch.float32, device=self.device)
+            check(self.lib.v2e_pack_conv_weight(_ptr(w), _ptr(wp), co, ci, kh, stream), "v2e_pack_conv_weight")
+            self._keep += [wp, b]
+            descs[i].weight = wp.data_ptr()
+            descs[i].bias = b.data_ptr()
+            descs[i].cin, descs[i].cout, descs[i].ksize = ci, co, kh
+        torch.cuda.synchronize(self.device)
+        assert descs[0].cin == cin and descs[22].cout == cout
+        self.descs = descs
+        self._ws = None
+
+    def forward(self, x, out=None):
+        import ctypes as C
+        n, c, h, w = x.shape
+        assert c == self.cin and x.dtype == torch.float32 and x.is_contiguous()
+        need = int(self.lib.v2e_unet_workspace_bytes(n, h, w, c))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
+              "v2e_unet_forward")
+        return out
+
+
+def time_coefficients(ts):
+    """[n_t][6] float32: fCoeff[0..3] (slomo.py:406-407) and wCoeff (:429), in Python doubles first."""
+    rows = []
+    for t in ts:
+        t = float(t)
+        temp = -t * (1 - t)
+        rows.append([temp, t * t, (1 - t) * (1 - t), temp, 1 - t, t])
+    return np.asarray(rows, dtype=np.float64).astype(np.float32)
+
+
+class SloMoEngine:
+    """Flow UNet + interpolation UNet + warps/fusion for batches of frame pairs, on device."""
+
+    def __init__(self, flow_state_dict, interp_state_dict, device="cuda"):
+        if not torch.cuda.is_available():
+            raise _capi.V2EAmdError("v2e_amd.SloMoEngine needs a ROCm GPU; there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = _capi.lib()
+        self.flow_net = HipUNet(flow_state_dict, 2, 4, self.device)
+        self.interp_net = HipUNet(interp_state_dict, 12, 5, self.device)
+        self._x2 = None
+
+    def _stream(self):
+        import ctypes as C
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def flow(self, I0, I1):
+        """flowOut = flow_estimator(cat(I0, I1)) (slomo.py:343); I0, I1: [B,1,H,W] float32."""
+        x = torch.cat((I0, I1), dim=1).contiguous()  # 2 channels; the large concats are fused in-kernel
+        return self.flow_net.forward(x)
+
+    def interpolate(self, I0, I1, ts, flow=None):
+        """Ft_p for every t in ts and every pair in the batch: returns [len(ts), B, 1, H, W]."""
+        B, _, H, W = I0.shape
+        I0 = I0.contiguous()
+        I1 = I1.contiguous()
+        if flow is None:
+            flow = self.flow(I0, I1)
+        nt = len(ts)
+        coef = torch.from_numpy(time_coefficients(ts)).to(self.device)
+        x12 = torch.empty((nt * B, 12, H, W), dtype=torch.float32, device=self.device)
+        check(self.lib.v2e_slomo_prep(_ptr(I0), _ptr(I1), _ptr(flow), _ptr(coef), nt, B, H, W, _ptr(x12), self._stream()),
+              "v2e_slomo_prep")
+        intrp = self.interp_net.forward(x12)
+        out = torch.empty((nt * B, 1, H, W), dtype=torch.float32, device=self.device)
+        check(self.lib.v2e_slomo_fuse(_ptr(I0), _ptr(I1), _ptr(x12), _ptr(intrp), _ptr(coef), nt, B, H, W, _ptr(out),
+                                      self._stream()), "v2e_slomo_fuse")
+        self.last = dict(flow=flow, x12=x12, intrp=intrp)
+        return out.view(nt, B, 1, H, W)
+
+
 class SuperSloMo(object):
-    pass
+    """Super SloMo class (MI355X implementation of v2ecore.slomo.SuperSloMo)."""
+
+    def __init__(self, model, auto_upsample, upsampling_factor, batch_size=1, video_path=None,
+                 vid_orig='original.avi', vid_slomo='slomo.avi', preview=False, avi_frame_rate=30):
+        if torch.cuda.is_available():
+            self.device = "cuda:0"  # slomo.py:84
+        else:
+            self.device = "cpu"
+            logger.warning('no ROCm GPU visible: v2e_amd.SuperSloMo cannot interpolate (no CPU fallback)')
+        self.checkpoint = model
+        self.batch_size = batch_size
+        if not auto_upsample and (not isinstance(upsampling_factor, int) or upsampling_factor < 2):
+            raise ValueError('upsampling_factor={} but must be an int value>1 when auto_upsample=True'.format(
+                upsampling_factor))  # slomo.py:91-94
+        self.upsampling_factor = upsampling_factor
+        self.auto_upsample = auto_upsample
+        if video_path is not None or preview:
+            raise NotImplementedError("v2e_amd.SuperSloMo: AVI output / preview are outside the hot path")
+        self.video_path = None
+        self.preview = False
+        self.vid_orig, self.vid_slomo, self.avi_frame_rate = vid_orig, vid_slomo, avi_frame_rate
+        self.model_loaded = False
+        self.engine = None
+        self.mean = 0.428  # slomo.py:148: Normalize(mean=[0.428], std=[1]) on the GPU path only
+        atexit.register(self.cleanup)
+
+    def cleanup(self):
+        pass
+
+    def _load_model(self):
+        if not os.path.isfile(self.checkpoint):
+            raise FileNotFoundError('SuperSloMo model checkpoint ' + str(self.checkpoint) +
+                                    ' does not exist or is not readable')  # slomo.py:203-205
+        logger.info('loading SuperSloMo model from ' + str(self.checkpoint))
+        d = torch.load(self.checkpoint, map_location="cpu", weights_only=False)
+        self.engine = SloMoEngine(d['state_dictFC'], d['state_dictAT'], self.device)  # slomo.py:225-227
+        self.model_loaded = True
+
+    @staticmethod
+    def _load_pair_tensor(files, idx, dim):
+        """dataloader.py:136-147: np.load -> PIL LANCZOS resize -> ToTensor ([1,H,W] float32 in 0..1)."""
+        from PIL import Image
+        out = []
+        for f in (files[idx], files[idx + 1]):
+            img = Image.fromarray(np.load(f)).resize(dim, Image.LANCZOS)
+            a = np.asarray(img)
+            if a.ndim == 2:
+                a = a[None]
+            else:
+                a = np.transpose(a, (2, 0, 1))
+            out.append(torch.from_numpy(a.astype(np.float32) / 255.0))  # ToTensor on uint8
+        return out
+
+    def interpolate(self, source_frame_path, output_folder, frame_size):
+        """Run interpolation; writes <idx>.png into output_folder (slomo.py:231-495)."""
+        from PIL import Image
+        if not output_folder:
+            raise ValueError('output_folder is None; it must be supplied to store the interpolated frames')
+        if self.device == "cpu":
+            raise _capi.V2EAmdError("v2e_amd.SuperSloMo needs a ROCm GPU; there is no CPU fallback")
+        nframes = len(os.listdir(source_frame_path))
+        if nframes / self.batch_size < 2:
+            logger.warning(f'only {nframes} input frames with batch_size={self.batch_size}, automatically '
+                           f'reducing batch size to provide at least 2 batches')
+            while nframes / self.batch_size < 2:
+                self.batch_size = int(self.batch_size / 2)
+        files = sorted(glob.glob("{}".format(source_frame_path) + "/*.npy"))  # dataloader.py:115
+        ori_dim = frame_size
+        dim = (int(ori_dim[0] / 32) * 32, int(ori_dim[1] / 32) * 32)  # dataloader.py:122-123
+        npairs = len(files) - 1
+        nbatches = (npairs + self.batch_size - 1) // self.batch_size
+        if nbatches < 2:
+            raise Exception('there are only {} batches in {} and we need at least 2; maybe you need to reduce batch '
+                            'size or increase number of input frames'.format(nbatches, source_frame_path))
+        if not self.model_loaded:
+            self._load_model()
+        outputFrameCounter = 0
+        inputFrameCounter = 0
+        upsamplingSum = 0
+        nUpsamplingSamples = 0
+        interpTimes = None
+        dev = self.engine.device
+        for b0 in range(0, npairs, self.batch_size):
+            idxs = list(range(b0, min(b0 + self.batch_size, npairs)))
+            pairs = [self._load_pair_tensor(files, i, dim) for i in idxs]
+            I0 = (torch.stack([p[0] for p in pairs]) - self.mean).to(dev)
+            I1 = (torch.stack([p[1] for p in pairs]) - self.mean).to(dev)
+            num_batch_frames = I0.shape[0]
+            flowOut = self.engine.flow(I0, I1)
+            if self.auto_upsample:  # slomo.py:352-379
+                v = flowOut.flatten(2, 3)
+                sp0 = torch.sqrt(v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1])
+                sp1 = torch.sqrt(v[:, 2] * v[:, 2] + v[:, 3] * v[:, 3])
+                maxSpeed = float(torch.max(torch.cat((sp0, sp1), 1)).cpu().item())
+                upsampling_factor = int(np.ceil(maxSpeed))
+                if self.upsampling_factor is not None and self.upsampling_factor > upsampling_factor:
+                    upsampling_factor = self.upsampling_factor
+            else:
+                upsampling_factor = self.upsampling_factor
+            if upsampling_factor < 2:
+                upsampling_factor = 2
+            nUpsamplingSamples += 1
+            upsamplingSum += upsampling_factor
+            numOutputFramesThisBatch = upsampling_factor * num_batch_frames
+            interframeTimes = inputFrameCounter + np.array(range(numOutputFramesThisBatch)) * (1 / upsampling_factor)
+            interpTimes = interframeTimes if interpTimes is None else np.concatenate((interpTimes, interframeTimes))
+            ts = [(k + 0.5) / upsampling_factor for k in range(upsampling_factor)]  # slomo.py:405
+            Ft = self.engine.interpolate(I0, I1, ts, flow=flowOut)  # [U,B,1,H,W]
+            # ToPILImage after revNormalize (slomo.py:153-161, 437): x*255 -> byte (truncation)
+            img_u8 = ((Ft + self.mean) * 255.0).to(torch.uint8).cpu().numpy()
+            for k in range(upsampling_factor):
+                for batchIndex in range(num_batch_frames):
+                    img = Image.fromarray(img_u8[k, batchIndex, 0], mode="L")
+                    img_resize = img.resize(ori_dim, Image.BILINEAR)
+                    outputFrameIdx = outputFrameCounter + upsampling_factor * batchIndex + k
+                    img_resize.save(os.path.join(output_folder, str(outputFrameIdx) + ".png"))
+            inputFrameCounter += num_batch_frames
+            outputFrameCounter += numOutputFramesThisBatch
+        avgUpsampling = upsamplingSum / nUpsamplingSamples
+        return interpTimes, avgUpsampling
+
+    def get_interpolated_timestamps(self, ts):  # slomo.py:540-564
+        new_ts = []
+        for i in range(ts.shape[0] - 1):
+            start, end = ts[i], ts[i + 1]
+            interpolated_ts = np.linspace(start, end, self.upsampling_factor, endpoint=False) + \
+                0.5 * (end - start) / self.upsampling_factor
+            new_ts.append(interpolated_ts)
+        return np.hstack(new_ts)
+
+
+def slomo_smoke():
+    """Tiny SloMo step on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke)."""
+    from oracle import oracle as orc
+    from .synth import int_gradient_frames, portable_unet_state_dict
+    H, W = 32, 64
+    fr = int_gradient_frames(2, H, W, seed=2, noise=8, as_array=True).astype(np.float32) / np.float32(255.0)
+    I0, I1 = fr[0:1, None] - np.float32(0.428), fr[1:2, None] - np.float32(0.428)
+    sd_f, sd_i = portable_unet_state_dict(2, 4, 201), portable_unet_state_dict(12, 5, 202)
+    eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
+                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, "cuda:0")
+    ts = [0.25, 0.75]
+    Ft = eng.interpolate(torch.from_numpy(I0).cuda(), torch.from_numpy(I1).cuda(), ts).cpu().numpy()
+    ref = orc.slomo_interpolate(I0, I1, ts, sd_f, sd_i)["Ft"]
+    err = float(np.max(np.abs(Ft - ref) / np.maximum(1.0, np.abs(ref))))
+    assert err < 1e-5, "slomo smoke mismatch %g" % err
+    print("smoke: slomo OK, max rel err vs oracle %.2e" % err)

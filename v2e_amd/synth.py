@@ -42,3 +42,35 @@ def sincos_gradient_frames(n, H, W, seed=1, sigma=3.0):
             f = f + sigma * rng.standard_normal((H, W))
         out[i] = np.clip(f, 0, 255).astype(np.uint8)
     return out
+
+
+def unet_layer_shapes(cin, cout):
+    """(name, cout, cin, k) of the 23 convolutions of model.UNet (model.py:184-196)."""
+    L = [("conv1", 32, cin, 7), ("conv2", 32, 32, 7)]
+    ch = [32, 64, 128, 256, 512, 512]
+    ks = [5, 3, 3, 3, 3]
+    for d in range(1, 6):
+        L.append(("down%d.conv1" % d, ch[d], ch[d - 1], ks[d - 1]))
+        L.append(("down%d.conv2" % d, ch[d], ch[d], ks[d - 1]))
+    up_in = [512, 512, 256, 128, 64]
+    up_out = [512, 256, 128, 64, 32]
+    for u in range(1, 6):
+        L.append(("up%d.conv1" % u, up_out[u - 1], up_in[u - 1], 3))
+        L.append(("up%d.conv2" % u, up_out[u - 1], 2 * up_out[u - 1], 3))
+    L.append(("conv3", cout, 32, 3))
+    return L
+
+
+def portable_unet_state_dict(cin, cout, seed, gain=1.7):
+    """Random-init UNet weights (numpy, torch key names) from integer draws only, so every
+    host regenerates the same bits: uniform(-b, b), b = gain / sqrt(fan_in) (the pretrained
+    SuperSloMo39.ckpt is not obtainable offline)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = {}
+    for name, co, ci, k in unet_layer_shapes(cin, cout):
+        bound = np.float32(gain / np.sqrt(ci * k * k))
+        u = rng.integers(0, 1 << 24, size=(co, ci, k, k), dtype=np.int64).astype(np.float32) / np.float32(1 << 23) - np.float32(1.0)
+        sd[name + ".weight"] = (u * bound).astype(np.float32)
+        ub = rng.integers(0, 1 << 24, size=(co,), dtype=np.int64).astype(np.float32) / np.float32(1 << 23) - np.float32(1.0)
+        sd[name + ".bias"] = (ub * bound).astype(np.float32)
+    return sd
