@@ -1,0 +1,117 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/v2e_amd.h declares
+(no compute calls), and the host logic of the drop-in classes behaves like the reference's."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "v2e_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(v2e_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from v2e_amd import _capi
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    assert sorted(_capi.SIGNATURES) == syms, "ctypes table and header disagree"
+    lib = _capi.lib()  # raises if the .so or a symbol is missing
+    for s in syms:
+        assert hasattr(lib, s)
+    assert lib.v2e_version() >= 100
+    assert lib.v2e_emu_npx_pad(260, 346) == 90112
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from v2e_amd._capi import ConvDesc, EmuParams, FrameRec
+    assert C.sizeof(FrameRec) == 32
+    assert C.sizeof(EmuParams) == 16 + 12 * 8 + 8 + 8
+    assert C.sizeof(ConvDesc) == 32 or C.sizeof(ConvDesc) == 28
+
+
+def test_emulator_constructor_surface():
+    import inspect
+    from v2e_amd import EventEmulator
+    ref_args = ["pos_thres", "neg_thres", "sigma_thres", "cutoff_hz", "leak_rate_hz", "refractory_period_s",
+                "shot_noise_rate_hz", "photoreceptor_noise", "leak_jitter_fraction", "noise_rate_cov_decades", "seed",
+                "output_folder", "dvs_h5", "dvs_aedat2", "dvs_aedat4", "dvs_text", "show_dvs_model_state",
+                "save_dvs_model_state", "output_width", "output_height", "device", "cs_lambda_pixels", "cs_tau_p_ms",
+                "hdr", "scidvs", "record_single_pixel_states", "label_signal_noise"]  # emulator.py:86-117
+    params = list(inspect.signature(EventEmulator.__init__).parameters)[1:]
+    assert params[:len(ref_args)] == ref_args
+    e = EventEmulator()
+    assert (e.pos_thres, e.neg_thres, e.sigma_thres, e.leak_rate_hz, e.cutoff_hz) == (0.2, 0.2, 0.03, 0.1, 0.0)
+    assert e.num_events_total == 0 and e.t_previous == 0
+    assert "lp_log_frame" in EventEmulator.MODEL_STATES and EventEmulator.SINGLE_PIXEL_STATES_FILENAME
+    e.set_dvs_params("noisy")  # emulator.py:525-535
+    assert (e.sigma_thres, e.cutoff_hz, e.leak_rate_hz, e.shot_noise_rate_hz, e.refractory_period_s) == (0.05, 30, 0.1, 5.0, 0)
+    assert e.pos_thres_nominal == 0.2
+    e.set_dvs_params("clean")
+    assert (e.sigma_thres, e.cutoff_hz, e.leak_rate_hz, e.shot_noise_rate_hz) == (0.02, 0, 0, 0)
+
+
+def test_emulator_errors_like_reference():
+    from v2e_amd import EventEmulator
+    e = EventEmulator()
+    e.t_previous = 1.0
+    with pytest.raises(ValueError):  # emulator.py:650-653
+        e.generate_events(np.zeros((4, 4), np.uint8), 0.5)
+    for kw in (dict(photoreceptor_noise=True, shot_noise_rate_hz=1.0, cutoff_hz=10), dict(cs_lambda_pixels=2.0),
+               dict(scidvs=True), dict(hdr=True), dict(show_dvs_model_state=["all"]),
+               dict(record_single_pixel_states=(1, 2))):
+        with pytest.raises(NotImplementedError):
+            EventEmulator(**kw)
+    with pytest.raises(ValueError):
+        EventEmulator(rng_mode="bogus")
+
+
+def test_no_cpu_fallback():
+    import torch
+    from v2e_amd import EventEmulator, V2EAmdError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    e = EventEmulator(device="cuda")
+    with pytest.raises(V2EAmdError):
+        e.generate_events(np.zeros((8, 8), np.uint8), 0.0)
+
+
+def test_slomo_constructor_surface():
+    import inspect
+    from v2e_amd import SuperSloMo
+    params = list(inspect.signature(SuperSloMo.__init__).parameters)[1:]
+    assert params == ["model", "auto_upsample", "upsampling_factor", "batch_size", "video_path", "vid_orig",
+                      "vid_slomo", "preview", "avi_frame_rate"]  # slomo.py:44-54
+    with pytest.raises(ValueError):  # slomo.py:91-94
+        SuperSloMo("x.ckpt", auto_upsample=False, upsampling_factor=1)
+    s = SuperSloMo("x.ckpt", auto_upsample=False, upsampling_factor=4)
+    ts = s.get_interpolated_timestamps(np.array([0.0, 1.0, 2.0]))  # slomo.py:540-564
+    assert np.allclose(ts, [0.125, 0.375, 0.625, 0.875, 1.125, 1.375, 1.625, 1.875])
+    with pytest.raises(ValueError):
+        s.interpolate("/nonexistent", None, (64, 32))
+
+
+def test_synthetic_generators_are_reproducible():
+    from v2e_amd.synth import int_gradient_frames, portable_unet_state_dict, unet_layer_shapes
+    import hashlib
+    a = int_gradient_frames(3, 20, 30, seed=1, noise=6, as_array=True)
+    assert hashlib.sha256(a.tobytes()).hexdigest()[:16] == hashlib.sha256(
+        int_gradient_frames(3, 20, 30, seed=1, noise=6, as_array=True).tobytes()).hexdigest()[:16]
+    assert a.dtype == np.uint8 and a.std() > 5
+    shapes = unet_layer_shapes(12, 5)
+    assert len(shapes) == 23 and shapes[13] == ("up1.conv2", 512, 1024, 3)
+    sd = portable_unet_state_dict(2, 4, 1)
+    n = sum(v.size for v in sd.values())
+    assert n == 19_786_660 or abs(n - 19.79e6) < 0.02e6  # 19.79 M params
+
+
+def test_time_coefficients_are_python_doubles_first():
+    from v2e_amd.slomo import time_coefficients
+    c = time_coefficients([0.05])
+    t = 0.05
+    assert c[0, 0] == np.float32(-t * (1 - t)) and c[0, 2] == np.float32((1 - t) * (1 - t)) and c[0, 4] == np.float32(1 - t)

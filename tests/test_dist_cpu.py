@@ -1,0 +1,64 @@
+"""CPU, gloo, world_size 2: the N>1 path (clip sharding + all-gather(v) of the event streams)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from v2e_amd.dist import EventStreamGatherer, clips_of_rank
+    g = EventStreamGatherer("cpu", world)
+    ok = True
+    for step in range(3):
+        n = 5 + 7 * rank + 3 * step           # ragged, different per rank and step
+        if step == 2 and rank == 1:
+            n = 0                              # empty stream on one rank
+        ev = torch.arange((n + 4) * 4, dtype=torch.float32).view(-1, 4) + 1000 * rank + 100 * step
+        g.submit(ev, n)
+        parts = g.result()
+        for r in range(world):
+            nr = 5 + 7 * r + 3 * step
+            if step == 2 and r == 1:
+                nr = 0
+            exp = (torch.arange((nr + 4) * 4, dtype=torch.float32).view(-1, 4) + 1000 * r + 100 * step)[:nr]
+            ok &= parts[r].shape == exp.shape and torch.equal(parts[r], exp)
+    ok &= clips_of_rank(8, world, rank) == list(range(rank, 8, world))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_event_stream_allgather_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
+
+
+def test_clip_sharding_covers_all_clips():
+    from v2e_amd.dist import clips_of_rank
+    for world in (1, 2, 4, 8):
+        allc = sorted(c for r in range(world) for c in clips_of_rank(8, world, r))
+        assert allc == list(range(8))

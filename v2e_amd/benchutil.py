@@ -1,0 +1,127 @@
+"""Side measurements reported by bench.py next to the headline number: the SuperSloMo
+path (interpolated frames/s, f32-MFMA roofline) and the emulator with many clips per launch
+(how far the same kernels go once the launch is large enough to leave the latency floor)."""
+import time
+
+import numpy as np
+import torch
+
+F32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: f32-input MFMA, dense
+HBM_PEAK = 8.0e12
+
+
+def unet_flops(cin, cout, h, w):
+    """2*MACs of model.UNet on one [cin,h,w] sample."""
+    from .synth import unet_layer_shapes
+    res = {"conv1": 0, "conv2": 0, "conv3": 0}
+    for d in range(1, 6):
+        res["down%d" % d] = d
+    for u in range(1, 6):
+        res["up%d" % u] = 5 - u
+    macs = 0
+    for name, co, ci, k in unet_layer_shapes(cin, cout):
+        lvl = res[name.split(".")[0]]
+        macs += (h >> lvl) * (w >> lvl) * co * ci * k * k
+    return 2 * macs
+
+
+def slomo_bench(device, B=4, U=10, H=256, W=320, iters=5):
+    """Interpolated frames/s of slomo.py:338-433 at 320x256 (346x260 source), 10x slowdown.
+
+    One iteration = one batch of B source pairs -> U*B interpolated frames: flow UNet on B
+    samples, prep, interpolation UNet on U*B samples, fuse.  Inputs resident in HBM.
+    """
+    from .slomo import SloMoEngine
+    from .synth import portable_unet_state_dict
+    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
+    eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
+                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(2)
+    I0 = torch.rand((B, 1, H, W), device=device, generator=g) - 0.428
+    I1 = torch.rand((B, 1, H, W), device=device, generator=g) - 0.428
+    ts = [(k + 0.5) / U for k in range(U)]
+    eng.interpolate(I0, I1, ts)  # warm-up (allocations)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        eng.interpolate(I0, I1, ts)
+    e1.record()
+    torch.cuda.synchronize(device)
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = B * unet_flops(2, 4, H, W) + U * B * unet_flops(12, 5, H, W)
+    # time of the interpolation UNet alone (the dominant kernels), for the roofline object
+    x12 = eng.last["x12"]
+    e0.record()
+    for _ in range(iters):
+        eng.interp_net.forward(x12)
+    e1.record()
+    torch.cuda.synchronize(device)
+    sec_u = e0.elapsed_time(e1) * 1e-3 / iters
+    fl_u = U * B * unet_flops(12, 5, H, W)
+    return {
+        "metric": "interpolated frames/s (SuperSloMo flow UNet + per-t warps + interpolation UNet + fusion)",
+        "value": round(U * B / sec, 2), "unit": "frames/s",
+        "config": {"workload": "BASELINE configs[2] SloMo stage: 320x256 (346x260 source), U=%d, batch of %d pairs, "
+                               "seeded random-init weights (checkpoint not available offline)" % (U, B)},
+        "dtype": "f32", "ms_per_batch": round(sec * 1e3, 3),
+        "gflop_per_frame": round(flops / (U * B) / 1e9, 2),
+        "roofline": {"bound": "mfma", "kernel": "k_conv (23 launches of the interpolation UNet)",
+                     "achieved": round(fl_u / sec_u / 1e12, 2), "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": round(fl_u / sec_u / F32_MFMA_PEAK, 4), "traffic": None,
+                     "whole_step_TFLOPs": round(flops / sec / 1e12, 2)},
+    }
+
+
+def batched_emulator_bench(device, n_clips=64, frames=60, H=260, W=346):
+    """Same emulator kernels, `n_clips` independent 346x260 clips advanced per launch."""
+    from .emulator import EventEmulator
+    from .engine import EmuEngine
+    kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak_rate_hz=.01,
+              shot_noise_rate_hz=.001, refractory_period_s=.0005)
+    proto = EventEmulator(device=device, seed=3, rng_mode="philox", **kw)
+    proto._thres_scalar = (0.2, 0.2)
+    proto._thres_is_scalar = False
+    P = proto._params()
+    eng = EmuEngine(H, W, n_clips=n_clips, device=device)
+    eng.alloc_state(True)
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    y = torch.arange(H, device=device, dtype=torch.float32).view(1, 1, H, 1)
+    x = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, 1, W)
+    i = torch.arange(frames + 1, device=device, dtype=torch.float32).view(-1, 1, 1, 1)
+    ph = torch.arange(n_clips, device=device, dtype=torch.float32).view(1, -1, 1, 1) * 7.0
+    f = 127 + 100 * torch.sin((x + 3 * i + ph) / 15.0) * torch.cos((y - 2 * i) / 20.0)
+    f = f + 3.0 * torch.randn(f.shape, device=device, generator=g)
+    fr = f.clamp_(0, 255).to(torch.uint8).contiguous()  # [F+1][NC][H][W]
+    del f
+    eng.init_state(P, fr[0].contiguous(), 0.0)
+    cap = 80000 * frames
+    ev = eng.event_buffer(cap)
+    recs = eng.alloc_recs(frames)
+    dt = 1.0 / 300.0
+    frames_run = fr[1:].contiguous()
+
+    def run(k):
+        t_prev = np.array([[(k * frames + j) * dt] * n_clips for j in range(frames)])
+        t_frame = t_prev + dt
+        eng.run(P, frames_run, t_prev, t_frame, 1 + k * frames, ev, recs, use_graph=1)
+
+    run(0)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    reps = 3
+    n_ev = 0
+    for k in range(1, 1 + reps):
+        run(k)
+        r = eng.recs_to_numpy(recs)
+        n_ev += int(r["n_events"].sum())
+    torch.cuda.synchronize(device)
+    sec = time.perf_counter() - t0
+    bpp = 53
+    byts = bpp * H * W * n_clips * frames * reps + 16 * n_ev
+    return {"value": round(n_ev / sec / 1e6, 1), "unit": "Mevents/s", "clips_per_launch": n_clips,
+            "frames_per_s_all_clips": round(n_clips * frames * reps / sec, 1),
+            "algorithmic_GBps": round(byts / sec / 1e9, 1), "hbm_frac": round(byts / sec / HBM_PEAK, 4),
+            "note": "same kernels as the headline run, %d clips advanced per launch" % n_clips}
