@@ -200,24 +200,25 @@ def main():
         r = eng.recs_to_numpy(recs)[:, 0]
         ev_per_frame = float(r["n_events"].mean())
         npx = H * W
-        per_launch_us = {k: prof[k] / prof["launches"] * 1e3 for k in ("count", "rank", "scan", "emit")}
-        # algorithmic bytes per launch: k_count owns frame + lp r/w + base r/w +
-        # thresholds + noise_rate; k_emit owns ts_mem r/w + 16 B per event
-        alg = {"count": (bpp - 8) * npx, "emit": 8 * npx + 16 * ev_per_frame}
-        dom = "count" if per_launch_us["count"] >= per_launch_us["emit"] else "emit"
-        ach = alg[dom] / (per_launch_us[dom] * 1e-6)
+        # fused pipeline: k_main(f) = emit(f-1) + count(f) owns the whole algorithmic traffic of a
+        # frame step (53 B/pixel + 16 B/event); k_refr re-reads cnt/ts_mem only
+        # when the refractory rule is active and otherwise exits at once.
+        per_launch_us = {"k_main": prof["count"] / (prof["launches"] + 1) * 1e3,
+                         "k_refr": prof["rank"] / prof["launches"] * 1e3}
         step_bytes = bpp * npx + 16 * ev_per_frame
+        ach = step_bytes / (per_launch_us["k_main"] * 1e-6)
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_%s" % dom,
+            "bound": "hbm", "kernel": "k_main",
             "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK, 5), "traffic": None,
-            "algorithmic_bytes_per_launch": int(alg[dom]),
+            "algorithmic_bytes_per_launch": int(step_bytes),
             "avg_launch_us": {k: round(v, 3) for k, v in per_launch_us.items()},
             "whole_step": {"algorithmic_bytes_per_frame": int(step_bytes),
                            "achieved_GBps": round(step_bytes * K * F / elapsed / 1e9, 2),
                            "frac": round(step_bytes * K * F / elapsed / HBM_PEAK, 5)},
-            "note": "avg_launch_us from hipEvents between launches (includes the ~1-2 us inter-kernel gap); "
-                    "346x260 state (2.9 MB) is L2/MALL resident, the path is launch-latency bound (DESIGN.md)",
+            "note": "avg_launch_us from hipEvents recorded before every launch on the launch stream (includes "
+                    "the inter-kernel gap); 346x260 state (2.9 MB) is L2/MALL resident and one frame is only "
+                    "1406 waves, so the path is bounded by per-launch latency, not HBM (DESIGN.md section 3)",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())

@@ -168,15 +168,18 @@ int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const
  * Philox-mode, fully device-resident multi-frame run: frames [n_frames][n_clips][H*W],
  * t_prev/t_frame host arrays [n_frames][n_clips].  Records for frame f go to
  * recs_dev[f][clip] (device, caller-owned).  No host synchronisation inside.
- * use_graph: 0 plain launches, 1 capture the launch sequence into a hipGraph (cached
- * while every baked-in pointer/size is unchanged), 2 instrumented (see v2e_emu_last_profile).
+ * use_graph, low two bits: 0 plain launches, 1 capture the launch sequence into a hipGraph
+ * (cached while every baked-in pointer/size is unchanged), 2 instrumented (see
+ * v2e_emu_last_profile).  |16 selects the unfused count/rank/scan/emit pipeline (kept for A/B
+ * measurements; default is the fused k_main [+ k_refr] pipeline, identical results).
  */
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames,
                 const double *t_prev, const double *t_frame, uint32_t frame_idx0, float *events,
                 uint64_t cap, v2e_frame_rec *recs_dev, int use_graph, void *stream);
 
-/* After a v2e_emu_run with use_graph == 2 (instrumented, blocking: a hipEvent between
- * every kernel): summed milliseconds per kernel class and launches per class. */
+/* After an instrumented v2e_emu_run (blocking: a hipEvent before every launch): summed
+ * milliseconds per kernel class and frames.  Fused pipeline: ms_count = k_main,
+ * ms_rank = k_refr, others 0; unfused pipeline: k_count, k_rank, k_scan, k_emit. */
 int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *ms_scan,
                          double *ms_emit, int *launches);
 

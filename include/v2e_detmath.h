@@ -170,10 +170,16 @@ V2E_HD void v2e_draw_init(uint64_t seed, uint32_t clip, uint32_t pixel,
 
 /* ------------------------------------------------ keyed bijection (shuffle) */
 /*
- * Philox-mode replacement for `idx = torch.randperm(n_i)` (emulator.py:868):
- * a keyed Feistel bijection on [0,n) with cycle walking (the construction used by
- * thrust::shuffle).  sigma(c) is the OUTPUT position of the event whose canonical
+ * Philox-mode replacement for `idx = torch.randperm(n_i)` (emulator.py:868): a keyed
+ * bijection on [0,n).  sigma(c) is the OUTPUT position of the event whose canonical
  * (ON-row-major-then-OFF-row-major) index is c, i.e. reference idx[sigma(c)] = c.
+ *
+ * Construction: mixed-radix Feistel (Black & Rogaway, "Ciphers with arbitrary finite
+ * domains") on [0,a) x [0,2^k), k ~ half the bits of n, a = ceil(n / 2^k), 4 rounds, plus
+ * cycle walking for the < 2^k ~ sqrt(n) values of [n, a*2^k).  The domain is within
+ * 1/sqrt(n) of n, so a walk is rare (a wave waits for its slowest lane), and splitting by a
+ * power of two makes init and apply shifts, masks, adds and two conditional subtractions: no
+ * division, no loops.  Integer arithmetic only, so host and device agree bit for bit.
  */
 V2E_HD uint32_t v2e_mix32(uint32_t x)
 {
@@ -181,18 +187,30 @@ V2E_HD uint32_t v2e_mix32(uint32_t x)
     return x;
 }
 
-typedef struct { uint32_t k[4]; uint32_t lbits, rbits, lmask, rmask; uint32_t n; } v2e_perm_t;
+V2E_HD uint32_t v2e_bits32(uint32_t x) /* number of bits needed to represent x (0 -> 0) */
+{
+    return x ? 32u - (uint32_t)__builtin_clz(x) : 0u;
+}
+
+typedef struct { uint32_t k[4]; uint32_t a, amask, sh, rmask, n; } v2e_perm_t;
 
 V2E_HD void v2e_perm_init(v2e_perm_t *p, uint64_t seed, uint32_t clip, uint32_t frame,
                           uint32_t iter, uint32_t n)
 {
-    v2e_philox4x32(iter, frame, V2E_STREAM_PERM, clip, (uint32_t)seed, (uint32_t)(seed >> 32), p->k);
-    uint32_t bits = 2;
-    while (bits < 32 && (1u << bits) < n) ++bits;
-    p->rbits = bits >> 1;
-    p->lbits = bits - p->rbits;
-    p->lmask = (1u << p->lbits) - 1u;
-    p->rmask = (1u << p->rbits) - 1u;
+    uint32_t h = v2e_mix32((uint32_t)seed ^ 0x9E3779B9u);
+    h = v2e_mix32(h + (uint32_t)(seed >> 32));
+    h = v2e_mix32(h + frame * 0x85EBCA6Bu + iter * 0xC2B2AE35u + clip * 0x27D4EB2Fu + V2E_STREAM_PERM);
+    p->k[0] = v2e_mix32(h + 0x165667B1u);
+    p->k[1] = v2e_mix32(h + 0x2CACCF62u);
+    p->k[2] = v2e_mix32(h + 0x43033713u);
+    p->k[3] = v2e_mix32(h + 0x59599EC4u);
+    const uint32_t nb = v2e_bits32(n > 1u ? n - 1u : 1u); /* bits of the largest index */
+    const uint32_t sh = nb >> 1;                           /* low part: 2^sh values */
+    const uint32_t a = ((n - 1u) >> sh) + 1u;              /* ceil(n / 2^sh), n >= 1 */
+    p->sh = sh;
+    p->rmask = (1u << sh) - 1u;
+    p->a = a;
+    p->amask = a > 1u ? (1u << v2e_bits32(a - 1u)) - 1u : 0u; /* 2^ceil(log2 a) - 1 < 2a */
     p->n = n;
 }
 
@@ -200,13 +218,17 @@ V2E_HD uint32_t v2e_perm_apply(const v2e_perm_t *p, uint32_t c)
 {
     uint32_t x = c;
     do {
-        uint32_t l = x >> p->rbits, r = x & p->rmask;   /* l: lbits, r: rbits */
+        uint32_t l = x >> p->sh, r = x & p->rmask; /* l in [0,a), r in [0,2^sh) */
         for (int round = 0; round < 4; ++round) {
-            /* unbalanced Feistel: alternate which half is hashed */
-            if ((round & 1) == 0) l = (l ^ v2e_mix32(r + p->k[round])) & p->lmask;
-            else                  r = (r ^ v2e_mix32(l + p->k[round])) & p->rmask;
+            if ((round & 1) == 0) { /* add a value <= amask < 2a, reduce with two subtractions */
+                l += v2e_mix32(r + p->k[round]) & p->amask;
+                if (l >= p->a) l -= p->a;
+                if (l >= p->a) l -= p->a;
+            } else {
+                r = (r + v2e_mix32(l + p->k[round])) & p->rmask;
+            }
         }
-        x = (l << p->rbits) | r;
+        x = (l << p->sh) | r;
     } while (x >= p->n);
     return x;
 }

@@ -61,10 +61,11 @@ def test_hip_philox_frame_api_matches_reference(name):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("use_graph", [0, 1, 16, 17])  # fused pipeline plain/graph, unfused plain/graph
 @pytest.mark.parametrize("name", PHILOX_FIXTURES)
 def test_hip_philox_device_resident_clip_matches_reference(name, use_graph):
-    """Whole clip on device (no host sync between frames; optionally one hipGraph)."""
+    """Whole clip on device (no host sync between frames; optionally one hipGraph), both the fused
+    k_main/k_refr pipeline and the unfused count/rank/scan/emit pipeline."""
     fx = PhiloxFixture(name)
     emu = _mk(fx, seed=fx.seed, rng_mode="philox")
     ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph)
@@ -234,3 +235,27 @@ def test_many_iterations_grow_scratch(oracle_lib):
         b = ora.generate_events(f, t)
         assert events_equal(a, b)
     assert ora.last["M"] > 64
+
+
+@pytest.mark.parametrize("use_graph", [1, 17])
+@pytest.mark.parametrize("refr", [0.0, 0.0004])
+def test_device_resident_clip_many_iterations(use_graph, refr, oracle_lib):
+    """> 31 events per pixel per frame: several 64-key chunks in the fused kernels, refractory on/off."""
+    from v2e_amd import EventEmulator
+    kw = dict(pos_thres=0.03, neg_thres=0.04, sigma_thres=0.01, cutoff_hz=200, leak_rate_hz=0.2, shot_noise_rate_hz=30.0,
+              refractory_period_s=refr)
+    rng = np.random.Generator(np.random.PCG64(17))
+    H, W = 37, 91
+    frames = [rng.integers(0, 256, size=(H, W)).astype(np.uint8) for _ in range(7)]
+    times = [0.01 * i for i in range(7)]
+    hip = EventEmulator(device="cuda", rng_mode="philox", seed=21, max_iters=1024, **kw)
+    ev, counts = hip.generate_events_batch(np.stack(frames), times, use_graph=use_graph, cap=6_000_000)
+    ora = oracle_lib.OracleEmulator(rng_mode="philox", seed=21, **kw)
+    oev = [ora.generate_events(f, t) for f, t in zip(frames, times)]
+    assert ora.last["M"] > 64
+    ref = np.concatenate([e for e in oev if e is not None])
+    assert list(counts) == [0 if e is None else len(e) for e in oev]
+    assert np.array_equal(ev, ref)
+    assert np.array_equal(hip.base_log_frame.cpu().numpy(), ora.base_log_frame)
+    if refr > 0:
+        assert np.array_equal(hip.timestamp_mem.cpu().numpy(), ora.timestamp_mem)

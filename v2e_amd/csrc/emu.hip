@@ -42,7 +42,22 @@ constexpr uint32_t CNT_SHOT_OFF = 1u << 26;
 
 struct FrameCtl {
     double t_prev, t_frame;
+    // per-frame scalars the reference evaluates once in Python doubles; filled by the host with the
+    // same IEEE operations (emulator_utils.py:80-84, 326-327) so kernels need not redo them per lane
+    double dt_over_tau; // delta_time / (1/(math.pi*2*cutoff_hz)), 0 when cutoff_hz <= 0
+    double shot_base;   // (shot_noise_rate_hz/2) * delta_time
 };
+
+__host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_hz, double shot_rate_hz)
+{
+    FrameCtl c;
+    c.t_prev = t_prev; c.t_frame = t_frame;
+    const double dt = t_frame - t_prev;
+    c.dt_over_tau = 0.0;
+    if (cutoff_hz > 0) { const double tau = 1.0 / (M_PI * 2 * cutoff_hz); c.dt_over_tau = dt / tau; }
+    c.shot_base = (shot_rate_hz / 2) * dt;
+    return c;
+}
 
 // (1./20)*math.log(20) as evaluated by CPython (emulator_utils.py:34)
 __device__ constexpr double LINLOG_F = 0x1.32c352f8fe941p-3;
@@ -68,6 +83,9 @@ struct KArgs {
     uint32_t *cnt;
     uint32_t *hist; // [n_clips][nkeys_cap][nwaves]
     uint32_t *tot;  // [n_clips][nkeys_cap]
+    // lin_log / inten01 of the 256 uint8 grey levels, built on device by k_lut with the same code
+    const float *lut_L;
+    const double *lut_I;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -95,30 +113,63 @@ template <typename R> __device__ __forceinline__ R div_floor(R a, R b)
     return fd;
 }
 
+// ---- wave64 reductions on the VALU data-parallel-primitive path (DPP), not through the LDS
+// crossbar (__shfl_* lowers to ds_bpermute, an LDS-latency operation per step; with one wave per
+// SIMD nothing hides it).  Within a 16-lane row: butterfly with quad_perm / row_half_mirror /
+// row_mirror; across the four rows: v_readlane + scalar ops, so results are wave-uniform SGPRs.
+#define V2E_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, true)
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, WAVE));
-    return v;
+    v = max(v, V2E_DPP(v, 0xB1));  // quad_perm [1,0,3,2]
+    v = max(v, V2E_DPP(v, 0x4E));  // quad_perm [2,3,0,1]
+    v = max(v, V2E_DPP(v, 0x141)); // row_half_mirror
+    v = max(v, V2E_DPP(v, 0x140)); // row_mirror
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t u)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    int v = (int)u;
+    v += V2E_DPP(v, 0xB1);
+    v += V2E_DPP(v, 0x4E);
+    v += V2E_DPP(v, 0x141);
+    v += V2E_DPP(v, 0x140);
+    return (uint32_t)(__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+                      __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
-// exclusive prefix sum across the 64 lanes
-__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane)
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t u)
 {
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        uint32_t t = __shfl_up(inc, o, WAVE);
-        if (lane >= o) inc += t;
-    }
-    return inc - v;
+    int v = (int)u;
+    v |= V2E_DPP(v, 0xB1);
+    v |= V2E_DPP(v, 0x4E);
+    v |= V2E_DPP(v, 0x141);
+    v |= V2E_DPP(v, 0x140);
+    return (uint32_t)(__builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) |
+                      __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48));
+}
+
+// exclusive prefix sum across the 64 lanes: Hillis-Steele inside each 16-lane row with
+// row_shr DPP (zero fill), row carries through v_readlane + scalar adds
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t u, int lane)
+{
+    int inc = (int)u;
+    inc += V2E_DPP(inc, 0x111); // row_shr:1
+    inc += V2E_DPP(inc, 0x112); // row_shr:2
+    inc += V2E_DPP(inc, 0x114); // row_shr:4
+    inc += V2E_DPP(inc, 0x118); // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(inc, 15), t1 = __builtin_amdgcn_readlane(inc, 31),
+              t2 = __builtin_amdgcn_readlane(inc, 47);
+    const int row = lane >> 4;
+    const int off = row == 0 ? 0 : (row == 1 ? t0 : (row == 2 ? t0 + t1 : t0 + t1 + t2));
+    return (uint32_t)(inc + off) - u;
+}
+
+// value of lane `idx` (idx wave-uniform) as a scalar
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int idx)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(idx));
 }
 
 // shot-noise decision, emulator_utils.py:326-349 (float64 compare of a float32 draw)
@@ -154,6 +205,16 @@ struct TsGen {
         return tab ? tab[i] : v2e_ts_formula((uint32_t)i, n, start, end, step);
     }
 };
+
+// lin_log(x) and (x+20)/275 for x = 0..255, evaluated by the very functions the per-pixel path
+// uses, so a lookup returns bit-identical values (uint8 frames only)
+__global__ void k_lut(float *lut_L, double *lut_I)
+{
+    const int i = threadIdx.x;
+    const double x = (double)i;
+    lut_L[i] = lin_log(x);
+    lut_I[i] = (x + 20.0) / 275.0;
+}
 
 // ------------------------------------------------------------------ k_init
 template <typename R, typename FT>
@@ -465,11 +526,11 @@ __global__ __launch_bounds__(BLOCK) void k_emit(KArgs a, const FrameCtl *__restr
             const unsigned long long bo = __ballot(pass && !neg);
             const unsigned long long bf = __ballot(pass && neg);
             if ((bo | bf) == 0ull) continue;
-            const uint32_t it_base = __shfl(kb_k, 2 * ii, WAVE);
-            const uint32_t tot_on = __shfl(t_k, 2 * ii, WAVE);
-            const uint32_t tot_off = __shfl(t_k, 2 * ii + 1, WAVE);
-            const uint32_t off_on = __shfl(o_k, 2 * ii, WAVE);
-            const uint32_t off_off = __shfl(o_k, 2 * ii + 1, WAVE);
+            const uint32_t it_base = lane_value(kb_k, 2 * ii);
+            const uint32_t tot_on = lane_value(t_k, 2 * ii);
+            const uint32_t tot_off = lane_value(t_k, 2 * ii + 1);
+            const uint32_t off_on = lane_value(o_k, 2 * ii);
+            const uint32_t off_off = lane_value(o_k, 2 * ii + 1);
             if (pass) {
                 uint32_t cidx = neg ? tot_on + off_off + (uint32_t)__popcll(bf & lt)
                                     : off_on + (uint32_t)__popcll(bo & lt);
@@ -538,6 +599,8 @@ __global__ __launch_bounds__(BLOCK) void k_permute(const float4 *__restrict__ in
     if (j < n) out[row0 + j] = in[row0 + (unsigned long long)idx[j]];
 }
 
+#include "emu_fused.h"
+
 } // namespace
 
 // =================================================================== host side
@@ -548,6 +611,14 @@ struct v2e_emu {
     void *lp = nullptr, *base = nullptr;
     float *ts_mem = nullptr, *pos_thres = nullptr, *neg_thres = nullptr, *noise_rate = nullptr;
     uint32_t *cnt = nullptr, *hist = nullptr, *tot = nullptr;
+    // fused pipeline scratch (double-buffered by frame parity)
+    int ngroups = 0;
+    float *lut_L = nullptr;
+    double *lut_I = nullptr;
+    uint32_t *cnt_b = nullptr;
+    uint16_t *gtot[2] = {nullptr, nullptr}; // [n_clips][nkeys_cap][ngp], key-major u16
+    int ngp = 0;
+    int *gmaxv[2] = {nullptr, nullptr};
     v2e_frame_rec *rec_ring = nullptr; // [RING][n_clips]
     FrameCtl *ctl_ring = nullptr;      // [RING][n_clips]
     FrameCtl *ctl_host = nullptr;      // pinned staging [RING][n_clips]
@@ -599,6 +670,7 @@ static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
     a.lp = h->lp; a.base = h->base; a.ts_mem = h->ts_mem;
     a.pos_thres = h->pos_thres; a.neg_thres = h->neg_thres; a.noise_rate = h->noise_rate;
     a.cnt = h->cnt; a.hist = h->hist; a.tot = h->tot;
+    a.lut_L = h->lut_L; a.lut_I = h->lut_I;
     return a;
 }
 
@@ -631,6 +703,12 @@ static int alloc_iter_scratch(v2e_emu *h, int max_iters)
     h->nkeys_cap = 2 * max_iters + 2;
     V2E_HIP(hipMalloc(&h->hist, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap * h->nwaves));
     V2E_HIP(hipMalloc(&h->tot, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap));
+    for (int q = 0; q < 2; ++q) {
+        if (h->gtot[q]) { V2E_HIP(hipFree(h->gtot[q])); h->gtot[q] = nullptr; }
+        V2E_HIP(hipMalloc(&h->gtot[q], sizeof(uint16_t) * (size_t)h->n_clips * h->ngp * h->nkeys_cap));
+        V2E_HIP(hipMemset(h->gtot[q], 0, sizeof(uint16_t) * (size_t)h->n_clips * h->ngp * h->nkeys_cap));
+        V2E_HIP(hipMemset(h->gmaxv[q], 0, sizeof(int) * (size_t)h->n_clips * h->ngroups));
+    }
     if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
     return 0;
 }
@@ -651,8 +729,16 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
     h->npx = H * W;
     h->npx_pad = v2e_emu_npx_pad(H, W);
     h->nwaves = (h->npx + WAVE - 1) / WAVE;
+    h->ngroups = (h->npx + BLOCK - 1) / BLOCK;
+    h->ngp = (h->ngroups + 511) / 512 * 512;
     V2E_HIP(hipMalloc(&h->cnt, sizeof(uint32_t) * (size_t)n_clips * h->npx_pad));
-    int rc = alloc_iter_scratch(h, max_iters);
+    V2E_HIP(hipMalloc(&h->cnt_b, sizeof(uint32_t) * (size_t)n_clips * h->npx_pad));
+    V2E_HIP(hipMalloc(&h->lut_L, sizeof(float) * 256));
+    V2E_HIP(hipMalloc(&h->lut_I, sizeof(double) * 256));
+    k_lut<<<1, 256>>>(h->lut_L, h->lut_I);
+    V2E_HIP(hipDeviceSynchronize());
+    for (int q = 0; q < 2; ++q) V2E_HIP(hipMalloc(&h->gmaxv[q], sizeof(int) * (size_t)n_clips * h->ngroups));
+    int rc = alloc_iter_scratch(h, max_iters); // also zeroes gtot/gmaxv (clean-row invariant)
     if (rc) return rc;
     V2E_HIP(hipMalloc(&h->rec_ring, sizeof(v2e_frame_rec) * RING * n_clips));
     V2E_HIP(hipMemset(h->rec_ring, 0, sizeof(v2e_frame_rec) * RING * n_clips));
@@ -672,6 +758,8 @@ int v2e_emu_destroy(v2e_emu *h)
     hipSetDevice(h->device);
     if (h->graph) hipGraphExecDestroy(h->graph);
     hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
+    hipFree(h->lut_L); hipFree(h->lut_I);
+    hipFree(h->cnt_b); hipFree(h->gtot[0]); hipFree(h->gtot[1]); hipFree(h->gmaxv[0]); hipFree(h->gmaxv[1]);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     hipFree(h->off_dev);
     if (h->off_host) hipHostFree(h->off_host);
@@ -723,11 +811,11 @@ int v2e_emu_init_state(v2e_emu *h, const v2e_emu_params *p, const void *frame, i
     return 0;
 }
 
-static int stage_ctl(v2e_emu *h, uint32_t frame_idx, const double *t_prev, const double *t_frame, hipStream_t s)
+static int stage_ctl(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, const double *t_prev, const double *t_frame, hipStream_t s)
 {
     const int slot = frame_idx % RING;
     FrameCtl *hc = h->ctl_host + (size_t)slot * h->n_clips;
-    for (int c = 0; c < h->n_clips; ++c) { hc[c].t_prev = t_prev[c]; hc[c].t_frame = t_frame[c]; }
+    for (int c = 0; c < h->n_clips; ++c) hc[c] = make_ctl(t_prev[c], t_frame[c], p->cutoff_hz, p->shot_noise_rate_hz);
     V2E_HIP(hipMemcpyAsync(h->ctl_ring + (size_t)slot * h->n_clips, hc, sizeof(FrameCtl) * h->n_clips,
                            hipMemcpyHostToDevice, s));
     return 0;
@@ -755,7 +843,7 @@ int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dt
     if (p->rng_mode == V2E_RNG_TAPE) V2E_REQUIRE(!(p->leak_rate_hz > 0) || leak_randn, "tape mode needs leak_randn");
     V2E_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    rc = stage_ctl(h, frame_idx, t_prev, t_frame, s);
+    rc = stage_ctl(h, p, frame_idx, t_prev, t_frame, s);
     if (rc) return rc;
     const int slot = frame_idx % RING;
     v2e_frame_rec *rec = h->rec_ring + (size_t)slot * h->n_clips;
@@ -907,6 +995,53 @@ static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, cons
     return 0;
 }
 
+// Fused pipeline: F+1 launches of k_main (+F of k_refr when the refractory period is non-zero).
+static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
+                             float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, hipEvent_t *evs = nullptr,
+                             int *n_marks = nullptr)
+{
+    const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
+    V2E_HIP(hipMemsetAsync(recs, 0, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
+    dim3 grid(h->ngroups, h->n_clips);
+    int mark = 0;
+    for (int f = 0; f <= n_frames; ++f) {
+        FusedArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.do_count = f < n_frames;
+        fa.do_emit = f > 0;
+        fa.frame = fa.do_count ? (const char *)frames + (size_t)f * h->n_clips * h->npx * esz : nullptr;
+        fa.ctl_c = h->run_ctl + (size_t)(fa.do_count ? f : 0) * h->n_clips;
+        fa.ctl_e = h->run_ctl + (size_t)(f > 0 ? f - 1 : 0) * h->n_clips;
+        fa.rec_e = recs + (size_t)(f > 0 ? f - 1 : 0) * h->n_clips;
+        fa.rec_ee = f >= 2 ? recs + (size_t)(f - 2) * h->n_clips : nullptr;
+        fa.fidx_base = h->run_fidx;
+        fa.fidx_c = (uint32_t)f;
+        fa.fidx_e = (uint32_t)(f > 0 ? f - 1 : 0);
+        fa.par_c = f & 1;
+        fa.par_e = (f + 1) & 1;
+        fa.ngroups = h->ngroups;
+        fa.cnt2[0] = h->cnt; fa.cnt2[1] = h->cnt_b;
+        fa.gtT2[0] = h->gtot[0]; fa.gtT2[1] = h->gtot[1];
+        fa.ngp = h->ngp;
+        fa.gmax2[0] = h->gmaxv[0]; fa.gmax2[1] = h->gmaxv[1];
+        fa.events = (float4 *)events;
+        fa.cap = cap;
+        if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
+        DISPATCH_FT(dtype, {
+            if (p->f64_state) k_main<double, FT><<<grid, BLOCK, 0, s>>>(a, fa);
+            else k_main<float, FT><<<grid, BLOCK, 0, s>>>(a, fa);
+        });
+        if (fa.do_count && p->refractory_period_s > 0) {
+            if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
+            k_refr<<<grid, BLOCK, 0, s>>>(a, fa.ctl_c, fa.cnt2[fa.par_c], fa.gtT2[fa.par_c], h->ngp, fa.gmax2[fa.par_c], h->ngroups);
+        }
+    }
+    if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
+    if (n_marks) *n_marks = mark;
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames, const double *t_prev,
                 const double *t_frame, uint32_t frame_idx0, float *events, uint64_t cap, v2e_frame_rec *recs_dev,
                 int use_graph, void *stream)
@@ -930,24 +1065,38 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         V2E_HIP(hipStreamSynchronize(s));
     }
     const size_t nct = (size_t)n_frames * h->n_clips;
-    for (size_t i = 0; i < nct; ++i) { h->run_ctl_host[i].t_prev = t_prev[i]; h->run_ctl_host[i].t_frame = t_frame[i]; }
+    for (size_t i = 0; i < nct; ++i) h->run_ctl_host[i] = make_ctl(t_prev[i], t_frame[i], p->cutoff_hz, p->shot_noise_rate_hz);
     *h->run_fidx_host = frame_idx0;
     V2E_HIP(hipMemcpyAsync(h->run_ctl, h->run_ctl_host, sizeof(FrameCtl) * nct, hipMemcpyHostToDevice, s));
     V2E_HIP(hipMemcpyAsync(h->run_fidx, h->run_fidx_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     KArgs a = make_kargs(h, p);
-    if (!use_graph) return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s);
-    if (use_graph == 2) { // instrumented: hipEvents between the kernels (bench.py roofline leg); blocking
-        const int ne = 4 * n_frames + 1;
+    const int mode = use_graph & 3;          // 0 plain launches, 1 hipGraph, 2 instrumented
+    const bool legacy = (use_graph & 16) != 0; // 4-kernel count/rank/scan/emit pipeline (kept for A/B)
+    auto enqueue = [&](hipStream_t st, hipEvent_t *evs, int *nm) -> int {
+        if (legacy) {
+            if (nm) *nm = 4 * n_frames + 1;
+            return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs);
+        }
+        return enqueue_run_fused(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs, nm);
+    };
+    if (mode == 0) return enqueue(s, nullptr, nullptr);
+    if (mode == 2) { // instrumented: a hipEvent before every launch (bench.py roofline leg); blocking
+        const int ne = 4 * n_frames + 4;
         std::vector<hipEvent_t> evs(ne);
         for (int i = 0; i < ne; ++i) V2E_HIP(hipEventCreate(&evs[i]));
-        rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, evs.data());
+        int marks = 0;
+        rc = enqueue(s, evs.data(), &marks);
         if (rc == 0) {
             V2E_HIP(hipStreamSynchronize(s));
             for (int k = 0; k < 4; ++k) h->prof_ms[k] = 0.0;
-            for (int i = 0; i < ne - 1; ++i) {
+            const bool refr = p->refractory_period_s > 0;
+            for (int i = 0; i < marks - 1; ++i) {
                 float ms = 0.f;
                 V2E_HIP(hipEventElapsedTime(&ms, evs[i], evs[i + 1]));
-                h->prof_ms[i & 3] += ms;
+                int cls;
+                if (legacy) cls = i & 3;
+                else cls = refr ? (i < 2 * n_frames ? (i & 1) : 0) : 0; // k_main / k_refr alternate, last is k_main
+                h->prof_ms[cls] += ms;
             }
             h->prof_launches = n_frames;
         }
@@ -961,12 +1110,13 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&a, sizeof(a)); push(&frames, sizeof(frames)); push(&dtype, sizeof(dtype)); push(&n_frames, sizeof(n_frames));
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
+    int lg = legacy ? 1 : 0; push(&lg, sizeof(lg));
     if (!h->graph || key != h->graph_key) {
         if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
         hipStream_t cs;
         V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs);
+        rc = enqueue(cs, nullptr, nullptr);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
         hipStreamDestroy(cs);

@@ -1,0 +1,441 @@
+// emu_fused.h -- fused device-resident pipeline of the DVS pixel model (included by emu.hip).
+//
+// Round-1 profiling (profiles/r01_*) showed that at 346x260 a frame is one wave per SIMD, so
+// what a kernel costs is its chain of DEPENDENT memory round trips plus launch latency, not its
+// arithmetic.  This pipeline therefore
+//   * needs only the two unavoidable grid-wide dependencies per frame (the global max M and the
+//     per-(iteration,polarity) totals), both read back through plain memory at the next launch:
+//       k_main(f) = emit(f-1) + count(f) for the same pixel in one thread,
+//       k_refr(f) = refractory re-count of frame f's workgroup totals, a no-op launch unless the
+//                   rule is active for that frame (device-side test on M);
+//   * issues every global load of both phases at the top of k_main, before any barrier;
+//   * has no atomics: each workgroup publishes its own max and key totals, consumers reduce
+//     them (M = max over workgroups; row prefix = sum over earlier workgroups, lane = key);
+//   * reads per-frame scalars from the host-filled FrameCtl and lin_log/inten01 of uint8 frames
+//     from a 256-entry table staged in LDS.
+//
+// Keys: 0 = shot ON, 1 = shot OFF, 2+2i = iteration i ON, 3+2i = iteration i OFF.
+// Scratch is double-buffered by frame parity (cnt, gtT, gmax): k_main reads frame f-1's while
+// writing frame f's.  Invariant: gtT[k][g] == 0 for k >= 2 + 2*gmax[g] (and for g >= ngroups).
+#pragma once
+
+struct FusedArgs {
+    const void *frame;           // frame f (count phase)
+    const FrameCtl *ctl_c;       // times of frame f
+    const FrameCtl *ctl_e;       // times of frame f-1
+    v2e_frame_rec *rec_e;        // record of frame f-1 (written here)
+    const v2e_frame_rec *rec_ee; // record of frame f-2 (event offset chain) or nullptr
+    const uint32_t *fidx_base;
+    uint32_t fidx_c, fidx_e;
+    int do_emit, do_count;
+    int par_c, par_e;
+    int ngroups;
+    uint32_t *cnt2[2];
+    uint16_t *gtT2[2];  // [n_clips][nkeys_cap][ngp] per-workgroup key totals (<= 256 each), key-major
+    int ngp;            // ngroups rounded up to 512 (one 16-byte load per lane covers 512 workgroups)
+    int *gmax2[2];      // [n_clips][ngroups], true (unclamped) per-workgroup max count
+    float4 *events;
+    unsigned long long cap;
+};
+
+constexpr int KPRE = 16; // keys of chunk 0 fetched before M is known (covers M <= 7)
+
+// exact floor(a/b) for a >= 0, b > 0: equals c10::div_floor_floating (whose fmod / re-divide /
+// "+1 if frac > 0.5" steps exist to return exactly this) without the fmod loop.
+template <typename R> __device__ __forceinline__ R floor_div_pos(R a, R b)
+{
+    if (!(b > (R)0) || !(a >= (R)0)) return div_floor<R>(a, b); // generic path keeps every corner case
+    if (a < b) return (R)0;
+    R q = floor(a / b);
+    R r = fma(-q, b, a); // exactly rounded a - q*b: its sign is the true sign
+    if (r < (R)0) q -= (R)1;
+    else if (r >= b) q += (R)1;
+    return q;
+}
+
+// max over all workgroups' published maxima (block-uniform result). One barrier pair.
+__device__ __forceinline__ int block_max_of_groups(const int *__restrict__ gm, int ngroups, int *s_red, int tid, int lane, int wave)
+{
+    int m = 0;
+    for (int k = tid; k < ngroups; k += BLOCK) m = max(m, gm[k]);
+    m = wave_max_i32(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    __syncthreads();
+    return m;
+}
+
+// One wave, one key: total over all workgroups and over the workgroups before g.  A 16-byte load
+// per lane covers 512 workgroups, so this is one load instruction per key for sensors up to
+// 512*256 pixels.  (tot, pre) are returned wave-uniform.
+__device__ __forceinline__ void key_totals(const uint16_t *__restrict__ row, int ngp, int g, int lane, uint32_t &tot_o,
+                                           uint32_t &pre_o)
+{
+    uint32_t tot = 0, pre = 0;
+    for (int c0 = 0; c0 < ngp; c0 += 512) {
+        const int gb = c0 + lane * 8;
+        const uint4 v = *(const uint4 *)(row + gb);
+        // two u16 counts per dword, each <= 256: add the four dwords lane-wise, then fold halves
+        const uint32_t s2 = v.x + v.y + v.z + v.w;
+        const uint32_t lane_tot = (s2 & 0xFFFFu) + (s2 >> 16);
+        tot += lane_tot;
+        if (gb + 8 <= g) {
+            pre += lane_tot;
+        } else if (gb < g) { // the one lane whose 8 workgroups straddle g
+            const uint32_t w[8] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16, v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pre += (gb + j < g) ? w[j] : 0u;
+        }
+    }
+    tot_o = wave_sum_u32(tot);
+    pre_o = wave_sum_u32(pre);
+}
+
+// Per-workgroup key totals of this frame's candidates.  REFR = false: every candidate counts
+// (speculative, right whenever the refractory rule is off); REFR = true: apply the rule against
+// a private copy of ts_mem.  Called by all 256 threads (barriers inside).  Keeps the row invariant.
+template <bool REFR>
+__device__ __forceinline__ void group_key_totals(const KArgs &a, uint32_t cw, float tsm, const TsGen &tg, int gmax,
+                                                 uint16_t *__restrict__ gcol, int ngp, uint32_t (*s_wcnt)[WAVE], int lane,
+                                                 int wave, int gmax_old)
+{
+    // gcol = &gtT[clip][0][g]; key k of this workgroup lives at gcol[k * ngp]
+    for (int k = 2 + 2 * gmax + (int)threadIdx.x; k < 2 + 2 * gmax_old; k += BLOCK) gcol[(size_t)k * ngp] = 0;
+    const int mag = (int)(cw & CNT_MASK);
+    const bool neg = (cw & CNT_NEG) != 0;
+    const int nk = 2 + 2 * gmax;
+    bool alive = true;
+    for (int kb = 0; kb < nk; kb += WAVE) {
+        uint32_t mine = 0;
+        const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
+        const int i_hi = (kb + WAVE - 2) / 2; // exclusive
+        for (int i = i_lo; i < i_hi && i < gmax && alive; ++i) {
+            const bool cand = mag > i;
+            if (__ballot(cand) == 0ull) { alive = false; break; }
+            bool pass = cand;
+            if (REFR) {
+                const float t = tg(i);
+                const float pt = (cand ? 1.0f : 0.0f) * t - tsm;
+                pass = pt > a.refr_f;
+                if (pass) tsm = t;
+            }
+            const unsigned long long bo = __ballot(pass && !neg);
+            const unsigned long long bf = __ballot(pass && neg);
+            const int kl = 2 + 2 * i - kb;
+            if (lane == kl) mine = (uint32_t)__popcll(bo);
+            if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+        }
+        if (kb == 0) {
+            const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
+            const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+            if (lane == 0) mine = (uint32_t)__popcll(so);
+            if (lane == 1) mine = (uint32_t)__popcll(sf);
+        }
+        s_wcnt[wave][lane] = mine;
+        __syncthreads();
+        if (wave == 0 && kb + lane < nk)
+            gcol[(size_t)(kb + lane) * ngp] = (uint16_t)(s_wcnt[0][lane] + s_wcnt[1][lane] + s_wcnt[2][lane] + s_wcnt[3][lane]);
+        __syncthreads();
+    }
+}
+
+template <typename R, typename FT>
+__global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
+{
+    __shared__ uint32_t s_T[WAVE], s_P[WAVE]; // per key of the current 64-key chunk: total / prefix over workgroups
+    __shared__ uint32_t s_wcnt[BLOCK / WAVE][WAVE];
+    __shared__ int s_red[BLOCK / WAVE];
+    __shared__ float s_lutL[256];
+    __shared__ double s_lutI[256];
+    constexpr bool U8 = sizeof(FT) == 1;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, g = blockIdx.x;
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const uint32_t fbase = fa.fidx_base ? *fa.fidx_base : 0u;
+
+    // ------------------------------------------------------------ all independent loads first
+    R b = (R)0, lp_old = (R)0;
+    float thp = 1.f, thn = 1.f, nr = 0.f, tsm = 0.f;
+    uint32_t cw_e = 0;
+    FT px = (FT)0;
+    if (valid) {
+        b = ((R *)a.base)[sp];
+        thp = a.pos_thres[sp];
+        thn = a.neg_thres[sp];
+        if (a.has_cutoff || (fa.do_emit && a.do_shot)) lp_old = ((R *)a.lp)[sp];
+        if (a.do_leak && fa.do_count) nr = a.noise_rate[sp];
+        if (a.has_refr && fa.do_emit) tsm = a.ts_mem[sp];
+        if (fa.do_emit) cw_e = fa.cnt2[fa.par_e][sp];
+        if (fa.do_count) px = ((const FT *)fa.frame)[(size_t)clip * a.npx + p];
+    }
+    if (U8 && fa.do_count) {
+        s_lutL[tid] = a.lut_L[tid];
+        s_lutI[tid] = a.lut_I[tid];
+    }
+    const uint16_t *gt = fa.gtT2[fa.par_e] + (size_t)clip * a.nkeys_cap * fa.ngp;
+    unsigned long long ev0 = 0;
+    int M = 0;
+    if (fa.do_emit) {
+        // the first KPRE keys, before M is known (rows are clean, so no key count is needed)
+        for (int k = wave; k < KPRE && k < a.nkeys_cap; k += BLOCK / WAVE) {
+            uint32_t t, q;
+            key_totals(gt + (size_t)k * fa.ngp, fa.ngp, g, lane, t, q);
+            if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+        }
+        if (fa.rec_ee) ev0 = fa.rec_ee[clip].ev_offset + fa.rec_ee[clip].n_events;
+        M = block_max_of_groups(fa.gmax2[fa.par_e] + (size_t)clip * fa.ngroups, fa.ngroups, s_red, tid, lane, wave);
+    } else if (U8 && fa.do_count) {
+        __syncthreads(); // LUT visible
+    }
+    bool b_dirty = false;
+
+    // ------------------------------------------------------------ emit(f-1)
+    if (fa.do_emit) {
+        v2e_frame_rec *rec = fa.rec_e;
+        if (M > a.max_iters) {
+            if (g == 0 && tid == 0) {
+                rec[clip].max_events = M;
+                rec[clip].flags |= V2E_FLAG_ITERS_CLAMPED;
+                rec[clip].ev_offset = ev0;
+            }
+        } else {
+            const uint32_t frame_idx = fbase + fa.fidx_e;
+            const int n = M > 0 ? M : 1;
+            const FrameCtl c = fa.ctl_e[clip];
+            const TsGen tg(c, n, nullptr);
+            const bool use_refr = a.has_refr && (a.refr > (c.t_frame - c.t_prev) / (double)n);
+            const uint32_t cw = cw_e;
+            const int mag = (int)(cw & CNT_MASK);
+            const bool neg = (cw & CNT_NEG) != 0;
+            float4 *ev = fa.events + (size_t)clip * fa.cap;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const float fx = (float)(p % a.W), fy = (float)(p / a.W);
+            const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
+            const int nk = 2 + 2 * M;
+            uint32_t carry = 0, sum_on = 0, sum_off = 0;
+            uint32_t son_tot = 0, soff_tot = 0, son_off = 0, soff_off = 0;
+            int fcount = 0;
+            bool dropped = false, alive = true;
+            for (int kb = 0; kb < nk; kb += WAVE) {
+                const int key = kb + lane;
+                // totals over all workgroups / over earlier workgroups for the keys not fetched yet
+                for (int k = (kb == 0 ? KPRE : 0) + wave; k < WAVE && kb + k < nk; k += BLOCK / WAVE) {
+                    uint32_t t, q;
+                    key_totals(gt + (size_t)(kb + k) * fa.ngp, fa.ngp, g, lane, t, q);
+                    if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+                }
+                // pass 1: which of my iterations survive; per-wave key counts
+                uint32_t mymask = 0, mine = 0;
+                const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
+                const int i_hi = (kb + WAVE - 2) / 2;
+                for (int i = i_lo; i < i_hi && i < M && alive; ++i) {
+                    const bool cand = mag > i;
+                    if (__ballot(cand) == 0ull) { alive = false; break; }
+                    bool pass = cand;
+                    if (use_refr) {
+                        const float t = tg(i);
+                        const float pt = (cand ? 1.0f : 0.0f) * t - tsm;
+                        pass = pt > a.refr_f;
+                        if (pass) tsm = t;
+                    }
+                    if (pass) { mymask |= 1u << (i - i_lo); ++fcount; }
+                    const unsigned long long bo = __ballot(pass && !neg);
+                    const unsigned long long bf = __ballot(pass && neg);
+                    const int kl = 2 + 2 * i - kb;
+                    if (lane == kl) mine = (uint32_t)__popcll(bo);
+                    if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+                }
+                if (kb == 0) {
+                    const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
+                    const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+                    if (lane == 0) mine = (uint32_t)__popcll(so);
+                    if (lane == 1) mine = (uint32_t)__popcll(sf);
+                }
+                s_wcnt[wave][lane] = mine;
+                __syncthreads();
+                const uint32_t T_k = key < nk ? s_T[lane] : 0u;
+                const uint32_t P_k = key < nk ? s_P[lane] : 0u;
+                uint32_t woff = 0;
+#pragma unroll
+                for (int q = 0; q < BLOCK / WAVE; ++q)
+                    if (q < wave) woff += s_wcnt[q][lane];
+                const uint32_t off_k = P_k + woff;
+                const uint32_t sig_T = (key >= 2 && key < nk) ? T_k : 0u;
+                const uint32_t kbase_k = carry + wave_excl_scan_u32(sig_T, lane);
+                const uint32_t chunk_total = wave_sum_u32(sig_T);
+                sum_on += wave_sum_u32((lane & 1) ? 0u : sig_T);
+                sum_off += wave_sum_u32((lane & 1) ? sig_T : 0u);
+                if (kb == 0) {
+                    son_tot = lane_value(T_k, 0); soff_tot = lane_value(T_k, 1);
+                    son_off = lane_value(off_k, 0); soff_off = lane_value(off_k, 1);
+                }
+                // pass 2: write this chunk's events
+                if (__ballot(mymask != 0u)) {
+                    uint32_t wm = wave_or_u32(mymask); // iterations in which some lane of the wave fires
+                    while (wm) {
+                        const int ii = __ffs(wm) - 1;
+                        wm &= wm - 1;
+                        const int i = i_lo + ii;
+                        const bool pass = (mymask >> ii) & 1u;
+                        const unsigned long long bo = __ballot(pass && !neg);
+                        const unsigned long long bf = __ballot(pass && neg);
+                        const int kl = 2 + 2 * i - kb;
+                        const uint32_t it_base = lane_value(kbase_k, kl);
+                        const uint32_t tot_on = lane_value(T_k, kl);
+                        const uint32_t tot_off = lane_value(T_k, kl + 1);
+                        const uint32_t off_on = lane_value(off_k, kl);
+                        const uint32_t off_off = lane_value(off_k, kl + 1);
+                        if (pass) {
+                            uint32_t cidx = neg ? tot_on + off_off + (uint32_t)__popcll(bf & lt)
+                                                : off_on + (uint32_t)__popcll(bo & lt);
+                            if (shuf) {
+                                v2e_perm_t pm;
+                                v2e_perm_init(&pm, a.seed, (uint32_t)clip, frame_idx, (uint32_t)i, tot_on + tot_off);
+                                cidx = v2e_perm_apply(&pm, cidx);
+                            }
+                            const unsigned long long row = ev0 + it_base + cidx;
+                            if (row < fa.cap) ev[row] = make_float4(tg(i), fx, fy, neg ? -1.0f : 1.0f);
+                            else dropped = true;
+                        }
+                    }
+                }
+                carry += chunk_total;
+                __syncthreads();
+            }
+            // shot-noise events after all signal events (ON block, OFF block), ts[-1], unshuffled
+            if (a.do_shot) {
+                const bool s_on = (cw & CNT_SHOT_ON) != 0, s_off = (cw & CNT_SHOT_OFF) != 0;
+                const unsigned long long so = __ballot(s_on), sf = __ballot(s_off);
+                if (so | sf) {
+                    const float tl = tg(n - 1);
+                    if (s_on) {
+                        const unsigned long long row = ev0 + carry + son_off + (uint32_t)__popcll(so & lt);
+                        if (row < fa.cap) ev[row] = make_float4(tl, fx, fy, 1.0f);
+                        else dropped = true;
+                    }
+                    if (s_off) {
+                        const unsigned long long row = ev0 + carry + son_tot + soff_off + (uint32_t)__popcll(sf & lt);
+                        if (row < fa.cap) ev[row] = make_float4(tl, fx, fy, -1.0f);
+                        else dropped = true;
+                    }
+                }
+            }
+            if (valid) { // emulator.py:936-942
+                const bool shot = a.do_shot && (cw & (CNT_SHOT_ON | CNT_SHOT_OFF));
+                if (fcount > 0 || shot) {
+                    const float dp = (float)(neg ? 0 : fcount) * thp;
+                    const float dn = (float)(neg ? fcount : 0) * thn;
+                    b = b + (R)dp;
+                    b = b - (R)dn;
+                    if (shot) b = lp_old;
+                    b_dirty = true;
+                }
+                if (use_refr && fcount > 0) a.ts_mem[sp] = tsm;
+            }
+            if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
+            if (g == 0 && tid == 0) {
+                rec[clip].max_events = M;
+                rec[clip].n_signal = carry;
+                rec[clip].n_events = carry + (a.do_shot ? son_tot + soff_tot : 0u);
+                rec[clip].n_on = sum_on + (a.do_shot ? son_tot : 0u);
+                rec[clip].n_off = sum_off + (a.do_shot ? soff_tot : 0u);
+                rec[clip].ev_offset = ev0;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------ count(f)
+    if (fa.do_count) {
+        const FrameCtl c = fa.ctl_c[clip];
+        const uint32_t frame_idx = fbase + fa.fidx_c;
+        const double delta_time = c.t_frame - c.t_prev;
+        int m = 0;
+        uint32_t cw = 0;
+        if (valid) {
+            float L;
+            double inten01;
+            if (U8) {
+                L = s_lutL[(int)px];
+                inten01 = s_lutI[(int)px];
+            } else {
+                const double x = (double)px;
+                L = lin_log(x);
+                inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
+            }
+            float r = 0.f, u = 0.f;
+            if (a.do_leak || a.do_shot) v2e_draw_frame(a.seed, (uint32_t)clip, frame_idx, (uint32_t)p, &r, &u);
+            R lpn;
+            if (a.has_cutoff) {
+                double eps = inten01 * c.dt_over_tau;
+                if (eps > 1.0) eps = 1.0;
+                lpn = (R)((1.0 - eps) * (double)lp_old + eps * (double)L);
+            } else {
+                lpn = (R)L;
+            }
+            ((R *)a.lp)[sp] = lpn;
+            if (a.do_leak) { // emulator_utils.py:126-129, float32 left to right
+                const float rate = (a.leak_hz_f * nr) * (1.0f - a.jit_f * r);
+                const float delta_leak = ((float)delta_time * rate) * thp;
+                b = b - (R)delta_leak;
+                b_dirty = true;
+            }
+            if (b_dirty) ((R *)a.base)[sp] = b;
+            const R diff = (lpn + (R)0.0f) - b;
+            const R pf = diff > (R)0 ? diff : (R)0;
+            const R nf = (-diff) > (R)0 ? -diff : (R)0;
+            const R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;
+            const R tnd = a.scalar_thres ? (R)a.neg_div : (R)thn;
+            // diff has one sign, so one of pf/nf is zero and floor(0/thr) = 0: one exact floor
+            // division serves both torch.div(..., rounding_mode='floor') calls (emulator_utils.py:154-157)
+            const bool is_pos = diff > (R)0;
+            const int q = (int)floor_div_pos<R>(is_pos ? pf : nf, is_pos ? tpd : tnd);
+            const int pc = is_pos ? q : 0, nc = is_pos ? 0 : q;
+            if (pc > 0) cw = (uint32_t)pc & CNT_MASK;
+            else if (nc > 0) cw = ((uint32_t)nc & CNT_MASK) | CNT_NEG;
+            if (a.do_shot) cw |= shot_bits(a, inten01, c.shot_base, thp, thn, u);
+            fa.cnt2[fa.par_c][sp] = cw;
+            m = pc > nc ? pc : nc;
+        }
+        m = wave_max_i32(m);
+        int *gmp = fa.gmax2[fa.par_c] + (size_t)clip * fa.ngroups + g;
+        const int gmax_old_raw = *gmp; // what this row was last written with (same parity, two frames ago)
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        const int gmax_raw = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+        if (tid == 0) *gmp = gmax_raw;
+        const int gmax = min(gmax_raw, a.max_iters), gmax_old = min(gmax_old_raw, a.max_iters);
+        uint16_t *gcol = fa.gtT2[fa.par_c] + (size_t)clip * a.nkeys_cap * fa.ngp + g;
+        const TsGen tg_unused(c, 1, nullptr);
+        group_key_totals<false>(a, cw, 0.f, tg_unused, gmax, gcol, fa.ngp, s_wcnt, lane, wave, gmax_old);
+    } else if (valid && b_dirty) {
+        ((R *)a.base)[sp] = b;
+    }
+}
+
+// Refractory re-count of frame f's workgroup totals; every workgroup exits at once unless the
+// rule is active for this frame (emulator.py:830: refractory_period_s > ts_step).
+__global__ __launch_bounds__(BLOCK) void k_refr(KArgs a, const FrameCtl *__restrict__ ctl, const uint32_t *__restrict__ cnt,
+                                                uint16_t *__restrict__ gtT, int ngp, const int *__restrict__ gmaxv, int ngroups)
+{
+    __shared__ uint32_t s_wcnt[BLOCK / WAVE][WAVE];
+    __shared__ int s_red[BLOCK / WAVE];
+    const int clip = blockIdx.y, g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int p = g * BLOCK + tid;
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const bool valid = p < a.npx;
+    const int *gm = gmaxv + (size_t)clip * ngroups;
+    const int gmax = min(gm[g], a.max_iters);
+    const uint32_t cw = valid ? cnt[sp] : 0u; // issued before M is known: one round trip
+    const float tsm = valid ? a.ts_mem[sp] : 0.f;
+    const int M = block_max_of_groups(gm, ngroups, s_red, tid, lane, wave);
+    if (M <= 0 || M > a.max_iters) return;
+    const FrameCtl c = ctl[clip];
+    if (!(a.refr > (c.t_frame - c.t_prev) / (double)M)) return;
+    if (gmax == 0) return;
+    const TsGen tg(c, M, nullptr);
+    group_key_totals<true>(a, cw, tsm, tg, gmax, gtT + (size_t)clip * a.nkeys_cap * ngp + g, ngp, s_wcnt, lane, wave, gmax);
+}
