@@ -194,23 +194,35 @@ V2E_HD uint32_t v2e_bits32(uint32_t x) /* number of bits needed to represent x (
 
 typedef struct { uint32_t k[4]; uint32_t a, amask, sh, rmask, n; } v2e_perm_t;
 
-V2E_HD void v2e_perm_init(v2e_perm_t *p, uint64_t seed, uint32_t clip, uint32_t frame,
-                          uint32_t iter, uint32_t n)
+/* the four round keys of (seed, clip, frame, iteration) */
+V2E_HD void v2e_perm_keys(uint64_t seed, uint32_t clip, uint32_t frame, uint32_t iter, uint32_t k[4])
 {
     uint32_t h = v2e_mix32((uint32_t)seed ^ 0x9E3779B9u);
     h = v2e_mix32(h + (uint32_t)(seed >> 32));
     h = v2e_mix32(h + frame * 0x85EBCA6Bu + iter * 0xC2B2AE35u + clip * 0x27D4EB2Fu + V2E_STREAM_PERM);
-    p->k[0] = v2e_mix32(h + 0x165667B1u);
-    p->k[1] = v2e_mix32(h + 0x2CACCF62u);
-    p->k[2] = v2e_mix32(h + 0x43033713u);
-    p->k[3] = v2e_mix32(h + 0x59599EC4u);
+    k[0] = v2e_mix32(h + 0x165667B1u);
+    k[1] = v2e_mix32(h + 0x2CACCF62u);
+    k[2] = v2e_mix32(h + 0x43033713u);
+    k[3] = v2e_mix32(h + 0x59599EC4u);
+}
+
+/* the domain split of n: low part 2^sh, high part a = ceil(n / 2^sh), amask = 2^ceil(log2 a) - 1 */
+V2E_HD void v2e_perm_shape(uint32_t n, uint32_t *sh_o, uint32_t *a_o, uint32_t *amask_o)
+{
     const uint32_t nb = v2e_bits32(n > 1u ? n - 1u : 1u); /* bits of the largest index */
-    const uint32_t sh = nb >> 1;                           /* low part: 2^sh values */
-    const uint32_t a = ((n - 1u) >> sh) + 1u;              /* ceil(n / 2^sh), n >= 1 */
-    p->sh = sh;
-    p->rmask = (1u << sh) - 1u;
-    p->a = a;
-    p->amask = a > 1u ? (1u << v2e_bits32(a - 1u)) - 1u : 0u; /* 2^ceil(log2 a) - 1 < 2a */
+    const uint32_t sh = nb >> 1;
+    const uint32_t a = ((n > 0u ? n - 1u : 0u) >> sh) + 1u;
+    *sh_o = sh;
+    *a_o = a;
+    *amask_o = a > 1u ? (1u << v2e_bits32(a - 1u)) - 1u : 0u; /* < 2a */
+}
+
+V2E_HD void v2e_perm_init(v2e_perm_t *p, uint64_t seed, uint32_t clip, uint32_t frame,
+                          uint32_t iter, uint32_t n)
+{
+    v2e_perm_keys(seed, clip, frame, iter, p->k);
+    v2e_perm_shape(n, &p->sh, &p->a, &p->amask);
+    p->rmask = (1u << p->sh) - 1u;
     p->n = n;
 }
 

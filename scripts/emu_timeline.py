@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""dev tool: in-kernel timeline (s_memrealtime stamps, 100 MHz) of one k_main launch."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bench import gen_frames_device, DEFAULT_KW, H, W, DT
+from v2e_amd import EventEmulator, _capi
+
+kw = dict(DEFAULT_KW)
+for a in sys.argv[1:]:
+    k, v = a.split("="); kw[k] = float(v)
+dev = torch.device("cuda")
+F = 100
+frames = gen_frames_device(2 * F + 1, 1, dev)
+emu = EventEmulator(device=dev, seed=1, rng_mode="philox", **kw)
+emu.generate_events(frames[0], 0.0)
+lib = C.CDLL(_capi.LIB_PATH)
+ng = C.c_int()
+lib.v2e_emu_debug_timeline(emu._engine._h, None, C.byref(ng))
+for s in range(2):
+    lo = 1 + s * F
+    emu.generate_events_batch(frames[lo:lo + F].contiguous(), [(lo + i) * DT for i in range(F)], return_device=True, use_graph=1)
+out = (C.c_uint64 * (16 * ng.value))()
+lib.v2e_emu_debug_timeline(emu._engine._h, out, None)
+t = np.frombuffer(out, dtype=np.uint64).reshape(ng.value, 16).astype(np.int64)
+t0 = t[:, 0].min()
+names = ["start", "loads issued+keytotals", "M known", "pass1 done", "barrier", "pass2 done", "emit loop end", "emit done", "count math done", "end"]
+print("blocks start spread: %.2f us" % ((t[:, 0].max() - t0) / 100.0))
+for i, n in enumerate(names):
+    col = t[:, i]
+    ok = col > 0
+    print("%-26s mean %+7.2f us  (min %+6.2f max %+6.2f) since first block start; mean since own start %6.2f" % (
+        n, (col[ok] - t0).mean() / 100.0, (col[ok] - t0).min() / 100.0, (col[ok] - t0).max() / 100.0, (col[ok] - t[ok, 0]).mean() / 100.0))

@@ -46,9 +46,14 @@ struct FrameCtl {
     // same IEEE operations (emulator_utils.py:80-84, 326-327) so kernels need not redo them per lane
     double dt_over_tau; // delta_time / (1/(math.pi*2*cutoff_hz)), 0 when cutoff_hz <= 0
     double shot_base;   // (shot_noise_rate_hz/2) * delta_time
+    // timestamp generator (emulator.py:791-796) and refractory switch (:830) for every iteration
+    // count n = 1..32, so the kernel needs no float64 division once the frame's max is known
+    float ts_start[32], ts_stepf[32];
+    uint32_t refr_mask; // bit n-1: refractory_period_s > delta_time / n
+    uint32_t pad_;
 };
 
-__host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_hz, double shot_rate_hz)
+__host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_hz, double shot_rate_hz, double refr_s)
 {
     FrameCtl c;
     c.t_prev = t_prev; c.t_frame = t_frame;
@@ -56,6 +61,15 @@ __host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_h
     c.dt_over_tau = 0.0;
     if (cutoff_hz > 0) { const double tau = 1.0 / (M_PI * 2 * cutoff_hz); c.dt_over_tau = dt / tau; }
     c.shot_base = (shot_rate_hz / 2) * dt;
+    c.refr_mask = 0; c.pad_ = 0;
+    const float end = (float)t_frame;
+    for (int n = 1; n <= 32; ++n) { // same IEEE operations as TsGen below
+        const double ts_step = dt / (double)n;
+        const float start = (float)(t_prev + ts_step);
+        c.ts_start[n - 1] = start;
+        c.ts_stepf[n - 1] = n > 1 ? (end - start) / (float)(n - 1) : 0.0f;
+        if (refr_s > ts_step) c.refr_mask |= 1u << (n - 1);
+    }
     return c;
 }
 
@@ -200,6 +214,7 @@ struct TsGen {
         end = (float)c.t_frame;
         step = (n_ > 1) ? (end - start) / (float)(n_ - 1) : 0.0f;
     }
+    __device__ __forceinline__ TsGen(float start_, float end_, float step_, int n_) : tab(nullptr), start(start_), end(end_), step(step_), n((uint32_t)n_) {}
     __device__ __forceinline__ float operator()(int i) const
     {
         return tab ? tab[i] : v2e_ts_formula((uint32_t)i, n, start, end, step);
@@ -631,6 +646,7 @@ struct v2e_emu {
     uint32_t *run_fidx_host = nullptr; // pinned
     hipGraphExec_t graph = nullptr;
     std::vector<unsigned char> graph_key;
+    unsigned long long *dbg = nullptr; // dev tool (v2e_emu_debug_timeline)
     double prof_ms[4] = {0, 0, 0, 0}; // count, rank, scan, emit (use_graph == 2)
     int prof_launches = 0;
 };
@@ -815,7 +831,7 @@ static int stage_ctl(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, co
 {
     const int slot = frame_idx % RING;
     FrameCtl *hc = h->ctl_host + (size_t)slot * h->n_clips;
-    for (int c = 0; c < h->n_clips; ++c) hc[c] = make_ctl(t_prev[c], t_frame[c], p->cutoff_hz, p->shot_noise_rate_hz);
+    for (int c = 0; c < h->n_clips; ++c) hc[c] = make_ctl(t_prev[c], t_frame[c], p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
     V2E_HIP(hipMemcpyAsync(h->ctl_ring + (size_t)slot * h->n_clips, hc, sizeof(FrameCtl) * h->n_clips,
                            hipMemcpyHostToDevice, s));
     return 0;
@@ -1026,6 +1042,7 @@ static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         fa.gmax2[0] = h->gmaxv[0]; fa.gmax2[1] = h->gmaxv[1];
         fa.events = (float4 *)events;
         fa.cap = cap;
+        fa.dbg = (h->dbg && f == n_frames / 2) ? h->dbg : nullptr; // dev timeline of one mid-run launch
         if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
         DISPATCH_FT(dtype, {
             if (p->f64_state) k_main<double, FT><<<grid, BLOCK, 0, s>>>(a, fa);
@@ -1065,7 +1082,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         V2E_HIP(hipStreamSynchronize(s));
     }
     const size_t nct = (size_t)n_frames * h->n_clips;
-    for (size_t i = 0; i < nct; ++i) h->run_ctl_host[i] = make_ctl(t_prev[i], t_frame[i], p->cutoff_hz, p->shot_noise_rate_hz);
+    for (size_t i = 0; i < nct; ++i) h->run_ctl_host[i] = make_ctl(t_prev[i], t_frame[i], p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
     *h->run_fidx_host = frame_idx0;
     V2E_HIP(hipMemcpyAsync(h->run_ctl, h->run_ctl_host, sizeof(FrameCtl) * nct, hipMemcpyHostToDevice, s));
     V2E_HIP(hipMemcpyAsync(h->run_fidx, h->run_fidx_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -1110,7 +1127,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&a, sizeof(a)); push(&frames, sizeof(frames)); push(&dtype, sizeof(dtype)); push(&n_frames, sizeof(n_frames));
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
-    int lg = legacy ? 1 : 0; push(&lg, sizeof(lg));
+    int lg = legacy ? 1 : 0; push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
     if (!h->graph || key != h->graph_key) {
         if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
         hipStream_t cs;
@@ -1127,6 +1144,24 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         h->graph_key = key;
     }
     V2E_HIP(hipGraphLaunch(h->graph, s));
+    return 0;
+}
+
+// dev tool (not part of the public header): enable / read back the in-kernel timeline of k_main
+int v2e_emu_debug_timeline(v2e_emu *h, unsigned long long *out_host /* [ngroups][16] or NULL to enable */, int *ngroups)
+{
+    V2E_REQUIRE(h, "null");
+    V2E_HIP(hipSetDevice(h->device));
+    if (!h->dbg) {
+        V2E_HIP(hipMalloc(&h->dbg, sizeof(unsigned long long) * 16 * h->ngroups));
+        V2E_HIP(hipMemset(h->dbg, 0, sizeof(unsigned long long) * 16 * h->ngroups));
+        if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+    }
+    if (ngroups) *ngroups = h->ngroups;
+    if (out_host) {
+        V2E_HIP(hipDeviceSynchronize());
+        V2E_HIP(hipMemcpy(out_host, h->dbg, sizeof(unsigned long long) * 16 * h->ngroups, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

@@ -36,7 +36,10 @@ struct FusedArgs {
     int *gmax2[2];      // [n_clips][ngroups], true (unclamped) per-workgroup max count
     float4 *events;
     unsigned long long cap;
+    unsigned long long *dbg; // dev tool: per-workgroup s_memrealtime stamps [ngroups][16] or nullptr
 };
+
+#define V2E_STAMP(i) do { if (fa.dbg && tid == 0) fa.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
 
 constexpr int KPRE = 16; // keys of chunk 0 fetched before M is known (covers M <= 7)
 
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
     const size_t sp = (size_t)clip * a.npx_pad + p;
     const uint32_t fbase = fa.fidx_base ? *fa.fidx_base : 0u;
 
+    V2E_STAMP(0);
     // ------------------------------------------------------------ all independent loads first
     R b = (R)0, lp_old = (R)0;
     float thp = 1.f, thn = 1.f, nr = 0.f, tsm = 0.f;
@@ -175,6 +179,20 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         s_lutL[tid] = a.lut_L[tid];
         s_lutI[tid] = a.lut_I[tid];
     }
+    // ---- arithmetic that depends on no memory, done while those loads are in flight
+    float rng_r = 0.f, rng_u = 0.f; // count(f): leak normal / shot uniform of this pixel
+    if (fa.do_count && valid && (a.do_leak || a.do_shot))
+        v2e_draw_frame(a.seed, (uint32_t)clip, fbase + fa.fidx_c, (uint32_t)p, &rng_r, &rng_u);
+    uint32_t pk[4] = {0, 0, 0, 0};  // emit(f-1): shuffle round keys of iteration `lane` (first chunk)
+    float tab_start = 0.f, tab_step = 0.f;
+    uint32_t refr_mask = 0;
+    if (fa.do_emit) {
+        if (a.shuffle && a.rng_mode == V2E_RNG_PHILOX) v2e_perm_keys(a.seed, (uint32_t)clip, fbase + fa.fidx_e, (uint32_t)lane, pk);
+        const FrameCtl *ce = fa.ctl_e + clip;
+        tab_start = ce->ts_start[lane & 31];
+        tab_step = ce->ts_stepf[lane & 31];
+        refr_mask = ce->refr_mask;
+    }
     const uint16_t *gt = fa.gtT2[fa.par_e] + (size_t)clip * a.nkeys_cap * fa.ngp;
     unsigned long long ev0 = 0;
     int M = 0;
@@ -186,7 +204,9 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
             if (lane == 0) { s_T[k] = t; s_P[k] = q; }
         }
         if (fa.rec_ee) ev0 = fa.rec_ee[clip].ev_offset + fa.rec_ee[clip].n_events;
+        V2E_STAMP(1);
         M = block_max_of_groups(fa.gmax2[fa.par_e] + (size_t)clip * fa.ngroups, fa.ngroups, s_red, tid, lane, wave);
+        V2E_STAMP(2);
     } else if (U8 && fa.do_count) {
         __syncthreads(); // LUT visible
     }
@@ -204,9 +224,18 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         } else {
             const uint32_t frame_idx = fbase + fa.fidx_e;
             const int n = M > 0 ? M : 1;
-            const FrameCtl c = fa.ctl_e[clip];
-            const TsGen tg(c, n, nullptr);
-            const bool use_refr = a.has_refr && (a.refr > (c.t_frame - c.t_prev) / (double)n);
+            const FrameCtl *ce = fa.ctl_e + clip;
+            TsGen tg(0.f, 0.f, 0.f, n);
+            bool use_refr;
+            if (n <= 32) { // host-filled tables: no float64 division on the critical path
+                tg = TsGen(__uint_as_float(lane_value(__float_as_uint(tab_start), n - 1)), (float)ce->t_frame,
+                           __uint_as_float(lane_value(__float_as_uint(tab_step), n - 1)), n);
+                use_refr = a.has_refr && ((refr_mask >> (n - 1)) & 1u);
+            } else {
+                const FrameCtl c = *ce;
+                tg = TsGen(c, n, nullptr);
+                use_refr = a.has_refr && (a.refr > (c.t_frame - c.t_prev) / (double)n);
+            }
             const uint32_t cw = cw_e;
             const int mag = (int)(cw & CNT_MASK);
             const bool neg = (cw & CNT_NEG) != 0;
@@ -255,7 +284,9 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                     if (lane == 1) mine = (uint32_t)__popcll(sf);
                 }
                 s_wcnt[wave][lane] = mine;
+                V2E_STAMP(3);
                 __syncthreads();
+                V2E_STAMP(4);
                 const uint32_t T_k = key < nk ? s_T[lane] : 0u;
                 const uint32_t P_k = key < nk ? s_P[lane] : 0u;
                 uint32_t woff = 0;
@@ -263,6 +294,12 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                 for (int q = 0; q < BLOCK / WAVE; ++q)
                     if (q < wave) woff += s_wcnt[q][lane];
                 const uint32_t off_k = P_k + woff;
+                // shuffle domain of iteration `lane` (first chunk), all iterations at once
+                uint32_t ps_sh = 0, ps_a = 1, ps_amask = 0, ps_n = 0;
+                if (shuf && kb == 0 && lane < 31 && 3 + 2 * lane < nk) {
+                    ps_n = s_T[2 + 2 * lane] + s_T[3 + 2 * lane];
+                    v2e_perm_shape(ps_n, &ps_sh, &ps_a, &ps_amask);
+                }
                 const uint32_t sig_T = (key >= 2 && key < nk) ? T_k : 0u;
                 const uint32_t kbase_k = carry + wave_excl_scan_u32(sig_T, lane);
                 const uint32_t chunk_total = wave_sum_u32(sig_T);
@@ -288,14 +325,22 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                         const uint32_t tot_off = lane_value(T_k, kl + 1);
                         const uint32_t off_on = lane_value(off_k, kl);
                         const uint32_t off_off = lane_value(off_k, kl + 1);
+                        v2e_perm_t pm;
+                        if (shuf) {
+                            if (kb == 0) { // keys / domain computed lane-parallel above: fetch as scalars
+                                pm.k[0] = lane_value(pk[0], ii); pm.k[1] = lane_value(pk[1], ii);
+                                pm.k[2] = lane_value(pk[2], ii); pm.k[3] = lane_value(pk[3], ii);
+                                pm.sh = lane_value(ps_sh, ii); pm.a = lane_value(ps_a, ii);
+                                pm.amask = lane_value(ps_amask, ii); pm.n = lane_value(ps_n, ii);
+                                pm.rmask = (1u << pm.sh) - 1u;
+                            } else {
+                                v2e_perm_init(&pm, a.seed, (uint32_t)clip, frame_idx, (uint32_t)i, tot_on + tot_off);
+                            }
+                        }
                         if (pass) {
                             uint32_t cidx = neg ? tot_on + off_off + (uint32_t)__popcll(bf & lt)
                                                 : off_on + (uint32_t)__popcll(bo & lt);
-                            if (shuf) {
-                                v2e_perm_t pm;
-                                v2e_perm_init(&pm, a.seed, (uint32_t)clip, frame_idx, (uint32_t)i, tot_on + tot_off);
-                                cidx = v2e_perm_apply(&pm, cidx);
-                            }
+                            if (shuf) cidx = v2e_perm_apply(&pm, cidx);
                             const unsigned long long row = ev0 + it_base + cidx;
                             if (row < fa.cap) ev[row] = make_float4(tg(i), fx, fy, neg ? -1.0f : 1.0f);
                             else dropped = true;
@@ -303,8 +348,10 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                     }
                 }
                 carry += chunk_total;
+                V2E_STAMP(5);
                 __syncthreads();
             }
+            V2E_STAMP(6);
             // shot-noise events after all signal events (ON block, OFF block), ts[-1], unshuffled
             if (a.do_shot) {
                 const bool s_on = (cw & CNT_SHOT_ON) != 0, s_off = (cw & CNT_SHOT_OFF) != 0;
@@ -347,6 +394,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         }
     }
 
+    V2E_STAMP(7);
     // ------------------------------------------------------------ count(f)
     if (fa.do_count) {
         const FrameCtl c = fa.ctl_c[clip];
@@ -365,8 +413,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                 L = lin_log(x);
                 inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
             }
-            float r = 0.f, u = 0.f;
-            if (a.do_leak || a.do_shot) v2e_draw_frame(a.seed, (uint32_t)clip, frame_idx, (uint32_t)p, &r, &u);
+            const float r = rng_r, u = rng_u;
             R lpn;
             if (a.has_cutoff) {
                 double eps = inten01 * c.dt_over_tau;
@@ -399,6 +446,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
             fa.cnt2[fa.par_c][sp] = cw;
             m = pc > nc ? pc : nc;
         }
+        V2E_STAMP(8);
         m = wave_max_i32(m);
         int *gmp = fa.gmax2[fa.par_c] + (size_t)clip * fa.ngroups + g;
         const int gmax_old_raw = *gmp; // what this row was last written with (same parity, two frames ago)
@@ -410,6 +458,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         uint16_t *gcol = fa.gtT2[fa.par_c] + (size_t)clip * a.nkeys_cap * fa.ngp + g;
         const TsGen tg_unused(c, 1, nullptr);
         group_key_totals<false>(a, cw, 0.f, tg_unused, gmax, gcol, fa.ngp, s_wcnt, lane, wave, gmax_old);
+        V2E_STAMP(9);
     } else if (valid && b_dirty) {
         ((R *)a.base)[sp] = b;
     }
