@@ -1,0 +1,15 @@
+#!/usr/bin/env python
+"""dev tool: run the interpolation UNet a few times (for rocprofv3 --kernel-trace)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from v2e_amd.slomo import HipUNet
+from v2e_amd.synth import portable_unet_state_dict
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device("cuda")
+net = HipUNet({k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}, 12, 5, dev)
+x = torch.rand((n, 12, 256, 320), device=dev) - 0.4
+for _ in range(3):
+    net.forward(x)
+torch.cuda.synchronize()
+print("done")

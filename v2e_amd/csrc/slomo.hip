@@ -74,11 +74,14 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
     constexpr int COT = CT * 32;
     constexpr int KK = KS * KS;
     constexpr int PATCH = CI_T * PH * PW;
+    constexpr int PATCH_PAD = (PATCH + 3) / 4 * 4; // keeps the weight slice 16-byte aligned in LDS
     constexpr int WTS = CI_T * KK * COT;
+    constexpr int NPE = (PATCH + NT - 1) / NT;     // patch elements staged per thread
+    constexpr int NWE = (WTS / 4 + NT - 1) / NT;   // weight float4s staged per thread
     static_assert(NPX % TW == 0, "tile");
     static_assert(CI_T % 2 == 0, "ci pairs");
-    __shared__ float smem[PATCH + WTS];
-    float *sp = smem, *sw = smem + PATCH;
+    __shared__ __attribute__((aligned(16))) float smem[PATCH_PAD + WTS];
+    float *sp = smem, *sw = smem + PATCH_PAD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hsel = lane >> 5, l31 = lane & 31;
@@ -88,6 +91,8 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
     const int n = bx / a.tiles_y;
     const int oy0 = ty_i * TH, ox0 = tx_i * TW;
     const int cobase = blockIdx.y * COT;
+    const int hw = a.h * a.w_;
+    const bool vecw = (a.cout & 3) == 0; // float4 weight rows (every layer but the 4/5-channel heads)
 
     int bofs[PT];
 #pragma unroll
@@ -97,6 +102,35 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
     }
     const int aofs = hsel * KK * COT + l31;
 
+    // ---- per-thread staging plan, computed once: which patch elements / weight rows this thread
+    // moves every chunk.  Patch element idx -> (ci, py, px) is the same in every chunk.
+    int pinfo[NPE]; // PRE == 0: ci*hw + gy*w + gx within one sample (or -1: zero padding / unused);
+                    // PRE != 0: packed (ci << 24 | py << 12 | px) (or -1)
+#pragma unroll
+    for (int j = 0; j < NPE; ++j) {
+        const int idx = tid + j * NT;
+        int v = -1;
+        if (idx < PATCH) {
+            const int ci = idx / (PH * PW);
+            const int r = idx - ci * (PH * PW);
+            const int py = r / PW, px = r - py * PW;
+            const int gy = oy0 + py - PAD, gx = ox0 + px - PAD;
+            if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_) v = PRE == 0 ? ci * hw + gy * a.w_ + gx : ((ci << 24) | (gy << 12) | gx);
+        }
+        pinfo[j] = v;
+    }
+    int woff[NWE]; // float4 slot q -> offset of its row start inside one chunk's weight block (or -1)
+#pragma unroll
+    for (int j = 0; j < NWE; ++j) {
+        const int q = tid + j * NT;
+        int v = -1;
+        if (q < WTS / 4) {
+            const int kk = (q * 4) / COT, co4 = (q * 4) - kk * COT;
+            if (cobase + co4 < a.cout) v = kk * a.cout + cobase + co4;
+        }
+        woff[j] = v;
+    }
+
     f32x16 acc[CT][PT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -105,27 +139,62 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
 
+    float pv[NPE];
+    float4 wv[NWE];
+    // fetch chunk `cb` into registers (global loads stay in flight while the MFMAs of the previous chunk run)
+    auto prefetch = [&](int cb) {
+        if (PRE == 0) {
+            // all CI_T channels of a chunk come from one concat source (c0 is a multiple of CI_T)
+            const float *src;
+            int cs, C;
+            if (cb < a.c0) { src = a.x0; cs = cb; C = a.c0; }
+            else { src = a.x1; cs = cb - a.c0; C = a.c1; }
+            const float *base = src + ((size_t)n * C + cs) * hw;
+#pragma unroll
+            for (int j = 0; j < NPE; ++j) pv[j] = pinfo[j] >= 0 ? base[pinfo[j]] : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPE; ++j) {
+                const int pi = pinfo[j];
+                pv[j] = pi >= 0 ? fetch<PRE>(a, n, cb + (pi >> 24), (pi >> 12) & 0xFFF, pi & 0xFFF) : 0.f;
+            }
+        }
+        const float *wb = a.w + (size_t)cb * KK * a.cout;
+        if (vecw) {
+#pragma unroll
+            for (int j = 0; j < NWE; ++j) wv[j] = woff[j] >= 0 ? *(const float4 *)(wb + woff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NWE; ++j) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (woff[j] >= 0) {
+                    const int kk = woff[j] / a.cout, co = woff[j] - kk * a.cout;
+                    const float *wr = wb + woff[j];
+                    t.x = wr[0];
+                    if (co + 1 < a.cout) t.y = wr[1];
+                    if (co + 2 < a.cout) t.z = wr[2];
+                    if (co + 3 < a.cout) t.w = wr[3];
+                }
+                wv[j] = t;
+            }
+        }
+    };
+
+    prefetch(0);
     for (int cb = 0; cb < a.cin; cb += CI_T) {
-        __syncthreads();
-        for (int idx = tid; idx < PATCH; idx += NT) {
-            const int ci = idx / (PH * PW);
-            const int r = idx - ci * (PH * PW);
-            const int py = r / PW, px = r - py * PW;
-            const int gy = oy0 + py - PAD, gx = ox0 + px - PAD;
-            const int c = cb + ci;
-            float v = 0.f;
-            if (c < a.cin && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_) v = fetch<PRE>(a, n, c, gy, gx);
-            sp[idx] = v;
+        __syncthreads(); // everyone is done reading the previous chunk from LDS
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {
+            const int idx = tid + j * NT;
+            if (idx < PATCH) sp[idx] = pv[j];
         }
-        for (int idx = tid; idx < WTS; idx += NT) {
-            const int kk = idx / COT, co = idx - kk * COT;
-            const int ci = kk / KK;
-            const int gco = cobase + co;
-            float v = 0.f;
-            if (cb + ci < a.cin && gco < a.cout) v = a.w[((size_t)cb * KK + kk) * a.cout + gco];
-            sw[idx] = v;
+#pragma unroll
+        for (int j = 0; j < NWE; ++j) {
+            const int q = tid + j * NT;
+            if (q < WTS / 4) *(float4 *)(sw + q * 4) = wv[j];
         }
         __syncthreads();
+        if (cb + CI_T < a.cin) prefetch(cb + CI_T);
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
@@ -165,6 +234,147 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
                     a.y[(((size_t)n * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
                 }
             }
+        }
+    }
+}
+
+// F.avg_pool2d(x, 2) as its own pass: [nc][2h][2w] -> [nc][h][w]; 4 outputs per thread
+__global__ __launch_bounds__(256) void k_avgpool2(const float *__restrict__ x, float *__restrict__ y, long long nc, int h, int w)
+{
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x; // group of 4 outputs along x
+    const int wq = w >> 2;
+    const long long total = nc * h * wq;
+    if (q >= total) return;
+    const int xq = (int)(q % wq);
+    const long long r = q / wq;
+    const int oy = (int)(r % h);
+    const long long c = r / h;
+    const float *p = x + ((c * (2 * h) + 2 * oy) * (long long)(2 * w)) + 8 * xq;
+    const float4 a0 = *(const float4 *)p, a1 = *(const float4 *)(p + 4);
+    const float4 b0 = *(const float4 *)(p + 2 * w), b1 = *(const float4 *)(p + 2 * w + 4);
+    float4 o;
+    o.x = (((a0.x + a0.y) + b0.x) + b0.y) * 0.25f;
+    o.y = (((a0.z + a0.w) + b0.z) + b0.w) * 0.25f;
+    o.z = (((a1.x + a1.y) + b1.x) + b1.y) * 0.25f;
+    o.w = (((a1.z + a1.w) + b1.z) + b1.w) * 0.25f;
+    *(float4 *)(y + (c * h + oy) * (long long)w + 4 * xq) = o;
+}
+
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) as its own pass:
+// [nc][h/2][w/2] -> [nc][h][w].  One thread = 4 consecutive outputs (one float4 store); the source
+// coordinates of outputs 4j..4j+3 are 2j-0.25, 2j+0.25, 2j+0.75, 2j+1.25, so the fractional weights
+// are the exact constants 0.75/0.25 that fetch<2> computes (0 at the clamped left/top edge), and
+// the products/sums are evaluated in the same order.
+__global__ __launch_bounds__(256) void k_upsample2(const float *__restrict__ x, float *__restrict__ y, long long nc, int h, int w)
+{
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int wq = w >> 2;
+    const long long total = nc * h * wq;
+    if (q >= total) return;
+    const int j = (int)(q % wq);
+    const long long r = q / wq;
+    const int gy = (int)(r % h);
+    const long long c = r / h;
+    const int sh = h >> 1, sw = w >> 1;
+    float ry = ((float)gy + 0.5f) * 0.5f - 0.5f;
+    ry = ry < 0.f ? 0.f : ry;
+    const int y0 = (int)ry;
+    const int y1 = y0 + (y0 < sh - 1 ? 1 : 0);
+    const float ly = ry - (float)y0, hy = 1.f - ly;
+    const float *p0 = x + (c * sh + y0) * (long long)sw, *p1 = x + (c * sh + y1) * (long long)sw;
+    // source columns 2j-1 .. 2j+2, clamped
+    const int cm = 2 * j - 1 < 0 ? 0 : 2 * j - 1, c0 = 2 * j, c1 = 2 * j + 1 < sw ? 2 * j + 1 : sw - 1,
+              c2 = 2 * j + 2 < sw ? 2 * j + 2 : sw - 1;
+    const float a_m = p0[cm], a_0 = p0[c0], a_1 = p0[c1], a_2 = p0[c2];
+    const float b_m = p1[cm], b_0 = p1[c0], b_1 = p1[c1], b_2 = p1[c2];
+    const float lx0 = j == 0 ? 0.f : 0.75f, hx0 = 1.f - lx0; // output 4j: x0 = 2j-1 (0 when clamped), x1 = x0+1
+    // when j == 0 the reference has x0 = 0, x1 = min(1, sw-1); a_m == a_0 there and lx = 0
+    const float t00 = j == 0 ? a_0 : a_m, t01 = j == 0 ? a_1 : a_0, u00 = j == 0 ? b_0 : b_m, u01 = j == 0 ? b_1 : b_0;
+    float4 o;
+    o.x = hy * (hx0 * t00 + lx0 * t01) + ly * (hx0 * u00 + lx0 * u01);
+    o.y = hy * (0.75f * a_0 + 0.25f * a_1) + ly * (0.75f * b_0 + 0.25f * b_1);
+    o.z = hy * (0.25f * a_0 + 0.75f * a_1) + ly * (0.25f * b_0 + 0.75f * b_1);
+    o.w = hy * (0.75f * a_1 + 0.25f * a_2) + ly * (0.75f * b_1 + 0.25f * b_2);
+    *(float4 *)(y + (c * h + gy) * (long long)w + 4 * j) = o;
+}
+
+// same, one output per thread, for widths that are not a multiple of 4
+__global__ __launch_bounds__(256) void k_upsample2_scalar(const float *__restrict__ x, float *__restrict__ y, long long nc, int h, int w)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = nc * h * w;
+    if (i >= total) return;
+    const int gx = (int)(i % w);
+    const long long r = i / w;
+    const int gy = (int)(r % h);
+    const long long c = r / h;
+    const int sh = h >> 1, sw = w >> 1;
+    float ry = ((float)gy + 0.5f) * 0.5f - 0.5f;
+    float rx = ((float)gx + 0.5f) * 0.5f - 0.5f;
+    ry = ry < 0.f ? 0.f : ry;
+    rx = rx < 0.f ? 0.f : rx;
+    const int y0 = (int)ry, x0 = (int)rx;
+    const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+    const float ly = ry - (float)y0, lx = rx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float *p = x + c * sh * sw;
+    y[i] = hy * (hx * p[y0 * sw + x0] + lx * p[y0 * sw + x1]) + ly * (hx * p[y1 * sw + x0] + lx * p[y1 * sw + x1]);
+}
+
+// Final UNet layer (32 -> 4/5 channels, 3x3): too few output channels for a 32-wide MFMA tile
+// (84 % of it would be padding), so one thread computes one pixel for all COUT channels on the
+// VALU from an LDS-staged input patch; weights are wave-uniform scalar loads.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv3x3_small(const float *__restrict__ x, const float *__restrict__ wp /* [cin][3][3][COUT] */,
+                                                       const float *__restrict__ bias, float *__restrict__ y, int n_img, int cin,
+                                                       int h, int w, int tiles_x, int tiles_y)
+{
+    constexpr int TW = 32, TH = 8, PH = TH + 2, PW = TW + 2, CI_T = 8;
+    __shared__ float sp[CI_T * PH * PW];
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    const int tx_i = bx % tiles_x; bx /= tiles_x;
+    const int ty_i = bx % tiles_y;
+    const int n = bx / tiles_y;
+    const int oy0 = ty_i * TH, ox0 = tx_i * TW;
+    const int ty = tid / TW, tx = tid % TW;
+    const int hw = h * w;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int cb = 0; cb < cin; cb += CI_T) {
+        __syncthreads();
+        for (int idx = tid; idx < CI_T * PH * PW; idx += 256) {
+            const int ci = idx / (PH * PW);
+            const int r = idx - ci * (PH * PW);
+            const int py = r / PW, px = r - py * PW;
+            const int gy = oy0 + py - 1, gx = ox0 + px - 1;
+            float v = 0.f;
+            if (cb + ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w) v = x[((size_t)n * cin + cb + ci) * hw + gy * w + gx];
+            sp[idx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < CI_T; ++ci) {
+            if (cb + ci >= cin) break;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = sp[(ci * PH + ty + ky) * PW + tx + kx];
+                    const float *wr = wp + ((size_t)(cb + ci) * 9 + ky * 3 + kx) * COUT;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wr[co], v, acc[co]);
+                }
+        }
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < h && ox < w) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v = acc[co] + bias[co];
+            v = v > 0.f ? v : v * 0.1f;
+            y[((size_t)n * COUT + co) * hw + oy * w + ox] = v;
         }
     }
 }
@@ -281,9 +491,14 @@ static void launch_conv(const ConvArgs &a0, hipStream_t s)
 template <int KS, int CI_T, int CT, int PRE>
 static void launch_conv_tw(const ConvArgs &a, hipStream_t s)
 {
-    if (a.w_ % 32 == 0 || (a.w_ % 16 != 0 && a.w_ % 8 != 0)) launch_conv<KS, CI_T, CT, 2, 4, 32, PRE>(a, s);
+    // pixel tile: prefer power-of-two widths that divide W (4 waves, one per SIMD); exact 20- / 10-wide
+    // tiles for the 16x20 and 8x10 levels of a 320x256 input; 32-wide with masking otherwise
+    if (a.w_ % 32 == 0) launch_conv<KS, CI_T, CT, 2, 4, 32, PRE>(a, s);
     else if (a.w_ % 16 == 0) launch_conv<KS, CI_T, CT, 2, 4, 16, PRE>(a, s);
-    else launch_conv<KS, CI_T, CT, 2, 4, 8, PRE>(a, s);
+    else if (a.w_ % 8 == 0) launch_conv<KS, CI_T, CT, 2, 4, 8, PRE>(a, s);
+    else if (a.w_ % 20 == 0 && a.h % 16 == 0) launch_conv<KS, CI_T, CT, 1, 10, 20, PRE>(a, s); // 10 waves: 3/3/2/2 per SIMD
+    else if (a.w_ % 10 == 0) launch_conv<KS, CI_T, CT, 1, 5, 10, PRE>(a, s);
+    else launch_conv<KS, CI_T, CT, 2, 4, 32, PRE>(a, s);
 }
 
 static int conv_dispatch(const ConvArgs &a, int ks, int pre, hipStream_t s)
@@ -336,11 +551,26 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     V2E_REQUIRE(pre == 0 || c1 == 0, "fused pool/upsample takes a single source");
     V2E_REQUIRE(pre != 2 || (h % 2 == 0 && w % 2 == 0), "upsample target must be even");
     V2E_REQUIRE(conv->cin % 2 == 0, "cin must be even");
+    V2E_REQUIRE(c1 == 0 || c0 % 8 == 0, "first concat source must be a multiple of 8 channels");
+    V2E_REQUIRE(h < 4096 && w < 4096, "image too large for the staging plan");
+    {
+        const int k = conv->ksize, ci = conv->cin;
+        V2E_REQUIRE((k == 3 && ci % 8 == 0) || (k == 5 && ci % 4 == 0) || (k == 7 && ci % 2 == 0),
+                    "cin must be a multiple of the channel chunk (8 for 3x3, 4 for 5x5, 2 for 7x7)");
+    }
     ConvArgs a;
     a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1;
     a.w = conv->weight; a.bias = conv->bias; a.y = y;
     a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout;
     a.tiles_x = a.tiles_y = 0;
+    if (conv->ksize == 3 && pre == 0 && c1 == 0 && (conv->cout == 4 || conv->cout == 5)) {
+        const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;
+        dim3 grid((unsigned)(n * tiles_x * tiles_y));
+        if (conv->cout == 4) k_conv3x3_small<4><<<grid, 256, 0, (hipStream_t)stream>>>(x0, conv->weight, conv->bias, y, n, conv->cin, h, w, tiles_x, tiles_y);
+        else k_conv3x3_small<5><<<grid, 256, 0, (hipStream_t)stream>>>(x0, conv->weight, conv->bias, y, n, conv->cin, h, w, tiles_x, tiles_y);
+        V2E_HIP(hipGetLastError());
+        return 0;
+    }
     int rc = conv_dispatch(a, conv->ksize, pre, (hipStream_t)stream);
     if (rc) { v2e_set_error("unsupported conv: k=%d pre=%d", conv->ksize, pre); return rc; }
     V2E_HIP(hipGetLastError());
@@ -352,8 +582,9 @@ int64_t v2e_unet_workspace_bytes(int n, int h, int w, int cin)
 {
     (void)cin;
     const int64_t hw = (int64_t)h * w;
-    // s1 32hw, s2 16hw, s3 8hw, s4 4hw, s5 2hw, two temporaries of 32hw
-    return (int64_t)n * hw * (32 + 16 + 8 + 4 + 2 + 32 + 32) * (int64_t)sizeof(float);
+    // s1 32hw, s2 16hw, s3 8hw, s4 4hw, s5 2hw, two temporaries of 32hw, one of 64hw for the
+    // pooled / upsampled input of the first conv of each down / up block
+    return (int64_t)n * hw * (32 + 16 + 8 + 4 + 2 + 32 + 32 + 64) * (int64_t)sizeof(float);
 }
 
 int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout, float *y, int n, int h, int w,
@@ -365,40 +596,62 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     const int64_t hw = (int64_t)h * w;
     float *ws = (float *)workspace;
     float *s1 = ws; float *s2 = s1 + n * hw * 32; float *s3 = s2 + n * hw * 16; float *s4 = s3 + n * hw * 8;
-    float *s5 = s4 + n * hw * 4; float *tA = s5 + n * hw * 2; float *tB = tA + n * hw * 32;
+    float *s5 = s4 + n * hw * 4; float *tA = s5 + n * hw * 2; float *tB = tA + n * hw * 32; float *tU = tB + n * hw * 32;
+    hipStream_t st = (hipStream_t)stream;
     int rc;
 #define CONV(X0, C0, X1, C1, PRE, IDX, Y, HH, WW)                                              \
     do {                                                                                        \
         rc = v2e_conv2d_lrelu((X0), (C0), (X1), (C1), (PRE), &cv[(IDX)], (Y), n, (HH), (WW), stream); \
         if (rc) return rc;                                                                      \
     } while (0)
+    // producer ops as their own streaming passes: measured faster than fusing them into the conv
+    // loader (the fused bilinear fetch costs 4 gathers + address math per staged element)
+#define POOL(X, C, HH, WW) /* (HH,WW) = output size */                                              \
+    k_avgpool2<<<v2e_cdiv((int64_t)n * (C) * (HH) * ((WW) / 4), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW))
+#define UPS(X, C, HH, WW)                                                                        \
+    do {                                                                                         \
+        if ((WW) % 4 == 0) k_upsample2<<<v2e_cdiv((int64_t)n * (C) * (HH) * ((WW) / 4), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW)); \
+        else k_upsample2_scalar<<<v2e_cdiv((int64_t)n * (C) * (HH) * (WW), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW)); \
+    } while (0)
     // conv1, conv2
     CONV(x, cin, nullptr, 0, 0, 0, tA, h, w);
     CONV(tA, 32, nullptr, 0, 0, 1, s1, h, w);
-    // down1..down5: avg_pool2d fused into the first conv of each block
-    CONV(s1, 32, nullptr, 0, 1, 2, tA, h / 2, w / 2);
+    // down1..down5
+    POOL(s1, 32, h / 2, w / 2);
+    CONV(tU, 32, nullptr, 0, 0, 2, tA, h / 2, w / 2);
     CONV(tA, 64, nullptr, 0, 0, 3, s2, h / 2, w / 2);
-    CONV(s2, 64, nullptr, 0, 1, 4, tA, h / 4, w / 4);
+    POOL(s2, 64, h / 4, w / 4);
+    CONV(tU, 64, nullptr, 0, 0, 4, tA, h / 4, w / 4);
     CONV(tA, 128, nullptr, 0, 0, 5, s3, h / 4, w / 4);
-    CONV(s3, 128, nullptr, 0, 1, 6, tA, h / 8, w / 8);
+    POOL(s3, 128, h / 8, w / 8);
+    CONV(tU, 128, nullptr, 0, 0, 6, tA, h / 8, w / 8);
     CONV(tA, 256, nullptr, 0, 0, 7, s4, h / 8, w / 8);
-    CONV(s4, 256, nullptr, 0, 1, 8, tA, h / 16, w / 16);
+    if ((w / 16) % 4 == 0) { POOL(s4, 256, h / 16, w / 16); CONV(tU, 256, nullptr, 0, 0, 8, tA, h / 16, w / 16); }
+    else CONV(s4, 256, nullptr, 0, 1, 8, tA, h / 16, w / 16);
     CONV(tA, 512, nullptr, 0, 0, 9, s5, h / 16, w / 16);
-    CONV(s5, 512, nullptr, 0, 1, 10, tA, h / 32, w / 32);
+    if ((w / 32) % 4 == 0) { POOL(s5, 512, h / 32, w / 32); CONV(tU, 512, nullptr, 0, 0, 10, tA, h / 32, w / 32); }
+    else CONV(s5, 512, nullptr, 0, 1, 10, tA, h / 32, w / 32);
     CONV(tA, 512, nullptr, 0, 0, 11, tB, h / 32, w / 32);
-    // up1..up5: bilinear x2 fused into conv1, skip concat fused into conv2 (x first, skip second)
-    CONV(tB, 512, nullptr, 0, 2, 12, tA, h / 16, w / 16);
+    // up1..up5: skip concat fused into conv2 (x first, skip second)
+    UPS(tB, 512, h / 16, w / 16);
+    CONV(tU, 512, nullptr, 0, 0, 12, tA, h / 16, w / 16);
     CONV(tA, 512, s5, 512, 0, 13, tB, h / 16, w / 16);
-    CONV(tB, 512, nullptr, 0, 2, 14, tA, h / 8, w / 8);
+    UPS(tB, 512, h / 8, w / 8);
+    CONV(tU, 512, nullptr, 0, 0, 14, tA, h / 8, w / 8);
     CONV(tA, 256, s4, 256, 0, 15, tB, h / 8, w / 8);
-    CONV(tB, 256, nullptr, 0, 2, 16, tA, h / 4, w / 4);
+    UPS(tB, 256, h / 4, w / 4);
+    CONV(tU, 256, nullptr, 0, 0, 16, tA, h / 4, w / 4);
     CONV(tA, 128, s3, 128, 0, 17, tB, h / 4, w / 4);
-    CONV(tB, 128, nullptr, 0, 2, 18, tA, h / 2, w / 2);
+    UPS(tB, 128, h / 2, w / 2);
+    CONV(tU, 128, nullptr, 0, 0, 18, tA, h / 2, w / 2);
     CONV(tA, 64, s2, 64, 0, 19, tB, h / 2, w / 2);
-    CONV(tB, 64, nullptr, 0, 2, 20, tA, h, w);
+    UPS(tB, 64, h, w);
+    CONV(tU, 64, nullptr, 0, 0, 20, tA, h, w);
     CONV(tA, 32, s1, 32, 0, 21, tB, h, w);
     // conv3 (+ leaky relu, model.py:225)
     CONV(tB, 32, nullptr, 0, 0, 22, y, h, w);
+#undef POOL
+#undef UPS
 #undef CONV
     return 0;
 }
