@@ -49,6 +49,7 @@ extern "C" {
 /* record flags */
 #define V2E_FLAG_EVENTS_DROPPED 1u /* event buffer capacity exceeded; counts are still exact */
 #define V2E_FLAG_ITERS_CLAMPED 2u  /* max events per pixel exceeded max_iters: frame NOT emitted */
+#define V2E_FLAG_SYNC_TIMEOUT 4u   /* in-kernel workgroup rendezvous timed out: results invalid */
 
 /*
  * DVS model parameters, read at every call (the reference reads plain attributes

@@ -259,3 +259,27 @@ def test_device_resident_clip_many_iterations(use_graph, refr, oracle_lib):
     assert np.array_equal(hip.base_log_frame.cpu().numpy(), ora.base_log_frame)
     if refr > 0:
         assert np.array_equal(hip.timestamp_mem.cpu().numpy(), ora.timestamp_mem)
+
+
+def test_event_stream_gatherer_nccl_single_rank():
+    """The RCCL code path of EventStreamGatherer (side stream, all_gather_into_tensor) with world_size 1."""
+    import os
+    import torch.distributed as dist
+    from v2e_amd.dist import EventStreamGatherer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        g = EventStreamGatherer(torch.device("cuda", 0), 1)
+        for n in (1000, 0, 37):
+            ev = torch.arange((n + 5) * 4, dtype=torch.float32, device="cuda").view(-1, 4)
+            g.submit(ev, n)
+            parts = g.result()
+            assert len(parts) == 1 and parts[0].shape == (n, 4)
+            assert torch.equal(parts[0], ev[:n])
+    finally:
+        if created:
+            dist.destroy_process_group()

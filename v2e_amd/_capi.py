@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libv2e_amd.so")
 
 DT_U8, DT_F32, DT_F64 = 0, 1, 2
 RNG_TAPE, RNG_PHILOX = 0, 1
-FLAG_EVENTS_DROPPED, FLAG_ITERS_CLAMPED = 1, 2
+FLAG_EVENTS_DROPPED, FLAG_ITERS_CLAMPED, FLAG_SYNC_TIMEOUT = 1, 2, 4
 
 
 class EmuParams(C.Structure):

@@ -37,6 +37,10 @@ struct FusedArgs {
     float4 *events;
     unsigned long long cap;
     unsigned long long *dbg; // dev tool: per-workgroup s_memrealtime stamps [ngroups][16] or nullptr
+    // In-kernel refractory fix-up (small grids whose workgroups are all co-resident): instead of the
+    // k_refr launch, frames on which the rule is active re-count inside k_main and synchronise the
+    // clip's workgroups with one counter per (frame, clip).  nullptr: k_refr launches are used.
+    unsigned *bar;      // [n_frames_of_run][n_clips], zeroed at run start
 };
 
 #define V2E_STAMP(i) do { if (fa.dbg && tid == 0) fa.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
@@ -143,6 +147,32 @@ __device__ __forceinline__ void group_key_totals(const KArgs &a, uint32_t cw, fl
     }
 }
 
+// Grid-wide rendezvous of the `target` workgroups of one clip (MI355X guide, Guideline 16 hand-off
+// in its counter form): every wave drains its stores, one lane does the agent-scope release, the
+// relaxed arrive, a relaxed bounded poll, and the agent-scope acquire; __syncthreads() extends it
+// to the workgroup.  Requires every workgroup of the grid to be resident (checked by the host).
+__device__ __forceinline__ bool clip_barrier(unsigned *ctr, unsigned target)
+{
+    __shared__ int s_ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > 2000000u) { ok = 0; break; } // bounded: never hang the GPU
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
 template <typename R, typename FT>
 __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
 {
@@ -195,8 +225,9 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
     }
     const uint16_t *gt = fa.gtT2[fa.par_e] + (size_t)clip * a.nkeys_cap * fa.ngp;
     unsigned long long ev0 = 0;
-    int M = 0;
+    int M = 0, gmax_own_e = 0;
     if (fa.do_emit) {
+        if (fa.bar) gmax_own_e = fa.gmax2[fa.par_e][(size_t)clip * fa.ngroups + g];
         // the first KPRE keys, before M is known (rows are clean, so no key count is needed)
         for (int k = wave; k < KPRE && k < a.nkeys_cap; k += BLOCK / WAVE) {
             uint32_t t, q;
@@ -239,6 +270,20 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
             const uint32_t cw = cw_e;
             const int mag = (int)(cw & CNT_MASK);
             const bool neg = (cw & CNT_NEG) != 0;
+            if (use_refr && fa.bar) {
+                // rare path: the totals published by count(f-1) ignore the refractory rule; re-count this
+                // workgroup with it, publish, wait for the clip's other workgroups, re-read the totals
+                const int gm = min(gmax_own_e, a.max_iters);
+                uint16_t *gcol_e = fa.gtT2[fa.par_e] + (size_t)clip * a.nkeys_cap * fa.ngp + g;
+                group_key_totals<true>(a, cw, tsm, tg, gm, gcol_e, fa.ngp, s_wcnt, lane, wave, gm);
+                const bool ok = clip_barrier(fa.bar + (size_t)fa.fidx_e * gridDim.y + clip, (unsigned)fa.ngroups);
+                if (!ok && tid == 0) atomicOr(&rec[clip].flags, V2E_FLAG_SYNC_TIMEOUT);
+                for (int k = wave; k < KPRE && k < a.nkeys_cap; k += BLOCK / WAVE) {
+                    uint32_t t, q;
+                    key_totals(gt + (size_t)k * fa.ngp, fa.ngp, g, lane, t, q);
+                    if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+                }
+            }
             float4 *ev = fa.events + (size_t)clip * fa.cap;
             const unsigned long long lt = (1ull << lane) - 1ull;
             const float fx = (float)(p % a.W), fy = (float)(p / a.W);

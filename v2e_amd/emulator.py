@@ -517,6 +517,9 @@ class EventEmulator(object):
         if (r["flags"] & _capi.FLAG_ITERS_CLAMPED).any():
             raise _capi.V2EAmdError("a pixel produced more than max_iters=%d events in one frame; "
                                     "construct with a larger max_iters" % eng.max_iters)
+        if (r["flags"] & _capi.FLAG_SYNC_TIMEOUT).any():
+            raise _capi.V2EAmdError("in-kernel workgroup rendezvous timed out (GPU oversubscribed?); "
+                                    "set V2E_AMD_NO_INKERNEL_SYNC=1 to use the two-launch pipeline")
         if (r["flags"] & _capi.FLAG_EVENTS_DROPPED).any():
             raise _capi.V2EAmdError("event buffer capacity %d exceeded (needed %d); pass a larger cap" % (
                 ev.shape[1], int(r["n_events"].sum())))
