@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the slomo / batched side measurements")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--force-allgather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,10 +106,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_allgather:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from v2e_amd import EventEmulator
@@ -123,7 +125,7 @@ def main():
     emu = EventEmulator(device=device, seed=clip_seed, rng_mode="philox", **DEFAULT_KW)
     emu.generate_events(frames_all[0], 0.0)  # first frame: state init, no events
     buf = torch.empty((F, H, W), dtype=torch.uint8, device=device)
-    gather = EventStreamGatherer(device, world) if (world > 1 and not args.no_allgather) else None
+    gather = EventStreamGatherer(device, world) if ((world > 1 or args.force_allgather) and not args.no_allgather) else None
 
     def step(s):
         lo = 1 + s * F
@@ -229,10 +231,18 @@ def main():
                 out["slomo"] = slomo_bench(device)
             except Exception as e:  # side measurements must never hide the headline number
                 out["extras_error"] = repr(e)[:300]
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its banner through C stdio; drain it so the JSON line is the last line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
