@@ -67,6 +67,22 @@ def emulator_bytes_per_pixel(kw):
     return b
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per k_main launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE
+    uncorrected -- our loads are 1-8 B per lane, for which the guide's x2 factor is uncalibrated).
+    Counters cannot be read from inside this process, so the value is the recorded one or null."""
+    path = os.path.join(ROOT, "profiles", "r01_emulator_pmc_hbm.txt")
+    try:
+        for line in open(path):
+            if line.startswith("# k_main"):
+                parts = line.split()
+                return int((float(parts[-2]) + float(parts[-1])) * 1024)
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(frames_host, budget_s=15.0):
     """CPU oracle (C restatement of the reference, 1 thread) on a bounded sample of the same clip."""
     from oracle import oracle as orc
@@ -212,7 +228,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_main",
             "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK, 5), "traffic": None,
+            "frac": round(ach / HBM_PEAK, 5), "traffic": pmc_traffic_per_launch(),
             "algorithmic_bytes_per_launch": int(step_bytes),
             "avg_launch_us": {k: round(v, 3) for k, v in per_launch_us.items()},
             "whole_step": {"algorithmic_bytes_per_frame": int(step_bytes),
@@ -226,9 +242,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())
         if not args.no_extras and world == 1:
             try:
-                from v2e_amd.benchutil import batched_emulator_bench, slomo_bench
+                from v2e_amd.benchutil import batched_emulator_bench, e2e_bench, hd_noisy_emulator_bench, slomo_bench
                 out["batched"] = batched_emulator_bench(device)
+                out["hd_noisy"] = hd_noisy_emulator_bench(device)
                 out["slomo"] = slomo_bench(device)
+                out["end_to_end"] = e2e_bench(device)
             except Exception as e:  # side measurements must never hide the headline number
                 out["extras_error"] = repr(e)[:300]
     if dist is not None:

@@ -225,6 +225,25 @@ int v2e_slomo_prep(const float *i0, const float *i1, const float *flow, const fl
 int v2e_slomo_fuse(const float *i0, const float *i1, const float *x12, const float *intrp,
                    const float *tcoef, int n_t, int b, int h, int w, float *out, void *stream);
 
+/* ------------------------------------------- SloMo <-> emulator hand-off */
+
+/*
+ * Pillow-exact 8-bit resampling of n images [ih][iw] -> [oh][ow] (dataloader.py:142 LANCZOS,
+ * slomo.py:439 BILINEAR).  Tables from v2e_amd/resample.py (libImaging/Resample.c
+ * precompute_coeffs + normalize_coeffs_8bpc): bounds [out][2] = (first tap, taps), coef
+ * [out][ksize] 22-bit fixed point.  tmp: device scratch [n][ih][ow] (horizontal pass output).
+ */
+int v2e_resample_u8(const uint8_t *in, uint8_t *tmp, uint8_t *out, int n, int ih, int iw, int oh, int ow,
+                    const int32_t *hbounds, const int32_t *hcoef, int hksize, const int32_t *vbounds,
+                    const int32_t *vcoef, int vksize, void *stream);
+
+/* ToTensor + Normalize(mean, 1): out = in / 255 - mean (slomo.py:148-162) */
+int v2e_u8_to_f32_norm(const uint8_t *in, float *out, int64_t n, float mean, void *stream);
+
+/* revNormalize + ToPILImage: out = (uint8)(int)((in + mean) * 255) (slomo.py:437); reorder != 0:
+ * in is [U][B][hw] (interpolation batch order), out is [B][U][hw] (time order, slomo.py:441) */
+int v2e_f32_to_u8_trunc(const float *in, uint8_t *out, int U, int B, int hw, float mean, int reorder, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

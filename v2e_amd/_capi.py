@@ -92,6 +92,9 @@ SIGNATURES = {
     "v2e_unet_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "v2e_unet_forward": (_i, [_vp, _i, C.POINTER(ConvDesc), _i, _vp, _i, _i, _i, _vp, _vp]),
     "v2e_slomo_prep": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "v2e_resample_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "v2e_u8_to_f32_norm": (_i, [_vp, _vp, _i64, C.c_float, _vp]),
+    "v2e_f32_to_u8_trunc": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _i, _vp]),
     "v2e_slomo_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 

@@ -125,3 +125,70 @@ def batched_emulator_bench(device, n_clips=64, frames=60, H=260, W=346):
             "frames_per_s_all_clips": round(n_clips * frames * reps / sec, 1),
             "algorithmic_GBps": round(byts / sec / 1e9, 1), "hbm_frac": round(byts / sec / HBM_PEAK, 4),
             "note": "same kernels as the headline run, %d clips advanced per launch" % n_clips}
+
+
+def hd_noisy_emulator_bench(device, frames=40, H=720, W=1280):
+    """BASELINE configs[3]: 1280x720, set_dvs_params('noisy'), 20x slowdown (dt = 1/600 s): compaction stress."""
+    import bench as B
+    from .emulator import EventEmulator
+    fr = B.gen_frames_device(frames + 1, 4, device, h=H, w=W)
+    emu = EventEmulator(device=device, seed=4, rng_mode="philox", **B.DEFAULT_KW)
+    emu.set_dvs_params("noisy")
+    dt = 1.0 / 600.0
+    emu.generate_events(fr[0], 0.0)
+    buf = fr[1:].contiguous()
+    reps, n_ev = 3, 0
+    cap = 4_000_000 * frames // 10
+    emu.generate_events_batch(buf, [(1 + i) * dt for i in range(frames)], return_device=True, cap=cap)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(1, 1 + reps):
+        ev, c = emu.generate_events_batch(buf, [(1 + k * frames + i) * dt for i in range(frames)], return_device=True, cap=cap)
+        n_ev += int(c.sum())
+    torch.cuda.synchronize(device)
+    sec = time.perf_counter() - t0
+    bpp = 45  # noisy preset: cutoff, leak, shot, no refractory (SURVEY.md 8(d))
+    byts = bpp * H * W * frames * reps + 16 * n_ev
+    return {"value": round(n_ev / sec / 1e6, 1), "unit": "Mevents/s", "frames_per_s": round(frames * reps / sec, 1),
+            "events_per_frame": round(n_ev / (frames * reps), 1), "algorithmic_GBps": round(byts / sec / 1e9, 1),
+            "hbm_frac": round(byts / sec / HBM_PEAK, 4),
+            "config": "BASELINE configs[3]: 1280x720, dvs_params noisy, dt=1/600 s, one clip, Philox"}
+
+
+def e2e_bench(device, n_src=31, U=10, H=260, W=346, batch=10, reps=3):
+    """BASELINE configs[2]: 346x260 uniform-random uint8 video (seed 2), 31 source frames @30 fps, U=10
+    -> 300 interpolated frames at 320x256 -> quantise/resize -> emulator, everything in HBM
+    (VideoToEvents).  Seeded random-init UNet weights."""
+    from .emulator import EventEmulator
+    from .pipeline import VideoToEvents
+    from .slomo import SloMoEngine
+    from .synth import portable_unet_state_dict
+    import bench as B
+    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
+    eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
+                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(2)
+    src = torch.randint(0, 256, (n_src, H, W), dtype=torch.uint8, device=device, generator=g)
+    dt_src = 1.0 / 30.0
+
+    def once(seed):
+        emu = EventEmulator(device=device, seed=seed, rng_mode="philox", **B.DEFAULT_KW)
+        pipe = VideoToEvents(eng, emu, U, batch_size=batch)
+        ev, counts, nfr = pipe.run(src, dt_src, return_device=True)
+        return int(counts.sum()), nfr
+
+    once(1)  # warm-up: allocations, graph capture
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    n_ev = n_fr = 0
+    for r in range(reps):
+        a, b = once(2 + r)
+        n_ev += a
+        n_fr += b
+    torch.cuda.synchronize(device)
+    sec = time.perf_counter() - t0
+    return {"interpolated_frames_per_s": round(n_fr / sec, 1), "Mevents_per_s": round(n_ev / sec / 1e6, 1),
+            "events_per_frame": round(n_ev / n_fr, 1), "ms_per_clip": round(sec / reps * 1e3, 2),
+            "config": "BASELINE configs[2]: 346x260 random uint8 video, %d source frames, U=%d, SloMo HIP -> Pillow-exact "
+                      "quantise/resize on device -> emulator HIP, batch %d pairs, frames never leave HBM" % (n_src, U, batch)}

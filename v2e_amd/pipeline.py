@@ -1,0 +1,102 @@
+"""Device-resident video -> events pipeline (BASELINE configs[2]).
+
+The reference's v2e.py runs its three stages through the filesystem: source frames as .npy,
+`SuperSloMo.interpolate` writes 8-bit PNGs (slomo.py:436-444), v2e.py reads them back
+(v2e.py:832) and calls `EventEmulator.generate_events` per frame.  `VideoToEvents` keeps every
+frame in HBM and produces the same uint8 frames for the emulator:
+
+  source uint8 [N,H,W] --Pillow-exact LANCZOS--> [N,h,w] --/255 - mean--> SloMo (HIP, all U time
+  points per batch) --(+mean)*255, byte truncation--> uint8 --Pillow-exact BILINEAR--> [P*U,H,W]
+  --> emulator (HIP, Philox, one device-resident run)
+
+Frame order and times follow slomo.py:391-400, 441 and v2e.py:794-797: output frame b*U + k of a
+batch, times (pair + k/U) * source frame interval.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import check
+from .resample import coeffs_8bpc
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class DeviceResampler:
+    """Pillow-exact uint8 resize [n,ih,iw] -> [n,oh,ow] on device (tables cached on device)."""
+
+    def __init__(self, in_hw, out_hw, filt, device):
+        self.ih, self.iw = in_hw
+        self.oh, self.ow = out_hw
+        self.device = torch.device(device)
+        self.lib = _capi.lib()
+        self.hb = self.hk = self.vb = self.vk = None
+        self.hks = self.vks = 0
+        if self.ow != self.iw:
+            b, k = coeffs_8bpc(self.iw, self.ow, filt)
+            self.hb, self.hk, self.hks = torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device), k.shape[1]
+        if self.oh != self.ih:
+            b, k = coeffs_8bpc(self.ih, self.oh, filt)
+            self.vb, self.vk, self.vks = torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device), k.shape[1]
+
+    def __call__(self, x):
+        assert x.dtype == torch.uint8 and x.is_contiguous() and tuple(x.shape[-2:]) == (self.ih, self.iw)
+        n = x.numel() // (self.ih * self.iw)
+        out = torch.empty((n, self.oh, self.ow), dtype=torch.uint8, device=self.device)
+        tmp = torch.empty((n, self.ih, self.ow), dtype=torch.uint8, device=self.device) if (self.ow != self.iw and self.oh != self.ih) else None
+        s = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.v2e_resample_u8(_ptr(x), _ptr(tmp), _ptr(out), n, self.ih, self.iw, self.oh, self.ow, _ptr(self.hb),
+                                       _ptr(self.hk), self.hks, _ptr(self.vb), _ptr(self.vk), self.vks, s), "v2e_resample_u8")
+        return out
+
+
+class VideoToEvents:
+    """SuperSloMo upsampling + DVS emulation of one clip without leaving HBM."""
+
+    def __init__(self, slomo_engine, emulator, upsampling_factor, batch_size=8, mean=0.428):
+        self.eng = slomo_engine
+        self.emu = emulator
+        self.U = int(upsampling_factor)
+        self.batch_size = int(batch_size)
+        self.mean = float(mean)
+        self.lib = _capi.lib()
+        self._rs_in = self._rs_out = None
+
+    def upsample(self, frames_u8):
+        """frames_u8: device uint8 [N,H,W] -> device uint8 [(N-1)*U, H, W], the frames the reference's
+        interpolate() would have written as PNGs (in order)."""
+        dev = self.eng.device
+        N, H, W = frames_u8.shape
+        dim = (int(W / 32) * 32, int(H / 32) * 32)  # (w, h), dataloader.py:122-123
+        w, h = dim
+        if self._rs_in is None or (self._rs_in.ih, self._rs_in.iw) != (H, W):
+            self._rs_in = DeviceResampler((H, W), (h, w), "lanczos", dev)
+            self._rs_out = DeviceResampler((h, w), (H, W), "bilinear", dev)
+        s = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        small = self._rs_in(frames_u8.contiguous())
+        x = torch.empty((N, 1, h, w), dtype=torch.float32, device=dev)
+        check(self.lib.v2e_u8_to_f32_norm(_ptr(small), _ptr(x), small.numel(), self.mean, s()), "v2e_u8_to_f32_norm")
+        U = self.U
+        ts = [(k + 0.5) / U for k in range(U)]
+        out = torch.empty(((N - 1) * U, H, W), dtype=torch.uint8, device=dev)
+        for b0 in range(0, N - 1, self.batch_size):
+            b1 = min(b0 + self.batch_size, N - 1)
+            B = b1 - b0
+            Ft = self.eng.interpolate(x[b0:b1], x[b0 + 1:b1 + 1], ts)  # [U,B,1,h,w]
+            q = torch.empty((B * U, h, w), dtype=torch.uint8, device=dev)
+            check(self.lib.v2e_f32_to_u8_trunc(_ptr(Ft), _ptr(q), U, B, h * w, self.mean, 1, s()), "v2e_f32_to_u8_trunc")
+            out[b0 * U:b1 * U] = self._rs_out(q)
+        return out
+
+    def run(self, frames_u8, src_frame_interval_s, return_device=False):
+        """Full pipeline; returns (events, counts_per_interpolated_frame, n_interpolated_frames)."""
+        up = self.upsample(frames_u8)
+        n = up.shape[0]
+        # interpTimes = pair + k/U in units of the source frame interval (slomo.py:391-400; v2e.py:794-797)
+        times = (np.arange(n) / self.U) * float(src_frame_interval_s)
+        ev, counts = self.emu.generate_events_batch(up, times, return_device=return_device)
+        return ev, counts, n
