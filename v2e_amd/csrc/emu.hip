@@ -648,6 +648,7 @@ struct v2e_emu {
     std::vector<unsigned char> graph_key;
     unsigned long long *dbg = nullptr; // dev tool (v2e_emu_debug_timeline)
     unsigned *run_bar = nullptr;       // [run_cap + 1][n_clips] rendezvous counters of the fused pipeline
+    uint32_t *pre32 = nullptr, *tot32 = nullptr; // k_scan2 outputs (large grids only)
     int max_resident_blocks = 0;       // k_main workgroups the device can hold at once (occupancy query)
     double prof_ms[4] = {0, 0, 0, 0}; // count, rank, scan, emit (use_graph == 2)
     int prof_launches = 0;
@@ -727,6 +728,14 @@ static int alloc_iter_scratch(v2e_emu *h, int max_iters)
         V2E_HIP(hipMemset(h->gtot[q], 0, sizeof(uint16_t) * (size_t)h->n_clips * h->ngp * h->nkeys_cap));
         V2E_HIP(hipMemset(h->gmaxv[q], 0, sizeof(int) * (size_t)h->n_clips * h->ngroups));
     }
+    if (h->pre32) { V2E_HIP(hipFree(h->pre32)); h->pre32 = nullptr; }
+    if (h->tot32) { V2E_HIP(hipFree(h->tot32)); h->tot32 = nullptr; }
+    if (h->ngroups > 1024) { // large grids: prefix-scan launch instead of per-workgroup re-reduction
+        V2E_HIP(hipMalloc(&h->pre32, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap * h->ngp));
+        V2E_HIP(hipMalloc(&h->tot32, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap));
+        V2E_HIP(hipMemset(h->pre32, 0, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap * h->ngp));
+        V2E_HIP(hipMemset(h->tot32, 0, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap));
+    }
     if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
     return 0;
 }
@@ -784,7 +793,7 @@ int v2e_emu_destroy(v2e_emu *h)
     hipSetDevice(h->device);
     if (h->graph) hipGraphExecDestroy(h->graph);
     hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
-    hipFree(h->lut_L); hipFree(h->lut_I);
+    hipFree(h->lut_L); hipFree(h->lut_I); hipFree(h->pre32); hipFree(h->tot32);
     hipFree(h->cnt_b); hipFree(h->gtot[0]); hipFree(h->gtot[1]); hipFree(h->gmaxv[0]); hipFree(h->gmaxv[1]);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     hipFree(h->off_dev);
@@ -1059,15 +1068,19 @@ static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         fa.cap = cap;
         fa.dbg = (h->dbg && f == n_frames / 2) ? h->dbg : nullptr; // dev timeline of one mid-run launch
         fa.bar = inkernel ? h->run_bar : nullptr;
+        fa.pre32 = h->pre32; fa.tot32 = h->tot32;
         if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
         DISPATCH_FT(dtype, {
             if (p->f64_state) k_main<double, FT><<<grid, BLOCK, 0, s>>>(a, fa);
             else k_main<float, FT><<<grid, BLOCK, 0, s>>>(a, fa);
         });
+        const bool scan2 = h->pre32 != nullptr;
         if (fa.do_count && has_refr && !inkernel) {
             if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
             k_refr<<<grid, BLOCK, 0, s>>>(a, fa.ctl_c, fa.cnt2[fa.par_c], fa.gtT2[fa.par_c], h->ngp, fa.gmax2[fa.par_c], h->ngroups);
         }
+        if (fa.do_count && scan2)
+            k_scan2<<<dim3(SCAN_BLOCKS, h->n_clips), BLOCK, 0, s>>>(a, fa.gtT2[fa.par_c], h->ngp, fa.gmax2[fa.par_c], h->ngroups, h->pre32, h->tot32);
     }
     if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
     if (n_marks) *n_marks = mark;

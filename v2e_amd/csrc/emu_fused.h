@@ -41,6 +41,10 @@ struct FusedArgs {
     // k_refr launch, frames on which the rule is active re-count inside k_main and synchronise the
     // clip's workgroups with one counter per (frame, clip).  nullptr: k_refr launches are used.
     unsigned *bar;      // [n_frames_of_run][n_clips], zeroed at run start
+    // Large grids (thousands of workgroups): a k_scan2 launch turns the per-workgroup key totals
+    // into exclusive prefixes once, instead of every workgroup re-reducing all of them.
+    const uint32_t *pre32; // [n_clips][nkeys_cap][ngp] or nullptr
+    const uint32_t *tot32; // [n_clips][nkeys_cap]
 };
 
 #define V2E_STAMP(i) do { if (fa.dbg && tid == 0) fa.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
@@ -228,11 +232,18 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
     int M = 0, gmax_own_e = 0;
     if (fa.do_emit) {
         if (fa.bar) gmax_own_e = fa.gmax2[fa.par_e][(size_t)clip * fa.ngroups + g];
-        // the first KPRE keys, before M is known (rows are clean, so no key count is needed)
-        for (int k = wave; k < KPRE && k < a.nkeys_cap; k += BLOCK / WAVE) {
-            uint32_t t, q;
-            key_totals(gt + (size_t)k * fa.ngp, fa.ngp, g, lane, t, q);
-            if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+        if (fa.pre32) { // prefixes already computed by k_scan2: two loads per key, lane = key
+            if (wave == 0) {
+                s_T[lane] = fa.tot32[(size_t)clip * a.nkeys_cap + lane];
+                s_P[lane] = fa.pre32[((size_t)clip * a.nkeys_cap + lane) * fa.ngp + g];
+            }
+        } else {
+            // the first KPRE keys, before M is known (rows are clean, so no key count is needed)
+            for (int k = wave; k < KPRE && k < a.nkeys_cap; k += BLOCK / WAVE) {
+                uint32_t t, q;
+                key_totals(gt + (size_t)k * fa.ngp, fa.ngp, g, lane, t, q);
+                if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+            }
         }
         if (fa.rec_ee) ev0 = fa.rec_ee[clip].ev_offset + fa.rec_ee[clip].n_events;
         V2E_STAMP(1);
@@ -296,10 +307,17 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
             for (int kb = 0; kb < nk; kb += WAVE) {
                 const int key = kb + lane;
                 // totals over all workgroups / over earlier workgroups for the keys not fetched yet
-                for (int k = (kb == 0 ? KPRE : 0) + wave; k < WAVE && kb + k < nk; k += BLOCK / WAVE) {
-                    uint32_t t, q;
-                    key_totals(gt + (size_t)(kb + k) * fa.ngp, fa.ngp, g, lane, t, q);
-                    if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+                if (fa.pre32) {
+                    if (kb > 0 && wave == 0 && key < nk) {
+                        s_T[lane] = fa.tot32[(size_t)clip * a.nkeys_cap + key];
+                        s_P[lane] = fa.pre32[((size_t)clip * a.nkeys_cap + key) * fa.ngp + g];
+                    }
+                } else {
+                    for (int k = (kb == 0 ? KPRE : 0) + wave; k < WAVE && kb + k < nk; k += BLOCK / WAVE) {
+                        uint32_t t, q;
+                        key_totals(gt + (size_t)(kb + k) * fa.ngp, fa.ngp, g, lane, t, q);
+                        if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+                    }
                 }
                 // pass 1: which of my iterations survive; per-wave key counts
                 uint32_t mymask = 0, mine = 0;
@@ -532,4 +550,40 @@ __global__ __launch_bounds__(BLOCK) void k_refr(KArgs a, const FrameCtl *__restr
     if (gmax == 0) return;
     const TsGen tg(c, M, nullptr);
     group_key_totals<true>(a, cw, tsm, tg, gmax, gtT + (size_t)clip * a.nkeys_cap * ngp + g, ngp, s_wcnt, lane, wave, gmax);
+}
+
+// Large grids: exclusive prefix over workgroups of every key row (u16 counts -> u32 prefixes) and
+// the row totals.  One workgroup per key (grid-stride over keys < 2 + 2M).
+__global__ __launch_bounds__(BLOCK) void k_scan2(KArgs a, const uint16_t *__restrict__ gtT, int ngp, const int *__restrict__ gmaxv,
+                                                 int ngroups, uint32_t *__restrict__ pre32, uint32_t *__restrict__ tot32)
+{
+    __shared__ int s_red[BLOCK / WAVE];
+    __shared__ uint32_t s_w[BLOCK / WAVE];
+    const int clip = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int M = block_max_of_groups(gmaxv + (size_t)clip * ngroups, ngroups, s_red, tid, lane, wave);
+    if (M > a.max_iters) return;
+    const int nk = 2 + 2 * M;
+    const int ipt = ngp / BLOCK; // ngp is a multiple of 512
+    for (int key = blockIdx.x; key < nk; key += gridDim.x) {
+        const uint16_t *row = gtT + ((size_t)clip * a.nkeys_cap + key) * ngp + (size_t)tid * ipt;
+        uint32_t *orow = pre32 + ((size_t)clip * a.nkeys_cap + key) * ngp + (size_t)tid * ipt;
+        uint32_t s = 0;
+        for (int j = 0; j < ipt; ++j) s += row[j];
+        const uint32_t ex = wave_excl_scan_u32(s, lane);
+        if (lane == WAVE - 1) s_w[wave] = ex + s;
+        __syncthreads();
+        uint32_t base = ex, total = 0;
+#pragma unroll
+        for (int q = 0; q < BLOCK / WAVE; ++q) {
+            if (q < wave) base += s_w[q];
+            total += s_w[q];
+        }
+        for (int j = 0; j < ipt; ++j) {
+            orow[j] = base;
+            base += row[j];
+        }
+        if (tid == 0) tot32[(size_t)clip * a.nkeys_cap + key] = total;
+        __syncthreads();
+    }
 }
