@@ -283,3 +283,33 @@ def test_event_stream_gatherer_nccl_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("api", ["frame", "clip"])
+def test_all_grey_levels_static_scene_and_tensor_input(api, oracle_lib):
+    """Every uint8 grey level (0..20 linear branch of lin_log, log(0) masked), a static scene (no signal
+    events -> None / zero counts), torch-tensor frames (test/leak_event_test.py passes tensors), reset()."""
+    from v2e_amd import EventEmulator
+    kw = dict(pos_thres=0.2, neg_thres=0.2, sigma_thres=0.03, cutoff_hz=300, leak_rate_hz=0.0, shot_noise_rate_hz=0.0,
+              refractory_period_s=0.0005)
+    ramp = np.tile(np.arange(256, dtype=np.uint8), (16, 1))           # [16,256]: all grey levels
+    frames = [ramp, ramp, ramp[:, ::-1].copy(), ramp[:, ::-1].copy(), np.zeros_like(ramp), np.full_like(ramp, 255), ramp]
+    times = [0.0, 0.01, 0.02, 0.03, 0.04, 0.05, 0.06]
+    ora = oracle_lib.OracleEmulator(rng_mode="philox", seed=8, **kw)
+    oev = [ora.generate_events(f, t) for f, t in zip(frames, times)]
+    hip = EventEmulator(device="cuda", rng_mode="philox", seed=8, **kw)
+    if api == "frame":
+        for k, (f, t) in enumerate(zip(frames, times)):
+            x = torch.from_numpy(f) if k % 2 == 0 else torch.from_numpy(f).cuda()  # CPU and CUDA tensors
+            ev = hip.generate_events(x, t)
+            assert events_equal(ev, oev[k]), "frame %d" % k
+    else:
+        ev, counts = hip.generate_events_batch(np.stack(frames), times)
+        assert list(counts) == [0 if e is None else len(e) for e in oev]
+        assert np.array_equal(ev, np.concatenate([e for e in oev if e is not None]))
+    assert oev[1] is None or len(oev[1]) < 50                           # static scene: no signal events
+    assert np.array_equal(hip.base_log_frame.cpu().numpy(), ora.base_log_frame)
+    assert hip.t_previous == times[-1] and hip.num_events_total == ora.num_events_total
+    # reset(): the next frame re-initialises the state like a fresh emulator
+    hip.reset()
+    assert hip.num_events_total == 0 and hip.generate_events(ramp, 1.0) is None

@@ -310,6 +310,12 @@ class EventEmulator(object):
         eng = self._ensure_engine(H, W)
         # thresholds are scalars (Python floats) until _init draws them; remember the
         # values current at this moment (set_dvs_params may have changed them)
+        if torch.is_tensor(self.pos_thres) or torch.is_tensor(self.neg_thres):
+            # re-initialisation after reset(): the per-pixel planes of the previous run are dropped and
+            # new ones are drawn around the same scalar thresholds (the reference's reset() leaves the old
+            # tensors in place, which its own _init cannot consume)
+            prev = self._thres_scalar or (float(self.pos_thres_nominal), float(self.neg_thres_nominal))
+            self.pos_thres, self.neg_thres = prev
         self._thres_scalar = (float(self.pos_thres), float(self.neg_thres))
         self._thres_is_scalar = not (self.sigma_thres > 0)
         eng.alloc_state(self.cutoff_hz > 0)
