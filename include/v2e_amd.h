@@ -244,6 +244,18 @@ int v2e_u8_to_f32_norm(const uint8_t *in, float *out, int64_t n, float mean, voi
  * in is [U][B][hw] (interpolation batch order), out is [B][U][hw] (time order, slomo.py:441) */
 int v2e_f32_to_u8_trunc(const float *in, uint8_t *out, int U, int B, int hw, float mean, int reorder, void *stream);
 
+/* ----------------------------------------------------- event sinks */
+
+/* AEDAT-2.0 records of aedat2_output.py:155-173: out_bytes gets n x 8 bytes (big-endian int32 address,
+ * big-endian int32 timestamp in us).  Layout constants as set in aedat2_output.py:41-77 for the sensor
+ * (346x260 / 240x180: xshift 12, yshift 22, pshift 11, flipx = flipy = 1; 640x480: 1, 11, 0).
+ * noise_from >= 0: events [noise_from, n) get the special-event bit (label_signal_noise). */
+int v2e_events_pack_aedat2(const float *events, void *out_bytes, int64_t n, int sizex, int sizey, int xshift,
+                           int yshift, int pshift, int flipx, int flipy, int64_t noise_from, void *stream);
+
+/* HDF5 "events" rows of emulator.py:955-965: uint32 [n][4] = (t*1e6 in float32, x, y, p with -1 -> 0) */
+int v2e_events_pack_h5(const float *events, uint32_t *out, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
