@@ -256,6 +256,13 @@ int v2e_events_pack_aedat2(const float *events, void *out_bytes, int64_t n, int 
 /* HDF5 "events" rows of emulator.py:955-965: uint32 [n][4] = (t*1e6 in float32, x, y, p with -1 -> 0) */
 int v2e_events_pack_h5(const float *events, uint32_t *out, int64_t n, void *stream);
 
+/* EventRenderer.accumulate_event_frame (renderer.py:368-400, hist2d_numba_seq v2e_utils.py:474-486):
+ * current_frame (float64 [bins_y][bins_x], device) = clip(current_frame + hist(ON) - hist(OFF), +-full_scale).
+ * scratch_diff: device int32 [bins_y][bins_x], zero on entry, left zero. */
+int v2e_events_accumulate_frame(const float *events, int64_t n, double *current_frame, int32_t *scratch_diff,
+                                int bins_y, int bins_x, double y_lo, double y_hi, double x_lo, double x_hi,
+                                double full_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

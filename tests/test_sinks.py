@@ -37,3 +37,27 @@ def test_hip_packers_match_reference_writer_bytes():
         assert np.array_equal(h5, z["h5_%dx%d" % (w, h)])
     with pytest.raises(ValueError):
         pack_aedat2(ev, 100, 100)
+
+
+@pytest.mark.gpu
+def test_event_frame_accumulator_matches_renderer_math():
+    """renderer.py:368-400 restated with numpy (hist2d_numba_seq semantics), incl. down-scaled output bins."""
+    import torch
+    from v2e_amd.sinks import EventFrameAccumulator
+    z = np.load(os.path.join(GOLDEN, "sinks.npz"))
+    ev = z["ev_346x260"]
+    for (bh, bw) in ((260, 346), (130, 173)):
+        acc = EventFrameAccumulator(bh, bw, full_scale_count=3, device="cuda")
+        cur = np.zeros((bh, bw))
+        for sl in (slice(0, 2000), slice(2000, 5000)):
+            e = ev[sl]
+            got = acc.accumulate(torch.from_numpy(e).cuda(), 260, 346).cpu().numpy()
+            on = e[:, 3] == 1
+            H = np.zeros((bh, bw))
+            for pol, sgn in ((on, 1), (~on, -1)):
+                i = (e[pol, 2].astype(np.float64) - 0) * (1 / ((260 - 0) / bh))
+                j = (e[pol, 1].astype(np.float64) - 0) * (1 / ((346 - 0) / bw))
+                ok = (i >= 0) & (i < bh) & (j >= 0) & (j < bw)
+                np.add.at(H, (i[ok].astype(int), j[ok].astype(int)), sgn)
+            cur = np.clip(cur + H, -3, 3)
+            assert np.array_equal(got, cur)

@@ -36,6 +36,30 @@ __global__ __launch_bounds__(256) void k_pack_h5(const float4 *__restrict__ ev, 
     out[i] = make_uint4((uint32_t)tus, (uint32_t)e.y, (uint32_t)e.z, (uint32_t)p);
 }
 
+// renderer.py:368-400 + v2e_utils.py:474-486 (hist2d_numba_seq): ON minus OFF event counts per output bin
+__global__ __launch_bounds__(256) void k_hist_events(const float4 *__restrict__ ev, long long n, int *__restrict__ diff, int bins_y,
+                                                     int bins_x, double y_lo, double x_lo, double delta_y, double delta_x)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 e = ev[i];
+    const double fi = ((double)e.z - y_lo) * delta_y; // tracks[0] = y
+    const double fj = ((double)e.y - x_lo) * delta_x; // tracks[1] = x
+    if (fi >= 0.0 && fi < (double)bins_y && fj >= 0.0 && fj < (double)bins_x)
+        atomicAdd(&diff[(int)fi * bins_x + (int)fj], e.w == 1.0f ? 1 : -1); // pol_on = (p == 1), off = not on
+}
+
+// currentFrame = clip(currentFrame + (img_on - img_off), -full_scale, +full_scale)   (renderer.py:396-400)
+__global__ __launch_bounds__(256) void k_frame_clip_add(double *__restrict__ cur, int *__restrict__ diff, int n, double full_scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = cur[i] + (double)diff[i];
+    v = v < -full_scale ? -full_scale : (v > full_scale ? full_scale : v);
+    cur[i] = v;
+    diff[i] = 0; // ready for the next slice
+}
+
 } // namespace
 
 extern "C" {
@@ -56,6 +80,19 @@ int v2e_events_pack_h5(const float *events, uint32_t *out, int64_t n, void *stre
     V2E_REQUIRE((events && out) || n == 0, "null");
     if (n <= 0) return 0;
     k_pack_h5<<<v2e_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const float4 *)events, (uint4 *)out, n);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_events_accumulate_frame(const float *events, int64_t n, double *current_frame, int32_t *scratch_diff, int bins_y,
+                                int bins_x, double y_lo, double y_hi, double x_lo, double x_hi, double full_scale, void *stream)
+{
+    V2E_REQUIRE(current_frame && scratch_diff && bins_y > 0 && bins_x > 0 && (events || n == 0), "bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const double delta_y = 1 / ((y_hi - y_lo) / bins_y), delta_x = 1 / ((x_hi - x_lo) / bins_x); // v2e_utils.py:478
+    if (n > 0)
+        k_hist_events<<<v2e_cdiv(n, 256), 256, 0, s>>>((const float4 *)events, n, scratch_diff, bins_y, bins_x, y_lo, x_lo, delta_y, delta_x);
+    k_frame_clip_add<<<v2e_cdiv((int64_t)bins_y * bins_x, 256), 256, 0, s>>>(current_frame, scratch_diff, bins_y * bins_x, full_scale);
     V2E_HIP(hipGetLastError());
     return 0;
 }
