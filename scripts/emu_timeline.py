@@ -26,7 +26,9 @@ t = np.frombuffer(out, dtype=np.uint64).reshape(ng.value, 16).astype(np.int64)
 t0 = t[:, 0].min()
 names = ["start", "loads issued+keytotals", "M known", "pass1 done", "barrier", "pass2 done", "emit loop end", "emit done", "count math done", "end"]
 print("blocks start spread: %.2f us" % ((t[:, 0].max() - t0) / 100.0))
-for i, n in enumerate(names):
+names += ["tg ready (10)", "emit setup done (11)", "late key totals done (12)"]
+order = [0, 1, 2, 10, 11, 12, 3, 4, 5, 6, 7, 8, 9]
+for i, n in [(k, names[k]) for k in order]:
     col = t[:, i]
     ok = col > 0
     print("%-26s mean %+7.2f us  (min %+6.2f max %+6.2f) since first block start; mean since own start %6.2f" % (

@@ -50,7 +50,7 @@ struct FrameCtl {
     // count n = 1..32, so the kernel needs no float64 division once the frame's max is known
     float ts_start[32], ts_stepf[32];
     uint32_t refr_mask; // bit n-1: refractory_period_s > delta_time / n
-    uint32_t pad_;
+    float ts_end;       // (float)t_frame
 };
 
 __host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_hz, double shot_rate_hz, double refr_s)
@@ -61,8 +61,9 @@ __host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_h
     c.dt_over_tau = 0.0;
     if (cutoff_hz > 0) { const double tau = 1.0 / (M_PI * 2 * cutoff_hz); c.dt_over_tau = dt / tau; }
     c.shot_base = (shot_rate_hz / 2) * dt;
-    c.refr_mask = 0; c.pad_ = 0;
+    c.refr_mask = 0;
     const float end = (float)t_frame;
+    c.ts_end = end;
     for (int n = 1; n <= 32; ++n) { // same IEEE operations as TsGen below
         const double ts_step = dt / (double)n;
         const float start = (float)(t_prev + ts_step);

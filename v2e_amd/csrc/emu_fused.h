@@ -49,7 +49,8 @@ struct FusedArgs {
 
 #define V2E_STAMP(i) do { if (fa.dbg && tid == 0) fa.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
 
-constexpr int KPRE = 16; // keys of chunk 0 fetched before M is known (covers M <= 7)
+constexpr int KPRE = 12; // keys of chunk 0 fetched before M is known (covers M <= 5)
+constexpr int KPW = KPRE / (BLOCK / WAVE); // of those, keys per wave
 
 // exact floor(a/b) for a >= 0, b > 0: equals c10::div_floor_floating (whose fmod / re-divide /
 // "+1 if frac > 0.5" steps exist to return exactly this) without the fmod loop.
@@ -74,7 +75,17 @@ __device__ __forceinline__ int block_max_of_groups(const int *__restrict__ gm, i
     __syncthreads();
     m = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     __syncthreads();
-    return m;
+    return __builtin_amdgcn_readfirstlane(m);
+}
+
+__device__ __forceinline__ int block_max_finish(int m, int *s_red, int lane, int wave)
+{
+    m = wave_max_i32(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(m); // make the uniformity visible: loops over M stay scalar
 }
 
 // One wave, one key: total over all workgroups and over the workgroups before g.  A 16-byte load
@@ -100,6 +111,24 @@ __device__ __forceinline__ void key_totals(const uint16_t *__restrict__ row, int
         }
     }
     tot_o = wave_sum_u32(tot);
+    pre_o = wave_sum_u32(pre);
+}
+
+// the reduction half of key_totals for one already-loaded 16-byte slice (ngp == 512: one slice per key)
+__device__ __forceinline__ void key_totals_loaded(const uint4 v, int g, int lane, uint32_t &tot_o, uint32_t &pre_o)
+{
+    const int gb = lane * 8;
+    const uint32_t s2 = v.x + v.y + v.z + v.w;
+    const uint32_t lane_tot = (s2 & 0xFFFFu) + (s2 >> 16);
+    uint32_t pre = 0;
+    if (gb + 8 <= g) {
+        pre = lane_tot;
+    } else if (gb < g) {
+        const uint32_t w[8] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16, v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre += (gb + j < g) ? w[j] : 0u;
+    }
+    tot_o = wave_sum_u32(lane_tot);
     pre_o = wave_sum_u32(pre);
 }
 
@@ -213,12 +242,30 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         s_lutL[tid] = a.lut_L[tid];
         s_lutI[tid] = a.lut_I[tid];
     }
+    // key rows of this wave's KPW keys and the workgroup maxima: issue the loads now, reduce later
+    const uint16_t *gt = fa.gtT2[fa.par_e] + (size_t)clip * a.nkeys_cap * fa.ngp;
+    const bool krow_fast = fa.do_emit && !fa.pre32 && fa.ngp == 512;
+    uint4 kv[KPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) kv[j] = make_uint4(0u, 0u, 0u, 0u);
+    int gm_part = 0;
+    if (fa.do_emit) {
+        if (krow_fast) {
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) kv[j] = *(const uint4 *)(gt + (size_t)(wave + (BLOCK / WAVE) * j) * 512 + lane * 8);
+        }
+        const int *gmv = fa.gmax2[fa.par_e] + (size_t)clip * fa.ngroups;
+        for (int k = tid; k < fa.ngroups; k += BLOCK) gm_part = max(gm_part, gmv[k]);
+    }
+    // keep every load above issued here (the scheduler otherwise sinks them next to their first use,
+    // which puts a full memory round trip back on the critical path); waits stay at the uses
+    __builtin_amdgcn_sched_barrier(0);
     // ---- arithmetic that depends on no memory, done while those loads are in flight
     float rng_r = 0.f, rng_u = 0.f; // count(f): leak normal / shot uniform of this pixel
     if (fa.do_count && valid && (a.do_leak || a.do_shot))
         v2e_draw_frame(a.seed, (uint32_t)clip, fbase + fa.fidx_c, (uint32_t)p, &rng_r, &rng_u);
     uint32_t pk[4] = {0, 0, 0, 0};  // emit(f-1): shuffle round keys of iteration `lane` (first chunk)
-    float tab_start = 0.f, tab_step = 0.f;
+    float tab_start = 0.f, tab_step = 0.f, tab_end = 0.f;
     uint32_t refr_mask = 0;
     if (fa.do_emit) {
         if (a.shuffle && a.rng_mode == V2E_RNG_PHILOX) v2e_perm_keys(a.seed, (uint32_t)clip, fbase + fa.fidx_e, (uint32_t)lane, pk);
@@ -226,19 +273,25 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         tab_start = ce->ts_start[lane & 31];
         tab_step = ce->ts_stepf[lane & 31];
         refr_mask = ce->refr_mask;
+        tab_end = ce->ts_end;
     }
-    const uint16_t *gt = fa.gtT2[fa.par_e] + (size_t)clip * a.nkeys_cap * fa.ngp;
     unsigned long long ev0 = 0;
     int M = 0, gmax_own_e = 0;
     if (fa.do_emit) {
-        if (fa.bar) gmax_own_e = fa.gmax2[fa.par_e][(size_t)clip * fa.ngroups + g];
+        if (fa.bar) gmax_own_e = __builtin_amdgcn_readfirstlane(fa.gmax2[fa.par_e][(size_t)clip * fa.ngroups + g]);
         if (fa.pre32) { // prefixes already computed by k_scan2: two loads per key, lane = key
             if (wave == 0) {
                 s_T[lane] = fa.tot32[(size_t)clip * a.nkeys_cap + lane];
                 s_P[lane] = fa.pre32[((size_t)clip * a.nkeys_cap + lane) * fa.ngp + g];
             }
+        } else if (krow_fast) {
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) { // the first KPRE keys, loaded above before M is known
+                uint32_t t, q;
+                key_totals_loaded(kv[j], g, lane, t, q);
+                if (lane == 0) { s_T[wave + (BLOCK / WAVE) * j] = t; s_P[wave + (BLOCK / WAVE) * j] = q; }
+            }
         } else {
-            // the first KPRE keys, before M is known (rows are clean, so no key count is needed)
             for (int k = wave; k < KPRE && k < a.nkeys_cap; k += BLOCK / WAVE) {
                 uint32_t t, q;
                 key_totals(gt + (size_t)k * fa.ngp, fa.ngp, g, lane, t, q);
@@ -247,7 +300,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         }
         if (fa.rec_ee) ev0 = fa.rec_ee[clip].ev_offset + fa.rec_ee[clip].n_events;
         V2E_STAMP(1);
-        M = block_max_of_groups(fa.gmax2[fa.par_e] + (size_t)clip * fa.ngroups, fa.ngroups, s_red, tid, lane, wave);
+        M = block_max_finish(gm_part, s_red, lane, wave);
         V2E_STAMP(2);
     } else if (U8 && fa.do_count) {
         __syncthreads(); // LUT visible
@@ -270,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
             TsGen tg(0.f, 0.f, 0.f, n);
             bool use_refr;
             if (n <= 32) { // host-filled tables: no float64 division on the critical path
-                tg = TsGen(__uint_as_float(lane_value(__float_as_uint(tab_start), n - 1)), (float)ce->t_frame,
+                tg = TsGen(__uint_as_float(lane_value(__float_as_uint(tab_start), n - 1)), tab_end,
                            __uint_as_float(lane_value(__float_as_uint(tab_step), n - 1)), n);
                 use_refr = a.has_refr && ((refr_mask >> (n - 1)) & 1u);
             } else {
@@ -278,6 +331,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                 tg = TsGen(c, n, nullptr);
                 use_refr = a.has_refr && (a.refr > (c.t_frame - c.t_prev) / (double)n);
             }
+            V2E_STAMP(10);
             const uint32_t cw = cw_e;
             const int mag = (int)(cw & CNT_MASK);
             const bool neg = (cw & CNT_NEG) != 0;
@@ -304,6 +358,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
             uint32_t son_tot = 0, soff_tot = 0, son_off = 0, soff_off = 0;
             int fcount = 0;
             bool dropped = false, alive = true;
+            V2E_STAMP(11);
             for (int kb = 0; kb < nk; kb += WAVE) {
                 const int key = kb + lane;
                 // totals over all workgroups / over earlier workgroups for the keys not fetched yet
@@ -319,6 +374,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                         if (lane == 0) { s_T[k] = t; s_P[k] = q; }
                     }
                 }
+                V2E_STAMP(12);
                 // pass 1: which of my iterations survive; per-wave key counts
                 uint32_t mymask = 0, mine = 0;
                 const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
@@ -512,10 +568,10 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         V2E_STAMP(8);
         m = wave_max_i32(m);
         int *gmp = fa.gmax2[fa.par_c] + (size_t)clip * fa.ngroups + g;
-        const int gmax_old_raw = *gmp; // what this row was last written with (same parity, two frames ago)
+        const int gmax_old_raw = __builtin_amdgcn_readfirstlane(*gmp); // what this row was last written with (two frames ago)
         if (lane == 0) s_red[wave] = m;
         __syncthreads();
-        const int gmax_raw = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+        const int gmax_raw = __builtin_amdgcn_readfirstlane(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
         if (tid == 0) *gmp = gmax_raw;
         const int gmax = min(gmax_raw, a.max_iters), gmax_old = min(gmax_old_raw, a.max_iters);
         uint16_t *gcol = fa.gtT2[fa.par_c] + (size_t)clip * a.nkeys_cap * fa.ngp + g;
@@ -540,7 +596,7 @@ __global__ __launch_bounds__(BLOCK) void k_refr(KArgs a, const FrameCtl *__restr
     const size_t sp = (size_t)clip * a.npx_pad + p;
     const bool valid = p < a.npx;
     const int *gm = gmaxv + (size_t)clip * ngroups;
-    const int gmax = min(gm[g], a.max_iters);
+    const int gmax = __builtin_amdgcn_readfirstlane(min(gm[g], a.max_iters));
     const uint32_t cw = valid ? cnt[sp] : 0u; // issued before M is known: one round trip
     const float tsm = valid ? a.ts_mem[sp] : 0.f;
     const int M = block_max_of_groups(gm, ngroups, s_red, tid, lane, wave);
