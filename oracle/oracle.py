@@ -287,6 +287,7 @@ class OracleEmulator:
                                 _p(neg_cnt), _p(shot_on), _p(shot_off), C.byref(M))
         assert rc == 0
         M = M.value
+        self.last_M = M
         n = M if M > 0 else 1
         ts = None
         if not philox:
