@@ -68,14 +68,14 @@ def emulator_bytes_per_pixel(kw):
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per k_main launch from the committed rocprofv3 PMC passes of this same command
+    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes of this same command
     (profiles/r01_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE
     uncorrected -- our loads are 1-8 B per lane, for which the guide's x2 factor is uncalibrated).
     Counters cannot be read from inside this process, so the value is the recorded one or null."""
     path = os.path.join(ROOT, "profiles", "r01_emulator_pmc_hbm.txt")
     try:
         for line in open(path):
-            if line.startswith("# k_main"):
+            if line.startswith("# k_step"):
                 parts = line.split()
                 return int((float(parts[-2]) + float(parts[-1])) * 1024)
     except Exception:
@@ -218,25 +218,30 @@ def main():
         r = eng.recs_to_numpy(recs)[:, 0]
         ev_per_frame = float(r["n_events"].mean())
         npx = H * W
-        # fused pipeline: k_main(f) = emit(f-1) + count(f) owns the whole algorithmic traffic of a
-        # frame step (53 B/pixel + 16 B/event); k_refr re-reads cnt/ts_mem only
-        # when the refractory rule is active and otherwise exits at once.
-        per_launch_us = {"k_main": prof["count"] / (prof["launches"] + 1) * 1e3,
-                         "k_refr": prof["rank"] / prof["launches"] * 1e3}
-        step_bytes = bpp * npx + 16 * ev_per_frame
-        ach = step_bytes / (per_launch_us["k_main"] * 1e-6)
+        # decoupled pipeline: k_step(f) = finalise(f-1) + count(f) is the frame-to-frame
+        # dependency chain and owns the per-pixel state traffic (53 B/pixel + the 4-byte count word written for
+        # the emission side); the emission batches (k_tot_multi + k_emit_multi, 16 B/event + 4 B/pixel re-read)
+        # run behind it on a second stream.
+        step_us = prof["count"] / (prof["launches"] + 1) * 1e3
+        step_bytes = (bpp + 4) * npx
+        emit_bytes = 16 * ev_per_frame + 2 * 4 * npx
+        ach = step_bytes / (step_us * 1e-6)
+        whole = (bpp * npx + 16 * ev_per_frame)
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_main",
+            "bound": "hbm", "kernel": "k_step",
             "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK, 5), "traffic": pmc_traffic_per_launch(),
             "algorithmic_bytes_per_launch": int(step_bytes),
-            "avg_launch_us": {k: round(v, 3) for k, v in per_launch_us.items()},
-            "whole_step": {"algorithmic_bytes_per_frame": int(step_bytes),
-                           "achieved_GBps": round(step_bytes * K * F / elapsed / 1e9, 2),
-                           "frac": round(step_bytes * K * F / elapsed / HBM_PEAK, 5)},
-            "note": "avg_launch_us from hipEvents recorded before every launch on the launch stream (includes "
-                    "the inter-kernel gap); 346x260 state (2.9 MB) is L2/MALL resident and one frame is only "
-                    "1406 waves, so the path is bounded by per-launch latency, not HBM (DESIGN.md section 3)",
+            "avg_launch_us": {"k_step": round(step_us, 3),
+                              "emission_batch(k_tot_multi+k_emit_multi)": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3)},
+            "emission": {"frames_per_batch": prof.get("frames_per_batch"), "algorithmic_bytes_per_frame": int(emit_bytes)},
+            "whole_step": {"algorithmic_bytes_per_frame": int(whole),
+                           "achieved_GBps": round(whole * K * F / elapsed / 1e9, 2),
+                           "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
+            "note": "avg_launch_us from hipEvents recorded before every k_step launch on its stream (includes the "
+                    "inter-kernel gap) and around every emission batch on the emission stream; 346x260 state (2.9 MB) is "
+                    "L2/MALL resident and one frame is only 1406 waves, so the chain is bounded by per-launch latency, "
+                    "not HBM (DESIGN.md section 3)",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())

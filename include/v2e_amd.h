@@ -171,18 +171,29 @@ int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const
  * recs_dev[f][clip] (device, caller-owned).  No host synchronisation inside.
  * use_graph, low two bits: 0 plain launches, 1 capture the launch sequence into a hipGraph
  * (cached while every baked-in pointer/size is unchanged), 2 instrumented (see
- * v2e_emu_last_profile).  |16 selects the unfused count/rank/scan/emit pipeline (kept for A/B
- * measurements; default is the fused k_main [+ k_refr] pipeline, identical results).
+ * v2e_emu_last_profile).  Default pipeline: the k_step dependency chain (one launch per frame:
+ * base/ts_mem update of frame f-1 + counts of frame f) with the event list built behind it, several
+ * frames per launch, on a second stream that joins `stream` before the call's work ends.
+ * That is the choice while a frame is a few workgroups per CU (latency-bound); larger grids use one
+ * k_main launch per frame with emission on the chain (each pixel touched once).  |32 forces the
+ * latter, |64 the former, |16 selects the unfused count/rank/scan/emit pipeline (kept for A/B
+ * measurements); all three give identical results.
  */
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames,
                 const double *t_prev, const double *t_frame, uint32_t frame_idx0, float *events,
                 uint64_t cap, v2e_frame_rec *recs_dev, int use_graph, void *stream);
 
 /* After an instrumented v2e_emu_run (blocking: a hipEvent before every launch): summed
- * milliseconds per kernel class and frames.  Fused pipeline: ms_count = k_main,
- * ms_rank = k_refr, others 0; unfused pipeline: k_count, k_rank, k_scan, k_emit. */
+ * milliseconds per kernel class and frames.  k_step pipeline: ms_count = the chain of
+ * launches + 1 k_step launches (first to last, gaps included), ms_emit = the emission batches
+ * (v2e_emu_last_profile_pipe), others 0; k_main pipeline: ms_count = k_main, ms_rank = k_refr;
+ * |16: k_count, k_rank, k_scan, k_emit. */
 int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *ms_scan,
                          double *ms_emit, int *launches);
+
+/* Default pipeline only: emission batches timed by the last instrumented run and the frames
+ * per emission batch this handle uses (chosen at create time; env V2E_AMD_PIPE_E overrides). */
+int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch);
 
 /* ------------------------------------------------------------- SuperSloMo */
 

@@ -61,11 +61,15 @@ def test_hip_philox_frame_api_matches_reference(name):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
 
 
-@pytest.mark.parametrize("use_graph", [0, 1, 16, 17])  # fused pipeline plain/graph, unfused plain/graph
+# use_graph: low bits 0 plain launches / 1 hipGraph; |64 k_step chain + deferred emission batches,
+# |32 one k_main per frame (emission on the chain), |16 unfused count/rank/scan/emit; none = size heuristic
+PIPELINES = [0, 1, 64, 65, 32, 33, 16, 17]
+
+
+@pytest.mark.parametrize("use_graph", PIPELINES)
 @pytest.mark.parametrize("name", PHILOX_FIXTURES)
 def test_hip_philox_device_resident_clip_matches_reference(name, use_graph):
-    """Whole clip on device (no host sync between frames; optionally one hipGraph), both the fused
-    k_main/k_refr pipeline and the unfused count/rank/scan/emit pipeline."""
+    """Whole clip on device (no host sync between frames; optionally one hipGraph), all three pipelines."""
     fx = PhiloxFixture(name)
     emu = _mk(fx, seed=fx.seed, rng_mode="philox")
     ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph)
@@ -81,6 +85,28 @@ def test_hip_philox_device_resident_clip_matches_reference(name, use_graph):
     if fx.ts_mem_sha:
         assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
+@pytest.mark.parametrize("pipe_e", [1, 2, 3, 5])
+@pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260"])
+def test_step_chain_pipeline_ring_wraps(name, pipe_e, monkeypatch):
+    """Few frames per emission batch: the ring of frame slots wraps several times within the fixture clip, the
+    step chain waits on emission batches, partial last batch."""
+    monkeypatch.setenv("V2E_AMD_PIPE_E", str(pipe_e))
+    fx = PhiloxFixture(name)
+    for use_graph in (64, 65):
+        emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+        ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph)
+        assert list(counts) == list(fx.n_events)
+        row = 0
+        for k, n in enumerate(counts):
+            if n:
+                assert sha(ev[row:row + n]) == fx.ev_sha[k], "frame %d event digest differs" % k
+            row += n
+        st = _state(emu)
+        assert sha(st["base_log_frame"]) == fx.base_sha
+        if fx.ts_mem_sha:
+            assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
 
 
 def test_split_clip_equals_whole_clip():
@@ -237,7 +263,7 @@ def test_many_iterations_grow_scratch(oracle_lib):
     assert ora.last["M"] > 64
 
 
-@pytest.mark.parametrize("use_graph", [1, 17])
+@pytest.mark.parametrize("use_graph", [65, 33, 17])
 @pytest.mark.parametrize("refr", [0.0, 0.0004])
 def test_device_resident_clip_many_iterations(use_graph, refr, oracle_lib):
     """> 31 events per pixel per frame: several 64-key chunks in the fused kernels, refractory on/off."""

@@ -616,6 +616,7 @@ __global__ __launch_bounds__(BLOCK) void k_permute(const float4 *__restrict__ in
 }
 
 #include "emu_fused.h"
+#include "emu_pipe.h"
 
 } // namespace
 
@@ -650,9 +651,24 @@ struct v2e_emu {
     unsigned long long *dbg = nullptr; // dev tool (v2e_emu_debug_timeline)
     unsigned *run_bar = nullptr;       // [run_cap + 1][n_clips] rendezvous counters of the fused pipeline
     uint32_t *pre32 = nullptr, *tot32 = nullptr; // k_scan2 outputs (large grids only)
+    int n_cu = 256;
     int max_resident_blocks = 0;       // k_main workgroups the device can hold at once (occupancy query)
     double prof_ms[4] = {0, 0, 0, 0}; // count, rank, scan, emit (use_graph == 2)
     int prof_launches = 0;
+    // decoupled pipeline (emu_pipe.h): ring of pipe_D = 2 * pipe_E frame slots + the emission stream
+    int pipe_E = 8, pipe_D = 16;
+    uint32_t *pipe_cnt = nullptr;  // [pipe_D][n_clips][npx_pad]
+    int *pipe_gmax = nullptr;      // [pipe_D][n_clips][ngroups]
+    float *pipe_tsold = nullptr;   // [pipe_D][n_clips][npx_pad], allocated on first use with a refractory period
+    uint16_t *pipe_gtT = nullptr;  // [pipe_D][n_clips][nkeys_cap][ngp]
+    int *pipe_rowext = nullptr;    // [pipe_D][n_clips][ngroups]
+    uint32_t *pipe_nw = nullptr;   // [pipe_D][n_clips][ngroups]
+    uint32_t *pipe_pre32 = nullptr, *pipe_tot32 = nullptr; // large grids: [pipe_E][n_clips][nkeys_cap][ngp] / [..][nkeys_cap]
+    unsigned long long *pipe_off = nullptr; // [2][n_clips] event offset at the start of the current / next emission batch
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_fork, ev_join;
+    double prof_emit_ms = 0.0;
+    int prof_emit_batches = 0;
 };
 
 static thread_local char g_err[512] = "";
@@ -729,6 +745,24 @@ static int alloc_iter_scratch(v2e_emu *h, int max_iters)
         V2E_HIP(hipMemset(h->gtot[q], 0, sizeof(uint16_t) * (size_t)h->n_clips * h->ngp * h->nkeys_cap));
         V2E_HIP(hipMemset(h->gmaxv[q], 0, sizeof(int) * (size_t)h->n_clips * h->ngroups));
     }
+    {
+        const size_t nrow = (size_t)h->pipe_D * h->n_clips * h->nkeys_cap * h->ngp, ng = (size_t)h->pipe_D * h->n_clips * h->ngroups;
+        if (h->pipe_gtT) { V2E_HIP(hipFree(h->pipe_gtT)); h->pipe_gtT = nullptr; }
+        V2E_HIP(hipMalloc(&h->pipe_gtT, sizeof(uint16_t) * nrow));
+        V2E_HIP(hipMemset(h->pipe_gtT, 0, sizeof(uint16_t) * nrow));
+        V2E_HIP(hipMemset(h->pipe_rowext, 0, sizeof(int) * ng));
+        V2E_HIP(hipMemset(h->pipe_gmax, 0, sizeof(int) * ng));
+        V2E_HIP(hipMemset(h->pipe_nw, 0, sizeof(uint32_t) * ng));
+        if (h->pipe_pre32) { V2E_HIP(hipFree(h->pipe_pre32)); h->pipe_pre32 = nullptr; }
+        if (h->pipe_tot32) { V2E_HIP(hipFree(h->pipe_tot32)); h->pipe_tot32 = nullptr; }
+        if (h->ngroups > 1024) {
+            const size_t npre = (size_t)h->pipe_E * h->n_clips * h->nkeys_cap * h->ngp;
+            V2E_HIP(hipMalloc(&h->pipe_pre32, sizeof(uint32_t) * npre));
+            V2E_HIP(hipMalloc(&h->pipe_tot32, sizeof(uint32_t) * (size_t)h->pipe_E * h->n_clips * h->nkeys_cap));
+            V2E_HIP(hipMemset(h->pipe_pre32, 0, sizeof(uint32_t) * npre));
+            V2E_HIP(hipMemset(h->pipe_tot32, 0, sizeof(uint32_t) * (size_t)h->pipe_E * h->n_clips * h->nkeys_cap));
+        }
+    }
     if (h->pre32) { V2E_HIP(hipFree(h->pre32)); h->pre32 = nullptr; }
     if (h->tot32) { V2E_HIP(hipFree(h->tot32)); h->tot32 = nullptr; }
     if (h->ngroups > 1024) { // large grids: prefix-scan launch instead of per-workgroup re-reduction
@@ -772,8 +806,24 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
         // the occupancy API can over-report by one workgroup per CU (MI355X guide): keep a margin
         per_cu = per_cu > 4 ? 4 : (per_cu > 1 ? per_cu - 1 : 0);
         h->max_resident_blocks = per_cu * ncu;
+        h->n_cu = ncu;
     }
     for (int q = 0; q < 2; ++q) V2E_HIP(hipMalloc(&h->gmaxv[q], sizeof(int) * (size_t)n_clips * h->ngroups));
+    {
+        // frames per emission launch: as many as keep the ring (count words + ts_mem copies) under ~1 GiB
+        size_t per_frame = (size_t)n_clips * h->npx_pad * 8, e = PIPE_E_MAX;
+        while (e > 4 && 2 * e * per_frame > ((size_t)1 << 30)) e >>= 1;
+        if (const char *ev = getenv("V2E_AMD_PIPE_E")) { int v = atoi(ev); if (v >= 1 && v <= PIPE_E_MAX) e = (size_t)v; }
+        h->pipe_E = (int)e;
+        h->pipe_D = 2 * h->pipe_E;
+        const size_t ng = (size_t)h->pipe_D * n_clips * h->ngroups;
+        V2E_HIP(hipMalloc(&h->pipe_cnt, sizeof(uint32_t) * (size_t)h->pipe_D * n_clips * h->npx_pad));
+        V2E_HIP(hipMalloc(&h->pipe_gmax, sizeof(int) * ng));
+        V2E_HIP(hipMalloc(&h->pipe_rowext, sizeof(int) * ng));
+        V2E_HIP(hipMalloc(&h->pipe_nw, sizeof(uint32_t) * ng));
+        V2E_HIP(hipMalloc(&h->pipe_off, sizeof(unsigned long long) * 2 * n_clips));
+        V2E_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    }
     int rc = alloc_iter_scratch(h, max_iters); // also zeroes gtot/gmaxv (clean-row invariant)
     if (rc) return rc;
     V2E_HIP(hipMalloc(&h->rec_ring, sizeof(v2e_frame_rec) * RING * n_clips));
@@ -795,6 +845,11 @@ int v2e_emu_destroy(v2e_emu *h)
     if (h->graph) hipGraphExecDestroy(h->graph);
     hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
     hipFree(h->lut_L); hipFree(h->lut_I); hipFree(h->pre32); hipFree(h->tot32);
+    hipFree(h->pipe_cnt); hipFree(h->pipe_gmax); hipFree(h->pipe_tsold); hipFree(h->pipe_gtT); hipFree(h->pipe_rowext);
+    hipFree(h->pipe_nw); hipFree(h->pipe_pre32); hipFree(h->pipe_tot32); hipFree(h->pipe_off);
+    for (hipEvent_t e : h->ev_fork) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_join) hipEventDestroy(e);
+    if (h->side) hipStreamDestroy(h->side);
     hipFree(h->cnt_b); hipFree(h->gtot[0]); hipFree(h->gtot[1]); hipFree(h->gmaxv[0]); hipFree(h->gmaxv[1]);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     hipFree(h->off_dev);
@@ -1089,6 +1144,93 @@ static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     return 0;
 }
 
+// Decoupled pipeline (emu_pipe.h): the k_step chain on `s`, emission batches on h->side.  With
+// ev_main / ev_side (instrumented run) an event is recorded before the first and after the last
+// k_step (events between dependent launches would lengthen the very gaps being measured) and
+// around every emission batch.
+static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
+                            float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, std::vector<hipEvent_t> *ev_main = nullptr,
+                            std::vector<hipEvent_t> *ev_side = nullptr)
+{
+    const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
+    const bool has_refr = p->refractory_period_s > 0;
+    V2E_REQUIRE(!has_refr || h->pipe_tsold, "pipe_tsold not allocated");
+    V2E_HIP(hipMemsetAsync(recs, 0, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
+    V2E_HIP(hipMemsetAsync(h->pipe_off, 0, sizeof(unsigned long long) * 2 * h->n_clips, s));
+    const int PIPE_E = h->pipe_E, PIPE_D = h->pipe_D;
+    const size_t st_px = (size_t)h->n_clips * h->npx_pad, st_g = (size_t)h->n_clips * h->ngroups;
+    auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t st) -> int {
+        if (!v) return 0;
+        hipEvent_t e;
+        V2E_HIP(hipEventCreate(&e));
+        v->push_back(e);
+        V2E_HIP(hipEventRecord(e, st));
+        return 0;
+    };
+    dim3 grid(h->ngroups, h->n_clips);
+    for (int f = 0; f <= n_frames; ++f) {
+        if (f % PIPE_E == 0 && f >= PIPE_D) // the slot this step writes was read by emission batch (f - PIPE_D) / PIPE_E
+            V2E_HIP(hipStreamWaitEvent(s, h->ev_join[(f - PIPE_D) / PIPE_E], 0));
+        StepArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.do_count = f < n_frames;
+        sa.do_final = f > 0;
+        const int sc = f % PIPE_D, se = (f + PIPE_D - 1) % PIPE_D;
+        sa.frame = sa.do_count ? (const char *)frames + (size_t)f * h->n_clips * h->npx * esz : nullptr;
+        sa.ctl_c = h->run_ctl + (size_t)(sa.do_count ? f : 0) * h->n_clips;
+        sa.ctl_e = h->run_ctl + (size_t)(f > 0 ? f - 1 : 0) * h->n_clips;
+        sa.fidx_base = h->run_fidx;
+        sa.fidx_c = (uint32_t)f;
+        sa.ngroups = h->ngroups;
+        sa.cnt_c = h->pipe_cnt + sc * st_px;
+        sa.cnt_e = h->pipe_cnt + se * st_px;
+        sa.gmax_c = h->pipe_gmax + sc * st_g;
+        sa.gmax_e = h->pipe_gmax + se * st_g;
+        sa.tsold_e = h->pipe_tsold ? h->pipe_tsold + se * st_px : nullptr;
+        sa.dbg = (h->dbg && f == n_frames / 2) ? h->dbg : nullptr;
+        if (f == 0 && mark(ev_main, s)) return V2E_EHIP;
+        DISPATCH_FT(dtype, {
+            if (p->f64_state) k_step<double, FT><<<grid, BLOCK, 0, s>>>(a, sa);
+            else k_step<float, FT><<<grid, BLOCK, 0, s>>>(a, sa);
+        });
+        if (f >= 1 && (f % PIPE_E == 0 || f == n_frames)) { // frames of batch b are final: emit them behind the chain
+            const int b = (f - 1) / PIPE_E;
+            EmitArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.ctl = h->run_ctl;
+            ea.recs = recs;
+            ea.fidx_base = h->run_fidx;
+            ea.f0 = b * PIPE_E;
+            ea.nE = f - ea.f0;
+            ea.D = PIPE_D;
+            ea.ngroups = h->ngroups; ea.ngp = h->ngp; ea.n_clips = h->n_clips;
+            ea.cnt = h->pipe_cnt; ea.gmax = h->pipe_gmax; ea.tsold = has_refr ? h->pipe_tsold : nullptr;
+            ea.gtT = h->pipe_gtT; ea.rowext = h->pipe_rowext; ea.nw = h->pipe_nw;
+            ea.pre32 = h->pipe_pre32; ea.tot32 = h->pipe_tot32;
+            ea.events = (float4 *)events; ea.cap = cap;
+            ea.off_in = h->pipe_off + (size_t)(b & 1) * h->n_clips;
+            ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * h->n_clips;
+            V2E_HIP(hipEventRecord(h->ev_fork[b], s));
+            V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
+            dim3 ge(h->ngroups, h->n_clips, ea.nE);
+            if (mark(ev_side, h->side)) return V2E_EHIP;
+            // While the step chain is latency-bound (a grid of a few workgroups per CU) the emission kernels must
+            // not fill the CUs, or the next k_step's workgroups queue behind them: a dynamic-LDS reservation caps
+            // them at 4 workgroups per CU (160 KB LDS).  Large grids are throughput-bound: no cap.
+            const int lds_pad = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu ? 32000 : 0;
+            k_tot_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
+            if (h->pipe_pre32) k_scan2_multi<<<dim3(SCAN_BLOCKS, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
+            k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
+            if (mark(ev_side, h->side)) return V2E_EHIP;
+            V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
+        }
+    }
+    if (mark(ev_main, s)) return V2E_EHIP;
+    V2E_HIP(hipStreamWaitEvent(s, h->ev_join[(n_frames - 1) / PIPE_E], 0)); // join: the run is complete on `s`
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames, const double *t_prev,
                 const double *t_frame, uint32_t frame_idx0, float *events, uint64_t cap, v2e_frame_rec *recs_dev,
                 int use_graph, void *stream)
@@ -1121,14 +1263,54 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     KArgs a = make_kargs(h, p);
     const int mode = use_graph & 3;          // 0 plain launches, 1 hipGraph, 2 instrumented
     const bool legacy = (use_graph & 16) != 0; // 4-kernel count/rank/scan/emit pipeline (kept for A/B)
+    // Default: the k_step chain + deferred emission batches while a frame is a few workgroups per CU (the run is
+    // bounded by the per-frame launch latency, so only the dependency chain may be on it); one k_main launch per
+    // frame with emission on the chain once the grid is large enough to be throughput-bound (each pixel touched
+    // once).  |32 / |64 force the one or the other.
+    const bool small_grid = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu;
+    const bool fused = !legacy && ((use_graph & 32) != 0 || (!(use_graph & 64) && !small_grid));
+    const bool pipe = !legacy && !fused;
+    if (pipe) { // everything the capture must not allocate
+        if (p->refractory_period_s > 0 && !h->pipe_tsold)
+            V2E_HIP(hipMalloc(&h->pipe_tsold, sizeof(float) * (size_t)h->pipe_D * h->n_clips * h->npx_pad));
+        const size_t nb = (size_t)(n_frames + h->pipe_E - 1) / h->pipe_E;
+        while (h->ev_fork.size() < nb) {
+            hipEvent_t e0, e1;
+            V2E_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+            V2E_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            h->ev_fork.push_back(e0);
+            h->ev_join.push_back(e1);
+        }
+    }
     auto enqueue = [&](hipStream_t st, hipEvent_t *evs, int *nm) -> int {
         if (legacy) {
             if (nm) *nm = 4 * n_frames + 1;
             return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs);
         }
-        return enqueue_run_fused(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs, nm);
+        if (fused) return enqueue_run_fused(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs, nm);
+        return enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st);
     };
     if (mode == 0) return enqueue(s, nullptr, nullptr);
+    if (mode == 2 && pipe) { // instrumented: step-chain time from events on `s`, emission batches from events on the side stream
+        std::vector<hipEvent_t> em, es;
+        rc = enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, &em, &es);
+        if (rc == 0) {
+            V2E_HIP(hipStreamSynchronize(s));
+            for (int k = 0; k < 4; ++k) h->prof_ms[k] = 0.0;
+            float ms = 0.f;
+            V2E_HIP(hipEventElapsedTime(&ms, em.front(), em.back()));
+            h->prof_ms[0] = ms; // n_frames + 1 k_step launches
+            for (size_t i = 0; i + 1 < es.size(); i += 2) {
+                V2E_HIP(hipEventElapsedTime(&ms, es[i], es[i + 1]));
+                h->prof_ms[3] += ms;
+            }
+            h->prof_launches = n_frames;
+            h->prof_emit_batches = (int)(es.size() / 2);
+        }
+        for (hipEvent_t e : em) hipEventDestroy(e);
+        for (hipEvent_t e : es) hipEventDestroy(e);
+        return rc;
+    }
     if (mode == 2) { // instrumented: a hipEvent before every launch (bench.py roofline leg); blocking
         const int ne = 4 * n_frames + 4;
         std::vector<hipEvent_t> evs(ne);
@@ -1159,7 +1341,8 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&a, sizeof(a)); push(&frames, sizeof(frames)); push(&dtype, sizeof(dtype)); push(&n_frames, sizeof(n_frames));
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
-    int lg = legacy ? 1 : 0; push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
+    int lg = legacy ? 1 : (fused ? 2 : 0); push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
+    push(&h->pipe_tsold, sizeof(h->pipe_tsold));
     int nis = getenv("V2E_AMD_NO_INKERNEL_SYNC") ? 1 : 0; push(&nis, sizeof(nis));
     if (!h->graph || key != h->graph_key) {
         if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
@@ -1203,6 +1386,14 @@ int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *
     V2E_REQUIRE(h && ms_count && ms_rank && ms_scan && ms_emit && launches, "null");
     *ms_count = h->prof_ms[0]; *ms_rank = h->prof_ms[1]; *ms_scan = h->prof_ms[2]; *ms_emit = h->prof_ms[3];
     *launches = h->prof_launches;
+    return 0;
+}
+
+int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch)
+{
+    V2E_REQUIRE(h && emit_batches && frames_per_batch, "null");
+    *emit_batches = h->prof_emit_batches;
+    *frames_per_batch = h->pipe_E;
     return 0;
 }
 

@@ -138,7 +138,7 @@ __device__ __forceinline__ void key_totals_loaded(const uint4 v, int g, int lane
 template <bool REFR>
 __device__ __forceinline__ void group_key_totals(const KArgs &a, uint32_t cw, float tsm, const TsGen &tg, int gmax,
                                                  uint16_t *__restrict__ gcol, int ngp, uint32_t (*s_wcnt)[WAVE], int lane,
-                                                 int wave, int gmax_old)
+                                                 int wave, int gmax_old, uint32_t *wg_events = nullptr)
 {
     // gcol = &gtT[clip][0][g]; key k of this workgroup lives at gcol[k * ngp]
     for (int k = 2 + 2 * gmax + (int)threadIdx.x; k < 2 + 2 * gmax_old; k += BLOCK) gcol[(size_t)k * ngp] = 0;
@@ -174,8 +174,11 @@ __device__ __forceinline__ void group_key_totals(const KArgs &a, uint32_t cw, fl
         }
         s_wcnt[wave][lane] = mine;
         __syncthreads();
-        if (wave == 0 && kb + lane < nk)
-            gcol[(size_t)(kb + lane) * ngp] = (uint16_t)(s_wcnt[0][lane] + s_wcnt[1][lane] + s_wcnt[2][lane] + s_wcnt[3][lane]);
+        if (wave == 0 && kb + lane < nk) {
+            const uint32_t v = s_wcnt[0][lane] + s_wcnt[1][lane] + s_wcnt[2][lane] + s_wcnt[3][lane];
+            gcol[(size_t)(kb + lane) * ngp] = (uint16_t)v;
+            if (wg_events) *wg_events += v; // wave 0, lane-wise partial sums of this workgroup's events
+        }
         __syncthreads();
     }
 }
@@ -610,8 +613,8 @@ __global__ __launch_bounds__(BLOCK) void k_refr(KArgs a, const FrameCtl *__restr
 
 // Large grids: exclusive prefix over workgroups of every key row (u16 counts -> u32 prefixes) and
 // the row totals.  One workgroup per key (grid-stride over keys < 2 + 2M).
-__global__ __launch_bounds__(BLOCK) void k_scan2(KArgs a, const uint16_t *__restrict__ gtT, int ngp, const int *__restrict__ gmaxv,
-                                                 int ngroups, uint32_t *__restrict__ pre32, uint32_t *__restrict__ tot32)
+__device__ __forceinline__ void scan2_body(const KArgs &a, const uint16_t *__restrict__ gtT, int ngp, const int *__restrict__ gmaxv,
+                                           int ngroups, uint32_t *__restrict__ pre32, uint32_t *__restrict__ tot32)
 {
     __shared__ int s_red[BLOCK / WAVE];
     __shared__ uint32_t s_w[BLOCK / WAVE];
@@ -642,4 +645,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan2(KArgs a, const uint16_t *__rest
         if (tid == 0) tot32[(size_t)clip * a.nkeys_cap + key] = total;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan2(KArgs a, const uint16_t *__restrict__ gtT, int ngp, const int *__restrict__ gmaxv,
+                                                 int ngroups, uint32_t *__restrict__ pre32, uint32_t *__restrict__ tot32)
+{
+    scan2_body(a, gtT, ngp, gmaxv, ngroups, pre32, tot32);
 }

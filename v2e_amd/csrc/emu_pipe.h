@@ -1,0 +1,539 @@
+// emu_pipe.h -- decoupled device-resident pipeline of the DVS pixel model (included by emu.hip).
+//
+// What the next frame needs from the previous one is only the pixel's own base_log_frame /
+// timestamp_mem update (emulator.py:936-942), and that needs, beyond the pixel's own counts, one
+// global number: the frame's max count M (it fixes the timestamps, hence the refractory test).
+// Where an event lands in the output list -- the prefix over all pixels, the per-iteration shuffle
+// -- is needed by nobody downstream.  So the frame-to-frame dependency chain is kept to
+//
+//   k_step(f)  = finalise(f-1) [M(f-1) from the published workgroup maxima; refractory pass count;
+//                base / ts_mem update] + count(f) [lin-log, low-pass, leak, floor-divide, shot
+//                noise, packed count word to a ring slot, workgroup max]
+//
+// one launch per frame, and everything about the event list runs behind it on a second stream,
+// E frames per launch, overlapping the chain:
+//
+//   k_tot_multi(f0..f0+E)   per-workgroup (iteration, polarity) totals, refractory rule applied
+//   [k_scan2_multi          large grids: prefixes over workgroups]
+//   k_emit_multi(f0..f0+E)  offsets, timestamps, shuffle, float4 rows, frame records
+//
+// (scripts/ubench_gridbar.hip: an in-kernel grid rendezvous costs 11-15 us on MI355X, a dependent
+// launch 3.5 us, so launch boundaries are the grid synchronisation.)  A ring of D = 2E frame slots
+// holds what the emission side reads: count words, workgroup maxima, and -- for frames on which
+// the refractory rule was active -- the ts_mem plane as it was before the update.
+#pragma once
+
+// frames per emission launch E (v2e_emu::pipe_E, chosen at create time from the ring's footprint) and
+// ring slots D = 2E: the emission of batch b overlaps the steps of batch b+1
+constexpr int PIPE_E_MAX = 16;
+
+struct StepArgs {
+    const void *frame;       // frame f (count)
+    const FrameCtl *ctl_c;   // times of frame f
+    const FrameCtl *ctl_e;   // times of frame f-1
+    const uint32_t *fidx_base;
+    uint32_t fidx_c;
+    int do_final, do_count, ngroups;
+    const uint32_t *cnt_e;   // [n_clips][npx_pad] count words of frame f-1
+    uint32_t *cnt_c;         //                    ... of frame f
+    const int *gmax_e;       // [n_clips][ngroups] workgroup maxima of frame f-1
+    int *gmax_c;
+    float *tsold_e;          // [n_clips][npx_pad] slot of frame f-1 (refractory frames only) or nullptr
+    unsigned long long *dbg;
+};
+
+#define V2E_STAMP_S(i) do { if (sa.dbg && tid == 0) sa.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
+
+template <typename R, typename FT>
+__global__ __launch_bounds__(BLOCK) void k_step(KArgs a, StepArgs sa)
+{
+    __shared__ int s_red[BLOCK / WAVE];
+    __shared__ float s_lutL[256];
+    __shared__ double s_lutI[256];
+    constexpr bool U8 = sizeof(FT) == 1;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, g = blockIdx.x;
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const uint32_t fbase = sa.fidx_base ? *sa.fidx_base : 0u;
+
+    __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
+    V2E_STAMP_S(0);
+    // ------------------------------------------------------------ all independent loads first
+    R b = (R)0, lp_old = (R)0;
+    float thp = 1.f, thn = 1.f, nr = 0.f, tsm = 0.f;
+    uint32_t cw_e = 0;
+    FT px = (FT)0;
+    if (valid) {
+        b = ((R *)a.base)[sp];
+        thp = a.pos_thres[sp];
+        thn = a.neg_thres[sp];
+        if (a.has_cutoff || (sa.do_final && a.do_shot)) lp_old = ((R *)a.lp)[sp];
+        if (a.do_leak && sa.do_count) nr = a.noise_rate[sp];
+        if (a.has_refr && sa.do_final) tsm = a.ts_mem[sp];
+        if (sa.do_final) cw_e = sa.cnt_e[sp];
+        if (sa.do_count) px = ((const FT *)sa.frame)[(size_t)clip * a.npx + p];
+    }
+    if (U8 && sa.do_count) {
+        s_lutL[tid] = a.lut_L[tid];
+        s_lutI[tid] = a.lut_I[tid];
+    }
+    int gm_part = 0;
+    if (sa.do_final) {
+        const int *gmv = sa.gmax_e + (size_t)clip * sa.ngroups;
+        for (int k = tid; k < sa.ngroups; k += BLOCK) gm_part = max(gm_part, gmv[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0); // keep the loads up here; waits stay at the uses
+    // ---- arithmetic that depends on no memory, done while those loads are in flight
+    float rng_r = 0.f, rng_u = 0.f;
+    if (sa.do_count && valid && (a.do_leak || a.do_shot))
+        v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c, (uint32_t)p, &rng_r, &rng_u);
+    V2E_STAMP_S(5);
+    float tab_start = 0.f, tab_step = 0.f, tab_end = 0.f;
+    uint32_t refr_mask = 0;
+    if (sa.do_final && a.has_refr) {
+        const FrameCtl *ce = sa.ctl_e + clip;
+        tab_start = ce->ts_start[lane & 31];
+        tab_step = ce->ts_stepf[lane & 31];
+        refr_mask = ce->refr_mask;
+        tab_end = ce->ts_end;
+    }
+    bool b_dirty = false;
+
+    // ------------------------------------------------------------ finalise(f-1): emulator.py:830-842, 936-942
+    if (sa.do_final) {
+        if (sa.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); V2E_STAMP_S(6); }
+        const int M = block_max_finish(gm_part, s_red, lane, wave); // its barriers also publish the LUT
+        V2E_STAMP_S(1);
+        if (M <= a.max_iters) { // beyond max_iters the run is flagged by the emission side and discarded
+            const int n = M > 0 ? M : 1;
+            const uint32_t cw = cw_e;
+            const int mag = (int)(cw & CNT_MASK);
+            const bool neg = (cw & CNT_NEG) != 0;
+            int fcount = mag;
+            if (a.has_refr) {
+                bool use_refr;
+                TsGen tg(0.f, 0.f, 0.f, n);
+                if (n <= 32) {
+                    tg = TsGen(__uint_as_float(lane_value(__float_as_uint(tab_start), n - 1)), tab_end,
+                               __uint_as_float(lane_value(__float_as_uint(tab_step), n - 1)), n);
+                    use_refr = (refr_mask >> (n - 1)) & 1u;
+                } else {
+                    const FrameCtl c = sa.ctl_e[clip];
+                    tg = TsGen(c, n, nullptr);
+                    use_refr = a.refr > (c.t_frame - c.t_prev) / (double)n;
+                }
+                if (use_refr) {
+                    // the emission side re-derives which iterations passed from ts_mem as it was
+                    if (valid) sa.tsold_e[sp] = tsm;
+                    fcount = 0;
+                    for (int i = 0; i < mag; ++i) {
+                        const float t = tg(i);
+                        const float pt = 1.0f * t - tsm;
+                        if (pt > a.refr_f) { tsm = t; ++fcount; }
+                    }
+                    if (valid && fcount > 0) a.ts_mem[sp] = tsm;
+                }
+            }
+            if (valid) {
+                const bool shot = a.do_shot && (cw & (CNT_SHOT_ON | CNT_SHOT_OFF));
+                if (fcount > 0 || shot) {
+                    const float dp = (float)(neg ? 0 : fcount) * thp;
+                    const float dn = (float)(neg ? fcount : 0) * thn;
+                    b = b + (R)dp;
+                    b = b - (R)dn;
+                    if (shot) b = lp_old;
+                    b_dirty = true;
+                }
+            }
+        }
+    } else if (U8 && sa.do_count) {
+        __syncthreads(); // LUT visible
+    }
+    V2E_STAMP_S(2);
+
+    // ------------------------------------------------------------ count(f)
+    if (sa.do_count) {
+        const FrameCtl c = sa.ctl_c[clip];
+        const double delta_time = c.t_frame - c.t_prev;
+        int m = 0;
+        uint32_t cw = 0;
+        if (valid) {
+            float L;
+            double inten01;
+            if (U8) {
+                L = s_lutL[(int)px];
+                inten01 = s_lutI[(int)px];
+            } else {
+                const double x = (double)px;
+                L = lin_log(x);
+                inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
+            }
+            const float r = rng_r, u = rng_u;
+            R lpn;
+            if (a.has_cutoff) {
+                double eps = inten01 * c.dt_over_tau;
+                if (eps > 1.0) eps = 1.0;
+                lpn = (R)((1.0 - eps) * (double)lp_old + eps * (double)L);
+            } else {
+                lpn = (R)L;
+            }
+            ((R *)a.lp)[sp] = lpn;
+            if (a.do_leak) { // emulator_utils.py:126-129, float32 left to right
+                const float rate = (a.leak_hz_f * nr) * (1.0f - a.jit_f * r);
+                const float delta_leak = ((float)delta_time * rate) * thp;
+                b = b - (R)delta_leak;
+                b_dirty = true;
+            }
+            if (b_dirty) ((R *)a.base)[sp] = b;
+            const R diff = (lpn + (R)0.0f) - b;
+            const R pf = diff > (R)0 ? diff : (R)0;
+            const R nf = (-diff) > (R)0 ? -diff : (R)0;
+            const R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;
+            const R tnd = a.scalar_thres ? (R)a.neg_div : (R)thn;
+            // diff has one sign, so one of pf/nf is zero and floor(0/thr) = 0: one exact floor
+            // division serves both torch.div(..., rounding_mode='floor') calls (emulator_utils.py:154-157)
+            const bool is_pos = diff > (R)0;
+            const int q = (int)floor_div_pos<R>(is_pos ? pf : nf, is_pos ? tpd : tnd);
+            const int pc = is_pos ? q : 0, nc = is_pos ? 0 : q;
+            if (pc > 0) cw = (uint32_t)pc & CNT_MASK;
+            else if (nc > 0) cw = ((uint32_t)nc & CNT_MASK) | CNT_NEG;
+            if (a.do_shot) cw |= shot_bits(a, inten01, c.shot_base, thp, thn, u);
+            sa.cnt_c[sp] = cw;
+            m = pc > nc ? pc : nc;
+        }
+        V2E_STAMP_S(3);
+        m = wave_max_i32(m);
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        if (tid == 0) sa.gmax_c[(size_t)clip * sa.ngroups + g] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    } else if (valid && b_dirty) {
+        ((R *)a.base)[sp] = b;
+    }
+    V2E_STAMP_S(4);
+}
+
+// ------------------------------------------------------------------ emission side
+struct EmitArgs {
+    const FrameCtl *ctl;     // [n_frames][n_clips] of the run
+    v2e_frame_rec *recs;     // [n_frames][n_clips]
+    const uint32_t *fidx_base;
+    int f0, nE, D;           // run-relative frames f0 .. f0+nE-1, frame f0+z in grid plane z; ring slot = frame % D
+    int ngroups, ngp, n_clips;
+    const uint32_t *cnt;     // ring bases (slot = frame % D)
+    const int *gmax;
+    const float *tsold;
+    uint16_t *gtT;           // [D][n_clips][nkeys_cap][ngp] per-workgroup key totals, key-major u16
+    int *rowext;             // [D][n_clips][ngroups] iterations up to which this workgroup's rows are non-zero
+    uint32_t *nw;            // [D][n_clips][ngroups] events of the workgroup in the slot's frame
+    uint32_t *pre32, *tot32; // large grids: [E][n_clips][nkeys_cap][ngp] / [E][n_clips][nkeys_cap]
+    float4 *events;
+    unsigned long long cap;
+    const unsigned long long *off_in; // [n_clips] event offset at the start of this batch
+    unsigned long long *off_out;      // [n_clips] ... of the next one
+};
+
+// Timestamps and refractory switch of one frame once its max count n is known (block-uniform).
+// The per-n tables of the frame's FrameCtl are fetched one entry per lane BEFORE n is known
+// (FrameTab), then broadcast: no memory round trip and no float64 division after the reduction.
+struct FrameTab {
+    float start, step, end;
+    uint32_t refr_mask;
+    __device__ __forceinline__ FrameTab(const FrameCtl *c, int lane)
+        : start(c->ts_start[lane & 31]), step(c->ts_stepf[lane & 31]), end(c->ts_end), refr_mask(c->refr_mask) {}
+};
+
+__device__ __forceinline__ TsGen frame_tsgen(const KArgs &a, const FrameCtl *c, const FrameTab &ft, int n, bool &use_refr)
+{
+    if (n <= 32) {
+        use_refr = a.has_refr && ((ft.refr_mask >> (n - 1)) & 1u);
+        return TsGen(__uint_as_float(lane_value(__float_as_uint(ft.start), n - 1)), ft.end,
+                     __uint_as_float(lane_value(__float_as_uint(ft.step), n - 1)), n);
+    }
+    const double t_prev = c->t_prev, t_frame = c->t_frame;
+    use_refr = a.has_refr && a.refr > (t_frame - t_prev) / (double)n;
+    FrameCtl cc;
+    cc.t_prev = t_prev; cc.t_frame = t_frame;
+    return TsGen(cc, n, nullptr);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_tot_multi(KArgs a, EmitArgs ea)
+{
+    __shared__ uint32_t s_wcnt[BLOCK / WAVE][WAVE];
+    __shared__ int s_red[BLOCK / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, g = blockIdx.x, fe = ea.f0 + (int)blockIdx.z, slot = fe % ea.D;
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
+    const size_t sg = ((size_t)slot * ea.n_clips + clip) * ea.ngroups;
+    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
+    const float tsm = (valid && ea.tsold) ? ea.tsold[sp] : 0.f; // meaningful only on refractory frames
+    const int *gmv = ea.gmax + sg;
+    int gm_part = 0;
+    for (int k = tid; k < ea.ngroups; k += BLOCK) gm_part = max(gm_part, gmv[k]);
+    const int gown = __builtin_amdgcn_readfirstlane(gmv[g]);
+    const int gmax_old = __builtin_amdgcn_readfirstlane(ea.rowext[sg + g]);
+    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
+    const FrameTab ft(c, lane);
+    const int M = block_max_finish(gm_part, s_red, lane, wave);
+    if (M > a.max_iters) { // frame is flagged by k_emit_multi; rows stay as they are
+        if (tid == 0) ea.nw[sg + g] = 0u;
+        return;
+    }
+    bool use_refr;
+    const TsGen tg = frame_tsgen(a, c, ft, M > 0 ? M : 1, use_refr);
+    const int gm = min(gown, a.max_iters);
+    uint16_t *gcol = ea.gtT + ((size_t)slot * ea.n_clips + clip) * a.nkeys_cap * ea.ngp + g;
+    uint32_t acc = 0;
+    if (use_refr) group_key_totals<true>(a, cw, tsm, tg, gm, gcol, ea.ngp, s_wcnt, lane, wave, gmax_old, &acc);
+    else group_key_totals<false>(a, cw, 0.f, tg, gm, gcol, ea.ngp, s_wcnt, lane, wave, gmax_old, &acc);
+    if (wave == 0) {
+        const uint32_t tot = wave_sum_u32(acc);
+        if (lane == 0) {
+            ea.nw[sg + g] = tot;
+            ea.rowext[sg + g] = gm;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan2_multi(KArgs a, EmitArgs ea)
+{
+    const int fe = ea.f0 + (int)blockIdx.z, slot = fe % ea.D;
+    scan2_body(a, ea.gtT + (size_t)slot * ea.n_clips * a.nkeys_cap * ea.ngp, ea.ngp, ea.gmax + (size_t)slot * ea.n_clips * ea.ngroups,
+               ea.ngroups, ea.pre32 + (size_t)blockIdx.z * ea.n_clips * a.nkeys_cap * ea.ngp,
+               ea.tot32 + (size_t)blockIdx.z * ea.n_clips * a.nkeys_cap);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_emit_multi(KArgs a, EmitArgs ea)
+{
+    __shared__ uint32_t s_T[WAVE], s_P[WAVE]; // per key of the current 64-key chunk: total / prefix over workgroups
+    __shared__ uint32_t s_wcnt[BLOCK / WAVE][WAVE];
+    __shared__ int s_red[BLOCK / WAVE];
+    __shared__ unsigned long long s_off[BLOCK / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
+    const size_t sg = ((size_t)slot * ea.n_clips + clip) * ea.ngroups;
+    const uint32_t fbase = ea.fidx_base ? *ea.fidx_base : 0u;
+    const uint32_t frame_idx = fbase + (uint32_t)fe;
+
+    // ------------------------------------------------------------ loads
+    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
+    float tsm = (valid && ea.tsold) ? ea.tsold[sp] : 0.f;
+    const uint16_t *gt = ea.gtT + ((size_t)slot * ea.n_clips + clip) * a.nkeys_cap * ea.ngp;
+    const uint32_t *pre32 = ea.pre32 ? ea.pre32 + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.ngp : nullptr;
+    const uint32_t *tot32 = ea.tot32 ? ea.tot32 + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap : nullptr;
+    const bool krow_fast = !pre32 && ea.ngp == 512;
+    uint4 kv[KPW];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) kv[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (krow_fast) {
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) kv[j] = *(const uint4 *)(gt + (size_t)(wave + (BLOCK / WAVE) * j) * 512 + lane * 8);
+    }
+    int gm_part = 0;
+    {
+        const int *gmv = ea.gmax + sg;
+        for (int k = tid; k < ea.ngroups; k += BLOCK) gm_part = max(gm_part, gmv[k]);
+    }
+    unsigned long long npart = 0; // events of the batch's earlier frames: this frame's offset within the batch
+    for (int j = 0; j < z; ++j) {
+        const uint32_t *nwj = ea.nw + ((size_t)((ea.f0 + j) % ea.D) * ea.n_clips + clip) * ea.ngroups;
+        for (int k = tid; k < ea.ngroups; k += BLOCK) npart += nwj[k];
+    }
+    const unsigned long long off_in = ea.off_in[clip];
+    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
+    const FrameTab ft(c, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t pk[4] = {0, 0, 0, 0}; // shuffle round keys of iteration `lane` (first chunk)
+    const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
+    if (shuf) v2e_perm_keys(a.seed, (uint32_t)clip, frame_idx, (uint32_t)lane, pk);
+    if (pre32) {
+        if (wave == 0) {
+            s_T[lane] = tot32[lane];
+            s_P[lane] = pre32[(size_t)lane * ea.ngp + g];
+        }
+    } else if (krow_fast) {
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) {
+            uint32_t t, q;
+            key_totals_loaded(kv[j], g, lane, t, q);
+            if (lane == 0) { s_T[wave + (BLOCK / WAVE) * j] = t; s_P[wave + (BLOCK / WAVE) * j] = q; }
+        }
+    } else {
+        for (int k = wave; k < KPRE && k < a.nkeys_cap; k += BLOCK / WAVE) {
+            uint32_t t, q;
+            key_totals(gt + (size_t)k * ea.ngp, ea.ngp, g, lane, t, q);
+            if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+        }
+    }
+    {
+        const uint32_t lo = wave_sum_u32((uint32_t)(npart & 0xFFFFFFull));
+        const uint32_t hi = wave_sum_u32((uint32_t)(npart >> 24));
+        if (lane == 0) s_off[wave] = (unsigned long long)lo + ((unsigned long long)hi << 24);
+    }
+    const int M = block_max_finish(gm_part, s_red, lane, wave);
+    const unsigned long long ev0 = off_in + s_off[0] + s_off[1] + s_off[2] + s_off[3];
+
+    v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips;
+    if (M > a.max_iters) {
+        if (g == 0 && tid == 0) {
+            rec[clip].max_events = M;
+            rec[clip].flags |= V2E_FLAG_ITERS_CLAMPED;
+            rec[clip].ev_offset = ev0;
+            if (z == ea.nE - 1) ea.off_out[clip] = ev0;
+        }
+        return;
+    }
+    const int n = M > 0 ? M : 1;
+    bool use_refr;
+    const TsGen tg = frame_tsgen(a, c, ft, n, use_refr);
+    const int mag = (int)(cw & CNT_MASK);
+    const bool neg = (cw & CNT_NEG) != 0;
+    float4 *ev = ea.events + (size_t)clip * ea.cap;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float fx = (float)(p % a.W), fy = (float)(p / a.W);
+    const int nk = 2 + 2 * M;
+    uint32_t carry = 0, sum_on = 0, sum_off = 0;
+    uint32_t son_tot = 0, soff_tot = 0, son_off = 0, soff_off = 0;
+    bool dropped = false, alive = true;
+    for (int kb = 0; kb < nk; kb += WAVE) {
+        const int key = kb + lane;
+        // totals over all workgroups / over earlier workgroups for the keys not fetched yet
+        if (pre32) {
+            if (kb > 0 && wave == 0 && key < nk) {
+                s_T[lane] = tot32[key];
+                s_P[lane] = pre32[(size_t)key * ea.ngp + g];
+            }
+        } else {
+            for (int k = (kb == 0 ? KPRE : 0) + wave; k < WAVE && kb + k < nk; k += BLOCK / WAVE) {
+                uint32_t t, q;
+                key_totals(gt + (size_t)(kb + k) * ea.ngp, ea.ngp, g, lane, t, q);
+                if (lane == 0) { s_T[k] = t; s_P[k] = q; }
+            }
+        }
+        // pass 1: which of my iterations survive; per-wave key counts
+        uint32_t mymask = 0, mine = 0;
+        const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
+        const int i_hi = (kb + WAVE - 2) / 2;
+        for (int i = i_lo; i < i_hi && i < M && alive; ++i) {
+            const bool cand = mag > i;
+            if (__ballot(cand) == 0ull) { alive = false; break; }
+            bool pass = cand;
+            if (use_refr) {
+                const float t = tg(i);
+                const float pt = (cand ? 1.0f : 0.0f) * t - tsm;
+                pass = pt > a.refr_f;
+                if (pass) tsm = t;
+            }
+            if (pass) mymask |= 1u << (i - i_lo);
+            const unsigned long long bo = __ballot(pass && !neg);
+            const unsigned long long bf = __ballot(pass && neg);
+            const int kl = 2 + 2 * i - kb;
+            if (lane == kl) mine = (uint32_t)__popcll(bo);
+            if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+        }
+        if (kb == 0) {
+            const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
+            const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+            if (lane == 0) mine = (uint32_t)__popcll(so);
+            if (lane == 1) mine = (uint32_t)__popcll(sf);
+        }
+        s_wcnt[wave][lane] = mine;
+        __syncthreads();
+        const uint32_t T_k = key < nk ? s_T[lane] : 0u;
+        const uint32_t P_k = key < nk ? s_P[lane] : 0u;
+        uint32_t woff = 0;
+#pragma unroll
+        for (int q = 0; q < BLOCK / WAVE; ++q)
+            if (q < wave) woff += s_wcnt[q][lane];
+        const uint32_t off_k = P_k + woff;
+        // shuffle domain of iteration `lane` (first chunk), all iterations at once
+        uint32_t ps_sh = 0, ps_a = 1, ps_amask = 0, ps_n = 0;
+        if (shuf && kb == 0 && lane < 31 && 3 + 2 * lane < nk) {
+            ps_n = s_T[2 + 2 * lane] + s_T[3 + 2 * lane];
+            v2e_perm_shape(ps_n, &ps_sh, &ps_a, &ps_amask);
+        }
+        const uint32_t sig_T = (key >= 2 && key < nk) ? T_k : 0u;
+        const uint32_t kbase_k = carry + wave_excl_scan_u32(sig_T, lane);
+        const uint32_t chunk_total = wave_sum_u32(sig_T);
+        sum_on += wave_sum_u32((lane & 1) ? 0u : sig_T);
+        sum_off += wave_sum_u32((lane & 1) ? sig_T : 0u);
+        if (kb == 0) {
+            son_tot = lane_value(T_k, 0); soff_tot = lane_value(T_k, 1);
+            son_off = lane_value(off_k, 0); soff_off = lane_value(off_k, 1);
+        }
+        // pass 2: write this chunk's events
+        if (__ballot(mymask != 0u)) {
+            uint32_t wm = wave_or_u32(mymask); // iterations in which some lane of the wave fires
+            while (wm) {
+                const int ii = __ffs(wm) - 1;
+                wm &= wm - 1;
+                const int i = i_lo + ii;
+                const bool pass = (mymask >> ii) & 1u;
+                const unsigned long long bo = __ballot(pass && !neg);
+                const unsigned long long bf = __ballot(pass && neg);
+                const int kl = 2 + 2 * i - kb;
+                const uint32_t it_base = lane_value(kbase_k, kl);
+                const uint32_t tot_on = lane_value(T_k, kl);
+                const uint32_t tot_off = lane_value(T_k, kl + 1);
+                const uint32_t off_on = lane_value(off_k, kl);
+                const uint32_t off_off = lane_value(off_k, kl + 1);
+                v2e_perm_t pm;
+                if (shuf) {
+                    if (kb == 0) { // keys / domain computed lane-parallel above: fetch as scalars
+                        pm.k[0] = lane_value(pk[0], ii); pm.k[1] = lane_value(pk[1], ii);
+                        pm.k[2] = lane_value(pk[2], ii); pm.k[3] = lane_value(pk[3], ii);
+                        pm.sh = lane_value(ps_sh, ii); pm.a = lane_value(ps_a, ii);
+                        pm.amask = lane_value(ps_amask, ii); pm.n = lane_value(ps_n, ii);
+                        pm.rmask = (1u << pm.sh) - 1u;
+                    } else {
+                        v2e_perm_init(&pm, a.seed, (uint32_t)clip, frame_idx, (uint32_t)i, tot_on + tot_off);
+                    }
+                }
+                if (pass) {
+                    uint32_t cidx = neg ? tot_on + off_off + (uint32_t)__popcll(bf & lt) : off_on + (uint32_t)__popcll(bo & lt);
+                    if (shuf) cidx = v2e_perm_apply(&pm, cidx);
+                    const unsigned long long row = ev0 + it_base + cidx;
+                    if (row < ea.cap) ev[row] = make_float4(tg(i), fx, fy, neg ? -1.0f : 1.0f);
+                    else dropped = true;
+                }
+            }
+        }
+        carry += chunk_total;
+        __syncthreads();
+    }
+    // shot-noise events after all signal events (ON block, OFF block), ts[-1], unshuffled
+    if (a.do_shot) {
+        const bool s_on = (cw & CNT_SHOT_ON) != 0, s_off = (cw & CNT_SHOT_OFF) != 0;
+        const unsigned long long so = __ballot(s_on), sf = __ballot(s_off);
+        if (so | sf) {
+            const float tl = tg(n - 1);
+            if (s_on) {
+                const unsigned long long row = ev0 + carry + son_off + (uint32_t)__popcll(so & lt);
+                if (row < ea.cap) ev[row] = make_float4(tl, fx, fy, 1.0f);
+                else dropped = true;
+            }
+            if (s_off) {
+                const unsigned long long row = ev0 + carry + son_tot + soff_off + (uint32_t)__popcll(sf & lt);
+                if (row < ea.cap) ev[row] = make_float4(tl, fx, fy, -1.0f);
+                else dropped = true;
+            }
+        }
+    }
+    if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
+    if (g == 0 && tid == 0) {
+        const uint32_t n_events = carry + (a.do_shot ? son_tot + soff_tot : 0u);
+        rec[clip].max_events = M;
+        rec[clip].n_signal = carry;
+        rec[clip].n_events = n_events;
+        rec[clip].n_on = sum_on + (a.do_shot ? son_tot : 0u);
+        rec[clip].n_off = sum_off + (a.do_shot ? soff_tot : 0u);
+        rec[clip].ev_offset = ev0;
+        if (z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events;
+    }
+}

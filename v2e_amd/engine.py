@@ -182,11 +182,14 @@ class EmuEngine:
               "v2e_emu_run")
 
     def last_profile(self):
-        """(ms_count, ms_rank, ms_scan, ms_emit, launches) of the last run(use_graph=2)."""
+        """Kernel-class times (ms) of the last run(use_graph=2); see v2e_emu_last_profile[_pipe]."""
         v = [C.c_double() for _ in range(4)]
         n = C.c_int()
         check(self.lib.v2e_emu_last_profile(self._h, *[C.byref(x) for x in v], C.byref(n)), "v2e_emu_last_profile")
-        return dict(count=v[0].value, rank=v[1].value, scan=v[2].value, emit=v[3].value, launches=n.value)
+        nb, fpb = C.c_int(), C.c_int()
+        check(self.lib.v2e_emu_last_profile_pipe(self._h, C.byref(nb), C.byref(fpb)), "v2e_emu_last_profile_pipe")
+        return dict(count=v[0].value, rank=v[1].value, scan=v[2].value, emit=v[3].value, launches=n.value,
+                    emit_batches=nb.value, frames_per_batch=fpb.value)
 
     def alloc_recs(self, n_frames):
         """Device record array [F][n_clips] (struct v2e_frame_rec = 32 bytes), cached per F so that
