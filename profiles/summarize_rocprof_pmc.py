@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""Per-kernel average of one PMC counter from a rocprofv3 --pmc results .db (ROCm 7.2 writes SQLite).
+usage: summarize_rocprof_pmc.py <dir-with-db> <COUNTER>"""
+import glob
+import sqlite3
+import sys
+
+
+def main(d, counter):
+    db = glob.glob(d + "/*/*.db")[0]
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
+    kcol = "kernel_name" if "kernel_name" in cols else "name"
+    q = ("select %s, count(*), avg(v) from (select %s, dispatch_id, sum(value) as v from counters_collection "
+         "where counter_name = ? group by %s, dispatch_id) group by %s order by sum(v) desc limit 8" % (kcol, kcol, kcol, kcol))
+    print("# %s per launch (sum over XCDs/instances), from %s" % (counter, db.split("/")[-1]))
+    for name, n, avg in con.execute(q, (counter,)):
+        print("%-70s launches %6d   avg %14.1f" % (name[:70], n, avg))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
