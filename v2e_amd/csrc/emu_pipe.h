@@ -27,6 +27,22 @@
 // ring slots D = 2E: the emission of batch b overlaps the steps of batch b+1
 constexpr int PIPE_E_MAX = 16;
 
+// The run's frame-index base lives in device memory (a captured graph is replayed with a new base), and the
+// Philox draw needs it first thing.  As a compiler-scheduled scalar load it ends up a dependent round trip in
+// front of every vector load; as a vector load it retires in order with them, so the draw could not overlap
+// their latency.  Hence by hand: issue the s_load early, wait for it (lgkmcnt) only where the draw starts.
+__device__ __forceinline__ uint32_t sload_u32_issue(const uint32_t *ptr)
+{
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(ptr) : "memory");
+    return v; // NOT valid until sload_wait(v)
+}
+__device__ __forceinline__ uint32_t sload_wait(uint32_t v)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
+    return v;
+}
+
 struct StepArgs {
     const void *frame;       // frame f (count)
     const FrameCtl *ctl_c;   // times of frame f
@@ -56,11 +72,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, StepArgs sa)
     const int p = g * BLOCK + tid;
     const bool valid = p < a.npx;
     const size_t sp = (size_t)clip * a.npx_pad + p;
-    const uint32_t fbase = sa.fidx_base ? *sa.fidx_base : 0u;
 
     __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
+    const uint32_t fbase_pending = sload_u32_issue(sa.fidx_base);
     V2E_STAMP_S(0);
-    // ------------------------------------------------------------ all independent loads first
+    // ------------------------------------------------------------ every load of the launch, back to back
+    // (vmcnt retires in order: a wait on any of them is a wait on all earlier ones, so nothing below may
+    // consume a loaded value before the last load has been issued -- hence registers, not loops/LDS, here)
     R b = (R)0, lp_old = (R)0;
     float thp = 1.f, thn = 1.f, nr = 0.f, tsm = 0.f;
     uint32_t cw_e = 0;
@@ -75,21 +93,20 @@ __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, StepArgs sa)
         if (sa.do_final) cw_e = sa.cnt_e[sp];
         if (sa.do_count) px = ((const FT *)sa.frame)[(size_t)clip * a.npx + p];
     }
+    float lutL_r = 0.f;
+    double lutI_r = 0.0;
     if (U8 && sa.do_count) {
-        s_lutL[tid] = a.lut_L[tid];
-        s_lutI[tid] = a.lut_I[tid];
+        lutL_r = a.lut_L[tid];
+        lutI_r = a.lut_I[tid];
     }
-    int gm_part = 0;
+    int gm0 = 0, gm1 = 0, gm2 = 0, gm3 = 0; // workgroup maxima of frame f-1: four per thread cover 1024 workgroups
+    const int *gmv = sa.gmax_e + (size_t)clip * sa.ngroups;
     if (sa.do_final) {
-        const int *gmv = sa.gmax_e + (size_t)clip * sa.ngroups;
-        for (int k = tid; k < sa.ngroups; k += BLOCK) gm_part = max(gm_part, gmv[k]);
+        if (tid < sa.ngroups) gm0 = gmv[tid];
+        if (tid + BLOCK < sa.ngroups) gm1 = gmv[tid + BLOCK];
+        if (tid + 2 * BLOCK < sa.ngroups) gm2 = gmv[tid + 2 * BLOCK];
+        if (tid + 3 * BLOCK < sa.ngroups) gm3 = gmv[tid + 3 * BLOCK];
     }
-    __builtin_amdgcn_sched_barrier(0); // keep the loads up here; waits stay at the uses
-    // ---- arithmetic that depends on no memory, done while those loads are in flight
-    float rng_r = 0.f, rng_u = 0.f;
-    if (sa.do_count && valid && (a.do_leak || a.do_shot))
-        v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c, (uint32_t)p, &rng_r, &rng_u);
-    V2E_STAMP_S(5);
     float tab_start = 0.f, tab_step = 0.f, tab_end = 0.f;
     uint32_t refr_mask = 0;
     if (sa.do_final && a.has_refr) {
@@ -99,6 +116,20 @@ __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, StepArgs sa)
         refr_mask = ce->refr_mask;
         tab_end = ce->ts_end;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- arithmetic that depends on no memory but fbase, done while those loads are in flight
+    const uint32_t fbase = sload_wait(fbase_pending);
+    float rng_r = 0.f, rng_u = 0.f;
+    if (sa.do_count && valid && (a.do_leak || a.do_shot))
+        v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c, (uint32_t)p, &rng_r, &rng_u);
+    V2E_STAMP_S(5);
+    if (U8 && sa.do_count) { // published by the barriers of block_max_finish / the one below
+        s_lutL[tid] = lutL_r;
+        s_lutI[tid] = lutI_r;
+    }
+    int gm_part = max(max(gm0, gm1), max(gm2, gm3));
+    if (sa.do_final)
+        for (int k = tid + 4 * BLOCK; k < sa.ngroups; k += BLOCK) gm_part = max(gm_part, gmv[k]);
     bool b_dirty = false;
 
     // ------------------------------------------------------------ finalise(f-1): emulator.py:830-842, 936-942
