@@ -496,16 +496,25 @@ static void launch_conv_tw(const ConvArgs &a, hipStream_t s)
     if (a.w_ % 32 == 0) launch_conv<KS, CI_T, CT, 2, 4, 32, PRE>(a, s);
     else if (a.w_ % 16 == 0) launch_conv<KS, CI_T, CT, 2, 4, 16, PRE>(a, s);
     else if (a.w_ % 8 == 0) launch_conv<KS, CI_T, CT, 2, 4, 8, PRE>(a, s);
-    else if (a.w_ % 20 == 0 && a.h % 16 == 0) launch_conv<KS, CI_T, CT, 1, 10, 20, PRE>(a, s); // 10 waves: 3/3/2/2 per SIMD
+    else if (a.w_ % 20 == 0 && a.h % 8 == 0) {
+        // 20-wide levels (16x20 of a 320x256 input): 8x20-pixel tiles, 5 waves.  What decides here is how evenly
+        // the workgroups spread over 256 CUs: 40 samples x 8 blocks of 64 channels = 320 ten-wave workgroups
+        // leave a quarter of the CUs with twice the work (68 TF/s); 1280 five-wave workgroups of 32 channels
+        // reach 92 TF/s.  The wider channel block only pays once there are >= 8 workgroups per CU.
+        const long wgs64 = (long)a.n * (a.h / 8) * (a.cout / 64);
+        if (CT == 2 && wgs64 < 2048) launch_conv<KS, CI_T, 1, 1, 5, 20, PRE>(a, s);
+        else launch_conv<KS, CI_T, CT, 1, 5, 20, PRE>(a, s);
+    }
     else if (a.w_ % 10 == 0) launch_conv<KS, CI_T, CT, 1, 5, 10, PRE>(a, s);
     else launch_conv<KS, CI_T, CT, 2, 4, 32, PRE>(a, s);
 }
 
 static int conv_dispatch(const ConvArgs &a, int ks, int pre, hipStream_t s)
 {
-    // wide channel tile only when it still leaves enough workgroups to fill 256 CUs
+    // 64-channel tiles only when that still leaves >= 16 workgroups per CU: measured on the 40-sample interpolation
+    // UNet, 32-channel tiles (twice the workgroups, ~30 fewer VGPRs) are faster at every level (forward 96.6 -> 104 TF/s)
     const long px_tiles = (long)a.n * ((a.h * a.w_ + 255) / 256);
-    const bool wide = a.cout >= 64 && px_tiles * (a.cout / 64) >= 512;
+    const bool wide = a.cout >= 64 && px_tiles * (a.cout / 64) >= 4096;
     if (ks == 7) {
         if (pre != 0) return V2E_EINVAL;
         if (a.cin % 4 == 0) launch_conv<7, 4, 1, 2, 4, 32, 0>(a, s);

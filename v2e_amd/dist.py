@@ -55,6 +55,10 @@ class EventStreamGatherer:
             if self.done_evt[slot] is not None:
                 main.wait_event(self.done_evt[slot])  # previous gather out of this staging slot
             ready = torch.cuda.Event()
+            # nt is allocated on the main stream and read by collectives on the side stream: tell the caching
+            # allocator, or the block could be handed out again on the main stream before the side stream read it
+            nt.record_stream(self.side)
+            self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 nmax_t = nt.clone()
                 dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX, group=self.group)
