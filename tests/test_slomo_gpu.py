@@ -63,7 +63,12 @@ CONV_CASES = [
     (3, 32, 32, 32, 1, 32, 64, 0),    # up5.conv2
     (3, 64, 0, 32, 1, 32, 64, 2),     # up5.conv1
     (3, 32, 0, 5, 2, 32, 64, 0),      # conv3 (cout not a multiple of 32)
-    (3, 128, 0, 128, 24, 32, 32, 0),  # many images: wide (64-channel) tiles selected
+    (3, 128, 0, 128, 24, 32, 32, 0),  # many images
+    (3, 8, 0, 128, 2048, 16, 16, 0),  # >= 16 workgroups per CU: wide (64-channel) tiles selected
+    (3, 64, 0, 64, 3, 16, 20, 0),     # 16x20 level of a 320x256 input: 8x20 five-wave tiles
+    (3, 64, 0, 64, 2, 8, 20, 0),
+    (3, 64, 0, 64, 3, 8, 10, 0),      # 8x10 level: two samples stacked per tile, odd sample count
+    (3, 32, 32, 96, 4, 8, 10, 0),     # ... with the fused concat
 ]
 
 

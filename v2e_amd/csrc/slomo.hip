@@ -63,14 +63,18 @@ __device__ __forceinline__ float fetch(const ConvArgs &a, int n, int c, int gy, 
     }
 }
 
-template <int KS, int CI_T, int CT, int PT, int WP, int TW, int PRE>
+// STK = 2: the tile is two whole samples stacked (levels whose sample is half a tile, 8x10 of a 320x256 input);
+// in the LDS patch the two share ONE zero row between them: [0][A rows][0][B rows][0].
+template <int KS, int CI_T, int CT, int PT, int WP, int TW, int PRE, int STK = 1>
 __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
 {
     constexpr int NT = WP * 64;
     constexpr int PAD = KS / 2;
     constexpr int NPX = WP * PT * 32;
     constexpr int TH = NPX / TW;
-    constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+    constexpr int THS = TH / STK; // rows per sample
+    constexpr int PH = TH + KS - 1 + (STK - 1), PW = TW + KS - 1;
+    static_assert(STK == 1 || (STK == 2 && KS == 3 && PRE == 0 && TH % 2 == 0), "stacked tiles: 3x3, plain fetch");
     constexpr int COT = CT * 32;
     constexpr int KK = KS * KS;
     constexpr int PATCH = CI_T * PH * PW;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
     int bx = blockIdx.x;
     const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
     const int ty_i = bx % a.tiles_y;
-    const int n = bx / a.tiles_y;
+    const int n = (bx / a.tiles_y) * STK; // first sample of the tile
     const int oy0 = ty_i * TH, ox0 = tx_i * TW;
     const int cobase = blockIdx.y * COT;
     const int hw = a.h * a.w_;
@@ -98,7 +102,8 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = (wave * PT + pt) * 32 + l31;
-        bofs[pt] = (hsel * PH + m / TW) * PW + (m % TW);
+        const int row = m / TW;
+        bofs[pt] = (hsel * PH + row + ((STK == 2 && row >= THS) ? 1 : 0)) * PW + (m % TW);
     }
     const int aofs = hsel * KK * COT + l31;
 
@@ -114,8 +119,15 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
             const int ci = idx / (PH * PW);
             const int r = idx - ci * (PH * PW);
             const int py = r / PW, px = r - py * PW;
-            const int gy = oy0 + py - PAD, gx = ox0 + px - PAD;
-            if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_) v = PRE == 0 ? ci * hw + gy * a.w_ + gx : ((ci << 24) | (gy << 12) | gx);
+            const int gx = ox0 + px - PAD;
+            if (STK == 2) { // bit 30: second sample of the tile
+                const int sidx = py > THS + 1 ? 1 : 0;
+                const int gy = sidx ? py - (THS + 2) : py - PAD;
+                if (py != THS + 1 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_ && n + sidx < a.n) v = (sidx << 30) | (ci * hw + gy * a.w_ + gx);
+            } else {
+                const int gy = oy0 + py - PAD;
+                if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_) v = PRE == 0 ? ci * hw + gy * a.w_ + gx : ((ci << 24) | (gy << 12) | gx);
+            }
         }
         pinfo[j] = v;
     }
@@ -151,7 +163,11 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
             else { src = a.x1; cs = cb - a.c0; C = a.c1; }
             const float *base = src + ((size_t)n * C + cs) * hw;
 #pragma unroll
-            for (int j = 0; j < NPE; ++j) pv[j] = pinfo[j] >= 0 ? base[pinfo[j]] : 0.f;
+            for (int j = 0; j < NPE; ++j) {
+                const int pi = pinfo[j];
+                if (STK == 2) pv[j] = pi >= 0 ? base[(size_t)(pi & 0x3FFFFFFF) + (size_t)(pi >> 30) * C * hw] : 0.f;
+                else pv[j] = pi >= 0 ? base[pi] : 0.f;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < NPE; ++j) {
@@ -221,8 +237,9 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = (wave * PT + pt) * 32 + l31;
-        const int oy = oy0 + m / TW, ox = ox0 + (m % TW);
-        const bool pok = oy < a.h && ox < a.w_;
+        const int row = m / TW, sidx = STK == 2 ? row / THS : 0;
+        const int oy = oy0 + row - sidx * THS, ox = ox0 + (m % TW);
+        const bool pok = oy < a.h && ox < a.w_ && n + sidx < a.n;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -231,11 +248,24 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
                 if (pok && ch < a.cout) {
                     float v = acc[ct][pt][r] + a.bias[ch];
                     v = v > 0.f ? v : v * 0.1f;
-                    a.y[(((size_t)n * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
+                    a.y[(((size_t)(n + sidx) * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
                 }
             }
         }
     }
+}
+
+// ... one output per thread, for widths that are not a multiple of 4
+__global__ __launch_bounds__(256) void k_avgpool2_scalar(const float *__restrict__ x, float *__restrict__ y, long long nc, int h, int w)
+{
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nc * h * w) return;
+    const int ox = (int)(q % w);
+    const long long r = q / w;
+    const int oy = (int)(r % h);
+    const long long c = r / h;
+    const float *p = x + ((c * (2 * h) + 2 * oy) * (long long)(2 * w)) + 2 * ox;
+    y[q] = (((p[0] + p[1]) + p[2 * w]) + p[2 * w + 1]) * 0.25f;
 }
 
 // F.avg_pool2d(x, 2) as its own pass: [nc][2h][2w] -> [nc][h][w]; 4 outputs per thread
@@ -488,6 +518,17 @@ static void launch_conv(const ConvArgs &a0, hipStream_t s)
     k_conv<KS, CI_T, CT, PT, WP, TW, PRE><<<grid, WP * 64, 0, s>>>(a);
 }
 
+// two whole samples per tile (sample height == half the tile height)
+template <int KS, int CI_T, int CT, int PT, int WP, int TW>
+static void launch_conv_stacked(const ConvArgs &a0, hipStream_t s)
+{
+    ConvArgs a = a0;
+    a.tiles_x = (a.w_ + TW - 1) / TW;
+    a.tiles_y = 1;
+    dim3 grid((unsigned)(((a.n + 1) / 2) * a.tiles_x), (unsigned)((a.cout + CT * 32 - 1) / (CT * 32)));
+    k_conv<KS, CI_T, CT, PT, WP, TW, 0, 2><<<grid, WP * 64, 0, s>>>(a);
+}
+
 template <int KS, int CI_T, int CT, int PRE>
 static void launch_conv_tw(const ConvArgs &a, hipStream_t s)
 {
@@ -505,7 +546,12 @@ static void launch_conv_tw(const ConvArgs &a, hipStream_t s)
         if (CT == 2 && wgs64 < 2048) launch_conv<KS, CI_T, 1, 1, 5, 20, PRE>(a, s);
         else launch_conv<KS, CI_T, CT, 1, 5, 20, PRE>(a, s);
     }
-    else if (a.w_ % 10 == 0) launch_conv<KS, CI_T, CT, 1, 5, 10, PRE>(a, s);
+    else if (a.w_ % 10 == 0) {
+        // 10-wide levels (8x10 of a 320x256 input): a 16x10 five-wave tile is two samples; one sample per tile
+        // would leave half of every MFMA column masked
+        if (KS == 3 && PRE == 0 && a.h == 8) launch_conv_stacked<3, CI_T, 1, 1, 5, 10>(a, s);
+        else launch_conv<KS, CI_T, CT, 1, 5, 10, PRE>(a, s);
+    }
     else launch_conv<KS, CI_T, CT, 2, 4, 32, PRE>(a, s);
 }
 
@@ -616,7 +662,10 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     // producer ops as their own streaming passes: measured faster than fusing them into the conv
     // loader (the fused bilinear fetch costs 4 gathers + address math per staged element)
 #define POOL(X, C, HH, WW) /* (HH,WW) = output size */                                              \
-    k_avgpool2<<<v2e_cdiv((int64_t)n * (C) * (HH) * ((WW) / 4), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW))
+    do {                                                                                         \
+        if ((WW) % 4 == 0) k_avgpool2<<<v2e_cdiv((int64_t)n * (C) * (HH) * ((WW) / 4), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW)); \
+        else k_avgpool2_scalar<<<v2e_cdiv((int64_t)n * (C) * (HH) * (WW), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW)); \
+    } while (0)
 #define UPS(X, C, HH, WW)                                                                        \
     do {                                                                                         \
         if ((WW) % 4 == 0) k_upsample2<<<v2e_cdiv((int64_t)n * (C) * (HH) * ((WW) / 4), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW)); \
@@ -635,11 +684,11 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     POOL(s3, 128, h / 8, w / 8);
     CONV(tU, 128, nullptr, 0, 0, 6, tA, h / 8, w / 8);
     CONV(tA, 256, nullptr, 0, 0, 7, s4, h / 8, w / 8);
-    if ((w / 16) % 4 == 0) { POOL(s4, 256, h / 16, w / 16); CONV(tU, 256, nullptr, 0, 0, 8, tA, h / 16, w / 16); }
-    else CONV(s4, 256, nullptr, 0, 1, 8, tA, h / 16, w / 16);
+    POOL(s4, 256, h / 16, w / 16);
+    CONV(tU, 256, nullptr, 0, 0, 8, tA, h / 16, w / 16);
     CONV(tA, 512, nullptr, 0, 0, 9, s5, h / 16, w / 16);
-    if ((w / 32) % 4 == 0) { POOL(s5, 512, h / 32, w / 32); CONV(tU, 512, nullptr, 0, 0, 10, tA, h / 32, w / 32); }
-    else CONV(s5, 512, nullptr, 0, 1, 10, tA, h / 32, w / 32);
+    POOL(s5, 512, h / 32, w / 32);
+    CONV(tU, 512, nullptr, 0, 0, 10, tA, h / 32, w / 32);
     CONV(tA, 512, nullptr, 0, 0, 11, tB, h / 32, w / 32);
     // up1..up5: skip concat fused into conv2 (x first, skip second)
     UPS(tB, 512, h / 16, w / 16);
