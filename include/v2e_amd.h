@@ -177,7 +177,10 @@ int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const
  * That is the choice while a frame is a few workgroups per CU (latency-bound); larger grids use one
  * k_main launch per frame with emission on the chain (each pixel touched once).  |32 forces the
  * latter, |64 the former, |16 selects the unfused count/rank/scan/emit pipeline (kept for A/B
- * measurements); all three give identical results.
+ * measurements); all three give identical results.  On grids of at most two workgroups per CU the
+ * chain takes two frames per launch (k_step2: the second frame's base update is speculative on the
+ * refractory rule being off, validated -- and on the rare miss repaired in-kernel -- by the next
+ * launch); |128 forces one frame per launch.
  */
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames,
                 const double *t_prev, const double *t_frame, uint32_t frame_idx0, float *events,
@@ -192,8 +195,9 @@ int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *
                          double *ms_emit, int *launches);
 
 /* Default pipeline only: emission batches timed by the last instrumented run and the frames
- * per emission batch this handle uses (chosen at create time; env V2E_AMD_PIPE_E overrides). */
-int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch);
+ * per emission batch this handle uses (chosen at create time; env V2E_AMD_PIPE_E overrides), and
+ * the number of chain launches ms_count covers (step_launches may be NULL). */
+int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch, int *step_launches);
 
 /* ------------------------------------------------------------- SuperSloMo */
 

@@ -36,16 +36,19 @@ def same(a, b):
 
 if __name__ == "__main__":
     kw = dict(DEFAULT_KW)
-    a = run("step chain + deferred emission, graph", kw, 1, keep=True)
+    a = run("step chain x2 + deferred emission, graph", kw, 1, keep=True)
     b = run("fused k_main per frame, graph", kw, 33, keep=True)
     print("   identical event streams:", same(a, b))
-    run("step chain, plain launches", kw, 0)
+    c = run("step chain x1, graph", kw, 129, keep=True)
+    print("   identical event streams:", same(a, c))
+    run("step chain x2, plain launches", kw, 0)
     run("legacy 4-kernel graph", kw, 17)
     k2 = dict(kw); k2["refractory_period_s"] = 0.0
     run("step chain, refractory 0", k2, 1)
     k3 = dict(k2); k3["leak_rate_hz"] = 0.0; k3["shot_noise_rate_hz"] = 0.0
     run("step chain, no refr/leak/shot (no Philox)", k3, 1)
     k4 = dict(kw); k4["refractory_period_s"] = 0.002  # rule active on most frames
-    a = run("step chain, refractory 2 ms (rule active)", k4, 1, keep=True)
+    run("step chain x1, refractory 2 ms (rule active)", k4, 129)
+    a = run("step chain x2, refractory 2 ms (rule active)", k4, 1, keep=True)
     b = run("fused k_main, refractory 2 ms", k4, 33, keep=True)
     print("   identical event streams:", same(a, b))

@@ -19,5 +19,5 @@ for s in range(3):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     pr = emu._engine.last_profile()
-    print("run %d: wall %.2f ms; step chain %.3f ms = %.2f us/launch; emission batches: %.3f ms total" % (
-        s, wall * 1e3, pr["count"], pr["count"] / (F + 1) * 1e3, pr["emit"]))
+    print("run %d: wall %.2f ms; step chain %.3f ms = %.2f us/frame (%d launches); emission batches: %.3f ms total in %d" % (
+        s, wall * 1e3, pr["count"], pr["count"] / F * 1e3, pr["step_launches"], pr["emit"], pr["emit_batches"]))

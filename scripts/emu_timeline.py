@@ -35,6 +35,8 @@ if not fused:
     for i, n in [(0, "start"), (5, "RNG done"), (6, "loads arrived"), (1, "M(f-1) known"), (2, "finalise done"), (3, "count math done"), (4, "end")]:
         col = t[:, i]
         ok = col > 0
+        if not ok.any():
+            continue
         print("%-18s mean %+7.2f us  (min %+6.2f max %+6.2f) since first block start; mean since own start %6.2f" % (
             n, (col[ok] - t0).mean() / 100.0, (col[ok] - t0).min() / 100.0, (col[ok] - t0).max() / 100.0, (col[ok] - t[ok, 0]).mean() / 100.0))
     sys.exit(0)

@@ -61,9 +61,10 @@ def test_hip_philox_frame_api_matches_reference(name):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
 
 
-# use_graph: low bits 0 plain launches / 1 hipGraph; |64 k_step chain + deferred emission batches,
-# |32 one k_main per frame (emission on the chain), |16 unfused count/rank/scan/emit; none = size heuristic
-PIPELINES = [0, 1, 64, 65, 32, 33, 16, 17]
+# use_graph: low bits 0 plain launches / 1 hipGraph; |64 k_step chain + deferred emission batches (two frames per
+# launch on small grids, |128: one), |32 one k_main per frame (emission on the chain), |16 unfused
+# count/rank/scan/emit; none = size heuristic
+PIPELINES = [0, 1, 64, 65, 192, 193, 32, 33, 16, 17]
 
 
 @pytest.mark.parametrize("use_graph", PIPELINES)
@@ -87,14 +88,14 @@ def test_hip_philox_device_resident_clip_matches_reference(name, use_graph):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
 
 
-@pytest.mark.parametrize("pipe_e", [1, 2, 3, 5])
+@pytest.mark.parametrize("pipe_e", [1, 2, 3, 4, 6])
 @pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260"])
 def test_step_chain_pipeline_ring_wraps(name, pipe_e, monkeypatch):
     """Few frames per emission batch: the ring of frame slots wraps several times within the fixture clip, the
     step chain waits on emission batches, partial last batch."""
     monkeypatch.setenv("V2E_AMD_PIPE_E", str(pipe_e))
     fx = PhiloxFixture(name)
-    for use_graph in (64, 65):
+    for use_graph in (64, 65, 192, 193):
         emu = _mk(fx, seed=fx.seed, rng_mode="philox")
         ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph)
         assert list(counts) == list(fx.n_events)
@@ -263,7 +264,7 @@ def test_many_iterations_grow_scratch(oracle_lib):
     assert ora.last["M"] > 64
 
 
-@pytest.mark.parametrize("use_graph", [65, 33, 17])
+@pytest.mark.parametrize("use_graph", [65, 193, 33, 17])
 @pytest.mark.parametrize("refr", [0.0, 0.0004])
 def test_device_resident_clip_many_iterations(use_graph, refr, oracle_lib):
     """> 31 events per pixel per frame: several 64-key chunks in the fused kernels, refractory on/off."""

@@ -664,11 +664,13 @@ struct v2e_emu {
     int *pipe_rowext = nullptr;    // [pipe_D][n_clips][ngroups]
     uint32_t *pipe_nw = nullptr;   // [pipe_D][n_clips][ngroups]
     uint32_t *pipe_pre32 = nullptr, *pipe_tot32 = nullptr; // large grids: [pipe_E][n_clips][nkeys_cap][ngp] / [..][nkeys_cap]
+    void *pipe_bck = nullptr, *pipe_lpn = nullptr; // [pipe_D][n_clips][npx_pad] float64 slots: k_step2 checkpoints (base before the
+                                                   // speculative finalise, lp after the frame); allocated on first use
     unsigned long long *pipe_off = nullptr; // [2][n_clips] event offset at the start of the current / next emission batch
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_fork, ev_join;
     double prof_emit_ms = 0.0;
-    int prof_emit_batches = 0;
+    int prof_emit_batches = 0, prof_step_launches = 0;
 };
 
 static thread_local char g_err[512] = "";
@@ -811,7 +813,7 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
     for (int q = 0; q < 2; ++q) V2E_HIP(hipMalloc(&h->gmaxv[q], sizeof(int) * (size_t)n_clips * h->ngroups));
     {
         // frames per emission launch: as many as keep the ring (count words + ts_mem copies) under ~1 GiB
-        size_t per_frame = (size_t)n_clips * h->npx_pad * 8, e = PIPE_E_MAX;
+        size_t per_frame = (size_t)n_clips * h->npx_pad * 24, e = PIPE_E_MAX;
         while (e > 4 && 2 * e * per_frame > ((size_t)1 << 30)) e >>= 1;
         if (const char *ev = getenv("V2E_AMD_PIPE_E")) { int v = atoi(ev); if (v >= 1 && v <= PIPE_E_MAX) e = (size_t)v; }
         h->pipe_E = (int)e;
@@ -846,7 +848,7 @@ int v2e_emu_destroy(v2e_emu *h)
     hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
     hipFree(h->lut_L); hipFree(h->lut_I); hipFree(h->pre32); hipFree(h->tot32);
     hipFree(h->pipe_cnt); hipFree(h->pipe_gmax); hipFree(h->pipe_tsold); hipFree(h->pipe_gtT); hipFree(h->pipe_rowext);
-    hipFree(h->pipe_nw); hipFree(h->pipe_pre32); hipFree(h->pipe_tot32); hipFree(h->pipe_off);
+    hipFree(h->pipe_nw); hipFree(h->pipe_bck); hipFree(h->pipe_lpn); hipFree(h->pipe_pre32); hipFree(h->pipe_tot32); hipFree(h->pipe_off);
     for (hipEvent_t e : h->ev_fork) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_join) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
@@ -1149,7 +1151,7 @@ static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
 // k_step (events between dependent launches would lengthen the very gaps being measured) and
 // around every emission batch.
 static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
-                            float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, std::vector<hipEvent_t> *ev_main = nullptr,
+                            float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, int K, std::vector<hipEvent_t> *ev_main = nullptr,
                             std::vector<hipEvent_t> *ev_side = nullptr)
 {
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
@@ -1157,6 +1159,7 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
     V2E_REQUIRE(!has_refr || h->pipe_tsold, "pipe_tsold not allocated");
     V2E_HIP(hipMemsetAsync(recs, 0, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
     V2E_HIP(hipMemsetAsync(h->pipe_off, 0, sizeof(unsigned long long) * 2 * h->n_clips, s));
+    if (K == 2) V2E_HIP(hipMemsetAsync(h->run_bar, 0, sizeof(unsigned) * (size_t)((n_frames + 1) / 2 + 1) * h->n_clips, s));
     const int PIPE_E = h->pipe_E, PIPE_D = h->pipe_D;
     const size_t st_px = (size_t)h->n_clips * h->npx_pad, st_g = (size_t)h->n_clips * h->ngroups;
     auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t st) -> int {
@@ -1168,7 +1171,39 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
         return 0;
     };
     dim3 grid(h->ngroups, h->n_clips);
-    for (int f = 0; f <= n_frames; ++f) {
+    // emission batch b = frames [b * E, f_end): launched once they are all final, behind the chain on h->side
+    auto launch_emission = [&](int b, int f_end) -> int {
+            EmitArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.ctl = h->run_ctl;
+            ea.recs = recs;
+            ea.fidx_base = h->run_fidx;
+            ea.f0 = b * PIPE_E;
+            ea.nE = f_end - ea.f0;
+            ea.D = PIPE_D;
+            ea.ngroups = h->ngroups; ea.ngp = h->ngp; ea.n_clips = h->n_clips;
+            ea.cnt = h->pipe_cnt; ea.gmax = h->pipe_gmax; ea.tsold = has_refr ? h->pipe_tsold : nullptr;
+            ea.gtT = h->pipe_gtT; ea.rowext = h->pipe_rowext; ea.nw = h->pipe_nw;
+            ea.pre32 = h->pipe_pre32; ea.tot32 = h->pipe_tot32;
+            ea.events = (float4 *)events; ea.cap = cap;
+            ea.off_in = h->pipe_off + (size_t)(b & 1) * h->n_clips;
+            ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * h->n_clips;
+            V2E_HIP(hipEventRecord(h->ev_fork[b], s));
+            V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
+            dim3 ge(h->ngroups, h->n_clips, ea.nE);
+            if (mark(ev_side, h->side)) return V2E_EHIP;
+            // While the step chain is latency-bound (a grid of a few workgroups per CU) the emission kernels must
+            // not fill the CUs, or the next k_step's workgroups queue behind them: a dynamic-LDS reservation caps
+            // them at 4 workgroups per CU (160 KB LDS).  Large grids are throughput-bound: no cap.
+            const int lds_pad = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu ? 32000 : 0;
+            k_tot_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
+            if (h->pipe_pre32) k_scan2_multi<<<dim3(SCAN_BLOCKS, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
+            k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
+            if (mark(ev_side, h->side)) return V2E_EHIP;
+            V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
+        return 0;
+    };
+    for (int f = 0; K == 1 && f <= n_frames; ++f) {
         if (f % PIPE_E == 0 && f >= PIPE_D) // the slot this step writes was read by emission batch (f - PIPE_D) / PIPE_E
             V2E_HIP(hipStreamWaitEvent(s, h->ev_join[(f - PIPE_D) / PIPE_E], 0));
         StepArgs sa;
@@ -1193,36 +1228,58 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
             if (p->f64_state) k_step<double, FT><<<grid, BLOCK, 0, s>>>(a, sa);
             else k_step<float, FT><<<grid, BLOCK, 0, s>>>(a, sa);
         });
-        if (f >= 1 && (f % PIPE_E == 0 || f == n_frames)) { // frames of batch b are final: emit them behind the chain
-            const int b = (f - 1) / PIPE_E;
-            EmitArgs ea;
-            memset(&ea, 0, sizeof(ea));
-            ea.ctl = h->run_ctl;
-            ea.recs = recs;
-            ea.fidx_base = h->run_fidx;
-            ea.f0 = b * PIPE_E;
-            ea.nE = f - ea.f0;
-            ea.D = PIPE_D;
-            ea.ngroups = h->ngroups; ea.ngp = h->ngp; ea.n_clips = h->n_clips;
-            ea.cnt = h->pipe_cnt; ea.gmax = h->pipe_gmax; ea.tsold = has_refr ? h->pipe_tsold : nullptr;
-            ea.gtT = h->pipe_gtT; ea.rowext = h->pipe_rowext; ea.nw = h->pipe_nw;
-            ea.pre32 = h->pipe_pre32; ea.tot32 = h->pipe_tot32;
-            ea.events = (float4 *)events; ea.cap = cap;
-            ea.off_in = h->pipe_off + (size_t)(b & 1) * h->n_clips;
-            ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * h->n_clips;
-            V2E_HIP(hipEventRecord(h->ev_fork[b], s));
-            V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
-            dim3 ge(h->ngroups, h->n_clips, ea.nE);
-            if (mark(ev_side, h->side)) return V2E_EHIP;
-            // While the step chain is latency-bound (a grid of a few workgroups per CU) the emission kernels must
-            // not fill the CUs, or the next k_step's workgroups queue behind them: a dynamic-LDS reservation caps
-            // them at 4 workgroups per CU (160 KB LDS).  Large grids are throughput-bound: no cap.
-            const int lds_pad = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu ? 32000 : 0;
-            k_tot_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
-            if (h->pipe_pre32) k_scan2_multi<<<dim3(SCAN_BLOCKS, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
-            k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
-            if (mark(ev_side, h->side)) return V2E_EHIP;
-            V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
+        if (f >= 1 && (f % PIPE_E == 0 || f == n_frames)) // frames of batch (f - 1) / E are final: emit them behind the chain
+            if (launch_emission((f - 1) / PIPE_E, f)) return V2E_EHIP;
+    }
+    // two frames per launch (k_step2): launch L counts frames 2L and 2L+1, finalises 2L-1 exactly and validates 2L-2
+    const size_t sz_r = p->f64_state ? 8 : 4;
+    const int n_launch2 = (n_frames + 1) / 2 + 1;
+    int emitted = 0; // emission batches launched so far
+    for (int L = 0; K == 2 && L < n_launch2; ++L) {
+        const int c0 = 2 * L, c1 = 2 * L + 1;
+        const bool has_c0 = c0 < n_frames, has_c1 = c1 < n_frames;
+        // the frame finalised exactly here: the last one counted before this launch
+        const int e1 = std::min(c0, n_frames) - 1;
+        const bool has_e1 = e1 >= 0;
+        // ... and the speculated one before it: e1 - 1 was speculated iff it is an even frame that had a partner
+        const int e2 = e1 - 1;
+        const bool has_e2 = has_e1 && e2 >= 0 && (e2 % 2 == 0);
+        if (c0 % PIPE_E == 0 && c0 >= PIPE_D && has_c0)
+            V2E_HIP(hipStreamWaitEvent(s, h->ev_join[(c0 - PIPE_D) / PIPE_E], 0));
+        auto slot = [&](int f) { return (size_t)(((f % PIPE_D) + PIPE_D) % PIPE_D); };
+        auto clampf = [&](int f) { return (size_t)std::min(std::max(f, 0), n_frames - 1); };
+        Step2Args sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.frame0 = has_c0 ? (const char *)frames + (size_t)c0 * h->n_clips * h->npx * esz : nullptr;
+        sa.frame1 = has_c1 ? (const char *)frames + (size_t)c1 * h->n_clips * h->npx * esz : nullptr;
+        sa.ctl_c0 = h->run_ctl + clampf(c0) * h->n_clips;
+        sa.ctl_c1 = h->run_ctl + clampf(c1) * h->n_clips;
+        sa.ctl_e1 = h->run_ctl + clampf(e1) * h->n_clips;
+        sa.ctl_e2 = h->run_ctl + clampf(e2) * h->n_clips;
+        sa.fidx_base = h->run_fidx;
+        sa.fidx_c0 = (uint32_t)c0; sa.fidx_c1 = (uint32_t)c1; sa.fidx_e1 = (uint32_t)std::max(e1, 0);
+        sa.has_e1 = has_e1; sa.has_e2 = has_e2; sa.ngroups = h->ngroups;
+        sa.cnt_e2 = h->pipe_cnt + slot(e2) * st_px; sa.cnt_e1 = h->pipe_cnt + slot(e1) * st_px;
+        sa.cnt_c0 = h->pipe_cnt + slot(c0) * st_px; sa.cnt_c1 = h->pipe_cnt + slot(c1) * st_px;
+        sa.gmax_e2 = h->pipe_gmax + slot(e2) * st_g; sa.gmax_e1 = h->pipe_gmax + slot(e1) * st_g;
+        sa.gmax_c0 = h->pipe_gmax + slot(c0) * st_g; sa.gmax_c1 = h->pipe_gmax + slot(c1) * st_g;
+        if (has_refr) {
+            sa.tsold_e2 = h->pipe_tsold + slot(e2) * st_px; sa.tsold_e1 = h->pipe_tsold + slot(e1) * st_px;
+            sa.bck_e2 = (const char *)h->pipe_bck + slot(e2) * st_px * sz_r; sa.lpn_e2 = (const char *)h->pipe_lpn + slot(e2) * st_px * sz_r;
+            sa.bck_c0 = (char *)h->pipe_bck + slot(c0) * st_px * sz_r; sa.lpn_c0 = (char *)h->pipe_lpn + slot(c0) * st_px * sz_r;
+        }
+        sa.bar = h->run_bar + (size_t)L * h->n_clips;
+        sa.rec_e1 = recs + clampf(e1) * h->n_clips;
+        sa.dbg = (h->dbg && L == n_launch2 / 2) ? h->dbg : nullptr;
+        if (L == 0 && mark(ev_main, s)) return V2E_EHIP;
+        DISPATCH_FT(dtype, {
+            if (p->f64_state) k_step2<double, FT><<<grid, BLOCK, 0, s>>>(a, sa);
+            else k_step2<float, FT><<<grid, BLOCK, 0, s>>>(a, sa);
+        });
+        // after this launch every frame <= e1 is final
+        while (emitted * PIPE_E < n_frames && std::min((emitted + 1) * PIPE_E, n_frames) - 1 <= e1) {
+            if (launch_emission(emitted, std::min((emitted + 1) * PIPE_E, n_frames))) return V2E_EHIP;
+            ++emitted;
         }
     }
     if (mark(ev_main, s)) return V2E_EHIP;
@@ -1270,9 +1327,18 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     const bool small_grid = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu;
     const bool fused = !legacy && ((use_graph & 32) != 0 || (!(use_graph & 64) && !small_grid));
     const bool pipe = !legacy && !fused;
+    // Two frames per launch (k_step2, second frame finalised speculatively) needs the grid co-resident for the
+    // rare in-kernel rendezvous of its recovery path: grids of at most two workgroups per CU.  |128 forces one
+    // frame per launch (also what a caller should pick for clips on which the refractory rule is mostly active).
+    const int K = (pipe && h->pipe_E % 2 == 0 && (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu && !(use_graph & 128) &&
+                   !getenv("V2E_AMD_NO_SPECULATION")) ? 2 : 1;
     if (pipe) { // everything the capture must not allocate
         if (p->refractory_period_s > 0 && !h->pipe_tsold)
             V2E_HIP(hipMalloc(&h->pipe_tsold, sizeof(float) * (size_t)h->pipe_D * h->n_clips * h->npx_pad));
+        if (K == 2 && p->refractory_period_s > 0 && !h->pipe_bck) {
+            V2E_HIP(hipMalloc(&h->pipe_bck, sizeof(double) * (size_t)h->pipe_D * h->n_clips * h->npx_pad));
+            V2E_HIP(hipMalloc(&h->pipe_lpn, sizeof(double) * (size_t)h->pipe_D * h->n_clips * h->npx_pad));
+        }
         const size_t nb = (size_t)(n_frames + h->pipe_E - 1) / h->pipe_E;
         while (h->ev_fork.size() < nb) {
             hipEvent_t e0, e1;
@@ -1288,18 +1354,19 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
             return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs);
         }
         if (fused) return enqueue_run_fused(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs, nm);
-        return enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st);
+        return enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, K);
     };
     if (mode == 0) return enqueue(s, nullptr, nullptr);
     if (mode == 2 && pipe) { // instrumented: step-chain time from events on `s`, emission batches from events on the side stream
         std::vector<hipEvent_t> em, es;
-        rc = enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, &em, &es);
+        rc = enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, K, &em, &es);
         if (rc == 0) {
             V2E_HIP(hipStreamSynchronize(s));
             for (int k = 0; k < 4; ++k) h->prof_ms[k] = 0.0;
             float ms = 0.f;
             V2E_HIP(hipEventElapsedTime(&ms, em.front(), em.back()));
-            h->prof_ms[0] = ms; // n_frames + 1 k_step launches
+            h->prof_ms[0] = ms; // n_frames + 1 k_step launches, or (n_frames + 1) / 2 + 1 k_step2 launches
+            h->prof_step_launches = K == 2 ? (n_frames + 1) / 2 + 1 : n_frames + 1;
             for (size_t i = 0; i + 1 < es.size(); i += 2) {
                 V2E_HIP(hipEventElapsedTime(&ms, es[i], es[i + 1]));
                 h->prof_ms[3] += ms;
@@ -1342,7 +1409,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
     int lg = legacy ? 1 : (fused ? 2 : 0); push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
-    push(&h->pipe_tsold, sizeof(h->pipe_tsold));
+    push(&h->pipe_tsold, sizeof(h->pipe_tsold)); push(&h->pipe_bck, sizeof(h->pipe_bck)); push(&K, sizeof(K));
     int nis = getenv("V2E_AMD_NO_INKERNEL_SYNC") ? 1 : 0; push(&nis, sizeof(nis));
     if (!h->graph || key != h->graph_key) {
         if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
@@ -1389,11 +1456,12 @@ int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *
     return 0;
 }
 
-int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch)
+int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch, int *step_launches)
 {
     V2E_REQUIRE(h && emit_batches && frames_per_batch, "null");
     *emit_batches = h->prof_emit_batches;
     *frames_per_batch = h->pipe_E;
+    if (step_launches) *step_launches = h->prof_step_launches;
     return 0;
 }
 

@@ -289,6 +289,301 @@ __device__ __forceinline__ TsGen frame_tsgen(const KArgs &a, const FrameCtl *c, 
     return TsGen(cc, n, nullptr);
 }
 
+// ------------------------------------------------------------------ two frames per launch
+// The launch-to-launch gap (~3.9 us) is longer than k_step itself (~2.5 us), so k_step2 takes two frames per
+// launch: after the exact finalise of the previous launch's last frame it counts frame c0, finalises it
+// SPECULATIVELY -- assuming the refractory rule is off for c0, which is all that needs the global max M(c0):
+// then the pixel's pass count is its own count -- and counts frame c1.  The next launch knows M(c0) and
+// validates: if the rule was in fact on (refractory_period_s > dt / M, about 1 % of the frames of the
+// benchmark clip), it restores base_log_frame from the checkpoint taken before the speculation, finalises c0
+// exactly, re-counts c1, republishes the workgroup maxima and runs ONE in-kernel grid rendezvous (clip_barrier,
+// 11-15 us, bounded spin) to learn the corrected M(c1).  lp_log_frame never depends on the speculation.
+// Needs every workgroup of the grid co-resident (checked by the host; small grids only).
+struct Step2Args {
+    const void *frame0, *frame1;     // frames c0, c1 (nullptr: absent)
+    const FrameCtl *ctl_c0, *ctl_c1; // their times
+    const FrameCtl *ctl_e1, *ctl_e2; // times of e1 (exact finalise; = c0 - 1) and e2 (validate; = c0 - 2)
+    const uint32_t *fidx_base;
+    uint32_t fidx_c0, fidx_c1, fidx_e1; // run-relative frame indices
+    int has_e1, has_e2, ngroups;
+    const uint32_t *cnt_e2;
+    uint32_t *cnt_e1, *cnt_c0, *cnt_c1;
+    const int *gmax_e2;
+    int *gmax_e1, *gmax_c0, *gmax_c1;
+    float *tsold_e2, *tsold_e1;
+    const void *bck_e2, *lpn_e2;     // checkpoint of e2: base before its finalise, lp after it
+    void *bck_c0, *lpn_c0;
+    unsigned *bar;                   // [n_clips] rendezvous counters of this launch (zeroed at run start)
+    v2e_frame_rec *rec_e1;           // record of e1: V2E_FLAG_SYNC_TIMEOUT lands here
+    unsigned long long *dbg;
+};
+
+// emulator.py:830-842, 936-942 for one pixel; M <= max_iters is the caller's business
+template <typename R>
+__device__ __forceinline__ void finalize_px(const KArgs &a, uint32_t cw, bool use_refr, const TsGen &tg, bool valid, size_t sp, float thp,
+                                            float thn, R lp_shot, float *tsold_slot, R &b, float &tsm, bool &b_dirty)
+{
+    const int mag = (int)(cw & CNT_MASK);
+    const bool neg = (cw & CNT_NEG) != 0;
+    int fcount = mag;
+    if (use_refr) {
+        if (valid) tsold_slot[sp] = tsm; // the emission side re-derives which iterations passed from ts_mem as it was
+        fcount = 0;
+        for (int i = 0; i < mag; ++i) {
+            const float t = tg(i);
+            const float pt = 1.0f * t - tsm;
+            if (pt > a.refr_f) { tsm = t; ++fcount; }
+        }
+        if (valid && fcount > 0) a.ts_mem[sp] = tsm;
+    }
+    if (valid) {
+        const bool shot = a.do_shot && (cw & (CNT_SHOT_ON | CNT_SHOT_OFF));
+        if (fcount > 0 || shot) {
+            const float dp = (float)(neg ? 0 : fcount) * thp;
+            const float dn = (float)(neg ? fcount : 0) * thn;
+            b = b + (R)dp;
+            b = b - (R)dn;
+            if (shot) b = lp_shot;
+            b_dirty = true;
+        }
+    }
+}
+
+// emulator_utils.py:137-173 for one pixel: signed count from lp and base (leak already applied)
+template <typename R>
+__device__ __forceinline__ uint32_t count_px(const KArgs &a, R lpn, R b, float thp, float thn, int &m)
+{
+    const R diff = (lpn + (R)0.0f) - b;
+    const R pf = diff > (R)0 ? diff : (R)0;
+    const R nf = (-diff) > (R)0 ? -diff : (R)0;
+    const R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;
+    const R tnd = a.scalar_thres ? (R)a.neg_div : (R)thn;
+    const bool is_pos = diff > (R)0;
+    const int q = (int)floor_div_pos<R>(is_pos ? pf : nf, is_pos ? tpd : tnd);
+    m = q;
+    if (q <= 0) return 0u;
+    return is_pos ? ((uint32_t)q & CNT_MASK) : (((uint32_t)q & CNT_MASK) | CNT_NEG);
+}
+
+// lin-log / inten01 / low-pass / leak of one pixel for one frame (emulator_utils.py:18-134)
+template <typename R, typename FT>
+__device__ __forceinline__ R photoreceptor_px(const KArgs &a, FT px, const float *s_lutL, const double *s_lutI, const FrameCtl &c, R lp_old,
+                                              float nr, float thp, float r, double &inten01, R &b, bool &b_dirty)
+{
+    constexpr bool U8 = sizeof(FT) == 1;
+    float L;
+    if (U8) {
+        L = s_lutL[(int)px];
+        inten01 = s_lutI[(int)px];
+    } else {
+        const double x = (double)px;
+        L = lin_log(x);
+        inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
+    }
+    R lpn;
+    if (a.has_cutoff) {
+        double eps = inten01 * c.dt_over_tau;
+        if (eps > 1.0) eps = 1.0;
+        lpn = (R)((1.0 - eps) * (double)lp_old + eps * (double)L);
+    } else {
+        lpn = (R)L;
+    }
+    if (a.do_leak) { // emulator_utils.py:126-129, float32 left to right
+        const double delta_time = c.t_frame - c.t_prev;
+        const float rate = (a.leak_hz_f * nr) * (1.0f - a.jit_f * r);
+        const float delta_leak = ((float)delta_time * rate) * thp;
+        b = b - (R)delta_leak;
+        b_dirty = true;
+    }
+    return lpn;
+}
+
+__device__ __forceinline__ void block_max2_finish(int &m1, int &m2, int (*s_red2)[BLOCK / WAVE], int lane, int wave)
+{
+    m1 = wave_max_i32(m1);
+    m2 = wave_max_i32(m2);
+    if (lane == 0) { s_red2[0][wave] = m1; s_red2[1][wave] = m2; }
+    __syncthreads();
+    m1 = max(max(s_red2[0][0], s_red2[0][1]), max(s_red2[0][2], s_red2[0][3]));
+    m2 = max(max(s_red2[1][0], s_red2[1][1]), max(s_red2[1][2], s_red2[1][3]));
+    __syncthreads();
+    m1 = __builtin_amdgcn_readfirstlane(m1);
+    m2 = __builtin_amdgcn_readfirstlane(m2);
+}
+
+#define V2E_STAMP_2(i) do { if (sa.dbg && tid == 0) sa.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
+
+template <typename R, typename FT>
+__global__ __launch_bounds__(BLOCK) void k_step2(KArgs a, Step2Args sa)
+{
+    __shared__ int s_red2[2][BLOCK / WAVE];
+    __shared__ int s_red[BLOCK / WAVE];
+    __shared__ float s_lutL[256];
+    __shared__ double s_lutI[256];
+    constexpr bool U8 = sizeof(FT) == 1;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, g = blockIdx.x;
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const bool has_c0 = sa.frame0 != nullptr, has_c1 = sa.frame1 != nullptr;
+
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t fbase_pending = sload_u32_issue(sa.fidx_base);
+    V2E_STAMP_2(0);
+    // ------------------------------------------------------------ every load of the launch, back to back
+    R b = (R)0, lp = (R)0;
+    float thp = 1.f, thn = 1.f, nr = 0.f, tsm = 0.f;
+    uint32_t cw_e1 = 0;
+    FT px0 = (FT)0, px1 = (FT)0;
+    if (valid) {
+        b = ((R *)a.base)[sp];
+        thp = a.pos_thres[sp];
+        thn = a.neg_thres[sp];
+        if (a.has_cutoff || a.do_shot) lp = ((R *)a.lp)[sp];
+        if (a.do_leak) nr = a.noise_rate[sp];
+        if (a.has_refr && sa.has_e1) tsm = a.ts_mem[sp];
+        if (sa.has_e1) cw_e1 = sa.cnt_e1[sp];
+        if (has_c0) px0 = ((const FT *)sa.frame0)[(size_t)clip * a.npx + p];
+        if (has_c1) px1 = ((const FT *)sa.frame1)[(size_t)clip * a.npx + p];
+    }
+    float lutL_r = 0.f;
+    double lutI_r = 0.0;
+    if (U8 && has_c0) {
+        lutL_r = a.lut_L[tid];
+        lutI_r = a.lut_I[tid];
+    }
+    int g1a = 0, g1b = 0, g1c = 0, g1d = 0, g2a = 0, g2b = 0, g2c = 0, g2d = 0; // maxima of e1 / e2: four per thread cover 1024 workgroups
+    const size_t sg = (size_t)clip * sa.ngroups;
+    if (sa.has_e1) {
+        const int *gmv = sa.gmax_e1 + sg;
+        if (tid < sa.ngroups) g1a = gmv[tid];
+        if (tid + BLOCK < sa.ngroups) g1b = gmv[tid + BLOCK];
+        if (tid + 2 * BLOCK < sa.ngroups) g1c = gmv[tid + 2 * BLOCK];
+        if (tid + 3 * BLOCK < sa.ngroups) g1d = gmv[tid + 3 * BLOCK];
+    }
+    const bool check_e2 = sa.has_e2 && a.has_refr;
+    if (check_e2) {
+        const int *gmv = sa.gmax_e2 + sg;
+        if (tid < sa.ngroups) g2a = gmv[tid];
+        if (tid + BLOCK < sa.ngroups) g2b = gmv[tid + BLOCK];
+        if (tid + 2 * BLOCK < sa.ngroups) g2c = gmv[tid + 2 * BLOCK];
+        if (tid + 3 * BLOCK < sa.ngroups) g2d = gmv[tid + 3 * BLOCK];
+    }
+    const FrameCtl *ce1 = sa.ctl_e1 + clip, *ce2 = sa.ctl_e2 + clip;
+    const FrameTab ft1(a.has_refr && sa.has_e1 ? ce1 : sa.ctl_c0 + clip, lane);
+    const FrameTab ft2(check_e2 ? ce2 : sa.ctl_c0 + clip, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- arithmetic that depends on no memory but fbase, done while those loads are in flight
+    const uint32_t fbase = sload_wait(fbase_pending);
+    float r0 = 0.f, u0 = 0.f, r1 = 0.f, u1 = 0.f;
+    if (valid && (a.do_leak || a.do_shot)) {
+        if (has_c0) v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c0, (uint32_t)p, &r0, &u0);
+        if (has_c1) v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c1, (uint32_t)p, &r1, &u1);
+    }
+    V2E_STAMP_2(5);
+    if (U8 && has_c0) { // published by the barriers of block_max2_finish
+        s_lutL[tid] = lutL_r;
+        s_lutI[tid] = lutI_r;
+    }
+    int M1 = max(max(g1a, g1b), max(g1c, g1d)), M2 = max(max(g2a, g2b), max(g2c, g2d));
+    if (sa.ngroups > 4 * BLOCK) {
+        if (sa.has_e1) for (int k = tid + 4 * BLOCK; k < sa.ngroups; k += BLOCK) M1 = max(M1, sa.gmax_e1[sg + k]);
+        if (check_e2) for (int k = tid + 4 * BLOCK; k < sa.ngroups; k += BLOCK) M2 = max(M2, sa.gmax_e2[sg + k]);
+    }
+    block_max2_finish(M1, M2, s_red2, lane, wave);
+    V2E_STAMP_2(1);
+    bool b_dirty = false;
+
+    // ------------------------------------------------------------ was the speculation on e2 right?
+    if (check_e2 && M2 <= a.max_iters) {
+        bool use_refr2;
+        const TsGen tg2 = frame_tsgen(a, ce2, ft2, M2 > 0 ? M2 : 1, use_refr2);
+        if (use_refr2) { // no: finalise e2 exactly from its checkpoint, re-count e1, learn the corrected M(e1)
+            uint32_t cw2 = 0;
+            R lp2 = (R)0;
+            if (valid) {
+                b = ((const R *)sa.bck_e2)[sp];
+                lp2 = ((const R *)sa.lpn_e2)[sp];
+                cw2 = sa.cnt_e2[sp];
+            }
+            finalize_px<R>(a, cw2, true, tg2, valid, sp, thp, thn, lp2, sa.tsold_e2, b, tsm, b_dirty);
+            int m = 0;
+            if (valid) {
+                if (a.do_leak) { // the leak step of e1 again (emulator_utils.py:126-129), same draw
+                    float r = 0.f, u = 0.f;
+                    v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_e1, (uint32_t)p, &r, &u);
+                    const FrameCtl c = *ce1;
+                    const double delta_time = c.t_frame - c.t_prev;
+                    const float rate = (a.leak_hz_f * nr) * (1.0f - a.jit_f * r);
+                    const float delta_leak = ((float)delta_time * rate) * thp;
+                    b = b - (R)delta_leak;
+                }
+                b_dirty = true;
+                const uint32_t shot_old = cw_e1 & (CNT_SHOT_ON | CNT_SHOT_OFF); // shot bits do not depend on base
+                cw_e1 = count_px<R>(a, lp, b, thp, thn, m) | shot_old;
+                sa.cnt_e1[sp] = cw_e1;
+            }
+            m = wave_max_i32(m);
+            if (lane == 0) s_red[wave] = m;
+            __syncthreads();
+            if (tid == 0) sa.gmax_e1[sg + g] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+            const bool ok = clip_barrier(sa.bar + clip, (unsigned)sa.ngroups);
+            if (!ok && tid == 0) atomicOr(&sa.rec_e1[clip].flags, V2E_FLAG_SYNC_TIMEOUT);
+            M1 = block_max_of_groups(sa.gmax_e1 + sg, sa.ngroups, s_red, tid, lane, wave);
+        }
+    }
+
+    // ------------------------------------------------------------ exact finalise of e1
+    if (sa.has_e1 && M1 <= a.max_iters) {
+        bool use_refr1 = false;
+        TsGen tg1(0.f, 0.f, 0.f, 1);
+        if (a.has_refr) tg1 = frame_tsgen(a, ce1, ft1, M1 > 0 ? M1 : 1, use_refr1);
+        finalize_px<R>(a, cw_e1, use_refr1, tg1, valid, sp, thp, thn, lp, sa.tsold_e1, b, tsm, b_dirty);
+    }
+    V2E_STAMP_2(2);
+
+    // ------------------------------------------------------------ count c0, speculative finalise, count c1
+    int m0 = 0, m1 = 0;
+    if (has_c0) {
+        if (valid) {
+            double inten01;
+            const FrameCtl c = sa.ctl_c0[clip];
+            const R lpn = photoreceptor_px<R, FT>(a, px0, s_lutL, s_lutI, c, lp, nr, thp, r0, inten01, b, b_dirty);
+            uint32_t cw = count_px<R>(a, lpn, b, thp, thn, m0);
+            if (a.do_shot) cw |= shot_bits(a, inten01, c.shot_base, thp, thn, u0);
+            sa.cnt_c0[sp] = cw;
+            lp = lpn;
+            if (has_c1) {
+                if (a.has_refr) { // checkpoint for the next launch's validation
+                    ((R *)sa.bck_c0)[sp] = b;
+                    ((R *)sa.lpn_c0)[sp] = lpn;
+                }
+                const TsGen none(0.f, 0.f, 0.f, 1);
+                finalize_px<R>(a, cw, false, none, valid, sp, thp, thn, lpn, nullptr, b, tsm, b_dirty); // speculation: rule off
+                const FrameCtl c1 = sa.ctl_c1[clip];
+                const R lpn1 = photoreceptor_px<R, FT>(a, px1, s_lutL, s_lutI, c1, lp, nr, thp, r1, inten01, b, b_dirty);
+                uint32_t cw1 = count_px<R>(a, lpn1, b, thp, thn, m1);
+                if (a.do_shot) cw1 |= shot_bits(a, inten01, c1.shot_base, thp, thn, u1);
+                sa.cnt_c1[sp] = cw1;
+                lp = lpn1;
+            }
+            ((R *)a.lp)[sp] = lp;
+        }
+        V2E_STAMP_2(3);
+        m0 = wave_max_i32(m0);
+        m1 = wave_max_i32(m1);
+        if (lane == 0) { s_red2[0][wave] = m0; s_red2[1][wave] = m1; }
+        __syncthreads();
+        if (tid == 0) {
+            sa.gmax_c0[sg + g] = max(max(s_red2[0][0], s_red2[0][1]), max(s_red2[0][2], s_red2[0][3]));
+            if (has_c1) sa.gmax_c1[sg + g] = max(max(s_red2[1][0], s_red2[1][1]), max(s_red2[1][2], s_red2[1][3]));
+        }
+    }
+    if (valid && b_dirty) ((R *)a.base)[sp] = b;
+    V2E_STAMP_2(4);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_tot_multi(KArgs a, EmitArgs ea)
 {
     __shared__ uint32_t s_wcnt[BLOCK / WAVE][WAVE];

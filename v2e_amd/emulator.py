@@ -518,8 +518,15 @@ class EventEmulator(object):
             cap = max(4 * H * W, 1 << 16) * min(nrun, 64)
         ev = eng.event_buffer(cap)
         recs = eng.alloc_recs(nrun)
-        eng.run(P, frames_dev[start:], t_prev, t_frames[start:], self.frame_counter, ev, recs, use_graph=int(use_graph))
+        ug = int(use_graph)
+        if getattr(self, "_refr_mostly_on", False):
+            ug |= 128  # one frame per launch: the two-frame chain would repair its speculation on most launches
+        eng.run(P, frames_dev[start:], t_prev, t_frames[start:], self.frame_counter, ev, recs, use_graph=ug)
         r = eng.recs_to_numpy(recs)[:, 0]
+        if self.refractory_period_s > 0:  # emulator.py:830 on the frames just run: how often was the rule active?
+            dts = np.asarray(t_frames[start:]) - np.asarray(t_prev)
+            m = np.maximum(r["max_events"], 1)
+            self._refr_mostly_on = bool(np.mean(self.refractory_period_s > dts / m) > 0.05)
         if (r["flags"] & _capi.FLAG_ITERS_CLAMPED).any():
             raise _capi.V2EAmdError("a pixel produced more than max_iters=%d events in one frame; "
                                     "construct with a larger max_iters" % eng.max_iters)

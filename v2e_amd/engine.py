@@ -186,10 +186,10 @@ class EmuEngine:
         v = [C.c_double() for _ in range(4)]
         n = C.c_int()
         check(self.lib.v2e_emu_last_profile(self._h, *[C.byref(x) for x in v], C.byref(n)), "v2e_emu_last_profile")
-        nb, fpb = C.c_int(), C.c_int()
-        check(self.lib.v2e_emu_last_profile_pipe(self._h, C.byref(nb), C.byref(fpb)), "v2e_emu_last_profile_pipe")
+        nb, fpb, nsl = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.v2e_emu_last_profile_pipe(self._h, C.byref(nb), C.byref(fpb), C.byref(nsl)), "v2e_emu_last_profile_pipe")
         return dict(count=v[0].value, rank=v[1].value, scan=v[2].value, emit=v[3].value, launches=n.value,
-                    emit_batches=nb.value, frames_per_batch=fpb.value)
+                    emit_batches=nb.value, frames_per_batch=fpb.value, step_launches=nsl.value)
 
     def alloc_recs(self, n_frames):
         """Device record array [F][n_clips] (struct v2e_frame_rec = 32 bytes), cached per F so that
