@@ -67,15 +67,15 @@ def emulator_bytes_per_pixel(kw):
     return b
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes of this same command
+def pmc_traffic_per_launch(kernel="k_step2"):
+    """HBM bytes per chain-kernel launch from the committed rocprofv3 PMC passes of this same command
     (profiles/r01_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE
     uncorrected -- our loads are 1-8 B per lane, for which the guide's x2 factor is uncalibrated).
     Counters cannot be read from inside this process, so the value is the recorded one or null."""
     path = os.path.join(ROOT, "profiles", "r01_emulator_pmc_hbm.txt")
     try:
         for line in open(path):
-            if line.startswith("# k_step"):
+            if line.startswith("# " + kernel + "<"):
                 parts = line.split()
                 return int((float(parts[-2]) + float(parts[-1])) * 1024)
     except Exception:
@@ -222,24 +222,27 @@ def main():
         # dependency chain and owns the per-pixel state traffic (53 B/pixel + the 4-byte count word written for
         # the emission side); the emission batches (k_tot_multi + k_emit_multi, 16 B/event + 4 B/pixel re-read)
         # run behind it on a second stream.
-        step_us = prof["count"] / (prof["launches"] + 1) * 1e3
-        step_bytes = (bpp + 4) * npx
+        n_step = max(prof.get("step_launches", 0), 1)
+        fpl = 2 if n_step < prof["launches"] else 1   # frames counted per chain launch (k_step2 : k_step)
+        kname = "k_step2" if fpl == 2 else "k_step"
+        step_us = prof["count"] / n_step * 1e3
+        step_bytes = (bpp + 4) * npx * fpl
         emit_bytes = 16 * ev_per_frame + 2 * 4 * npx
         ach = step_bytes / (step_us * 1e-6)
         whole = (bpp * npx + 16 * ev_per_frame)
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_step",
+            "bound": "hbm", "kernel": kname,
             "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK, 5), "traffic": pmc_traffic_per_launch(),
-            "algorithmic_bytes_per_launch": int(step_bytes),
-            "avg_launch_us": {"k_step": round(step_us, 3),
-                              "emission_batch(k_tot_multi+k_emit_multi)": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3)},
+            "frac": round(ach / HBM_PEAK, 5), "traffic": pmc_traffic_per_launch(kname),
+            "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
+            "avg_launch_us": {kname: round(step_us, 3),
+                              "emission_batch(k_tot_multi+k_frame_multi+k_emit2_multi)": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3)},
             "emission": {"frames_per_batch": prof.get("frames_per_batch"), "algorithmic_bytes_per_frame": int(emit_bytes)},
             "whole_step": {"algorithmic_bytes_per_frame": int(whole),
                            "achieved_GBps": round(whole * K * F / elapsed / 1e9, 2),
                            "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
-            "note": "avg_launch_us from hipEvents recorded before every k_step launch on its stream (includes the "
-                    "inter-kernel gap) and around every emission batch on the emission stream; 346x260 state (2.9 MB) is "
+            "note": "avg_launch_us: HIP events before the first and after the last chain launch on its stream (includes "
+                    "the inter-kernel gaps) and around every emission batch on the emission stream; 346x260 state (2.9 MB) is "
                     "L2/MALL resident and one frame is only 1406 waves, so the chain is bounded by per-launch latency, "
                     "not HBM (DESIGN.md section 3)",
         }

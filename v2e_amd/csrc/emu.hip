@@ -664,6 +664,8 @@ struct v2e_emu {
     int *pipe_rowext = nullptr;    // [pipe_D][n_clips][ngroups]
     uint32_t *pipe_nw = nullptr;   // [pipe_D][n_clips][ngroups]
     uint32_t *pipe_pre32 = nullptr, *pipe_tot32 = nullptr; // large grids: [pipe_E][n_clips][nkeys_cap][ngp] / [..][nkeys_cap]
+    FrameTable *pipe_ftab = nullptr;  // [pipe_E][n_clips] per-frame tables of the emission side (ngp == 512 only)
+    uint32_t *pipe_pre512 = nullptr;  // [pipe_E][n_clips][FT_KEYS][512]
     void *pipe_bck = nullptr, *pipe_lpn = nullptr; // [pipe_D][n_clips][npx_pad] float64 slots: k_step2 checkpoints (base before the
                                                    // speculative finalise, lp after the frame); allocated on first use
     unsigned long long *pipe_off = nullptr; // [2][n_clips] event offset at the start of the current / next emission batch
@@ -825,6 +827,11 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
         V2E_HIP(hipMalloc(&h->pipe_nw, sizeof(uint32_t) * ng));
         V2E_HIP(hipMalloc(&h->pipe_off, sizeof(unsigned long long) * 2 * n_clips));
         V2E_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        if (h->ngp == 512) {
+            V2E_HIP(hipMalloc(&h->pipe_ftab, sizeof(FrameTable) * (size_t)h->pipe_E * n_clips));
+            V2E_HIP(hipMalloc(&h->pipe_pre512, sizeof(uint32_t) * (size_t)h->pipe_E * n_clips * FT_KEYS * 512));
+            V2E_HIP(hipMemset(h->pipe_ftab, 0, sizeof(FrameTable) * (size_t)h->pipe_E * n_clips));
+        }
     }
     int rc = alloc_iter_scratch(h, max_iters); // also zeroes gtot/gmaxv (clean-row invariant)
     if (rc) return rc;
@@ -848,7 +855,7 @@ int v2e_emu_destroy(v2e_emu *h)
     hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
     hipFree(h->lut_L); hipFree(h->lut_I); hipFree(h->pre32); hipFree(h->tot32);
     hipFree(h->pipe_cnt); hipFree(h->pipe_gmax); hipFree(h->pipe_tsold); hipFree(h->pipe_gtT); hipFree(h->pipe_rowext);
-    hipFree(h->pipe_nw); hipFree(h->pipe_bck); hipFree(h->pipe_lpn); hipFree(h->pipe_pre32); hipFree(h->pipe_tot32); hipFree(h->pipe_off);
+    hipFree(h->pipe_nw); hipFree(h->pipe_ftab); hipFree(h->pipe_pre512); hipFree(h->pipe_bck); hipFree(h->pipe_lpn); hipFree(h->pipe_pre32); hipFree(h->pipe_tot32); hipFree(h->pipe_off);
     for (hipEvent_t e : h->ev_fork) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_join) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
@@ -1194,11 +1201,21 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
             if (mark(ev_side, h->side)) return V2E_EHIP;
             // While the step chain is latency-bound (a grid of a few workgroups per CU) the emission kernels must
             // not fill the CUs, or the next k_step's workgroups queue behind them: a dynamic-LDS reservation caps
-            // them at 4 workgroups per CU (160 KB LDS).  Large grids are throughput-bound: no cap.
+            // them at 4 workgroups per CU (160 KB LDS; k_emit2_multi uses its reservation for the event records).
+            // Large grids are throughput-bound: no cap.
             const int lds_pad = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu ? 32000 : 0;
-            k_tot_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
+            static const bool no_tables = getenv("V2E_AMD_NO_FRAME_TABLES") != nullptr;
+            ea.ftab = no_tables ? nullptr : h->pipe_ftab;
+            ea.pre512 = h->pipe_pre512;
+            constexpr int REC_LDS = 32000; // k_emit2_multi: 4 waves x 2000 event records (a wave has at most 64 x 31)
+            ea.capw = REC_LDS / 4 / (BLOCK / WAVE);
+            k_tot_multi<<<ge, BLOCK, lds_pad / 2, h->side>>>(a, ea); // the light kernel of the two: 8 per CU measured best
             if (h->pipe_pre32) k_scan2_multi<<<dim3(SCAN_BLOCKS, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
-            k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
+            if (ea.ftab) {
+                k_frame_multi<<<dim3(1, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
+                k_emit2_multi<<<ge, BLOCK, REC_LDS, h->side>>>(a, ea);
+            }
+            k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea); // frames without a table (M > 31); exits at once otherwise
             if (mark(ev_side, h->side)) return V2E_EHIP;
             V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
         return 0;

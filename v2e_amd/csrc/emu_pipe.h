@@ -263,6 +263,21 @@ struct EmitArgs {
     unsigned long long cap;
     const unsigned long long *off_in; // [n_clips] event offset at the start of this batch
     unsigned long long *off_out;      // [n_clips] ... of the next one
+    // small grids (ngp == 512): per-frame tables built once by k_frame_multi instead of by every wave
+    struct FrameTable *ftab;          // [E][n_clips]
+    uint32_t *pre512;                 // [E][n_clips][FT_KEYS][512] exclusive prefix over workgroups per key
+    int capw;                         // event records per wave that fit the dynamic LDS of k_emit2_multi
+};
+
+constexpr int FT_KEYS = 64; // keys covered by the frame table: shot pair + iterations 0..30
+struct FrameTable {
+    int M;                      // max count of the frame
+    uint32_t n_events;          // all events of the frame (sum of the workgroups' counts)
+    uint32_t big;               // M > 31 (or > max_iters): the frame goes through k_emit_multi instead
+    uint32_t pad[5];
+    uint32_t T[FT_KEYS];        // events per key over all workgroups
+    uint32_t kbase[FT_KEYS];    // first row of the key's iteration within the frame (prefix over signal keys)
+    uint32_t perm[32][8];       // per iteration: shuffle round keys k0..k3, sh, a, amask, n
 };
 
 // Timestamps and refractory switch of one frame once its max count n is known (block-uniform).
@@ -646,6 +661,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit_multi(KArgs a, EmitArgs ea)
     const size_t sg = ((size_t)slot * ea.n_clips + clip) * ea.ngroups;
     const uint32_t fbase = ea.fidx_base ? *ea.fidx_base : 0u;
     const uint32_t frame_idx = fbase + (uint32_t)fe;
+    if (ea.ftab && !ea.ftab[(size_t)z * ea.n_clips + clip].big) return; // k_emit2_multi's frame
 
     // ------------------------------------------------------------ loads
     const uint32_t cw = valid ? ea.cnt[sp] : 0u;
@@ -861,5 +877,226 @@ __global__ __launch_bounds__(BLOCK) void k_emit_multi(KArgs a, EmitArgs ea)
         rec[clip].n_off = sum_off + (a.do_shot ? soff_tot : 0u);
         rec[clip].ev_offset = ev0;
         if (z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events;
+    }
+}
+
+// ------------------------------------------------------------------ per-frame tables (small grids)
+// One workgroup per (frame, clip): everything about a frame's event list that is the same for all of its
+// workgroups -- M, the per-key totals and their prefix over keys, the prefix over workgroups of every key row,
+// the shuffle parameters of every iteration -- computed once instead of by each of the frame's 1408 waves.
+__global__ __launch_bounds__(BLOCK) void k_frame_multi(KArgs a, EmitArgs ea)
+{
+    __shared__ int s_red[BLOCK / WAVE];
+    __shared__ uint32_t s_T[FT_KEYS];
+    __shared__ uint32_t s_nw[BLOCK / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const size_t sg = ((size_t)slot * ea.n_clips + clip) * ea.ngroups;
+    int gm_part = 0;
+    uint32_t nsum = 0;
+    for (int k = tid; k < ea.ngroups; k += BLOCK) {
+        gm_part = max(gm_part, ea.gmax[sg + k]);
+        nsum += ea.nw[sg + k];
+    }
+    nsum = wave_sum_u32(nsum);
+    if (lane == 0) s_nw[wave] = nsum;
+    const int M = block_max_finish(gm_part, s_red, lane, wave);
+    const uint32_t N = s_nw[0] + s_nw[1] + s_nw[2] + s_nw[3];
+    FrameTable *ft = ea.ftab + (size_t)z * ea.n_clips + clip;
+    const bool big = M > 31 || M > a.max_iters;
+    if (tid == 0) {
+        ft->M = M;
+        ft->n_events = M > a.max_iters ? 0u : N;
+        ft->big = big ? 1u : 0u;
+    }
+    if (big) return;
+    const int nk = 2 + 2 * M; // <= 64
+    const uint16_t *gt = ea.gtT + ((size_t)slot * ea.n_clips + clip) * a.nkeys_cap * 512;
+    uint32_t *pre = ea.pre512 + ((size_t)z * ea.n_clips + clip) * FT_KEYS * 512;
+    for (int k = wave; k < nk; k += BLOCK / WAVE) { // one wave per key row: 512 workgroups, 8 per lane
+        const uint4 v = *(const uint4 *)(gt + (size_t)k * 512 + lane * 8);
+        const uint32_t w[8] = {v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16, v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16};
+        const uint32_t lane_tot = w[0] + w[1] + w[2] + w[3] + w[4] + w[5] + w[6] + w[7];
+        uint32_t run = wave_excl_scan_u32(lane_tot, lane);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)(run + lane_tot), WAVE - 1);
+        uint32_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] = run; run += w[j]; }
+        uint4 *dst = (uint4 *)(pre + (size_t)k * 512 + lane * 8);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        if (lane == 0) s_T[k] = tot;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int key = lane;
+        const uint32_t T_k = key < nk ? s_T[key] : 0u;
+        const uint32_t sig_T = key >= 2 ? T_k : 0u;
+        const uint32_t kbase = wave_excl_scan_u32(sig_T, lane);
+        const uint32_t n_signal = wave_sum_u32(sig_T);
+        const uint32_t sum_on = wave_sum_u32((lane & 1) ? 0u : sig_T), sum_off = wave_sum_u32((lane & 1) ? sig_T : 0u);
+        ft->T[lane] = T_k;
+        ft->kbase[lane] = kbase;
+        if (lane < 32) {
+            uint32_t pk[4] = {0, 0, 0, 0}, ps_sh = 0, ps_a = 1, ps_amask = 0, ps_n = 0;
+            if (a.shuffle && a.rng_mode == V2E_RNG_PHILOX && lane < 31 && 3 + 2 * lane < nk) {
+                const uint32_t fbase = ea.fidx_base ? *ea.fidx_base : 0u;
+                ps_n = s_T[2 + 2 * lane] + s_T[3 + 2 * lane];
+                v2e_perm_shape(ps_n, &ps_sh, &ps_a, &ps_amask);
+                v2e_perm_keys(a.seed, (uint32_t)clip, fbase + (uint32_t)fe, (uint32_t)lane, pk);
+            }
+            uint4 *pp = (uint4 *)ft->perm[lane];
+            pp[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            pp[1] = make_uint4(ps_sh, ps_a, ps_amask, ps_n);
+        }
+        if (lane == 0) {
+            v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips + clip;
+            const uint32_t son = a.do_shot ? s_T[0] : 0u, soff = a.do_shot ? s_T[1] : 0u;
+            rec->max_events = M;
+            rec->n_signal = n_signal;
+            rec->n_events = n_signal + son + soff;
+            rec->n_on = sum_on + son;
+            rec->n_off = sum_off + soff;
+        }
+    }
+}
+
+// Emission for frames with a table (M <= 31, one 64-key chunk).  Pass 1 is pixel-parallel as before (which of
+// my iterations pass; ballots give the rank among the wave's same-polarity events of the iteration) but instead
+// of writing events iteration by iteration -- a wave-uniform loop whose shuffle arithmetic runs for the few
+// lanes that fire -- every passing (lane, iteration) leaves a 4-byte record in LDS, and the wave then walks its
+// own records with all lanes busy: one event per lane, parameters gathered by lane index (ds_bpermute).
+__global__ __launch_bounds__(BLOCK) void k_emit2_multi(KArgs a, EmitArgs ea)
+{
+    extern __shared__ uint32_t s_rec[]; // [BLOCK / WAVE][capw]
+    __shared__ uint32_t s_wcnt[BLOCK / WAVE][WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const FrameTable *ft = ea.ftab + (size_t)z * ea.n_clips + clip;
+    if (ft->big) return; // k_emit_multi's frame
+    const int M = __builtin_amdgcn_readfirstlane(ft->M);
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
+
+    // ------------------------------------------------------------ loads
+    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
+    float tsm = (valid && ea.tsold) ? ea.tsold[sp] : 0.f;
+    const int nk = 2 + 2 * M;
+    const int key = lane;
+    const uint32_t T_k = ft->T[key], kbase_k = ft->kbase[key]; // zero / total beyond the frame's keys
+    uint32_t P_k = 0;
+    if (key < nk) P_k = ea.pre512[(((size_t)z * ea.n_clips + clip) * FT_KEYS + key) * 512 + g];
+    const uint4 pa = lane < 32 ? ((const uint4 *)ft->perm[lane])[0] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 pb = lane < 32 ? ((const uint4 *)ft->perm[lane])[1] : make_uint4(0u, 1u, 0u, 0u);
+    unsigned long long ev0 = ea.off_in[clip];
+    for (int j = 0; j < z; ++j) ev0 += ea.ftab[(size_t)j * ea.n_clips + clip].n_events;
+    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
+    const FrameTab ftb(c, lane);
+    const int n = M > 0 ? M : 1;
+    bool use_refr;
+    const TsGen tg = frame_tsgen(a, c, ftb, n, use_refr);
+    const int mag = (int)(cw & CNT_MASK);
+    const bool neg = (cw & CNT_NEG) != 0;
+    float4 *ev = ea.events + (size_t)clip * ea.cap;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float fx = (float)(p % a.W), fy = (float)(p / a.W);
+    const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
+    uint32_t *rec_w = s_rec + (size_t)wave * ea.capw;
+
+    // ------------------------------------------------------------ pass 1: records + per-wave key counts
+    uint32_t mine = 0, nrec = 0;
+    for (int i = 0; i < M; ++i) {
+        const bool cand = mag > i;
+        if (__ballot(cand) == 0ull) break;
+        bool pass = cand;
+        if (use_refr) {
+            const float t = tg(i);
+            const float pt = (cand ? 1.0f : 0.0f) * t - tsm;
+            pass = pt > a.refr_f;
+            if (pass) tsm = t;
+        }
+        const unsigned long long bo = __ballot(pass && !neg);
+        const unsigned long long bf = __ballot(pass && neg);
+        const int kl = 2 + 2 * i;
+        if (lane == kl) mine = (uint32_t)__popcll(bo);
+        if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+        if (pass) {
+            const uint32_t rank = (uint32_t)__popcll((neg ? bf : bo) & lt);
+            const uint32_t pos = nrec + (uint32_t)__popcll((bo | bf) & lt);
+            if (pos < (uint32_t)ea.capw) rec_w[pos] = (uint32_t)lane | ((uint32_t)i << 6) | ((neg ? 1u : 0u) << 11) | (rank << 12);
+        }
+        nrec += (uint32_t)__popcll(bo | bf);
+    }
+    {
+        const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
+        const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+        if (lane == 0) mine = (uint32_t)__popcll(so);
+        if (lane == 1) mine = (uint32_t)__popcll(sf);
+    }
+    s_wcnt[wave][lane] = mine;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int q = 0; q < BLOCK / WAVE; ++q)
+        if (q < wave) woff += s_wcnt[q][lane];
+    const uint32_t off_k = P_k + woff;
+    const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)(kbase_k + T_k), WAVE - 1); // all signal events of the frame
+    bool dropped = nrec > (uint32_t)ea.capw;
+
+    // ------------------------------------------------------------ pass 2: one event per lane
+    const uint32_t nrec_c = min(nrec, (uint32_t)ea.capw);
+    for (uint32_t e0 = 0; e0 < nrec_c; e0 += WAVE) {
+        const bool has = e0 + lane < nrec_c;
+        const uint32_t r = has ? rec_w[e0 + lane] : 0u;
+        const int src = (int)(r & 63u), i = (int)((r >> 6) & 31u);
+        const bool eneg = (r >> 11) & 1u;
+        const uint32_t rank = r >> 12;
+        const int kl = 2 + 2 * i;
+        const uint32_t it_base = (uint32_t)__shfl((int)kbase_k, kl);
+        const uint32_t tot_on = (uint32_t)__shfl((int)T_k, kl);
+        const uint32_t off = (uint32_t)__shfl((int)off_k, kl + (eneg ? 1 : 0));
+        const float ex = __shfl(fx, src), ey = __shfl(fy, src);
+        uint32_t cidx = (eneg ? tot_on : 0u) + off + rank;
+        if (shuf) {
+            v2e_perm_t pm;
+            pm.k[0] = (uint32_t)__shfl((int)pa.x, i); pm.k[1] = (uint32_t)__shfl((int)pa.y, i);
+            pm.k[2] = (uint32_t)__shfl((int)pa.z, i); pm.k[3] = (uint32_t)__shfl((int)pa.w, i);
+            pm.sh = (uint32_t)__shfl((int)pb.x, i); pm.a = (uint32_t)__shfl((int)pb.y, i);
+            pm.amask = (uint32_t)__shfl((int)pb.z, i); pm.n = (uint32_t)__shfl((int)pb.w, i);
+            pm.rmask = (1u << pm.sh) - 1u;
+            if (has) cidx = v2e_perm_apply(&pm, cidx);
+        }
+        if (has) {
+            const unsigned long long row = ev0 + it_base + cidx;
+            if (row < ea.cap) ev[row] = make_float4(tg(i), ex, ey, eneg ? -1.0f : 1.0f);
+            else dropped = true;
+        }
+    }
+    // shot-noise events after all signal events (ON block, OFF block), ts[-1], unshuffled
+    const uint32_t son_tot = lane_value(T_k, 0), soff_tot = lane_value(T_k, 1);
+    if (a.do_shot) {
+        const uint32_t son_off = lane_value(off_k, 0), soff_off = lane_value(off_k, 1);
+        const bool s_on = (cw & CNT_SHOT_ON) != 0, s_off = (cw & CNT_SHOT_OFF) != 0;
+        const unsigned long long so = __ballot(s_on), sf = __ballot(s_off);
+        if (so | sf) {
+            const float tl = tg(n - 1);
+            if (s_on) {
+                const unsigned long long row = ev0 + carry + son_off + (uint32_t)__popcll(so & lt);
+                if (row < ea.cap) ev[row] = make_float4(tl, fx, fy, 1.0f);
+                else dropped = true;
+            }
+            if (s_off) {
+                const unsigned long long row = ev0 + carry + son_tot + soff_off + (uint32_t)__popcll(sf & lt);
+                if (row < ea.cap) ev[row] = make_float4(tl, fx, fy, -1.0f);
+                else dropped = true;
+            }
+        }
+    }
+    v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips;
+    if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
+    if (g == 0 && tid == 0) {
+        rec[clip].ev_offset = ev0;
+        if (z == ea.nE - 1) ea.off_out[clip] = ev0 + carry + (a.do_shot ? son_tot + soff_tot : 0u);
     }
 }
