@@ -1134,10 +1134,13 @@ static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         fa.dbg = (h->dbg && f == n_frames / 2) ? h->dbg : nullptr; // dev timeline of one mid-run launch
         fa.bar = inkernel ? h->run_bar : nullptr;
         fa.pre32 = h->pre32; fa.tot32 = h->tot32;
+        static const bool no_rec = getenv("V2E_AMD_NO_EVENT_RECORDS") != nullptr;
+        fa.capw = no_rec ? 0 : 512; // 8 KB of records per workgroup; a wave with more events in a frame takes the iteration loop
+        const size_t rec_lds = sizeof(uint32_t) * (size_t)fa.capw * (BLOCK / WAVE);
         if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
         DISPATCH_FT(dtype, {
-            if (p->f64_state) k_main<double, FT><<<grid, BLOCK, 0, s>>>(a, fa);
-            else k_main<float, FT><<<grid, BLOCK, 0, s>>>(a, fa);
+            if (p->f64_state) k_main<double, FT><<<grid, BLOCK, rec_lds, s>>>(a, fa);
+            else k_main<float, FT><<<grid, BLOCK, rec_lds, s>>>(a, fa);
         });
         const bool scan2 = h->pre32 != nullptr;
         if (fa.do_count && has_refr && !inkernel) {

@@ -45,6 +45,10 @@ struct FusedArgs {
     // into exclusive prefixes once, instead of every workgroup re-reducing all of them.
     const uint32_t *pre32; // [n_clips][nkeys_cap][ngp] or nullptr
     const uint32_t *tot32; // [n_clips][nkeys_cap]
+    // Event records (dynamic LDS, capw 4-byte records per wave; 0: off): in the first 64-key chunk every passing
+    // (lane, iteration) leaves a record and the wave then writes its events one per lane, instead of iteration by
+    // iteration with the shuffle arithmetic running for the few lanes that fire.
+    int capw;
 };
 
 #define V2E_STAMP(i) do { if (fa.dbg && tid == 0) fa.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
@@ -212,6 +216,7 @@ __device__ __forceinline__ bool clip_barrier(unsigned *ctr, unsigned target)
 template <typename R, typename FT>
 __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
 {
+    extern __shared__ uint32_t s_dynrec[]; // [BLOCK / WAVE][fa.capw] event records
     __shared__ uint32_t s_T[WAVE], s_P[WAVE]; // per key of the current 64-key chunk: total / prefix over workgroups
     __shared__ uint32_t s_wcnt[BLOCK / WAVE][WAVE];
     __shared__ int s_red[BLOCK / WAVE];
@@ -359,6 +364,8 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
             const int nk = 2 + 2 * M;
             uint32_t carry = 0, sum_on = 0, sum_off = 0;
             uint32_t son_tot = 0, soff_tot = 0, son_off = 0, soff_off = 0;
+            uint32_t nrec = 0; // event records of this wave (first chunk)
+            uint32_t *rec_w = s_dynrec + (size_t)wave * fa.capw;
             int fcount = 0;
             bool dropped = false, alive = true;
             V2E_STAMP(11);
@@ -398,6 +405,14 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                     const int kl = 2 + 2 * i - kb;
                     if (lane == kl) mine = (uint32_t)__popcll(bo);
                     if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+                    if (kb == 0 && fa.capw > 0) {
+                        if (pass) {
+                            const uint32_t rank = (uint32_t)__popcll((neg ? bf : bo) & lt);
+                            const uint32_t pos = nrec + (uint32_t)__popcll((bo | bf) & lt);
+                            if (pos < (uint32_t)fa.capw) rec_w[pos] = (uint32_t)lane | ((uint32_t)i << 6) | ((neg ? 1u : 0u) << 11) | (rank << 12);
+                        }
+                        nrec += (uint32_t)__popcll(bo | bf);
+                    }
                 }
                 if (kb == 0) {
                     const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
@@ -432,7 +447,35 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
                     son_off = lane_value(off_k, 0); soff_off = lane_value(off_k, 1);
                 }
                 // pass 2: write this chunk's events
-                if (__ballot(mymask != 0u)) {
+                if (kb == 0 && fa.capw > 0 && nrec <= (uint32_t)fa.capw) { // one event per lane from the wave's records
+                    for (uint32_t e0 = 0; e0 < nrec; e0 += WAVE) {
+                        const bool has = e0 + lane < nrec;
+                        const uint32_t r = has ? rec_w[e0 + lane] : 0u;
+                        const int src = (int)(r & 63u), i = (int)((r >> 6) & 31u);
+                        const bool eneg = (r >> 11) & 1u;
+                        const uint32_t rank = r >> 12;
+                        const int kl = 2 + 2 * i;
+                        const uint32_t it_base = (uint32_t)__shfl((int)kbase_k, kl);
+                        const uint32_t tot_on = (uint32_t)__shfl((int)T_k, kl);
+                        const uint32_t off = (uint32_t)__shfl((int)off_k, kl + (eneg ? 1 : 0));
+                        const float ex = __shfl(fx, src), ey = __shfl(fy, src);
+                        uint32_t cidx = (eneg ? tot_on : 0u) + off + rank;
+                        if (shuf) {
+                            v2e_perm_t pm;
+                            pm.k[0] = (uint32_t)__shfl((int)pk[0], i); pm.k[1] = (uint32_t)__shfl((int)pk[1], i);
+                            pm.k[2] = (uint32_t)__shfl((int)pk[2], i); pm.k[3] = (uint32_t)__shfl((int)pk[3], i);
+                            pm.sh = (uint32_t)__shfl((int)ps_sh, i); pm.a = (uint32_t)__shfl((int)ps_a, i);
+                            pm.amask = (uint32_t)__shfl((int)ps_amask, i); pm.n = (uint32_t)__shfl((int)ps_n, i);
+                            pm.rmask = (1u << pm.sh) - 1u;
+                            if (has) cidx = v2e_perm_apply(&pm, cidx);
+                        }
+                        if (has) {
+                            const unsigned long long row = ev0 + it_base + cidx;
+                            if (row < fa.cap) ev[row] = make_float4(tg(i), ex, ey, eneg ? -1.0f : 1.0f);
+                            else dropped = true;
+                        }
+                    }
+                } else if (__ballot(mymask != 0u)) {
                     uint32_t wm = wave_or_u32(mymask); // iterations in which some lane of the wave fires
                     while (wm) {
                         const int ii = __ffs(wm) - 1;
