@@ -110,6 +110,37 @@ def test_step_chain_pipeline_ring_wraps(name, pipe_e, monkeypatch):
             assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
 
 
+@pytest.mark.parametrize("refr", [0.0005, 0.002])
+def test_pipelines_agree_on_benchmark_clip(refr, oracle_lib):
+    """BASELINE configs[1] at full size (346x260, 300 frames, dt = 1/300 s): every device-resident pipeline gives the
+    same event stream, records and final state.  refr = 0.5 ms: the two-frame chain mis-speculates on ~1 % of the
+    frames; 2 ms: on most of them (in-kernel repair path on every launch)."""
+    from v2e_amd import EventEmulator
+    from v2e_amd.synth import sincos_gradient_frames
+    F = 300
+    frames = sincos_gradient_frames(F + 1, 260, 346, seed=1)
+    times = [i / 300 for i in range(F + 1)]
+    kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak_rate_hz=.01, shot_noise_rate_hz=.001,
+              refractory_period_s=refr)
+    ref = None
+    for use_graph in (1, 129, 33, 17):  # two-frame chain, one-frame chain, k_main per frame, 4-kernel
+        emu = EventEmulator(device="cuda", seed=1, rng_mode="philox", **kw)
+        ev, counts = emu.generate_events_batch(frames, times, use_graph=use_graph)
+        st = (sha(ev), list(counts), sha(emu.base_log_frame.cpu().numpy()), sha(emu.timestamp_mem.cpu().numpy()),
+              sha(emu.lp_log_frame.cpu().numpy()))
+        if ref is None:
+            ref = st
+            assert counts.sum() > 5_000_000
+        else:
+            assert st == ref, "pipeline use_graph=%d differs" % use_graph
+    # ... and it is the CPU oracle's stream, event for event (about 10 M events)
+    ora = oracle_lib.OracleEmulator(seed=1, rng_mode="philox", **kw)
+    oev = [ora.generate_events(f, t) for f, t in zip(frames, times)]
+    assert ref[1] == [0 if e is None else len(e) for e in oev]
+    assert ref[0] == sha(np.concatenate([e for e in oev if e is not None]))
+    assert ref[2] == sha(ora.base_log_frame)
+
+
 def test_split_clip_equals_whole_clip():
     """Two consecutive device-resident runs == one run (state and frame counter carry over)."""
     fx = PhiloxFixture("philox_refractory_346x260")
