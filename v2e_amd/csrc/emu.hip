@@ -1217,8 +1217,10 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
             if (ea.ftab) {
                 k_frame_multi<<<dim3(1, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
                 k_emit2_multi<<<ge, BLOCK, REC_LDS, h->side>>>(a, ea);
+                k_emit_big<<<dim3(64, h->n_clips), BLOCK, 0, h->side>>>(a, ea); // frames without a table (M > 31), if any
+            } else {
+                k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
             }
-            k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea); // frames without a table (M > 31); exits at once otherwise
             if (mark(ev_side, h->side)) return V2E_EHIP;
             V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
         return 0;

@@ -647,14 +647,15 @@ __global__ __launch_bounds__(BLOCK) void k_scan2_multi(KArgs a, EmitArgs ea)
                ea.tot32 + (size_t)blockIdx.z * ea.n_clips * a.nkeys_cap);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_emit_multi(KArgs a, EmitArgs ea)
+// the iteration-by-iteration event writer for workgroup g of batch frame z (any M, any grid size)
+__device__ __forceinline__ void emit_frame_iterwise(const KArgs &a, const EmitArgs &ea, const int g, const int z)
 {
     __shared__ uint32_t s_T[WAVE], s_P[WAVE]; // per key of the current 64-key chunk: total / prefix over workgroups
     __shared__ uint32_t s_wcnt[BLOCK / WAVE][WAVE];
     __shared__ int s_red[BLOCK / WAVE];
     __shared__ unsigned long long s_off[BLOCK / WAVE];
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int clip = blockIdx.y, fe = ea.f0 + z, slot = fe % ea.D;
     const int p = g * BLOCK + tid;
     const bool valid = p < a.npx;
     const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
@@ -877,6 +878,24 @@ __global__ __launch_bounds__(BLOCK) void k_emit_multi(KArgs a, EmitArgs ea)
         rec[clip].n_off = sum_off + (a.do_shot ? soff_tot : 0u);
         rec[clip].ev_offset = ev0;
         if (z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_emit_multi(KArgs a, EmitArgs ea)
+{
+    emit_frame_iterwise(a, ea, (int)blockIdx.x, (int)blockIdx.z);
+}
+
+// With per-frame tables only frames with M > 31 are left for the iteration-wise writer: a small grid walks them
+// (none, on almost every batch) instead of a full grid launching just to find that out.
+__global__ __launch_bounds__(BLOCK) void k_emit_big(KArgs a, EmitArgs ea)
+{
+    for (int z = 0; z < ea.nE; ++z) {
+        if (!ea.ftab[(size_t)z * ea.n_clips + blockIdx.y].big) continue;
+        for (int g = (int)blockIdx.x; g < ea.ngroups; g += (int)gridDim.x) {
+            emit_frame_iterwise(a, ea, g, z);
+            __syncthreads();
+        }
     }
 }
 
