@@ -26,6 +26,9 @@
 // frames per emission launch E (v2e_emu::pipe_E, chosen at create time from the ring's footprint) and
 // ring slots D = 2E: the emission of batch b overlaps the steps of batch b+1
 constexpr int PIPE_E_MAX = 16;
+#ifndef WT_EVENTS
+#define WT_EVENTS 1
+#endif
 
 // The run's frame-index base lives in device memory (a captured graph is replayed with a new base), and the
 // Philox draw needs it first thing.  As a compiler-scheduled scalar load it ends up a dependent round trip in
@@ -985,6 +988,21 @@ __global__ __launch_bounds__(BLOCK) void k_frame_multi(KArgs a, EmitArgs ea)
 // of writing events iteration by iteration -- a wave-uniform loop whose shuffle arithmetic runs for the few
 // lanes that fire -- every passing (lane, iteration) leaves a 4-byte record in LDS, and the wave then walks its
 // own records with all lanes busy: one event per lane, parameters gathered by lane index (ds_bpermute).
+// Event rows written through to memory (system-scope buffer store): they are final output that nothing on the
+// device reads back, and as dirty L2 lines they would be written back by the release at the end of every chain
+// launch that happens to run meanwhile.
+typedef float v2e_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_event_wt(float4 *ev_clip, unsigned long long row, float t, float x, float y, float pol)
+{
+    if (WT_EVENTS && row < 0x7000000ull) { // byte offset below 2^31
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)ev_clip, 0, 0x7fffffff, 0x00020000);
+        const v2e_f4 v = {t, x, y, pol};
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(row * 16ull), 0, 17); // sc0 sc1
+    } else {
+        ev_clip[row] = make_float4(t, x, y, pol);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_emit2_multi(KArgs a, EmitArgs ea)
 {
     extern __shared__ uint32_t s_rec[]; // [BLOCK / WAVE][capw]
@@ -1088,7 +1106,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit2_multi(KArgs a, EmitArgs ea)
         }
         if (has) {
             const unsigned long long row = ev0 + it_base + cidx;
-            if (row < ea.cap) ev[row] = make_float4(tg(i), ex, ey, eneg ? -1.0f : 1.0f);
+            if (row < ea.cap) store_event_wt(ev, row, tg(i), ex, ey, eneg ? -1.0f : 1.0f);
             else dropped = true;
         }
     }
@@ -1102,12 +1120,12 @@ __global__ __launch_bounds__(BLOCK) void k_emit2_multi(KArgs a, EmitArgs ea)
             const float tl = tg(n - 1);
             if (s_on) {
                 const unsigned long long row = ev0 + carry + son_off + (uint32_t)__popcll(so & lt);
-                if (row < ea.cap) ev[row] = make_float4(tl, fx, fy, 1.0f);
+                if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, 1.0f);
                 else dropped = true;
             }
             if (s_off) {
                 const unsigned long long row = ev0 + carry + son_tot + soff_off + (uint32_t)__popcll(sf & lt);
-                if (row < ea.cap) ev[row] = make_float4(tl, fx, fy, -1.0f);
+                if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, -1.0f);
                 else dropped = true;
             }
         }
