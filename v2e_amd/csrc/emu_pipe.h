@@ -522,8 +522,8 @@ __global__ __launch_bounds__(BLOCK) void k_step2(KArgs a, Step2Args sa)
             R lp2 = (R)0;
             if (valid) {
                 b = ((const R *)sa.bck_e2)[sp];
-                lp2 = ((const R *)sa.lpn_e2)[sp];
                 cw2 = sa.cnt_e2[sp];
+                if (cw2 & (CNT_SHOT_ON | CNT_SHOT_OFF)) lp2 = ((const R *)sa.lpn_e2)[sp]; // only shot pixels reset to lp
             }
             finalize_px<R>(a, cw2, true, tg2, valid, sp, thp, thn, lp2, sa.tsold_e2, b, tsm, b_dirty);
             int m = 0;
@@ -573,9 +573,9 @@ __global__ __launch_bounds__(BLOCK) void k_step2(KArgs a, Step2Args sa)
             sa.cnt_c0[sp] = cw;
             lp = lpn;
             if (has_c1) {
-                if (a.has_refr) { // checkpoint for the next launch's validation
+                if (a.has_refr) { // checkpoint for the next launch's validation (lp only where a shot event resets base to it)
                     ((R *)sa.bck_c0)[sp] = b;
-                    ((R *)sa.lpn_c0)[sp] = lpn;
+                    if (cw & (CNT_SHOT_ON | CNT_SHOT_OFF)) ((R *)sa.lpn_c0)[sp] = lpn;
                 }
                 const TsGen none(0.f, 0.f, 0.f, 1);
                 finalize_px<R>(a, cw, false, none, valid, sp, thp, thn, lpn, nullptr, b, tsm, b_dirty); // speculation: rule off
