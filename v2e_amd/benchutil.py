@@ -25,10 +25,10 @@ def unet_flops(cin, cout, h, w):
     return 2 * macs
 
 
-def slomo_bench(device, B=4, U=10, H=256, W=320, iters=5):
+def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5):
     """Interpolated frames/s of slomo.py:338-433 at 320x256 (346x260 source), 10x slowdown.
 
-    One iteration = one batch of B source pairs -> U*B interpolated frames: flow UNet on B
+    One iteration = one batch of B source pairs (B = 8, the v2e CLI default --batch_size) -> U*B interpolated frames: flow UNet on B
     samples, prep, interpolation UNet on U*B samples, fuse.  Inputs resident in HBM.
     """
     from .slomo import SloMoEngine
