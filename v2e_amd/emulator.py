@@ -61,6 +61,22 @@ class _TorchTape:
         return torch.exp(math.log(10) * cov * randn)  # emulator.py:504-505
 
 
+class _OneHostThread:
+    """Tape mode issues a handful of small torch CPU ops per frame (randn / rand of one frame, a randperm per
+    iteration).  Their values do not depend on the intra-op thread count, but on a many-core host fanning each of
+    them out over the OpenMP pool costs milliseconds: 250 -> 1 170 frames/s on the MI355X box with one thread."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n != 1:
+            torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        if self.n != 1:
+            torch.set_num_threads(self.n)
+        return False
+
+
 def _as_f32_tensor(a):
     return a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
 
@@ -349,6 +365,12 @@ class EventEmulator(object):
         new_frame: np.ndarray or torch tensor [height, width]; t_frame: seconds.
         Returns np.ndarray [N,4] float32 rows [t, x, y, p(+1/-1)] or None.
         """
+        if self.rng_mode == "tape":
+            with _OneHostThread():
+                return self._generate_events(new_frame, t_frame)
+        return self._generate_events(new_frame, t_frame)
+
+    def _generate_events(self, new_frame, t_frame):
         if self.frame_h5_dataset is not None:
             self.frame_h5_dataset[self.frame_counter] = np.asarray(new_frame).astype(np.uint8)
         self.frame_counter += 1
@@ -415,26 +437,34 @@ class EventEmulator(object):
         events = None
         ev = eng.event_buffer(max(n_events, 1))
         eng.emit(P, fidx, ev, ts_dev, ev_offset0=[0])
-        if tape and n_signal > 0:
+        if tape and n_signal > 0 and any(q is not None for q in perms):
+            # events_curr_iter[idx] for every iteration (emulator.py:868-869) as ONE gather: the per-iteration
+            # permutations, offset to absolute rows, in one pinned upload and one launch
             if eng._events_tmp is None or eng._events_tmp.shape != ev.shape:
                 eng._events_tmp = torch.empty_like(ev)
             out = eng._events_tmp
+            idx_all = np.empty(n_signal, dtype=np.int32)
             row = 0
-            any_perm = False
             for i in range(M):
                 n_i = int(itc[i, 0]) + int(itc[i, 1])
                 if n_i > 0:
                     idx = perms[i]
-                    idx = idx if torch.is_tensor(idx) else torch.from_numpy(np.ascontiguousarray(idx))
-                    idx_dev = idx.to(torch.int32).to(dev)
-                    eng.permute(ev, out, idx_dev, row, n_i)  # events_curr_iter[idx], emulator.py:869
-                    any_perm = True
+                    idx = idx.numpy() if torch.is_tensor(idx) else np.asarray(idx)
+                    np.add(idx, row, out=idx_all[row:row + n_i], casting="unsafe")
                 row += n_i
-            if any_perm:
-                if n_events > n_signal:
-                    out[0, n_signal:n_events] = ev[0, n_signal:n_events]
-                eng._events, eng._events_tmp = out, ev
-                ev = out
+            pin = getattr(self, "_idx_pin", None)
+            if pin is None or pin.numel() < n_signal:
+                cap_n = max(n_signal, 1 << 16) * 2
+                self._idx_pin = pin = torch.empty(cap_n, dtype=torch.int32).pin_memory()
+                self._idx_dev = torch.empty(cap_n, dtype=torch.int32, device=dev)
+            pin[:n_signal].copy_(torch.from_numpy(idx_all))
+            idx_dev = self._idx_dev[:n_signal]
+            idx_dev.copy_(pin[:n_signal], non_blocking=True)
+            eng.permute(ev, out, idx_dev, 0, n_signal)
+            if n_events > n_signal:
+                out[0, n_signal:n_events] = ev[0, n_signal:n_events]
+            eng._events, eng._events_tmp = out, ev
+            ev = out
         if n_events > 0:
             events = ev[0, :n_events].cpu().numpy()
 
