@@ -141,6 +141,30 @@ def test_pipelines_agree_on_benchmark_clip(refr, oracle_lib):
     assert ref[2] == sha(ora.base_log_frame)
 
 
+@pytest.mark.parametrize("chunk", [1, 2, 3, 5])
+def test_clip_in_small_runs_equals_whole_clip(chunk):
+    """Runs of 1, 2, 3, 5 frames (odd and even: the two-frame chain's last launch differs) chained through the
+    carried state == one run."""
+    fx = PhiloxFixture("philox_refractory_346x260")
+    emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+    evs, cnts = [], []
+    for lo in range(0, len(fx.frames), chunk):
+        ev, c = emu.generate_events_batch(fx.frames[lo:lo + chunk], fx.times[lo:lo + chunk])
+        if ev is not None:
+            evs.append(ev)
+        cnts += list(c)
+    assert cnts == list(fx.n_events)
+    ev = np.concatenate(evs)
+    row = 0
+    for k, n in enumerate(cnts):
+        if n:
+            assert sha(ev[row:row + n]) == fx.ev_sha[k], "frame %d event digest differs" % k
+        row += n
+    st = _state(emu)
+    assert sha(st["base_log_frame"]) == fx.base_sha
+    assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
+
+
 def test_split_clip_equals_whole_clip():
     """Two consecutive device-resident runs == one run (state and frame counter carry over)."""
     fx = PhiloxFixture("philox_refractory_346x260")

@@ -620,6 +620,24 @@ __global__ __launch_bounds__(BLOCK) void k_permute(const float4 *__restrict__ in
 
 } // namespace
 
+// Zero-fill as a KERNEL node.  hipMemsetAsync captured into a hipGraph turned out unreliable for small buffers on
+// this runtime (ROCm 7.0 / HIP 7.0.5): from the third launch of the same graph exec a 16..160-byte memset node wrote
+// the high half of an address instead of zeros (frame-record flags, the emission offsets, the rendezvous counters).
+namespace {
+__global__ void k_zero_words(uint32_t *p, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+} // namespace
+static inline hipError_t zero_async(void *p, size_t bytes, hipStream_t s)
+{
+    const size_t n = (bytes + 3) / 4; // all callers pass multiples of 4
+    if (n == 0) return hipSuccess;
+    k_zero_words<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((uint32_t *)p, n);
+    return hipGetLastError();
+}
+
 // =================================================================== host side
 struct v2e_emu {
     int H, W, n_clips, max_iters, device;
@@ -948,7 +966,7 @@ int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dt
     if (rc) return rc;
     const int slot = frame_idx % RING;
     v2e_frame_rec *rec = h->rec_ring + (size_t)slot * h->n_clips;
-    V2E_HIP(hipMemsetAsync(rec, 0, sizeof(v2e_frame_rec) * h->n_clips, s));
+    V2E_HIP(zero_async(rec, sizeof(v2e_frame_rec) * h->n_clips, s));
     KArgs a = make_kargs(h, p);
     rc = launch_count(h, a, p->f64_state, frame, dtype, h->ctl_ring + (size_t)slot * h->n_clips, nullptr, frame_idx,
                       leak_randn, shot_rand, rec, s);
@@ -1072,7 +1090,7 @@ static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, cons
 {
 #define V2E_MARK(i) do { if (evs) V2E_HIP(hipEventRecord(evs[(i)], s)); } while (0)
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
-    V2E_HIP(hipMemsetAsync(recs, 0, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
+    V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
     dim3 gridw(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), h->n_clips);
     for (int f = 0; f < n_frames; ++f) {
         const void *fr = (const char *)frames + (size_t)f * h->n_clips * h->npx * esz;
@@ -1102,13 +1120,13 @@ static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
                              int *n_marks = nullptr)
 {
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
-    V2E_HIP(hipMemsetAsync(recs, 0, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
+    V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
     dim3 grid(h->ngroups, h->n_clips);
     int mark = 0;
     const bool has_refr = p->refractory_period_s > 0;
     const bool inkernel = has_refr && !getenv("V2E_AMD_NO_INKERNEL_SYNC") &&
                           (long long)h->ngroups * h->n_clips <= (long long)h->max_resident_blocks;
-    if (inkernel) V2E_HIP(hipMemsetAsync(h->run_bar, 0, sizeof(unsigned) * (size_t)(n_frames + 1) * h->n_clips, s));
+    if (inkernel) V2E_HIP(zero_async(h->run_bar, sizeof(unsigned) * (size_t)(n_frames + 1) * h->n_clips, s));
     for (int f = 0; f <= n_frames; ++f) {
         FusedArgs fa;
         memset(&fa, 0, sizeof(fa));
@@ -1167,9 +1185,9 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
     const bool has_refr = p->refractory_period_s > 0;
     V2E_REQUIRE(!has_refr || h->pipe_tsold, "pipe_tsold not allocated");
-    V2E_HIP(hipMemsetAsync(recs, 0, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
-    V2E_HIP(hipMemsetAsync(h->pipe_off, 0, sizeof(unsigned long long) * 2 * h->n_clips, s));
-    if (K == 2) V2E_HIP(hipMemsetAsync(h->run_bar, 0, sizeof(unsigned) * (size_t)((n_frames + 1) / 2 + 1) * h->n_clips, s));
+    V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
+    V2E_HIP(zero_async(h->pipe_off, sizeof(unsigned long long) * 2 * h->n_clips, s));
+    if (K == 2) V2E_HIP(zero_async(h->run_bar, sizeof(unsigned) * (size_t)((n_frames + 1) / 2 + 1) * h->n_clips, s));
     const int PIPE_E = h->pipe_E, PIPE_D = h->pipe_D;
     const size_t st_px = (size_t)h->n_clips * h->npx_pad, st_g = (size_t)h->n_clips * h->ngroups;
     auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t st) -> int {
