@@ -73,6 +73,9 @@ typedef struct v2e_emu_params {
     double shot_noise_inten_factor; /* emulator.py:210, 0.25 */
     float pos_pre_scalar, neg_pre_scalar; /* nominal/thres when scalar_thres (host torch.div) */
     uint64_t seed;          /* philox key */
+    int32_t log_input;      /* hdr=True (emulator.py:304, 666): frames are already log intensity, no lin_log;
+                               the state is float64 even without a cutoff (f64_state must be 1) */
+    int32_t reserved0;
 } v2e_emu_params;
 
 /* Per-(frame, clip) result record, written on device. */

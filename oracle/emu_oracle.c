@@ -138,12 +138,13 @@ EXPORT int v2e_oracle_init_state(const v2e_emu_params *P, int H, int W, const do
     float ln10cov = (float)(log(10.0) * P->noise_rate_cov_decades);
     for (int64_t p = 0; p < npx; ++p) {
         double x = frame[p];
-        float L = lin_log(x);
+        double Ld = P->log_input ? x : (double)lin_log(x); /* emulator.py:666 */
+        float L = (float)Ld;
         if (P->f64_state) {
             double inten01 = (x + 20.0) / 275.0;
             double eps = inten01 * dt_over_tau;
             if (eps > 1.0) eps = 1.0;
-            double lp = (1.0 - eps) * (double)L + eps * (double)L; /* lp initialised to L */
+            double lp = (1.0 - eps) * Ld + eps * Ld; /* lp initialised to L */
             ((double *)lp_v)[p] = lp;
             ((double *)base_v)[p] = lp;
         } else {
@@ -208,7 +209,8 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
     int32_t M = 0;
     for (int64_t p = 0; p < npx; ++p) {
         double x = frame[p];
-        float L = lin_log(x);
+        double Ld = P->log_input ? x : (double)lin_log(x); /* emulator.py:666 */
+        float L = (float)Ld;
         double inten01 = use_inten ? (x + 20.0) / 275.0 : 0.0;
         float r = 0.0f, u = 0.0f;
         if (P->rng_mode == V2E_RNG_PHILOX) {
@@ -228,7 +230,9 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
             double *lp = (double *)lp_v, *base = (double *)base_v;
             double eps = inten01 * dt_over_tau;
             if (eps > 1.0) eps = 1.0;
-            double lpn = (1.0 - eps) * lp[p] + eps * (double)L;
+            /* low_pass_filter returns log_new_frame itself when cutoff_hz <= 0 (emulator_utils.py:76-78): float64 state
+             * without a cutoff only happens with log-encoded input */
+            double lpn = (P->cutoff_hz > 0) ? (1.0 - eps) * lp[p] + eps * Ld : Ld;
             lp[p] = lpn;
             double b = base[p];
             if (do_leak) b = b - (double)delta_leak;

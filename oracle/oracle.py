@@ -151,7 +151,8 @@ class OracleEmulator:
     def __init__(self, pos_thres=0.2, neg_thres=0.2, sigma_thres=0.03, cutoff_hz=0.0,
                  leak_rate_hz=0.1, refractory_period_s=0.0, shot_noise_rate_hz=0.0,
                  leak_jitter_fraction=0.1, noise_rate_cov_decades=0.1, seed=0,
-                 rng_mode="tape", tape=None, shuffle=True, clip=0):
+                 rng_mode="tape", tape=None, shuffle=True, clip=0, hdr=False):
+        self.log_input = bool(hdr)  # emulator.py:304
         self.pos_thres = pos_thres
         self.neg_thres = neg_thres
         self.pos_thres_nominal = pos_thres
@@ -208,7 +209,8 @@ class OracleEmulator:
 
     def _params(self):
         P = EmuParams()
-        P.f64_state = 1 if self.cutoff_hz > 0 else 0
+        P.f64_state = 1 if (self.cutoff_hz > 0 or self.log_input) else 0
+        P.log_input = 1 if self.log_input else 0
         P.scalar_thres = 0 if self.sigma_thres > 0 else 1
         P.rng_mode = RNG_PHILOX if self.rng_mode == "philox" else RNG_TAPE
         P.shuffle = 1 if self.shuffle else 0

@@ -8,9 +8,10 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TAPE_FIXTURES = ["tape_defaults_40x48", "tape_noisy_40x48", "tape_clean_40x48", "tape_f32state_40x48",
-                 "tape_scalarthres_40x48", "tape_refractory_float_33x37", "tape_moving_dot_64x64_40fr"]
+                 "tape_scalarthres_40x48", "tape_refractory_float_33x37", "tape_moving_dot_64x64_40fr",
+                 "tape_hdr_40x48", "tape_hdr_nocutoff_40x48"]  # hdr: tests/golden/make_golden_hdr.py
 PHILOX_FIXTURES = ["philox_moving_dot_64x64", "philox_defaults_346x260", "philox_noisy_346x260",
-                   "philox_refractory_346x260", "philox_noisy_1280x720"]
+                   "philox_refractory_346x260", "philox_noisy_1280x720", "philox_hdr_97x131"]
 
 
 def sha(a):

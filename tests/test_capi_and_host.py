@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from v2e_amd._capi import ConvDesc, EmuParams, FrameRec
     assert C.sizeof(FrameRec) == 32
-    assert C.sizeof(EmuParams) == 16 + 12 * 8 + 8 + 8
+    assert C.sizeof(EmuParams) == 16 + 12 * 8 + 8 + 8 + 8  # ... + log_input, reserved0
     assert C.sizeof(ConvDesc) == 32 or C.sizeof(ConvDesc) == 28
 
 
@@ -63,7 +63,7 @@ def test_emulator_errors_like_reference():
     with pytest.raises(ValueError):  # emulator.py:650-653
         e.generate_events(np.zeros((4, 4), np.uint8), 0.5)
     for kw in (dict(photoreceptor_noise=True, shot_noise_rate_hz=1.0, cutoff_hz=10), dict(cs_lambda_pixels=2.0),
-               dict(scidvs=True), dict(hdr=True), dict(show_dvs_model_state=["all"]),
+               dict(scidvs=True), dict(show_dvs_model_state=["all"]),
                dict(record_single_pixel_states=(1, 2))):
         with pytest.raises(NotImplementedError):
             EventEmulator(**kw)

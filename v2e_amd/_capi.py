@@ -36,6 +36,8 @@ class EmuParams(C.Structure):
         ("pos_pre_scalar", C.c_float),
         ("neg_pre_scalar", C.c_float),
         ("seed", C.c_uint64),
+        ("log_input", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

@@ -81,7 +81,7 @@ struct KArgs {
     int W, npx, nwaves, nkeys_cap, max_iters;
     long long npx_pad;
     int scalar_thres, rng_mode, shuffle;
-    int do_leak, do_shot, use_inten, has_cutoff, has_refr;
+    int do_leak, do_shot, use_inten, has_cutoff, has_refr, log_input;
     double cutoff_two_pi; // math.pi*2*cutoff_hz
     double pos_div, neg_div;
     float pos_nom_f, neg_nom_f, pos_pre_scalar, neg_pre_scalar;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BLOCK) void k_init(KArgs a, const FT *__restrict__ 
     const size_t sp = (size_t)clip * a.npx_pad + p;
     const size_t fp = (size_t)clip * a.npx + p;
     double x = (double)frame[fp];
-    float L = lin_log(x);
+    const double L = a.log_input ? x : (double)lin_log(x); // emulator.py:666
     R lp;
     if (a.has_cutoff) {
         double delta_time = t_frame - 0.0;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
         const size_t fp = (size_t)clip * a.npx + p;
         const double delta_time = c.t_frame - c.t_prev;
         double x = (double)frame[fp];
-        float L = lin_log(x);
+        const double L = a.log_input ? x : (double)lin_log(x); // emulator.py:666
         double inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
         float r = 0.f, u = 0.f;
         const bool shot_here = a.do_shot && (a.rng_mode == V2E_RNG_PHILOX || shot_tape != nullptr);
@@ -713,6 +713,7 @@ static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
     a.do_leak = p->leak_rate_hz > 0; a.do_shot = p->shot_noise_rate_hz > 0;
     a.has_cutoff = p->cutoff_hz > 0; a.has_refr = p->refractory_period_s > 0;
     a.use_inten = a.has_cutoff || a.do_shot;
+    a.log_input = p->log_input != 0;
     a.cutoff_two_pi = M_PI * 2 * p->cutoff_hz;
     a.pos_div = p->pos_thres_scalar; a.neg_div = p->neg_thres_scalar;
     a.pos_nom_f = (float)p->pos_thres_nominal; a.neg_nom_f = (float)p->neg_thres_nominal;
@@ -736,7 +737,7 @@ static int check_params(const v2e_emu *h, const v2e_emu_params *p)
 {
     V2E_REQUIRE(h && p, "null handle/params");
     V2E_REQUIRE(h->lp && h->base && h->pos_thres && h->neg_thres, "state not bound (v2e_emu_bind_state)");
-    V2E_REQUIRE((p->f64_state != 0) == (p->cutoff_hz > 0), "f64_state must equal (cutoff_hz > 0)");
+    V2E_REQUIRE((p->f64_state != 0) == (p->cutoff_hz > 0 || p->log_input != 0), "f64_state must equal (cutoff_hz > 0 || log_input)");
     V2E_REQUIRE(!(p->leak_rate_hz > 0) || h->noise_rate, "leak enabled but noise_rate plane not bound");
     V2E_REQUIRE(!(p->refractory_period_s > 0) || h->ts_mem, "refractory enabled but ts_mem plane not bound");
     return 0;

@@ -568,14 +568,14 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
         int m = 0;
         uint32_t cw = 0;
         if (valid) {
-            float L;
+            double L; // lin-log of the frame, or the frame itself when it is log-encoded already (emulator.py:666)
             double inten01;
             if (U8) {
-                L = s_lutL[(int)px];
+                L = a.log_input ? (double)px : (double)s_lutL[(int)px];
                 inten01 = s_lutI[(int)px];
             } else {
                 const double x = (double)px;
-                L = lin_log(x);
+                L = a.log_input ? x : (double)lin_log(x);
                 inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
             }
             const float r = rng_r, u = rng_u;

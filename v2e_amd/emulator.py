@@ -20,7 +20,8 @@ Random numbers come in two modes, selected with the extra key
 
 The reference's research-only pixel variants are not part of the hot path and raise
 NotImplementedError here: photoreceptor_noise, CSDVS (cs_lambda_pixels), SCIDVS,
-hdr, show_dvs_model_state, record_single_pixel_states.
+show_dvs_model_state, record_single_pixel_states.  `hdr=True` (log-encoded input, emulator.py:304,
+666) is supported.
 """
 import atexit
 import logging
@@ -138,7 +139,6 @@ class EventEmulator(object):
         if photoreceptor_noise: unsupported.append("photoreceptor_noise")
         if cs_lambda_pixels is not None: unsupported.append("cs_lambda_pixels (CSDVS)")
         if scidvs: unsupported.append("scidvs")
-        if hdr: unsupported.append("hdr")
         if show_dvs_model_state is not None: unsupported.append("show_dvs_model_state")
         if record_single_pixel_states is not None: unsupported.append("record_single_pixel_states")
         if unsupported:
@@ -171,7 +171,7 @@ class EventEmulator(object):
         self.show_dvs_model_state = None
         self.save_dvs_model_state = save_dvs_model_state
         self.label_signal_noise = label_signal_noise
-        self.log_input = False
+        self.log_input = bool(hdr)  # emulator.py:304: frames are log-encoded already
         self.scidvs = False
         self.csdvs_enabled = False
         self.seed = seed
@@ -294,7 +294,8 @@ class EventEmulator(object):
     def _params(self) -> EmuParams:
         """Snapshot the (mutable) attributes into the C struct, every call."""
         P = EmuParams()
-        P.f64_state = 1 if self.cutoff_hz > 0 else 0
+        P.f64_state = 1 if (self.cutoff_hz > 0 or self.log_input) else 0
+        P.log_input = 1 if self.log_input else 0
         P.scalar_thres = 1 if self._thres_scalar is not None and self._thres_is_scalar else 0
         P.rng_mode = RNG_PHILOX if self.rng_mode == "philox" else RNG_TAPE
         P.shuffle = 1 if self.shuffle else 0
@@ -334,7 +335,7 @@ class EventEmulator(object):
             self.pos_thres, self.neg_thres = prev
         self._thres_scalar = (float(self.pos_thres), float(self.neg_thres))
         self._thres_is_scalar = not (self.sigma_thres > 0)
-        eng.alloc_state(self.cutoff_hz > 0)
+        eng.alloc_state(self.cutoff_hz > 0 or self.log_input)
         P = self._params()
         tp = tn = nr = None
         if self.rng_mode == "tape":
@@ -394,7 +395,7 @@ class EventEmulator(object):
         P = self._params()
         if bool(P.f64_state) != eng.f64_state:
             raise ValueError("cutoff_hz changed sign after the first frame: the state dtype "
-                             "(float64 iff cutoff_hz > 0) is fixed by the first frame")
+                             "(float64 iff cutoff_hz > 0 or hdr) is fixed by the first frame")
         tape = self.rng_mode == "tape"
         dev = eng.device
 
