@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""dev tool: fused vs unfused pipeline at 1280x720 noisy."""
+"""dev tool: k_main per frame (default at this size) vs k_step chain vs unfused pipeline at 1280x720 noisy."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ from v2e_amd import EventEmulator
 dev = torch.device("cuda")
 H, W, F = 720, 1280, 40
 fr = B.gen_frames_device(F + 1, 4, dev, h=H, w=W)
-for label, ug in (("fused graph", 1), ("legacy graph", 17)):
+for label, ug in (("k_main graph", 33), ("k_step chain graph", 65), ("legacy graph", 17)):
     emu = EventEmulator(device=dev, seed=4, rng_mode="philox", **B.DEFAULT_KW)
     emu.set_dvs_params("noisy")
     dt = 1 / 600.0
