@@ -1,10 +1,8 @@
 #!/usr/bin/env python
-"""dev tool: frames-per-emission-launch sweep of the decoupled pipeline, hipGraph vs plain launches."""
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from emu_ab import run
-from bench import DEFAULT_KW
-for E in (4, 8, 16, 32):
-    os.environ["V2E_AMD_PIPE_E"] = str(E)
-    run("E=%d graph" % E, dict(DEFAULT_KW), 1)
-    run("E=%d plain launches" % E, dict(DEFAULT_KW), 0)
+"""dev tool: frames-per-emission-launch sweep of the default device-resident pipeline (hipGraph)."""
+import sys, os, subprocess
+here = os.path.dirname(os.path.abspath(__file__))
+code = "import sys; sys.path.insert(0, %r); from emu_ab import run; from bench import DEFAULT_KW; run(%%r, dict(DEFAULT_KW), 1, steps=20)" % here
+for E in (8, 16, 24, 32):
+    e = dict(os.environ); e["V2E_AMD_PIPE_E"] = str(E)
+    subprocess.run([sys.executable, "-c", code % ("E=%d" % E)], env=e)

@@ -25,7 +25,7 @@
 
 // frames per emission launch E (v2e_emu::pipe_E, chosen at create time from the ring's footprint) and
 // ring slots D = 2E: the emission of batch b overlaps the steps of batch b+1
-constexpr int PIPE_E_MAX = 16;
+constexpr int PIPE_E_MAX = 32;
 #ifndef WT_EVENTS
 #define WT_EVENTS 1
 #endif
