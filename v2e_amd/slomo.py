@@ -261,21 +261,3 @@ class SuperSloMo(object):
                 0.5 * (end - start) / self.upsampling_factor
             new_ts.append(interpolated_ts)
         return np.hstack(new_ts)
-
-
-def slomo_smoke():
-    """Tiny SloMo step on cuda:0 checked against the CPU oracle (used by __graft_entry__.smoke)."""
-    from oracle import oracle as orc
-    from .synth import int_gradient_frames, portable_unet_state_dict
-    H, W = 32, 64
-    fr = int_gradient_frames(2, H, W, seed=2, noise=8, as_array=True).astype(np.float32) / np.float32(255.0)
-    I0, I1 = fr[0:1, None] - np.float32(0.428), fr[1:2, None] - np.float32(0.428)
-    sd_f, sd_i = portable_unet_state_dict(2, 4, 201), portable_unet_state_dict(12, 5, 202)
-    eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
-                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, "cuda:0")
-    ts = [0.25, 0.75]
-    Ft = eng.interpolate(torch.from_numpy(I0).cuda(), torch.from_numpy(I1).cuda(), ts).cpu().numpy()
-    ref = orc.slomo_interpolate(I0, I1, ts, sd_f, sd_i)["Ft"]
-    err = float(np.max(np.abs(Ft - ref) / np.maximum(1.0, np.abs(ref))))
-    assert err < 1e-5, "slomo smoke mismatch %g" % err
-    print("smoke: slomo OK, max rel err vs oracle %.2e" % err)
