@@ -274,6 +274,12 @@ int v2e_events_pack_aedat2(const float *events, void *out_bytes, int64_t n, int 
 /* HDF5 "events" rows of emulator.py:955-965: uint32 [n][4] = (t*1e6 in float32, x, y, p with -1 -> 0) */
 int v2e_events_pack_h5(const float *events, uint32_t *out, int64_t n, void *stream);
 
+/* Lossless 8-byte wire format of an event row [t, x, y, p] (emulator.py:1024-1059 builds them as float32[4]):
+ * bits 63..32 the float32 bits of t, 31..18 x, 17..4 y, bit 0 (p > 0); x, y < 16384.  Used by the multi-GPU
+ * all-gather of the event streams (half the bytes over xGMI); unpack restores the float32 rows exactly. */
+int v2e_events_pack64(const float *events, uint64_t *out, int64_t n, void *stream);
+int v2e_events_unpack64(const uint64_t *in, float *events, int64_t n, void *stream);
+
 /* EventRenderer.accumulate_event_frame (renderer.py:368-400, hist2d_numba_seq v2e_utils.py:474-486):
  * current_frame (float64 [bins_y][bins_x], device) = clip(current_frame + hist(ON) - hist(OFF), +-full_scale).
  * scratch_diff: device int32 [bins_y][bins_x], zero on entry, left zero. */

@@ -17,6 +17,12 @@ def _free_port():
     return p
 
 
+def _rows(n, rank, step):
+    """n event rows (t, x, y, p) that differ per rank and step; t includes a negative value (sign bit on the wire)."""
+    k = torch.arange(n, dtype=torch.float32)
+    return torch.stack([k * 1e-3 - 0.002 + rank + 0.1 * step, (k + 13 * rank) % 346, (k * 7 + step) % 260, (k % 2) * 2 - 1], dim=1).contiguous()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -28,14 +34,14 @@ def _worker(rank, world, port, q):
         n = 5 + 7 * rank + 3 * step           # ragged, different per rank and step
         if step == 2 and rank == 1:
             n = 0                              # empty stream on one rank
-        ev = torch.arange((n + 4) * 4, dtype=torch.float32).view(-1, 4) + 1000 * rank + 100 * step
+        ev = _rows(n + 4, rank, step)
         g.submit(ev, n)
         parts = g.result()
         for r in range(world):
             nr = 5 + 7 * r + 3 * step
             if step == 2 and r == 1:
                 nr = 0
-            exp = (torch.arange((nr + 4) * 4, dtype=torch.float32).view(-1, 4) + 1000 * r + 100 * step)[:nr]
+            exp = _rows(nr + 4, r, step)[:nr]
             ok &= parts[r].shape == exp.shape and torch.equal(parts[r], exp)
     ok &= clips_of_rank(8, world, rank) == list(range(rank, 8, world))
     q.put((rank, bool(ok)))

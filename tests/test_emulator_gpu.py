@@ -343,6 +343,21 @@ def test_device_resident_clip_many_iterations(use_graph, refr, oracle_lib):
         assert np.array_equal(hip.timestamp_mem.cpu().numpy(), ora.timestamp_mem)
 
 
+def test_event_wire_format_roundtrip():
+    """v2e_events_pack64 / unpack64: real event rows survive the 8-byte wire format bit for bit, and the device
+    packer agrees with the CPU one used by the gloo tests."""
+    from v2e_amd.dist import pack_events64, unpack_events64
+    fx = PhiloxFixture("philox_moving_dot_64x64")
+    ev = np.concatenate([e for e in fx.events if len(e)])
+    extra = np.array([[-0.25, 1279, 719, -1], [3.5e-4, 0, 0, 1], [1e9, 16383, 16383, 1]], np.float32)  # corner values
+    ev = np.concatenate([ev, extra]).astype(np.float32)
+    d = torch.from_numpy(ev).cuda()
+    w = pack_events64(d)
+    assert torch.equal(w.cpu(), pack_events64(torch.from_numpy(ev)))
+    back = unpack_events64(w)
+    assert np.array_equal(back.cpu().numpy().view(np.uint32), ev.view(np.uint32))
+
+
 def test_event_stream_gatherer_nccl_single_rank():
     """The RCCL code path of EventStreamGatherer (side stream, all_gather_into_tensor) with world_size 1."""
     import os
@@ -357,7 +372,8 @@ def test_event_stream_gatherer_nccl_single_rank():
     try:
         g = EventStreamGatherer(torch.device("cuda", 0), 1)
         for n in (1000, 0, 37):
-            ev = torch.arange((n + 5) * 4, dtype=torch.float32, device="cuda").view(-1, 4)
+            k = torch.arange(n + 5, dtype=torch.float32, device="cuda")
+            ev = torch.stack([k * 1e-3 - 0.002, k % 346, (k * 7) % 260, (k % 2) * 2 - 1], dim=1).contiguous()  # (t, x, y, p) rows
             g.submit(ev, n)
             parts = g.result()
             assert len(parts) == 1 and parts[0].shape == (n, 4)

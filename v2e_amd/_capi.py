@@ -100,6 +100,8 @@ SIGNATURES = {
     "v2e_f32_to_u8_trunc": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _i, _vp]),
     "v2e_events_pack_aedat2": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "v2e_events_pack_h5": (_i, [_vp, _vp, _i64, _vp]),
+    "v2e_events_pack64": (_i, [_vp, _vp, _i64, _vp]),
+    "v2e_events_unpack64": (_i, [_vp, _vp, _i64, _vp]),
     "v2e_events_accumulate_frame": (_i, [_vp, _i64, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _vp]),
     "v2e_slomo_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }

@@ -60,6 +60,25 @@ __global__ __launch_bounds__(256) void k_frame_clip_add(double *__restrict__ cur
     diff[i] = 0; // ready for the next slice
 }
 
+// 8-byte wire format of an event row (include/v2e_amd.h)
+__global__ __launch_bounds__(256) void k_pack64(const float4 *__restrict__ ev, unsigned long long *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 e = ev[i];
+    out[i] = ((unsigned long long)__float_as_uint(e.x) << 32) | ((unsigned long long)((unsigned)e.y & 0x3FFFu) << 18) |
+             ((unsigned long long)((unsigned)e.z & 0x3FFFu) << 4) | (e.w > 0.f ? 1ull : 0ull);
+}
+
+__global__ __launch_bounds__(256) void k_unpack64(const unsigned long long *__restrict__ in, float4 *__restrict__ ev, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long v = in[i];
+    ev[i] = make_float4(__uint_as_float((unsigned)(v >> 32)), (float)((unsigned)(v >> 18) & 0x3FFFu), (float)((unsigned)(v >> 4) & 0x3FFFu),
+                        (v & 1ull) ? 1.0f : -1.0f);
+}
+
 } // namespace
 
 extern "C" {
@@ -80,6 +99,24 @@ int v2e_events_pack_h5(const float *events, uint32_t *out, int64_t n, void *stre
     V2E_REQUIRE((events && out) || n == 0, "null");
     if (n <= 0) return 0;
     k_pack_h5<<<v2e_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const float4 *)events, (uint4 *)out, n);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_events_pack64(const float *events, uint64_t *out, int64_t n, void *stream)
+{
+    V2E_REQUIRE((events && out) || n == 0, "null");
+    if (n <= 0) return 0;
+    k_pack64<<<v2e_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const float4 *)events, (unsigned long long *)out, n);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_events_unpack64(const uint64_t *in, float *events, int64_t n, void *stream)
+{
+    V2E_REQUIRE((events && in) || n == 0, "null");
+    if (n <= 0) return 0;
+    k_unpack64<<<v2e_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const unsigned long long *)in, (float4 *)events, n);
     V2E_HIP(hipGetLastError());
     return 0;
 }

@@ -5,8 +5,12 @@ independent units and the compute needs no collective. 
 exchange step BASELINE.json names is the all-gather(v) of the ranks' event streams, which
 `EventStreamGatherer` runs on a side stream so that it overlaps the next step's kernels.
 xGMI is point-to-point, so the payload is kept as one large message per rank per step
-(a 300-frame step is ~10 M events = ~170 MB per rank) rather than one per frame.
+(a 300-frame step is ~10 M events per rank) rather than one per frame, and it travels in the
+lossless 8-byte wire format of include/v2e_amd.h (float32 bits of t | x | y | polarity) instead of
+float32[4] rows: one GPU emits ~100 GB/s of rows, eight of them more than a GPU's xGMI links can take in.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -16,13 +20,52 @@ def clips_of_rank(n_clips, world, rank):
     return [c for c in range(n_clips) if c % world == rank]
 
 
+def pack_events64(ev, out=None):
+    """[n,4] float32 rows (t, x, y, p) -> [n] int64 words, lossless (include/v2e_amd.h v2e_events_pack64)."""
+    n = int(ev.shape[0])
+    if out is None:
+        out = torch.empty((n,), dtype=torch.int64, device=ev.device)
+    if n == 0:
+        return out
+    if ev.is_cuda:
+        from . import _capi
+        s = C.c_void_p(torch.cuda.current_stream(ev.device).cuda_stream)
+        _capi.check(_capi.lib().v2e_events_pack64(C.c_void_p(ev.data_ptr()), C.c_void_p(out.data_ptr()), n, s), "v2e_events_pack64")
+    else:  # CPU tensors (gloo tests): the same bit layout with torch ops
+        e = ev.contiguous()
+        t = e[:, 0].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        out[:n] = (t << 32) | ((e[:, 1].to(torch.int64) & 0x3FFF) << 18) | ((e[:, 2].to(torch.int64) & 0x3FFF) << 4) | \
+            (e[:, 3] > 0).to(torch.int64)
+    return out
+
+
+def unpack_events64(words):
+    """Inverse of pack_events64: [n] int64 -> [n,4] float32 rows, bit for bit what was packed."""
+    n = int(words.shape[0])
+    ev = torch.empty((n, 4), dtype=torch.float32, device=words.device)
+    if n == 0:
+        return ev
+    if words.is_cuda:
+        from . import _capi
+        s = C.c_void_p(torch.cuda.current_stream(words.device).cuda_stream)
+        w = words.contiguous()
+        _capi.check(_capi.lib().v2e_events_unpack64(C.c_void_p(w.data_ptr()), C.c_void_p(ev.data_ptr()), n, s), "v2e_events_unpack64")
+    else:
+        w = words.contiguous()
+        ev[:, 0] = (w >> 32).to(torch.int32).view(torch.float32)  # arithmetic shift keeps the sign bit of t
+        ev[:, 1] = ((w >> 18) & 0x3FFF).to(torch.float32)
+        ev[:, 2] = ((w >> 4) & 0x3FFF).to(torch.float32)
+        ev[:, 3] = (w & 1).to(torch.float32) * 2 - 1
+    return ev
+
+
 class EventStreamGatherer:
     """all-gather(v) of per-rank event lists [n_r,4] float32 -> every rank gets all of them.
 
-    submit(ev, n) snapshots the first n rows of `ev` (device tensor) into a staging buffer and
-    enqueues, on a side stream: MAX-all-reduce of n, all-gather of the counts, all-gather of the
-    row-padded payload.  result() returns (list of per-rank [n_r,4] views in rank order) of the
-    most recent completed submit.  On CPU tensors (gloo, tests) everything runs inline.
+    submit(ev, n) packs the first n rows of `ev` (device tensor) into a staging buffer (8 bytes per event) and
+    enqueues, on a side stream: MAX-all-reduce of n, all-gather of the counts, all-gather of the padded
+    payload.  result() returns the per-rank [n_r,4] float32 lists (unpacked on demand) of the most recent
+    completed submit, in rank order.  On CPU tensors (gloo, tests) everything runs inline.
     """
 
     def __init__(self, device, world, group=None):
@@ -42,7 +85,7 @@ class EventStreamGatherer:
     def _ensure(self, slot, rows):
         s = self.staging[slot]
         if s is None or s.shape[0] < rows:
-            self.staging[slot] = torch.empty((max(rows, 1), 4), dtype=torch.float32, device=self.device)
+            self.staging[slot] = torch.empty((max(rows, 1),), dtype=torch.int64, device=self.device)
         return self.staging[slot]
 
     def submit(self, ev, n):
@@ -64,7 +107,7 @@ class EventStreamGatherer:
                 dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX, group=self.group)
             nmax = int(nmax_t.item())  # small host sync; the previous payload gather is already enqueued
             st = self._ensure(slot, nmax)
-            st[:n].copy_(ev[:n], non_blocking=True)
+            pack_events64(ev[:n], st)  # main stream: the event buffer may be overwritten by the next step
             ready.record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
@@ -76,14 +119,14 @@ class EventStreamGatherer:
             dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX, group=self.group)
             nmax = int(nmax_t.item())
             st = self._ensure(slot, nmax)
-            st[:n].copy_(ev[:n])
+            pack_events64(ev[:n], st)
             self._collect(st, nt, nmax)
 
     def _collect(self, st, nt, nmax):
         counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
         out = self.out
         if out is None or out.shape[0] < self.world * max(nmax, 1):
-            out = torch.empty((self.world * max(nmax, 1), 4), dtype=torch.float32, device=self.device)
+            out = torch.empty((self.world * max(nmax, 1),), dtype=torch.int64, device=self.device)
         payload = st[:max(nmax, 1)]
         if self.cuda:
             dist.all_gather_into_tensor(counts, nt, group=self.group)
@@ -96,14 +139,14 @@ class EventStreamGatherer:
             dist.all_gather(pl, payload.contiguous(), group=self.group)
             out = torch.cat(pl)
         self.out, self.counts, self.nmax = out, counts, max(nmax, 1)
-        self.bytes_gathered += self.world * max(nmax, 1) * 16
+        self.bytes_gathered += self.world * max(nmax, 1) * 8
 
     def wait(self):
         if self.cuda:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
 
     def result(self):
-        """Per-rank event lists of the last submit, in rank order (call wait() first)."""
+        """Per-rank event lists [n_r,4] float32 of the last submit, in rank order (call wait() first)."""
         self.wait()
         c = self.counts.cpu().tolist()
-        return [self.out[r * self.nmax: r * self.nmax + c[r]] for r in range(self.world)]
+        return [unpack_events64(self.out[r * self.nmax: r * self.nmax + c[r]]) for r in range(self.world)]
