@@ -1202,46 +1202,46 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
     dim3 grid(h->ngroups, h->n_clips);
     // emission batch b = frames [b * E, f_end): launched once they are all final, behind the chain on h->side
     auto launch_emission = [&](int b, int f_end) -> int {
-            EmitArgs ea;
-            memset(&ea, 0, sizeof(ea));
-            ea.ctl = h->run_ctl;
-            ea.recs = recs;
-            ea.fidx_base = h->run_fidx;
-            ea.f0 = b * PIPE_E;
-            ea.nE = f_end - ea.f0;
-            ea.D = PIPE_D;
-            ea.ngroups = h->ngroups; ea.ngp = h->ngp; ea.n_clips = h->n_clips;
-            ea.cnt = h->pipe_cnt; ea.gmax = h->pipe_gmax; ea.tsold = has_refr ? h->pipe_tsold : nullptr;
-            ea.gtT = h->pipe_gtT; ea.rowext = h->pipe_rowext; ea.nw = h->pipe_nw;
-            ea.pre32 = h->pipe_pre32; ea.tot32 = h->pipe_tot32;
-            ea.events = (float4 *)events; ea.cap = cap;
-            ea.off_in = h->pipe_off + (size_t)(b & 1) * h->n_clips;
-            ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * h->n_clips;
-            V2E_HIP(hipEventRecord(h->ev_fork[b], s));
-            V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
-            dim3 ge(h->ngroups, h->n_clips, ea.nE);
-            if (mark(ev_side, h->side)) return V2E_EHIP;
-            // While the step chain is latency-bound (a grid of a few workgroups per CU) the emission kernels must
-            // not fill the CUs, or the next k_step's workgroups queue behind them: a dynamic-LDS reservation caps
-            // them at 4 workgroups per CU (160 KB LDS; k_emit2_multi uses its reservation for the event records).
-            // Large grids are throughput-bound: no cap.
-            const int lds_pad = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu ? 32000 : 0;
-            static const bool no_tables = getenv("V2E_AMD_NO_FRAME_TABLES") != nullptr;
-            ea.ftab = no_tables ? nullptr : h->pipe_ftab;
-            ea.pre512 = h->pipe_pre512;
-            constexpr int REC_LDS = 32000; // k_emit2_multi: 4 waves x 2000 event records (a wave has at most 64 x 31)
-            ea.capw = REC_LDS / 4 / (BLOCK / WAVE);
-            k_tot_multi<<<ge, BLOCK, lds_pad / 2, h->side>>>(a, ea); // the light kernel of the two: 8 per CU measured best
-            if (h->pipe_pre32) k_scan2_multi<<<dim3(SCAN_BLOCKS, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
-            if (ea.ftab) {
-                k_frame_multi<<<dim3(1, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
-                k_emit2_multi<<<ge, BLOCK, REC_LDS, h->side>>>(a, ea);
-                k_emit_big<<<dim3(64, h->n_clips), BLOCK, 0, h->side>>>(a, ea); // frames without a table (M > 31), if any
-            } else {
-                k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
-            }
-            if (mark(ev_side, h->side)) return V2E_EHIP;
-            V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
+        EmitArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.ctl = h->run_ctl;
+        ea.recs = recs;
+        ea.fidx_base = h->run_fidx;
+        ea.f0 = b * PIPE_E;
+        ea.nE = f_end - ea.f0;
+        ea.D = PIPE_D;
+        ea.ngroups = h->ngroups; ea.ngp = h->ngp; ea.n_clips = h->n_clips;
+        ea.cnt = h->pipe_cnt; ea.gmax = h->pipe_gmax; ea.tsold = has_refr ? h->pipe_tsold : nullptr;
+        ea.gtT = h->pipe_gtT; ea.rowext = h->pipe_rowext; ea.nw = h->pipe_nw;
+        ea.pre32 = h->pipe_pre32; ea.tot32 = h->pipe_tot32;
+        ea.events = (float4 *)events; ea.cap = cap;
+        ea.off_in = h->pipe_off + (size_t)(b & 1) * h->n_clips;
+        ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * h->n_clips;
+        V2E_HIP(hipEventRecord(h->ev_fork[b], s));
+        V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
+        dim3 ge(h->ngroups, h->n_clips, ea.nE);
+        if (mark(ev_side, h->side)) return V2E_EHIP;
+        // While the step chain is latency-bound (a grid of a few workgroups per CU) the emission kernels must
+        // not fill the CUs, or the next k_step's workgroups queue behind them: a dynamic-LDS reservation caps
+        // them at 4 workgroups per CU (160 KB LDS; k_emit2_multi uses its reservation for the event records).
+        // Large grids are throughput-bound: no cap.
+        const int lds_pad = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu ? 32000 : 0;
+        static const bool no_tables = getenv("V2E_AMD_NO_FRAME_TABLES") != nullptr;
+        ea.ftab = no_tables ? nullptr : h->pipe_ftab;
+        ea.pre512 = h->pipe_pre512;
+        constexpr int REC_LDS = 32000; // k_emit2_multi: 4 waves x 2000 event records (a wave has at most 64 x 31)
+        ea.capw = REC_LDS / 4 / (BLOCK / WAVE);
+        k_tot_multi<<<ge, BLOCK, lds_pad / 2, h->side>>>(a, ea); // the light kernel of the two: 8 per CU measured best
+        if (h->pipe_pre32) k_scan2_multi<<<dim3(SCAN_BLOCKS, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
+        if (ea.ftab) {
+            k_frame_multi<<<dim3(1, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
+            k_emit2_multi<<<ge, BLOCK, REC_LDS, h->side>>>(a, ea);
+            k_emit_big<<<dim3(64, h->n_clips), BLOCK, 0, h->side>>>(a, ea); // frames without a table (M > 31), if any
+        } else {
+            k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
+        }
+        if (mark(ev_side, h->side)) return V2E_EHIP;
+        V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
         return 0;
     };
     for (int f = 0; K == 1 && f <= n_frames; ++f) {
