@@ -75,7 +75,9 @@ typedef struct v2e_emu_params {
     uint64_t seed;          /* philox key */
     int32_t log_input;      /* hdr=True (emulator.py:304, 666): frames are already log intensity, no lin_log;
                                the state is float64 even without a cutoff (f64_state must be 1) */
-    int32_t reserved0;
+    int32_t photoreceptor_noise; /* emulator.py:694-703: low-passed Gaussian noise on the photoreceptor output instead of
+                                    Poisson shot events (frame-at-a-time API only); pass shot_noise_rate_hz = 0 with it */
+    double photoreceptor_noise_vrms; /* emulator_utils.py:177-290, evaluated by the host */
 } v2e_emu_params;
 
 /* Per-(frame, clip) result record, written on device. */
@@ -116,6 +118,12 @@ int v2e_emu_bind_state(v2e_emu *h, void *lp, void *base, float *ts_mem,
 int v2e_emu_init_state(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype,
                        double t_frame, const float *thres_pos, const float *thres_neg,
                        const float *noise_rate, void *stream);
+
+/* Photoreceptor-noise state (emulator.py:684, 694-703): pn_arr is the float64 plane [n_clips][npx_pad]
+ * `photoreceptor_noise_arr` (caller-owned, zero on the first frame); randn_tape the float32 draws
+ * torch.randn(shape) of the coming frame in tape mode (NULL in Philox mode).  Both are consumed by the next
+ * v2e_emu_count when params.photoreceptor_noise is set; NULL pn_arr switches the feature off. */
+int v2e_emu_set_pnoise(v2e_emu *h, void *pn_arr, const float *randn_tape);
 
 /*
  * Front half of one time step for all clips: photoreceptor, IIR, leak, event

@@ -54,6 +54,7 @@ V2E_HD void v2e_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 #define V2E_STREAM_THRES 1u /* per pixel: [0],[1] pos-threshold normal, [2],[3] neg-threshold normal */
 #define V2E_STREAM_RATE  2u /* per pixel: [0],[1] noise-rate normal */
 #define V2E_STREAM_PERM  3u /* per (frame, iteration): shuffle key */
+#define V2E_STREAM_PNOISE 4u /* per (pixel, frame): [0],[1] photoreceptor-noise normal */
 
 /* 24-bit uniform in [0,1): same granularity as torch's f32 uniform. */
 V2E_HD float v2e_u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
@@ -154,6 +155,14 @@ V2E_HD void v2e_draw_frame(uint64_t seed, uint32_t clip, uint32_t frame, uint32_
     v2e_philox4x32(pixel, frame, V2E_STREAM_FRAME, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
     *leak_randn = v2e_normal(o[0], o[1]);
     *shot_u = v2e_u01(o[2]);
+}
+
+/* Per-(pixel,frame) photoreceptor-noise draw (emulator.py:698 in philox mode). */
+V2E_HD float v2e_draw_pnoise(uint64_t seed, uint32_t clip, uint32_t frame, uint32_t pixel)
+{
+    uint32_t o[4];
+    v2e_philox4x32(pixel, frame, V2E_STREAM_PNOISE, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return v2e_normal(o[0], o[1]);
 }
 
 /* Per-pixel first-frame draws (emulator.py:459-471, 501-505 in philox mode). */

@@ -84,6 +84,11 @@ EXPORT void v2e_oracle_philox_frame(uint64_t seed, uint32_t clip, uint32_t frame
     }
 }
 
+EXPORT void v2e_oracle_philox_pnoise(uint64_t seed, uint32_t clip, uint32_t frame, int64_t npx, float *out)
+{
+    for (int64_t p = 0; p < npx; ++p) out[p] = v2e_draw_pnoise(seed, clip, frame, (uint32_t)p);
+}
+
 EXPORT void v2e_oracle_philox_init(uint64_t seed, uint32_t clip, int64_t npx, float *n_pos,
                                    float *n_neg, float *n_rate)
 {
@@ -192,7 +197,8 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
                             const float *leak_randn, const float *shot_rand, void *lp_v,
                             void *base_v, const float *pos_thres, const float *neg_thres,
                             const float *noise_rate, int32_t *pos_cnt, int32_t *neg_cnt,
-                            uint8_t *shot_on, uint8_t *shot_off, int32_t *M_out)
+                            uint8_t *shot_on, uint8_t *shot_off, int32_t *M_out,
+                            double *pn_arr /* photoreceptor_noise_arr or NULL */, const float *pn_randn /* tape draws or NULL */)
 {
     int64_t npx = (int64_t)H * W;
     double delta_time = t_frame - t_prev;
@@ -237,7 +243,18 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
             double b = base[p];
             if (do_leak) b = b - (double)delta_leak;
             base[p] = b;
-            double diff = (lpn + (double)0.0f) - b;
+            double pn = (double)0.0f;
+            if (P->photoreceptor_noise && pn_arr) {
+                /* emulator.py:694-701: noise = vrms * randn (float32); low_pass_filter(noise, arr, None, dt, cutoff):
+                 * eps = dt/tau is a Python float and NOT clamped; (1-eps)*arr is float64, eps*noise float32 */
+                float rn = (P->rng_mode == V2E_RNG_PHILOX) ? v2e_draw_pnoise(P->seed, clip, frame_idx, (uint32_t)p) : pn_randn[p];
+                float noise = (float)P->photoreceptor_noise_vrms * rn;
+                double eps_n = delta_time / tau;
+                float term2 = (float)eps_n * noise;
+                pn = (1.0 - eps_n) * pn_arr[p] + (double)term2;
+                pn_arr[p] = pn;
+            }
+            double diff = (lpn + pn) - b;
             double pf = diff > 0 ? diff : 0.0, nf = (-diff) > 0 ? -diff : 0.0;
             double tp = P->scalar_thres ? P->pos_thres_scalar : (double)pos_thres[p];
             double tn = P->scalar_thres ? P->neg_thres_scalar : (double)neg_thres[p];

@@ -123,6 +123,12 @@ def philox_frame(seed, clip, frame, npx):
     return a, b
 
 
+def philox_pnoise(seed, clip, frame, npx):
+    a = np.empty(npx, np.float32)
+    lib().v2e_oracle_philox_pnoise(C.c_uint64(seed), C.c_uint32(clip), C.c_uint32(frame), C.c_int64(npx), _p(a))
+    return a
+
+
 def philox_init(seed, clip, npx):
     a = np.empty(npx, np.float32)
     b = np.empty(npx, np.float32)
@@ -151,8 +157,14 @@ class OracleEmulator:
     def __init__(self, pos_thres=0.2, neg_thres=0.2, sigma_thres=0.03, cutoff_hz=0.0,
                  leak_rate_hz=0.1, refractory_period_s=0.0, shot_noise_rate_hz=0.0,
                  leak_jitter_fraction=0.1, noise_rate_cov_decades=0.1, seed=0,
-                 rng_mode="tape", tape=None, shuffle=True, clip=0, hdr=False):
+                 rng_mode="tape", tape=None, shuffle=True, clip=0, hdr=False, photoreceptor_noise=False,
+                 photoreceptor_noise_vrms=None):
         self.log_input = bool(hdr)  # emulator.py:304
+        # emulator.py:192-205, 694-703; the vrms itself (emulator_utils.py:177-290, unseeded numpy draws in the
+        # reference) is an input here
+        self.photoreceptor_noise = bool(photoreceptor_noise)
+        self.photoreceptor_noise_vrms = photoreceptor_noise_vrms
+        self.photoreceptor_noise_arr = None
         self.pos_thres = pos_thres
         self.neg_thres = neg_thres
         self.pos_thres_nominal = pos_thres
@@ -211,6 +223,8 @@ class OracleEmulator:
         P = EmuParams()
         P.f64_state = 1 if (self.cutoff_hz > 0 or self.log_input) else 0
         P.log_input = 1 if self.log_input else 0
+        P.photoreceptor_noise = 1 if self.photoreceptor_noise else 0
+        P.photoreceptor_noise_vrms = float(self.photoreceptor_noise_vrms or 0.0)
         P.scalar_thres = 0 if self.sigma_thres > 0 else 1
         P.rng_mode = RNG_PHILOX if self.rng_mode == "philox" else RNG_TAPE
         P.shuffle = 1 if self.shuffle else 0
@@ -224,7 +238,8 @@ class OracleEmulator:
         P.leak_jitter_fraction = self.leak_jitter_fraction
         P.noise_rate_cov_decades = self.noise_rate_cov_decades
         P.refractory_period_s = self.refractory_period_s
-        P.shot_noise_rate_hz = self.shot_noise_rate_hz
+        # with photoreceptor noise the shot-event generator and its base reset are skipped (emulator.py:893, 940)
+        P.shot_noise_rate_hz = 0.0 if self.photoreceptor_noise else self.shot_noise_rate_hz
         P.shot_noise_inten_factor = self.SHOT_NOISE_INTEN_FACTOR
         if P.scalar_thres:
             import torch
@@ -279,6 +294,12 @@ class OracleEmulator:
         shot_on = np.zeros((H, W), np.uint8)
         shot_off = np.zeros((H, W), np.uint8)
         M = C.c_int32(0)
+        pn_rand = None
+        if self.photoreceptor_noise:
+            if self.photoreceptor_noise_arr is None:
+                self.photoreceptor_noise_arr = np.zeros((H, W), np.float64)  # emulator.py:684
+            if not philox:
+                pn_rand = np.ascontiguousarray(self.tape.randn((H, W)))  # emulator.py:698, before the leak draw
         leak = None
         if not philox and self.leak_rate_hz > 0:
             leak = np.ascontiguousarray(self.tape.randn((H, W)))
@@ -286,7 +307,8 @@ class OracleEmulator:
                                 C.c_uint32(fidx), C.c_uint32(self.clip), _p(leak), None,
                                 _p(self.lp_log_frame), _p(self.base_log_frame), _p(self.pos_thres_arr),
                                 _p(self.neg_thres_arr), _p(self.noise_rate_array), _p(pos_cnt),
-                                _p(neg_cnt), _p(shot_on), _p(shot_off), C.byref(M))
+                                _p(neg_cnt), _p(shot_on), _p(shot_off), C.byref(M),
+                                _p(self.photoreceptor_noise_arr) if self.photoreceptor_noise else None, _p(pn_rand))
         assert rc == 0
         M = M.value
         self.last_M = M
@@ -316,7 +338,7 @@ class OracleEmulator:
             for i in range(M):
                 n_i = int(itc[2 * i]) + int(itc[2 * i + 1])
                 perms.append(self.tape.randperm(n_i, fidx, i) if n_i > 0 else None)
-            if self.shot_noise_rate_hz > 0:
+            if self.shot_noise_rate_hz > 0 and not self.photoreceptor_noise:
                 u = np.ascontiguousarray(self.tape.rand((H, W)))
                 rc = L.v2e_oracle_shot(C.byref(P), H, W, _p(frame), C.c_double(t_prev),
                                        C.c_double(t_frame), _p(u), _p(self.pos_thres_arr),

@@ -9,9 +9,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TAPE_FIXTURES = ["tape_defaults_40x48", "tape_noisy_40x48", "tape_clean_40x48", "tape_f32state_40x48",
                  "tape_scalarthres_40x48", "tape_refractory_float_33x37", "tape_moving_dot_64x64_40fr",
-                 "tape_hdr_40x48", "tape_hdr_nocutoff_40x48"]  # hdr: tests/golden/make_golden_hdr.py
+                 "tape_hdr_40x48", "tape_hdr_nocutoff_40x48",  # hdr: tests/golden/make_golden_hdr.py
+                 "tape_pnoise_40x48"]  # photoreceptor noise: tests/golden/make_golden_pnoise.py
 PHILOX_FIXTURES = ["philox_moving_dot_64x64", "philox_defaults_346x260", "philox_noisy_346x260",
-                   "philox_refractory_346x260", "philox_noisy_1280x720", "philox_hdr_97x131"]
+                   "philox_refractory_346x260", "philox_noisy_1280x720", "philox_hdr_97x131",
+                   "philox_pnoise_97x131"]
+PNOISE_VRMS = 0.03125  # the noise amplitude the photoreceptor-noise fixtures were generated with
 
 
 def sha(a):
@@ -25,6 +28,8 @@ class TapeFixture:
         self.frames = z["frames"]
         self.times = z["times"]
         self.kw = json.loads(str(z["kw"]))
+        if self.kw.get("photoreceptor_noise"):
+            self.kw["photoreceptor_noise_vrms"] = PNOISE_VRMS
         self.preset = str(z["preset"]) or None
         self.seed = int(z["seed"])
         n = int(z["n_items"])
@@ -44,6 +49,8 @@ class PhiloxFixture:
         self.name = name
         self.times = z["times"]
         self.kw = json.loads(str(z["kw"]))
+        if self.kw.get("photoreceptor_noise"):
+            self.kw["photoreceptor_noise_vrms"] = PNOISE_VRMS
         self.preset = str(z["preset"]) or None
         self.seed = int(z["seed"])
         self.n_events = z["n_events"]

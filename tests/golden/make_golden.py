@@ -141,6 +141,8 @@ class PhiloxSource:
         self.frame_idx = 0
         self._orig = {}
         self.linspace_checked = 0
+        self.pnoise = False     # photoreceptor_noise: the first randn of a frame is the noise draw
+        self.randn_calls = 0
 
     def __enter__(self):
         for name in ("randn", "rand", "randperm", "linspace"):
@@ -148,6 +150,9 @@ class PhiloxSource:
         src = self
 
         def randn(*a, **k):
+            src.randn_calls += 1
+            if src.pnoise and src.randn_calls == 1:  # emulator.py:698 comes before the leak draw of the frame
+                return torch.from_numpy(orc.philox_pnoise(src.seed, 0, src.frame_idx, src.H * src.W).reshape(src.H, src.W))
             r, _ = orc.philox_frame(src.seed, 0, src.frame_idx, src.H * src.W)
             return torch.from_numpy(r.reshape(src.H, src.W))
 
@@ -200,8 +205,10 @@ def run_reference_philox(frames, times, kw, preset, seed):
         nr = np.array([orc.lib().v2e_oracle_det_expf(float(np.float32(lnc * v))) for v in n_rate], np.float32)
         ref.noise_rate_array = torch.from_numpy(nr.reshape(H, W))
     with PhiloxSource(seed, H, W) as src:
+        src.pnoise = bool(kw.get("photoreceptor_noise"))
         for k in range(1, len(frames)):
             src.frame_idx = k
+            src.randn_calls = 0
             src.t_prev = float(ref.t_previous)
             src.t_frame = float(times[k])
             evs.append(ref.generate_events(frames[k], times[k]))

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from v2e_amd._capi import ConvDesc, EmuParams, FrameRec
     assert C.sizeof(FrameRec) == 32
-    assert C.sizeof(EmuParams) == 16 + 12 * 8 + 8 + 8 + 8  # ... + log_input, reserved0
+    assert C.sizeof(EmuParams) == 16 + 12 * 8 + 8 + 8 + 8 + 8  # ... + log_input, photoreceptor_noise, vrms
     assert C.sizeof(ConvDesc) == 32 or C.sizeof(ConvDesc) == 28
 
 
@@ -62,11 +62,15 @@ def test_emulator_errors_like_reference():
     e.t_previous = 1.0
     with pytest.raises(ValueError):  # emulator.py:650-653
         e.generate_events(np.zeros((4, 4), np.uint8), 0.5)
-    for kw in (dict(photoreceptor_noise=True, shot_noise_rate_hz=1.0, cutoff_hz=10), dict(cs_lambda_pixels=2.0),
-               dict(scidvs=True), dict(show_dvs_model_state=["all"]),
+    for kw in (dict(cs_lambda_pixels=2.0), dict(scidvs=True), dict(show_dvs_model_state=["all"]),
                dict(record_single_pixel_states=(1, 2))):
         with pytest.raises(NotImplementedError):
             EventEmulator(**kw)
+    with pytest.raises(SystemExit):  # emulator.py:196-204: v2e_quit when the rate or the cutoff is zero
+        EventEmulator(photoreceptor_noise=True, shot_noise_rate_hz=0.0, cutoff_hz=10)
+    e = EventEmulator(photoreceptor_noise=True, shot_noise_rate_hz=1.0, cutoff_hz=10, rng_mode="philox")
+    with pytest.raises(NotImplementedError):  # device-resident clips: frame API only
+        e.generate_events_batch(np.zeros((2, 4, 4), np.uint8), [0.0, 0.1])
     with pytest.raises(ValueError):
         EventEmulator(rng_mode="bogus")
 

@@ -68,7 +68,7 @@ PIPELINES = [0, 1, 64, 65, 192, 193, 32, 33, 16, 17]
 
 
 @pytest.mark.parametrize("use_graph", PIPELINES)
-@pytest.mark.parametrize("name", PHILOX_FIXTURES)
+@pytest.mark.parametrize("name", [n for n in PHILOX_FIXTURES if "pnoise" not in n])  # photoreceptor noise: frame API only
 def test_hip_philox_device_resident_clip_matches_reference(name, use_graph):
     """Whole clip on device (no host sync between frames; optionally one hipGraph), all three pipelines."""
     fx = PhiloxFixture(name)

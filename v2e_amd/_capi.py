@@ -37,7 +37,8 @@ class EmuParams(C.Structure):
         ("neg_pre_scalar", C.c_float),
         ("seed", C.c_uint64),
         ("log_input", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("photoreceptor_noise", C.c_int32),
+        ("photoreceptor_noise_vrms", C.c_double),
     ]
 
 
@@ -77,6 +78,7 @@ SIGNATURES = {
     "v2e_emu_npx_pad": (_i64, [_i, _i]),
     "v2e_emu_bind_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v2e_emu_init_state": (_i, [_vp, _PP, _vp, _i, _d, _vp, _vp, _vp, _vp]),
+    "v2e_emu_set_pnoise": (_i, [_vp, _vp, _vp]),
     "v2e_emu_count": (_i, [_vp, _PP, _vp, _i, C.POINTER(_d), C.POINTER(_d), _u32, _vp, _vp, _vp]),
     "v2e_emu_read_rec": (_i, [_vp, _u32, C.POINTER(FrameRec), _vp]),
     "v2e_emu_shot": (_i, [_vp, _PP, _vp, _i, _u32, _vp, _vp]),

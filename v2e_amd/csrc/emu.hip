@@ -101,6 +101,10 @@ struct KArgs {
     // lin_log / inten01 of the 256 uint8 grey levels, built on device by k_lut with the same code
     const float *lut_L;
     const double *lut_I;
+    // photoreceptor noise (frame-at-a-time API): state plane, tape draws (or nullptr), vrms as float32
+    void *pn_arr;
+    const float *pn_tape;
+    float pn_vrms_f;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -337,7 +341,17 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
             b = b - (R)delta_leak;
             ((R *)a.base)[sp] = b;
         }
-        R diff = (lpn + (R)0.0f) - b;
+        R pn = (R)0.0f;
+        if (a.pn_arr) { // emulator.py:694-701: float32 white noise through low_pass_filter(noise, arr, None, dt, cutoff)
+            const float rn = a.rng_mode == V2E_RNG_PHILOX ? v2e_draw_pnoise(a.seed, (uint32_t)clip, frame_idx, (uint32_t)p) : a.pn_tape[fp];
+            const float noise = a.pn_vrms_f * rn;                // python float * float32 tensor
+            const double eps_n = delta_time / (1.0 / a.cutoff_two_pi); // emulator_utils.py:97, not clamped
+            const float term2 = (float)eps_n * noise;            // eps * float32 tensor
+            const double pnn = (1.0 - eps_n) * (double)((R *)a.pn_arr)[sp] + (double)term2;
+            ((R *)a.pn_arr)[sp] = (R)pnn;
+            pn = (R)pnn;
+        }
+        R diff = (lpn + pn) - b; // photoreceptor + photoreceptor_noise_arr - base_log_frame (emulator.py:751)
         R pf = diff > (R)0 ? diff : (R)0;
         R nf = (-diff) > (R)0 ? -diff : (R)0;
         R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;
@@ -646,6 +660,8 @@ struct v2e_emu {
     void *lp = nullptr, *base = nullptr;
     float *ts_mem = nullptr, *pos_thres = nullptr, *neg_thres = nullptr, *noise_rate = nullptr;
     uint32_t *cnt = nullptr, *hist = nullptr, *tot = nullptr;
+    void *pn_arr = nullptr;           // photoreceptor_noise_arr plane (v2e_emu_set_pnoise)
+    const float *pn_tape = nullptr;
     // fused pipeline scratch (double-buffered by frame parity)
     int ngroups = 0;
     float *lut_L = nullptr;
@@ -730,6 +746,7 @@ static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
     a.pos_thres = h->pos_thres; a.neg_thres = h->neg_thres; a.noise_rate = h->noise_rate;
     a.cnt = h->cnt; a.hist = h->hist; a.tot = h->tot;
     a.lut_L = h->lut_L; a.lut_I = h->lut_I;
+    if (p->photoreceptor_noise) { a.pn_arr = h->pn_arr; a.pn_tape = h->pn_tape; a.pn_vrms_f = (float)p->photoreceptor_noise_vrms; }
     return a;
 }
 
@@ -953,6 +970,14 @@ static int launch_count(v2e_emu *h, const KArgs &a, int f64_state, const void *f
     return 0;
 }
 
+int v2e_emu_set_pnoise(v2e_emu *h, void *pn_arr, const float *randn_tape)
+{
+    V2E_REQUIRE(h, "null");
+    h->pn_arr = pn_arr;
+    h->pn_tape = randn_tape;
+    return 0;
+}
+
 int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, const double *t_prev,
                   const double *t_frame, uint32_t frame_idx, const float *leak_randn, const float *shot_rand,
                   void *stream)
@@ -961,6 +986,11 @@ int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dt
     if (rc) return rc;
     V2E_REQUIRE(frame && t_prev && t_frame, "null frame/time");
     if (p->rng_mode == V2E_RNG_TAPE) V2E_REQUIRE(!(p->leak_rate_hz > 0) || leak_randn, "tape mode needs leak_randn");
+    if (p->photoreceptor_noise) {
+        V2E_REQUIRE(h->pn_arr && p->f64_state && p->cutoff_hz > 0, "photoreceptor noise needs its plane (v2e_emu_set_pnoise) and a cutoff");
+        V2E_REQUIRE(!(p->shot_noise_rate_hz > 0), "photoreceptor noise replaces shot events: pass shot_noise_rate_hz = 0");
+        V2E_REQUIRE(p->rng_mode != V2E_RNG_TAPE || h->pn_tape, "tape mode needs the photoreceptor-noise draws");
+    }
     V2E_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     rc = stage_ctl(h, p, frame_idx, t_prev, t_frame, s);
@@ -1336,6 +1366,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(p->rng_mode == V2E_RNG_PHILOX, "v2e_emu_run is the device-resident Philox path");
+    V2E_REQUIRE(!p->photoreceptor_noise, "photoreceptor noise is implemented by the frame-at-a-time API only");
     V2E_REQUIRE(frames && t_prev && t_frame && events && recs_dev && n_frames > 0, "bad run args");
     V2E_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;

@@ -19,9 +19,9 @@ Random numbers come in two modes, selected with the extra key
            copy of the event list.  `generate_events_batch` keeps a whole clip on device.
 
 The reference's research-only pixel variants are not part of the hot path and raise
-NotImplementedError here: photoreceptor_noise, CSDVS (cs_lambda_pixels), SCIDVS,
-show_dvs_model_state, record_single_pixel_states.  `hdr=True` (log-encoded input, emulator.py:304,
-666) is supported.
+NotImplementedError here: CSDVS (cs_lambda_pixels), SCIDVS, show_dvs_model_state,
+record_single_pixel_states.  `hdr=True` (log-encoded input, emulator.py:304, 666) is supported, and so is
+`photoreceptor_noise=True` (emulator.py:694-703) in the frame-at-a-time API.
 """
 import atexit
 import logging
@@ -60,6 +60,28 @@ class _TorchTape:
 
     def exp_noise_rate(self, cov, randn):
         return torch.exp(math.log(10) * cov * randn)  # emulator.py:504-505
+
+
+def photoreceptor_noise_vrms(shot_noise_rate_hz, f3db, sample_rate_hz, pos_thr, neg_thr, sigma_thr):
+    """Gaussian RMS amplitude (ln units) to inject before the photoreceptor low-pass so that threshold crossings of
+    the filtered noise occur at the requested event rate: the curve fit of Graca & Delbruck (2021) evaluated over
+    sampled thresholds, then scaled by the noise-equivalent-bandwidth factor of this IIR measured on a white
+    sequence (what emulator_utils.py:177-290 computes; like there, the draws are unseeded numpy ones)."""
+    rate_per_bw = (shot_noise_rate_hz / f3db) / 2  # the fit is for ON events only
+    x = math.log10(rate_per_bw)
+    rng = np.random.default_rng()
+    n = 300
+    thr = np.minimum(pos_thr + sigma_thr * rng.standard_normal(n), neg_thr + sigma_thr * np.random.default_rng().standard_normal(n))
+    y = -0.0026 * x ** 3 - 0.036 * x ** 2 - 0.1949 * x + 0.321  # log10(thr / vn)
+    vn = float(np.mean(thr / 10 ** y))
+    tau = 1 / (f3db * 2 * math.pi)
+    dt = 1 / sample_rate_hz
+    rin = vn * np.random.default_rng().standard_normal(np.arange(0, 1000 * tau, dt).shape)
+    eps = dt / tau
+    rout = np.zeros_like(rin)
+    for i in range(1, len(rin)):
+        rout[i] = rout[i - 1] * (1 - eps) + rin[i] * eps
+    return float(np.std(rin) / np.std(rout) * vn)
 
 
 class _OneHostThread:
@@ -134,9 +156,9 @@ class EventEmulator(object):
             shuffle: bool = True,
             tape=None,
             max_iters: int = 64,
+            photoreceptor_noise_vrms: Optional[float] = None,
     ):
         unsupported = []
-        if photoreceptor_noise: unsupported.append("photoreceptor_noise")
         if cs_lambda_pixels is not None: unsupported.append("cs_lambda_pixels (CSDVS)")
         if scidvs: unsupported.append("scidvs")
         if show_dvs_model_state is not None: unsupported.append("show_dvs_model_state")
@@ -161,7 +183,13 @@ class EventEmulator(object):
         self.leak_rate_hz = leak_rate_hz
         self.refractory_period_s = refractory_period_s
         self.shot_noise_rate_hz = shot_noise_rate_hz
-        self.photoreceptor_noise = False
+        self.photoreceptor_noise = bool(photoreceptor_noise)
+        self.photoreceptor_noise_vrms = photoreceptor_noise_vrms  # None: computed like emulator_utils.py:177-290
+        self._pn_last_rate = None
+        self.photoreceptor_noise_arr = None
+        if self.photoreceptor_noise and (shot_noise_rate_hz == 0 or cutoff_hz == 0):  # emulator.py:196-204 (v2e_quit)
+            logger.error('--photoreceptor_noise needs a finite --shot_noise_rate_hz and --cutoff_hz')
+            raise SystemExit(1)
         self.leak_jitter_fraction = leak_jitter_fraction
         self.noise_rate_cov_decades = noise_rate_cov_decades
         self.SHOT_NOISE_INTEN_FACTOR = 0.25
@@ -288,6 +316,7 @@ class EventEmulator(object):
         self.frame_counter = 0
         self.timestamp_mem = None
         self.noise_rate_array = None
+        self.photoreceptor_noise_arr = None
         self._initialized = False
 
     # ------------------------------------------------------------- parameters
@@ -308,7 +337,10 @@ class EventEmulator(object):
         P.leak_jitter_fraction = float(self.leak_jitter_fraction)
         P.noise_rate_cov_decades = float(self.noise_rate_cov_decades)
         P.refractory_period_s = float(self.refractory_period_s)
-        P.shot_noise_rate_hz = float(self.shot_noise_rate_hz)
+        # photoreceptor noise replaces the shot-event generator and its base reset (emulator.py:893, 940)
+        P.shot_noise_rate_hz = 0.0 if self.photoreceptor_noise else float(self.shot_noise_rate_hz)
+        P.photoreceptor_noise = 1 if self.photoreceptor_noise else 0
+        P.photoreceptor_noise_vrms = float(getattr(self, "_pn_vrms", 0.0) or 0.0)
         P.shot_noise_inten_factor = float(self.SHOT_NOISE_INTEN_FACTOR)
         if P.scalar_thres:  # emulator.py:475-478 with Python-float thresholds
             P.pos_pre_scalar = float(torch.div(self.pos_thres_nominal, P.pos_thres_scalar))
@@ -399,6 +431,22 @@ class EventEmulator(object):
         tape = self.rng_mode == "tape"
         dev = eng.device
 
+        pn_draw = None
+        if self.photoreceptor_noise:  # emulator.py:694-703
+            if self.photoreceptor_noise_arr is None:  # zeros_like(lp_log_frame) on the first frame (emulator.py:684)
+                self._pn_plane = torch.zeros((1, eng.npx_pad), dtype=torch.float64, device=dev)
+                self.photoreceptor_noise_arr = eng.plane(self._pn_plane)
+            rate = 1.0 / (t_frame - t_prev)
+            if self.photoreceptor_noise_vrms is not None:
+                self._pn_vrms = float(self.photoreceptor_noise_vrms)
+            elif self._pn_last_rate is None or abs(rate / self._pn_last_rate - 1) >= 0.1:  # emulator_utils.py:217-220
+                self._pn_vrms = photoreceptor_noise_vrms(self.shot_noise_rate_hz, self.cutoff_hz, rate, self.pos_thres_nominal,
+                                                         self.neg_thres_nominal, self.sigma_thres)
+                self._pn_last_rate = rate
+            P = self._params()
+            if tape:
+                pn_draw = _as_f32_tensor(self._tape.randn((H, W))).to(dev)  # before the leak draw, as in the reference
+            eng.set_pnoise(self._pn_plane, pn_draw)
         leak = None
         if tape and self.leak_rate_hz > 0:
             leak = _as_f32_tensor(self._tape.randn((H, W))).to(dev)
@@ -425,7 +473,7 @@ class EventEmulator(object):
             for i in range(M):
                 n_i = int(itc[i, 0]) + int(itc[i, 1])
                 perms.append(self._tape.randperm(n_i, fidx, i) if n_i > 0 else None)
-            if self.shot_noise_rate_hz > 0:
+            if self.shot_noise_rate_hz > 0 and not self.photoreceptor_noise:
                 u = _as_f32_tensor(self._tape.rand((H, W))).to(dev)
                 eng.shot(P, frame_dev, fidx, u)
                 eng.rank(P, fidx, ts_dev)
@@ -514,6 +562,8 @@ class EventEmulator(object):
         """
         if self.rng_mode != "philox":
             raise ValueError("generate_events_batch needs rng_mode='philox' (tape mode needs the host per frame)")
+        if self.photoreceptor_noise:
+            raise NotImplementedError("photoreceptor_noise is implemented by the frame-at-a-time API (generate_events) only")
         if isinstance(frames, np.ndarray):
             if frames.dtype not in (np.uint8, np.float32, np.float64):
                 frames = frames.astype(np.float64)

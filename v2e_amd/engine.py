@@ -123,6 +123,11 @@ class EmuEngine:
                                      _dbl_array(t_prev), _dbl_array(t_frame), int(frame_idx),
                                      _ptr(leak_randn), _ptr(shot_rand), self.stream), "v2e_emu_count")
 
+    def set_pnoise(self, pn_plane, randn_tape=None):
+        """photoreceptor_noise_arr plane [n_clips][npx_pad] float64 (+ the frame's torch.randn draws in tape mode) for
+        the next count(); None switches the feature off."""
+        check(self.lib.v2e_emu_set_pnoise(self._h, _ptr(pn_plane), _ptr(randn_tape)), "v2e_emu_set_pnoise")
+
     def shot(self, P, frame_dev, frame_idx, shot_rand):
         check(self.lib.v2e_emu_shot(self._h, C.byref(P), _ptr(frame_dev), _DT[frame_dev.dtype],
                                     int(frame_idx), _ptr(shot_rand), self.stream), "v2e_emu_shot")
