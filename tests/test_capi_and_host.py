@@ -119,3 +119,14 @@ def test_time_coefficients_are_python_doubles_first():
     c = time_coefficients([0.05])
     t = 0.05
     assert c[0, 0] == np.float32(-t * (1 - t)) and c[0, 2] == np.float32((1 - t) * (1 - t)) and c[0, 4] == np.float32(1 - t)
+
+
+def test_photoreceptor_noise_amplitude_port():
+    """The noise-amplitude estimate (emulator_utils.py:177-290 restated; unseeded draws like the reference) lands where
+    the reference's does for the v2e defaults: 0.0615 +- 0.001 measured with the reference function itself."""
+    from v2e_amd.emulator import photoreceptor_noise_vrms
+    v = [photoreceptor_noise_vrms(1.0, 300.0, 3000.0, 0.2, 0.2, 0.03) for _ in range(4)]
+    assert 0.055 < np.mean(v) < 0.068
+    # lower rate per Hz of bandwidth -> less noise needed; higher threshold -> more
+    assert photoreceptor_noise_vrms(0.01, 300.0, 3000.0, 0.2, 0.2, 0.03) < np.mean(v)
+    assert photoreceptor_noise_vrms(1.0, 300.0, 3000.0, 0.4, 0.4, 0.03) > np.mean(v)
