@@ -205,6 +205,13 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
 int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *ms_scan,
                          double *ms_emit, int *launches);
 
+/* The launch schedule v2e_emu_run uses for n_frames frames (no GPU needed; for tests and tooling): returns the number
+ * of chain launches and, if out != NULL, writes per launch 8 int32: the frames it counts (c0, c1), the frame it
+ * finalises exactly (e1), the speculated frame it validates (e2), the emission batch it must wait for before reusing
+ * ring slots, the first and the number of emission batches that become launchable after it, 0; -1 = none.
+ * frames_per_launch: 1 (k_step) or 2 (k_step2, frames_per_batch even). */
+int v2e_emu_pipe_plan(int n_frames, int frames_per_batch, int frames_per_launch, int32_t *out, int cap);
+
 /* Default pipeline only: emission batches timed by the last instrumented run and the frames
  * per emission batch this handle uses (chosen at create time; env V2E_AMD_PIPE_E overrides), and
  * the number of chain launches ms_count covers (step_launches may be NULL). */

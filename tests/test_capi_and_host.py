@@ -130,3 +130,48 @@ def test_photoreceptor_noise_amplitude_port():
     # lower rate per Hz of bandwidth -> less noise needed; higher threshold -> more
     assert photoreceptor_noise_vrms(0.01, 300.0, 3000.0, 0.2, 0.2, 0.03) < np.mean(v)
     assert photoreceptor_noise_vrms(1.0, 300.0, 3000.0, 0.4, 0.4, 0.03) > np.mean(v)
+
+
+@pytest.mark.parametrize("K", [1, 2])
+def test_pipeline_launch_schedule_invariants(K):
+    """v2e_emu_pipe_plan, the schedule v2e_emu_run enqueues: every frame is counted exactly once and in order,
+    finalised exactly once by a later launch, speculated frames (and only those) are validated by the launch after,
+    an emission batch is launched once and only after all its frames are final, and no ring slot is overwritten before
+    the emission batch that reads it was waited for."""
+    import ctypes as C
+    from v2e_amd import _capi
+    lib = _capi.lib()
+    for E in (2, 4, 16, 32) if K == 2 else (1, 2, 3, 5, 16, 32):
+        D = 2 * E
+        for F in list(range(1, 3 * D + 4)) + [300]:
+            n = lib.v2e_emu_pipe_plan(F, E, K, None, 0)
+            buf = (C.c_int32 * (8 * n))()
+            assert lib.v2e_emu_pipe_plan(F, E, K, buf, n) == n
+            plan = np.frombuffer(buf, dtype=np.int32).reshape(n, 8)
+            counted_at, final_at, spec_at, emitted_at, waited = {}, {}, {}, {}, set()
+            nb = (F + E - 1) // E
+            for L, (c0, c1, e1, e2, wb, ef, ec, _) in enumerate(plan):
+                if wb >= 0:
+                    assert wb in emitted_at and emitted_at[wb] < L, "waits for a batch that was never launched"
+                    waited.add(wb)
+                for c in (c0, c1):
+                    if c >= 0:
+                        assert c not in counted_at and c == len(counted_at), "frames must be counted once, in order"
+                        # the slot of frame c was last used by frame c - D: its batch must have been waited for
+                        assert c < D or (c - D) // E in waited, "ring slot reused before its emission batch was waited for"
+                        counted_at[c] = L
+                if e1 >= 0:
+                    assert e1 in counted_at and counted_at[e1] < L and e1 not in final_at
+                    final_at[e1] = L
+                if e2 >= 0:
+                    assert spec_at.get(e2) == L - 1, "validates a frame the previous launch did not speculate on"
+                    final_at[e2] = L
+                if K == 2 and c0 >= 0 and c1 >= 0:
+                    spec_at[c0] = L  # c0 is finalised speculatively when it has a partner
+                for b in range(ef, ef + ec):
+                    assert b not in emitted_at
+                    assert all(f in final_at for f in range(b * E, min((b + 1) * E, F))), "batch launched before its frames are final"
+                    emitted_at[b] = L
+            assert sorted(counted_at) == list(range(F)) and sorted(final_at) == list(range(F))
+            assert all(f in final_at and final_at[f] == L + 1 for f, L in spec_at.items()), "every speculation is validated"
+            assert sorted(emitted_at) == list(range(nb))

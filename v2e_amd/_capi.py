@@ -91,6 +91,7 @@ SIGNATURES = {
                          _vp, _i, _vp]),
     "v2e_emu_last_profile": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),
                                   C.POINTER(_i)]),
+    "v2e_emu_pipe_plan": (_i, [_i, _i, _i, _vp, _i]),
     "v2e_emu_last_profile_pipe": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "v2e_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_conv2d_lrelu": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(ConvDesc), _vp, _i, _i, _i, _vp]),

@@ -1205,6 +1205,49 @@ static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     return 0;
 }
 
+// The launch schedule of the decoupled pipeline, as plain data (also exported for the CPU tests).  One entry per
+// chain launch: the frames it counts (c0, c1), the frame it finalises exactly (e1) and the speculated frame it
+// validates (e2) -- -1 where absent --, the emission batch whose completion it must wait for before overwriting
+// ring slots (wait_batch), and the emission batches [emit_first, emit_first + emit_count) that become launchable
+// once it is enqueued, batch b covering frames [b * E, min((b + 1) * E, n_frames)).
+struct PipeLaunch { int c0, c1, e1, e2, wait_batch, emit_first, emit_count; };
+
+static std::vector<PipeLaunch> pipe_plan(int n_frames, int E, int K)
+{
+    const int D = 2 * E;
+    std::vector<PipeLaunch> plan;
+    int emitted = 0;
+    auto take_final_batches = [&](PipeLaunch &pl, int last_final) { // batches all of whose frames are <= last_final
+        pl.emit_first = emitted;
+        while (emitted * E < n_frames && std::min((emitted + 1) * E, n_frames) - 1 <= last_final) ++emitted;
+        pl.emit_count = emitted - pl.emit_first;
+    };
+    if (K == 1) {
+        for (int f = 0; f <= n_frames; ++f) { // k_step(f) = finalise(f - 1) + count(f)
+            PipeLaunch pl;
+            pl.c0 = f < n_frames ? f : -1; pl.c1 = -1; pl.e1 = f - 1; pl.e2 = -1;
+            pl.wait_batch = (f % E == 0 && f >= D && f < n_frames) ? (f - D) / E : -1;
+            take_final_batches(pl, f - 1);
+            plan.push_back(pl);
+        }
+    } else {
+        const int n_launch = (n_frames + 1) / 2 + 1;
+        for (int L = 0; L < n_launch; ++L) { // k_step2: counts 2L and 2L+1, finalises the last frame counted before, validates the one before that
+            PipeLaunch pl;
+            const int c0 = 2 * L, c1 = 2 * L + 1;
+            pl.c0 = c0 < n_frames ? c0 : -1;
+            pl.c1 = c1 < n_frames ? c1 : -1;
+            pl.e1 = std::min(c0, n_frames) - 1;
+            // e1 - 1 was finalised speculatively iff it is an even frame (a c0) that had a partner -- which e1 is
+            pl.e2 = (pl.e1 >= 1 && (pl.e1 - 1) % 2 == 0) ? pl.e1 - 1 : -1;
+            pl.wait_batch = (pl.c0 >= 0 && c0 % E == 0 && c0 >= D) ? (c0 - D) / E : -1;
+            take_final_batches(pl, pl.e1);
+            plan.push_back(pl);
+        }
+    }
+    return plan;
+}
+
 // Decoupled pipeline (emu_pipe.h): the k_step chain on `s`, emission batches on h->side.  With
 // ev_main / ev_side (instrumented run) an event is recorded before the first and after the last
 // k_step (events between dependent launches would lengthen the very gaps being measured) and
@@ -1274,9 +1317,17 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
         V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
         return 0;
     };
-    for (int f = 0; K == 1 && f <= n_frames; ++f) {
-        if (f % PIPE_E == 0 && f >= PIPE_D) // the slot this step writes was read by emission batch (f - PIPE_D) / PIPE_E
-            V2E_HIP(hipStreamWaitEvent(s, h->ev_join[(f - PIPE_D) / PIPE_E], 0));
+    const std::vector<PipeLaunch> plan = pipe_plan(n_frames, PIPE_E, K);
+    auto emit_ready = [&](const PipeLaunch &pl) -> int {
+        for (int b = pl.emit_first; b < pl.emit_first + pl.emit_count; ++b)
+            if (launch_emission(b, std::min((b + 1) * PIPE_E, n_frames))) return V2E_EHIP;
+        return 0;
+    };
+    for (size_t li = 0; K == 1 && li < plan.size(); ++li) {
+        const PipeLaunch &pl = plan[li];
+        const int f = (int)li;
+        if (pl.wait_batch >= 0) // the slot this step writes was read by that emission batch
+            V2E_HIP(hipStreamWaitEvent(s, h->ev_join[pl.wait_batch], 0));
         StepArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.do_count = f < n_frames;
@@ -1299,24 +1350,16 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
             if (p->f64_state) k_step<double, FT><<<grid, BLOCK, 0, s>>>(a, sa);
             else k_step<float, FT><<<grid, BLOCK, 0, s>>>(a, sa);
         });
-        if (f >= 1 && (f % PIPE_E == 0 || f == n_frames)) // frames of batch (f - 1) / E are final: emit them behind the chain
-            if (launch_emission((f - 1) / PIPE_E, f)) return V2E_EHIP;
+        if (emit_ready(pl)) return V2E_EHIP; // batches whose frames are all final: emit them behind the chain
     }
     // two frames per launch (k_step2): launch L counts frames 2L and 2L+1, finalises 2L-1 exactly and validates 2L-2
     const size_t sz_r = p->f64_state ? 8 : 4;
     const int n_launch2 = (n_frames + 1) / 2 + 1;
-    int emitted = 0; // emission batches launched so far
-    for (int L = 0; K == 2 && L < n_launch2; ++L) {
-        const int c0 = 2 * L, c1 = 2 * L + 1;
-        const bool has_c0 = c0 < n_frames, has_c1 = c1 < n_frames;
-        // the frame finalised exactly here: the last one counted before this launch
-        const int e1 = std::min(c0, n_frames) - 1;
-        const bool has_e1 = e1 >= 0;
-        // ... and the speculated one before it: e1 - 1 was speculated iff it is an even frame that had a partner
-        const int e2 = e1 - 1;
-        const bool has_e2 = has_e1 && e2 >= 0 && (e2 % 2 == 0);
-        if (c0 % PIPE_E == 0 && c0 >= PIPE_D && has_c0)
-            V2E_HIP(hipStreamWaitEvent(s, h->ev_join[(c0 - PIPE_D) / PIPE_E], 0));
+    for (int L = 0; K == 2 && L < (int)plan.size(); ++L) {
+        const PipeLaunch &pl = plan[L];
+        const int c0 = 2 * L, c1 = 2 * L + 1, e1 = pl.e1, e2 = pl.e1 - 1;
+        const bool has_c0 = pl.c0 >= 0, has_c1 = pl.c1 >= 0, has_e1 = pl.e1 >= 0, has_e2 = pl.e2 >= 0;
+        if (pl.wait_batch >= 0) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[pl.wait_batch], 0));
         auto slot = [&](int f) { return (size_t)(((f % PIPE_D) + PIPE_D) % PIPE_D); };
         auto clampf = [&](int f) { return (size_t)std::min(std::max(f, 0), n_frames - 1); };
         Step2Args sa;
@@ -1347,11 +1390,7 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
             if (p->f64_state) k_step2<double, FT><<<grid, BLOCK, 0, s>>>(a, sa);
             else k_step2<float, FT><<<grid, BLOCK, 0, s>>>(a, sa);
         });
-        // after this launch every frame <= e1 is final
-        while (emitted * PIPE_E < n_frames && std::min((emitted + 1) * PIPE_E, n_frames) - 1 <= e1) {
-            if (launch_emission(emitted, std::min((emitted + 1) * PIPE_E, n_frames))) return V2E_EHIP;
-            ++emitted;
-        }
+        if (emit_ready(pl)) return V2E_EHIP; // after this launch every frame <= e1 is final
     }
     if (mark(ev_main, s)) return V2E_EHIP;
     V2E_HIP(hipStreamWaitEvent(s, h->ev_join[(n_frames - 1) / PIPE_E], 0)); // join: the run is complete on `s`
@@ -1526,6 +1565,22 @@ int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *
     *ms_count = h->prof_ms[0]; *ms_rank = h->prof_ms[1]; *ms_scan = h->prof_ms[2]; *ms_emit = h->prof_ms[3];
     *launches = h->prof_launches;
     return 0;
+}
+
+int v2e_emu_pipe_plan(int n_frames, int frames_per_batch, int frames_per_launch, int32_t *out, int cap)
+{
+    V2E_REQUIRE(n_frames > 0 && frames_per_batch > 0 && (frames_per_launch == 1 || (frames_per_launch == 2 && frames_per_batch % 2 == 0)),
+                "bad plan arguments");
+    const std::vector<PipeLaunch> plan = pipe_plan(n_frames, frames_per_batch, frames_per_launch);
+    if (out) {
+        V2E_REQUIRE(cap >= (int)plan.size(), "plan buffer too small");
+        for (size_t i = 0; i < plan.size(); ++i) {
+            const PipeLaunch &p = plan[i];
+            const int32_t row[8] = {p.c0, p.c1, p.e1, p.e2, p.wait_batch, p.emit_first, p.emit_count, 0};
+            memcpy(out + 8 * i, row, sizeof(row));
+        }
+    }
+    return (int)plan.size();
 }
 
 int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch, int *step_launches)
