@@ -68,3 +68,51 @@ def test_clip_sharding_covers_all_clips():
     for world in (1, 2, 4, 8):
         allc = sorted(c for r in range(world) for c in clips_of_rank(8, world, r))
         assert allc == list(range(8))
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from v2e_amd.dist import EventStreamGatherer
+    g = EventStreamGatherer(dev, world)
+    ok = True
+    for step in range(4):
+        n = 1000 + 50000 * rank + 7 * step     # unequal per rank: the padded size must come from the gathered counts
+        if step == 3 and rank == 0:
+            n = 0
+        ev = _rows(n + 4, rank, step).to(dev)
+        # keep the main stream busy so that a count read on the wrong stream would race the collective
+        _ = torch.randn(2048, 2048, device=dev) @ torch.randn(2048, 2048, device=dev)
+        g.submit(ev, n)
+        parts = g.result()
+        for r in range(world):
+            nr = 1000 + 50000 * r + 7 * step
+            if step == 3 and r == 0:
+                nr = 0
+            exp = _rows(nr + 4, r, step)[:nr]
+            ok &= parts[r].shape == exp.shape and torch.equal(parts[r].cpu(), exp)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_event_stream_allgather_nccl_world2_unequal_counts():
+    """RCCL path with two ranks and rank-dependent row counts (needs two GPUs; the 1-GPU test box skips it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}

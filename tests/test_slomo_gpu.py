@@ -69,6 +69,17 @@ CONV_CASES = [
     (3, 64, 0, 64, 2, 8, 20, 0),
     (3, 64, 0, 64, 3, 8, 10, 0),      # 8x10 level: two samples stacked per tile, odd sample count
     (3, 32, 32, 96, 4, 8, 10, 0),     # ... with the fused concat
+    # wide (64-channel, CT=2) tiles: conv_dispatch (slomo.hip) selects them once px_tiles * cout/64 >= 4096, which the
+    # 80/100-sample batches of the bench line reach at the 160x128 level (down1, up4) -- same instantiations here
+    (5, 64, 0, 64, 52, 128, 160, 0),  # k_conv<5,4,2,2,4,32,0>: down1.conv2 as the 80-sample batch runs it (52*80 tiles)
+    (5, 8, 0, 64, 52, 128, 160, 1),   # k_conv<5,4,2,2,4,32,1>: fused avg_pool2d loader
+    (5, 4, 0, 128, 300, 20, 96, 0),   # ... ragged tile rows, two channel blocks
+    (3, 128, 0, 64, 52, 128, 160, 0), # launch_conv_tw<3,8,2,0> at TW=32: up4.conv1
+    (3, 8, 8, 64, 52, 128, 160, 0),   # ... with the fused concat (up4.conv2)
+    (3, 16, 0, 64, 52, 128, 160, 1),  # launch_conv_tw<3,8,2,1> at TW=32
+    (3, 16, 0, 64, 52, 128, 160, 2),  # launch_conv_tw<3,8,2,2> at TW=32
+    (3, 8, 0, 128, 300, 20, 96, 2),   # ... ragged tile rows
+    (3, 16, 0, 128, 104, 64, 80, 0),  # wide at an 80-wide level (TW=16)
 ]
 
 
@@ -122,6 +133,56 @@ def test_interpolation_matches_reference_golden():
     assert relerr(eng.last["flow"].cpu().numpy(), z["flow"]) < TOL
     assert relerr(eng.last["intrp"].cpu().numpy().reshape(nt, b, 5, 64, 96), z["intrp"]) < TOL
     assert relerr(Ft.cpu().numpy(), z["Ft"]) < TOL
+
+
+def test_interpolation_matches_reference_at_benchmark_shape():
+    """BASELINE configs[2] SloMo stage as bench.py runs it: 320x256 (346x260 source), U=10, batch of 8 pairs ->
+    80 samples through the interpolation UNet (the wide k_conv<5,4,2,...> / <3,8,2,...,32> tiles are dispatched at
+    the 160x128 level).  The fixture holds the reference's result for 2 pairs; they are tiled 4x, and every copy
+    must match (flow, Ft in full; the interpolation UNet's raw output on the fixture's stride-8 lattice)."""
+    from test_slomo_oracle_golden import bench_shape_inputs
+    z = np.load(os.path.join(GOLDEN, "slomo_320x256.npz"))
+    I0, I1 = bench_shape_inputs(z)
+    ts = list(z["ts"])
+    sf, si = (int(v) for v in z["seeds"])
+    eng, _, _ = _engine(sf, si)
+    rep = 4
+    tI0 = torch.from_numpy(np.tile(I0, (rep, 1, 1, 1))).cuda()
+    tI1 = torch.from_numpy(np.tile(I1, (rep, 1, 1, 1))).cuda()
+    Ft = eng.interpolate(tI0, tI1, ts).cpu().numpy()          # [10, 8, 1, 256, 320]
+    nt, b = len(ts), I0.shape[0]
+    assert Ft.shape == (nt, rep * b, 1, 256, 320)
+    flow = eng.last["flow"].cpu().numpy()
+    intrp = eng.last["intrp"].cpu().numpy().reshape(nt, rep * b, 5, 256, 320)
+    for r in range(rep):
+        sl = slice(r * b, (r + 1) * b)
+        assert relerr(flow[sl], z["flow"]) < TOL
+        assert relerr(intrp[:, sl, :, ::8, ::8], z["intrp_lattice"]) < TOL
+        assert relerr(Ft[:, sl], z["Ft"]) < TOL
+    # copies are the same arithmetic on the same data: bit-identical regardless of the sample's tile position
+    assert np.array_equal(Ft[:, :b], Ft[:, b:2 * b]) and np.array_equal(intrp[:, :b], intrp[:, 3 * b:])
+
+
+def test_interpolation_matches_reference_at_trained_scale():
+    """conv3 heads scaled so |flow| reaches 30 px and the visibility logit 100 (fixture generated by the reference);
+    tolerance as in tests/test_slomo_oracle_golden.py: 1e-5 of each tensor's scale (the scaled heads magnify the
+    reference's own f32 summation-order noise), 1e-4 absolute on Ft."""
+    from test_slomo_oracle_golden import TRAINED_SCALE_FT_TOL, close_scaled
+    from v2e_amd.slomo import SloMoEngine
+    from v2e_amd.synth import portable_unet_state_dict
+    z = np.load(os.path.join(GOLDEN, "slomo_trained_scale_64x96.npz"))
+    I0, I1 = _pairs(z)
+    ts = list(z["ts"])
+    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
+    for sd, s in zip((sd_f, sd_i), z["conv3_scale"]):
+        sd["conv3.weight"] = sd["conv3.weight"] * np.float32(s)
+        sd["conv3.bias"] = sd["conv3.bias"] * np.float32(s)
+    eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
+                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, "cuda")
+    Ft = eng.interpolate(torch.from_numpy(I0).cuda(), torch.from_numpy(I1).cuda(), ts).cpu().numpy()
+    assert close_scaled(eng.last["flow"].cpu().numpy(), z["flow"]) < TOL
+    assert close_scaled(eng.last["intrp"].cpu().numpy().reshape(len(ts), I0.shape[0], 5, 64, 96), z["intrp"]) < TOL
+    assert np.max(np.abs(Ft.astype(np.float64) - z["Ft"])) < TRAINED_SCALE_FT_TOL
 
 
 def test_warp_blend_fusion_match_reference_golden():

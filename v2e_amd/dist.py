@@ -63,8 +63,8 @@ class EventStreamGatherer:
     """all-gather(v) of per-rank event lists [n_r,4] float32 -> every rank gets all of them.
 
     submit(ev, n) packs the first n rows of `ev` (device tensor) into a staging buffer (8 bytes per event) and
-    enqueues, on a side stream: MAX-all-reduce of n, all-gather of the counts, all-gather of the padded
-    payload.  result() returns the per-rank [n_r,4] float32 lists (unpacked on demand) of the most recent
+    enqueues, on a side stream: all-gather of the counts (read back on that stream: every rank pads to the same
+    maximum), all-gather of the padded payload.  result() returns the per-rank [n_r,4] float32 lists (unpacked on demand) of the most recent
     completed submit, in rank order.  On CPU tensors (gloo, tests) everything runs inline.
     """
 
@@ -103,43 +103,40 @@ class EventStreamGatherer:
             nt.record_stream(self.side)
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
-                nmax_t = nt.clone()
-                dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX, group=self.group)
-            nmax = int(nmax_t.item())  # small host sync; the previous payload gather is already enqueued
+                counts = torch.empty(self.world, dtype=torch.int64, device=self.device)
+                dist.all_gather_into_tensor(counts, nt, group=self.group)
+                # read back ON the stream the collective ran on (a read on the main stream would not be ordered
+                # after it, and every rank must size the payload gather from the same numbers)
+                counts_host = counts.cpu()
+            nmax = max(int(counts_host.max()), 1)
             st = self._ensure(slot, nmax)
             pack_events64(ev[:n], st)  # main stream: the event buffer may be overwritten by the next step
             ready.record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
-                self._collect(st, nt, nmax)
+                out = self._out_buffer(nmax)
+                dist.all_gather_into_tensor(out[:self.world * nmax], st[:nmax], group=self.group)
                 self.done_evt[slot] = torch.cuda.Event()
                 self.done_evt[slot].record(self.side)
         else:
-            nmax_t = nt.clone()
-            dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX, group=self.group)
-            nmax = int(nmax_t.item())
-            st = self._ensure(slot, nmax)
-            pack_events64(ev[:n], st)
-            self._collect(st, nt, nmax)
-
-    def _collect(self, st, nt, nmax):
-        counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
-        out = self.out
-        if out is None or out.shape[0] < self.world * max(nmax, 1):
-            out = torch.empty((self.world * max(nmax, 1),), dtype=torch.int64, device=self.device)
-        payload = st[:max(nmax, 1)]
-        if self.cuda:
-            dist.all_gather_into_tensor(counts, nt, group=self.group)
-            dist.all_gather_into_tensor(out[:self.world * max(nmax, 1)], payload, group=self.group)
-        else:
             cl = [torch.zeros_like(nt) for _ in range(self.world)]
             dist.all_gather(cl, nt, group=self.group)
-            counts = torch.cat(cl)
-            pl = [torch.empty_like(payload) for _ in range(self.world)]
-            dist.all_gather(pl, payload.contiguous(), group=self.group)
+            counts_host = torch.cat(cl)
+            nmax = max(int(counts_host.max()), 1)
+            st = self._ensure(slot, nmax)
+            pack_events64(ev[:n], st)
+            pl = [torch.empty_like(st[:nmax]) for _ in range(self.world)]
+            dist.all_gather(pl, st[:nmax].contiguous(), group=self.group)
             out = torch.cat(pl)
-        self.out, self.counts, self.nmax = out, counts, max(nmax, 1)
-        self.bytes_gathered += self.world * max(nmax, 1) * 8
+        self.out, self.counts, self.nmax = out, [int(c) for c in counts_host.tolist()], nmax
+        self.bytes_gathered += self.world * nmax * 8
+
+    def _out_buffer(self, nmax):
+        out = self.out
+        if out is None or not out.is_cuda or out.shape[0] < self.world * nmax:
+            out = torch.empty((self.world * nmax,), dtype=torch.int64, device=self.device)
+            out.record_stream(self.side)
+        return out
 
     def wait(self):
         if self.cuda:
@@ -148,5 +145,5 @@ class EventStreamGatherer:
     def result(self):
         """Per-rank event lists [n_r,4] float32 of the last submit, in rank order (call wait() first)."""
         self.wait()
-        c = self.counts.cpu().tolist()
+        c = self.counts
         return [unpack_events64(self.out[r * self.nmax: r * self.nmax + c[r]]) for r in range(self.world)]
