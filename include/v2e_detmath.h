@@ -50,7 +50,7 @@ V2E_HD void v2e_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 }
 
 /* Stream ids (counter word 2). */
-#define V2E_STREAM_FRAME 0u /* per (pixel, frame): [0],[1] leak normal, [2] shot uniform */
+#define V2E_STREAM_FRAME 0u /* per (pixel, frame pair): [0],[1] two leak normals, [2],[3] two shot uniforms */
 #define V2E_STREAM_THRES 1u /* per pixel: [0],[1] pos-threshold normal, [2],[3] neg-threshold normal */
 #define V2E_STREAM_RATE  2u /* per pixel: [0],[1] noise-rate normal */
 #define V2E_STREAM_PERM  3u /* per (frame, iteration): shuffle key */
@@ -147,14 +147,48 @@ V2E_HD float v2e_normal(uint32_t a, uint32_t b)
     return rad * c;
 }
 
-/* Per-(pixel,frame) draws: leak jitter normal and shot-noise uniform. */
+/* Two independent standard normals from two Philox words: both branches of one Box-Muller transform. */
+V2E_HD void v2e_normal2(uint32_t a, uint32_t b, float *n_cos, float *n_sin)
+{
+    float u1 = v2e_u01_open0(a);
+    float u2 = v2e_u01(b);
+    float rad = sqrtf(-2.0f * v2e_det_logf(u1));
+    float s, c;
+    v2e_det_sincos2pi(u2, &s, &c);
+    *n_cos = rad * c;
+    *n_sin = rad * s;
+}
+
+/*
+ * Per-(pixel, frame) draws: leak-jitter normal and shot-noise uniform.  ONE Philox4x32-10 call serves the two
+ * consecutive frames of a pair q = (frame + 1) >> 1 (frames 2q-1 and 2q; frame 0 is the first frame, which draws
+ * from the THRES / RATE streams only): words [0],[1] -> both Box-Muller branches (cosine: the odd frame, sine: the
+ * even frame), [2] -> the odd frame's uniform, [3] -> the even frame's.  A kernel that advances both frames of a
+ * pair in one launch (k_step2) pays for one call; v2e_draw_frame is the same stream read one frame at a time.
+ */
+V2E_HD uint32_t v2e_frame_pair(uint32_t frame) { return (frame + 1u) >> 1; }
+V2E_HD uint32_t v2e_frame_half(uint32_t frame) { return (frame + 1u) & 1u; } /* 0: odd frame (first of its pair) */
+
+V2E_HD void v2e_draw_pair(uint64_t seed, uint32_t clip, uint32_t pair, uint32_t pixel, int want_normal,
+                          float *randn_odd, float *u_odd, float *randn_even, float *u_even)
+{
+    uint32_t o[4];
+    v2e_philox4x32(pixel, pair, V2E_STREAM_FRAME, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    *randn_odd = 0.0f;
+    *randn_even = 0.0f;
+    if (want_normal) v2e_normal2(o[0], o[1], randn_odd, randn_even);
+    *u_odd = v2e_u01(o[2]);
+    *u_even = v2e_u01(o[3]);
+}
+
 V2E_HD void v2e_draw_frame(uint64_t seed, uint32_t clip, uint32_t frame, uint32_t pixel,
                            float *leak_randn, float *shot_u)
 {
-    uint32_t o[4];
-    v2e_philox4x32(pixel, frame, V2E_STREAM_FRAME, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-    *leak_randn = v2e_normal(o[0], o[1]);
-    *shot_u = v2e_u01(o[2]);
+    float r0, u0, r1, u1;
+    v2e_draw_pair(seed, clip, v2e_frame_pair(frame), pixel, 1, &r0, &u0, &r1, &u1);
+    const int even = (int)v2e_frame_half(frame);
+    *leak_randn = even ? r1 : r0;
+    *shot_u = even ? u1 : u0;
 }
 
 /* Per-(pixel,frame) photoreceptor-noise draw (emulator.py:698 in philox mode). */

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
         float r = 0.f, u = 0.f;
         const bool shot_here = a.do_shot && (a.rng_mode == V2E_RNG_PHILOX || shot_tape != nullptr);
         if (a.rng_mode == V2E_RNG_PHILOX) {
-            if (a.do_leak || a.do_shot)
+            if ((a.do_leak && a.jit_f != 0.f) || a.do_shot)
                 v2e_draw_frame(a.seed, (uint32_t)clip, frame_idx, (uint32_t)p, &r, &u);
         } else {
             if (a.do_leak) r = leak_tape[fp];

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_main(KArgs a, FusedArgs fa)
     __builtin_amdgcn_sched_barrier(0);
     // ---- arithmetic that depends on no memory, done while those loads are in flight
     float rng_r = 0.f, rng_u = 0.f; // count(f): leak normal / shot uniform of this pixel
-    if (fa.do_count && valid && (a.do_leak || a.do_shot))
+    if (fa.do_count && valid && ((a.do_leak && a.jit_f != 0.f) || a.do_shot))
         v2e_draw_frame(a.seed, (uint32_t)clip, fbase + fa.fidx_c, (uint32_t)p, &rng_r, &rng_u);
     uint32_t pk[4] = {0, 0, 0, 0};  // emit(f-1): shuffle round keys of iteration `lane` (first chunk)
     float tab_start = 0.f, tab_step = 0.f, tab_end = 0.f;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, StepArgs sa)
     // ---- arithmetic that depends on no memory but fbase, done while those loads are in flight
     const uint32_t fbase = sload_wait(fbase_pending);
     float rng_r = 0.f, rng_u = 0.f;
-    if (sa.do_count && valid && (a.do_leak || a.do_shot))
+    if (sa.do_count && valid && ((a.do_leak && a.jit_f != 0.f) || a.do_shot))
         v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c, (uint32_t)p, &rng_r, &rng_u);
     V2E_STAMP_S(5);
     if (U8 && sa.do_count) { // published by the barriers of block_max_finish / the one below
@@ -495,9 +495,15 @@ __global__ __launch_bounds__(BLOCK) void k_step2(KArgs a, Step2Args sa)
     // ---- arithmetic that depends on no memory but fbase, done while those loads are in flight
     const uint32_t fbase = sload_wait(fbase_pending);
     float r0 = 0.f, u0 = 0.f, r1 = 0.f, u1 = 0.f;
-    if (valid && (a.do_leak || a.do_shot)) {
-        if (has_c0) v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c0, (uint32_t)p, &r0, &u0);
-        if (has_c1) v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c1, (uint32_t)p, &r1, &u1);
+    const bool need_r = a.do_leak && a.jit_f != 0.f; // a zero jitter fraction multiplies the normal away (emulator_utils.py:126)
+    if (valid && (need_r || a.do_shot)) {
+        const uint32_t f0 = fbase + sa.fidx_c0;
+        if (has_c0 && has_c1 && v2e_frame_half(f0) == 0u) { // c0, c1 are the two frames of one pair: one Philox call
+            v2e_draw_pair(a.seed, (uint32_t)clip, v2e_frame_pair(f0), (uint32_t)p, need_r, &r0, &u0, &r1, &u1);
+        } else {
+            if (has_c0) v2e_draw_frame(a.seed, (uint32_t)clip, f0, (uint32_t)p, &r0, &u0);
+            if (has_c1) v2e_draw_frame(a.seed, (uint32_t)clip, fbase + sa.fidx_c1, (uint32_t)p, &r1, &u1);
+        }
     }
     V2E_STAMP_2(5);
     if (U8 && has_c0) { // published by the barriers of block_max2_finish
