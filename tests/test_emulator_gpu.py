@@ -61,10 +61,11 @@ def test_hip_philox_frame_api_matches_reference(name):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
 
 
-# use_graph: low bits 0 plain launches / 1 hipGraph; |64 k_step chain + deferred emission batches (two frames per
-# launch on small grids, |128: one), |32 one k_main per frame (emission on the chain), |16 unfused
-# count/rank/scan/emit; none = size heuristic
-PIPELINES = [0, 1, 64, 65, 192, 193, 32, 33, 16, 17]
+# use_graph: low bits 0 plain launches / 1 hipGraph; no pipeline bit: k_chain (K frames per launch, state in registers)
+# wherever it can run, |256 insists on it; the earlier pipelines: |64 k_step chain + deferred emission batches (two
+# frames per launch on small grids, |128: one), |32 one k_main per frame (emission on the chain), |16 unfused
+# count/rank/scan/emit, |512 their size heuristic
+PIPELINES = [0, 1, 256, 257, 64, 65, 192, 193, 32, 33, 16, 17, 513]
 
 
 @pytest.mark.parametrize("use_graph", PIPELINES)
@@ -110,6 +111,30 @@ def test_step_chain_pipeline_ring_wraps(name, pipe_e, monkeypatch):
             assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
 
 
+@pytest.mark.parametrize("chain_k", [1, 2, 3, 5, 8, 32])
+@pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260", "philox_defaults_346x260"])
+def test_chain_launch_lengths_and_ring_wrap(name, chain_k, monkeypatch):
+    """k_chain with few frames per launch: the ring of 3 K frame slots wraps several times within the fixture clip,
+    launches wait on emission batches, partial last launch; with the refractory fixture every launch redoes its
+    predecessor (rule on in most frames), several passes per launch once K > 1."""
+    monkeypatch.setenv("V2E_AMD_CHAIN_K", str(chain_k))
+    fx = PhiloxFixture(name)
+    for use_graph in (256, 257):
+        emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+        ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph)
+        assert list(counts) == list(fx.n_events)
+        row = 0
+        for k, n in enumerate(counts):
+            if n:
+                assert sha(ev[row:row + n]) == fx.ev_sha[k], "frame %d event digest differs" % k
+            row += n
+        st = _state(emu)
+        assert sha(st["base_log_frame"]) == fx.base_sha
+        assert sha(st["lp_log_frame"]) == fx.lp_sha
+        if fx.ts_mem_sha:
+            assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
+
+
 @pytest.mark.parametrize("refr", [0.0005, 0.002])
 def test_pipelines_agree_on_benchmark_clip(refr, oracle_lib):
     """BASELINE configs[1] at full size (346x260, 300 frames, dt = 1/300 s): every device-resident pipeline gives the
@@ -123,7 +148,7 @@ def test_pipelines_agree_on_benchmark_clip(refr, oracle_lib):
     kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak_rate_hz=.01, shot_noise_rate_hz=.001,
               refractory_period_s=refr)
     ref = None
-    for use_graph in (1, 129, 33, 17):  # two-frame chain, one-frame chain, k_main per frame, 4-kernel
+    for use_graph in (257, 65, 129, 33, 17):  # k_chain, two-frame chain, one-frame chain, k_main per frame, 4-kernel
         emu = EventEmulator(device="cuda", seed=1, rng_mode="philox", **kw)
         ev, counts = emu.generate_events_batch(frames, times, use_graph=use_graph)
         st = (sha(ev), list(counts), sha(emu.base_log_frame.cpu().numpy()), sha(emu.timestamp_mem.cpu().numpy()),
@@ -319,7 +344,7 @@ def test_many_iterations_grow_scratch(oracle_lib):
     assert ora.last["M"] > 64
 
 
-@pytest.mark.parametrize("use_graph", [65, 193, 33, 17])
+@pytest.mark.parametrize("use_graph", [257, 65, 193, 33, 17])
 @pytest.mark.parametrize("refr", [0.0, 0.0004])
 def test_device_resident_clip_many_iterations(use_graph, refr, oracle_lib):
     """> 31 events per pixel per frame: several 64-key chunks in the fused kernels, refractory on/off."""

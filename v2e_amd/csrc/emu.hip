@@ -51,6 +51,8 @@ struct FrameCtl {
     float ts_start[32], ts_stepf[32];
     uint32_t refr_mask; // bit n-1: refractory_period_s > delta_time / n
     float ts_end;       // (float)t_frame
+    uint32_t refr_on_n; // smallest iteration count n >= 1 for which the rule is on (0xFFFFFFFF: never); the predicate is monotone in n
+    uint32_t pad_;
 };
 
 __host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_hz, double shot_rate_hz, double refr_s)
@@ -70,6 +72,18 @@ __host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_h
         c.ts_start[n - 1] = start;
         c.ts_stepf[n - 1] = n > 1 ? (end - start) / (float)(n - 1) : 0.0f;
         if (refr_s > ts_step) c.refr_mask |= 1u << (n - 1);
+    }
+    c.refr_on_n = 0xFFFFFFFFu;
+    c.pad_ = 0u;
+    if (refr_s > 0) { // emulator.py:830 `refractory_period_s > ts_step`, ts_step = delta_time / n: first n that satisfies it
+        const double g = dt / refr_s;
+        if (!(g > 4.0e9)) {
+            long long n0 = (long long)std::floor(g) - 2;
+            if (n0 < 1) n0 = 1;
+            while (!(refr_s > dt / (double)n0) && n0 < 0xFFFFFFFEll) ++n0;
+            while (n0 > 1 && refr_s > dt / (double)(n0 - 1)) --n0;
+            c.refr_on_n = (uint32_t)n0;
+        }
     }
     return c;
 }
@@ -631,6 +645,7 @@ __global__ __launch_bounds__(BLOCK) void k_permute(const float4 *__restrict__ in
 
 #include "emu_fused.h"
 #include "emu_pipe.h"
+#include "emu_chain.h"
 
 } // namespace
 
@@ -707,6 +722,19 @@ struct v2e_emu {
     std::vector<hipEvent_t> ev_fork, ev_join;
     double prof_emit_ms = 0.0;
     int prof_emit_batches = 0, prof_step_launches = 0;
+    // K-frames-per-launch chain (emu_chain.h); allocated on first use by v2e_emu_run
+    int ch_K = 0, ch_D = 0, ch_nwp = 0, ch_launch_cap = 0, ch_resident_clips = 0, ch_max_blocks = 0;
+    uint32_t *ch_cnt = nullptr;     // [ch_D][n_clips][npx_pad]
+    uint16_t *ch_wmax = nullptr;    // [ch_D][n_clips][ch_nwp]
+    uint8_t *ch_wtot = nullptr;     // [ch_D][n_clips][nkeys_cap][ch_nwp]
+    float *ch_tsold = nullptr;      // [ch_D][n_clips][npx_pad] (refractory runs)
+    uint32_t *ch_gM = nullptr;      // [ch_launch_cap][ch_K + 1][n_clips][ch_K]
+    unsigned *ch_bar = nullptr;     // [ch_launch_cap][ch_K][n_clips]
+    void *ch_base2 = nullptr, *ch_lp2 = nullptr; // second set of state planes (ping-pong between launches)
+    float *ch_ts2 = nullptr;
+    CFrame *ch_cf = nullptr;        // [ch_K][n_clips]
+    uint32_t *ch_cT = nullptr, *ch_ckbase = nullptr, *ch_cperm = nullptr, *ch_cpre = nullptr;
+    int ch_nkeys_cap = 0;           // nkeys_cap the chain scratch was sized for
 };
 
 static thread_local char g_err[512] = "";
@@ -895,6 +923,9 @@ int v2e_emu_destroy(v2e_emu *h)
     for (hipEvent_t e : h->ev_fork) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_join) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
+    hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_gM); hipFree(h->ch_bar);
+    hipFree(h->ch_base2); hipFree(h->ch_lp2); hipFree(h->ch_ts2); hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase);
+    hipFree(h->ch_cperm); hipFree(h->ch_cpre);
     hipFree(h->cnt_b); hipFree(h->gtot[0]); hipFree(h->gtot[1]); hipFree(h->gmaxv[0]); hipFree(h->gmaxv[1]);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     hipFree(h->off_dev);
@@ -1398,6 +1429,190 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
     return 0;
 }
 
+// ------------------------------------------------------------------ K frames per launch (emu_chain.h)
+static int chain_frames_per_launch(const v2e_emu *h)
+{
+    // the launch boundary (~4 us) is paid once per K frames; a redo (rule-on frame: ~1 % of the frames of the benchmark
+    // clip) repeats a whole launch, and the ring is 3 K frame slots: 16 frames keep both small
+    int K = 16;
+    if (const char *ev = getenv("V2E_AMD_CHAIN_K")) { const int v = atoi(ev); if (v >= 1 && v <= CHAIN_K_MAX) K = v; }
+    return K;
+}
+
+// scratch of the chain pipeline: everything a captured run must not allocate
+static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
+{
+    const int K = chain_frames_per_launch(h);
+    const bool has_refr = p->refractory_period_s > 0;
+    if (h->ch_K != K || h->ch_nkeys_cap != h->nkeys_cap) {
+        hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_cf); hipFree(h->ch_cT);
+        hipFree(h->ch_ckbase); hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_gM); hipFree(h->ch_bar);
+        h->ch_cnt = nullptr; h->ch_wmax = nullptr; h->ch_wtot = nullptr; h->ch_tsold = nullptr; h->ch_cf = nullptr; h->ch_cT = nullptr;
+        h->ch_ckbase = nullptr; h->ch_cperm = nullptr; h->ch_cpre = nullptr; h->ch_gM = nullptr; h->ch_bar = nullptr;
+        h->ch_launch_cap = 0;
+        h->ch_K = K;
+        h->ch_D = 3 * K; // batch b is read by its emission while launch b + 1 validates it and launch b + 2 writes its own slots
+        h->ch_nwp = (h->ngroups * (BLOCK / WAVE) + 15) / 16 * 16;
+        h->ch_nkeys_cap = h->nkeys_cap;
+        const size_t nc = (size_t)h->n_clips;
+        V2E_HIP(hipMalloc(&h->ch_cnt, sizeof(uint32_t) * h->ch_D * nc * h->npx_pad));
+        V2E_HIP(hipMalloc(&h->ch_wmax, sizeof(uint16_t) * h->ch_D * nc * h->ch_nwp));
+        V2E_HIP(hipMemset(h->ch_wmax, 0, sizeof(uint16_t) * h->ch_D * nc * h->ch_nwp));
+        V2E_HIP(hipMalloc(&h->ch_wtot, (size_t)h->ch_D * nc * h->nkeys_cap * h->ch_nwp));
+        V2E_HIP(hipMemset(h->ch_wtot, 0, (size_t)h->ch_D * nc * h->nkeys_cap * h->ch_nwp));
+        V2E_HIP(hipMalloc(&h->ch_cf, sizeof(CFrame) * K * nc));
+        V2E_HIP(hipMemset(h->ch_cf, 0, sizeof(CFrame) * K * nc));
+        V2E_HIP(hipMalloc(&h->ch_cT, sizeof(uint32_t) * K * nc * h->nkeys_cap));
+        V2E_HIP(hipMalloc(&h->ch_ckbase, sizeof(uint32_t) * K * nc * h->nkeys_cap));
+        V2E_HIP(hipMalloc(&h->ch_cperm, sizeof(uint32_t) * K * nc * h->max_iters * 8));
+        V2E_HIP(hipMalloc(&h->ch_cpre, sizeof(uint32_t) * K * nc * h->nkeys_cap * h->ch_nwp));
+        int per_cu = 0;
+        V2E_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<double, uint8_t>, BLOCK, 0));
+        per_cu = per_cu > 4 ? 4 : (per_cu > 1 ? per_cu - 1 : 0); // the API can over-report by one per CU (MI355X guide)
+        h->ch_max_blocks = per_cu * h->n_cu;
+        if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+    }
+    const int n_launch = (n_frames + K - 1) / K + 1;
+    if (has_refr) {
+        if (!h->ch_tsold) V2E_HIP(hipMalloc(&h->ch_tsold, sizeof(float) * (size_t)h->ch_D * h->n_clips * h->npx_pad));
+        if (!h->ch_base2) {
+            const size_t n = (size_t)h->n_clips * h->npx_pad;
+            V2E_HIP(hipMalloc(&h->ch_base2, sizeof(double) * n));
+            V2E_HIP(hipMalloc(&h->ch_lp2, sizeof(double) * n));
+            V2E_HIP(hipMalloc(&h->ch_ts2, sizeof(float) * n));
+            V2E_HIP(hipMemset(h->ch_base2, 0, sizeof(double) * n));
+            V2E_HIP(hipMemset(h->ch_lp2, 0, sizeof(double) * n));
+            V2E_HIP(hipMemset(h->ch_ts2, 0, sizeof(float) * n));
+        }
+        if (n_launch > h->ch_launch_cap) {
+            hipFree(h->ch_gM); hipFree(h->ch_bar);
+            h->ch_launch_cap = n_launch;
+            V2E_HIP(hipMalloc(&h->ch_gM, sizeof(uint32_t) * (size_t)n_launch * (K + 1) * h->n_clips * K));
+            V2E_HIP(hipMalloc(&h->ch_bar, sizeof(unsigned) * (size_t)n_launch * K * h->n_clips));
+            if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+        }
+    }
+    const size_t nb = (size_t)n_launch;
+    while (h->ev_fork.size() < nb) {
+        hipEvent_t e0, e1;
+        V2E_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        V2E_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        h->ev_fork.push_back(e0);
+        h->ev_join.push_back(e1);
+    }
+    return 0;
+}
+
+// can this run go through k_chain?  (the redo path needs the grid co-resident for its rendezvous)
+static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p)
+{
+    if (h->max_iters > CHAIN_MAX_ITERS) return false;
+    if (p->refractory_period_s > 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<double, uint8_t>, BLOCK, 0) != hipSuccess) return false;
+        per_cu = per_cu > 4 ? 4 : (per_cu > 1 ? per_cu - 1 : 0);
+        if ((long long)h->ngroups > (long long)per_cu * h->n_cu) return false;
+    }
+    return true;
+}
+
+static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
+                             float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, std::vector<hipEvent_t> *ev_main = nullptr,
+                             std::vector<hipEvent_t> *ev_side = nullptr)
+{
+    const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
+    const bool has_refr = p->refractory_period_s > 0;
+    const int K = h->ch_K, D = h->ch_D, NC = h->n_clips;
+    const int nB = (n_frames + K - 1) / K;           // batches = chain launches with frames
+    const int nL = has_refr ? nB + 1 : nB;           // + the tail launch that validates the last batch
+    V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * NC, s));
+    V2E_HIP(zero_async(h->pipe_off, sizeof(unsigned long long) * 2 * NC, s));
+    if (has_refr) {
+        V2E_HIP(zero_async(h->ch_gM, sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K, s));
+        V2E_HIP(zero_async(h->ch_bar, sizeof(unsigned) * (size_t)nL * K * NC, s));
+    }
+    auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t st) -> int {
+        if (!v) return 0;
+        hipEvent_t e;
+        V2E_HIP(hipEventCreate(&e));
+        v->push_back(e);
+        V2E_HIP(hipEventRecord(e, st));
+        return 0;
+    };
+    // clips resident at once: with a refractory period every workgroup of a clip must be resident for the redo rendezvous
+    int gy = NC;
+    if (has_refr) gy = std::max(1, std::min(NC, h->ch_max_blocks / std::max(h->ngroups, 1)));
+    dim3 grid(h->ngroups, gy);
+    const bool small_grid = (long long)h->ngroups * gy <= 4ll * h->n_cu;
+    auto launch_emission = [&](int b) -> int {
+        CEmitArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.ctl = h->run_ctl; ea.recs = recs; ea.fidx_base = h->run_fidx;
+        ea.f0 = b * K; ea.nE = std::min((b + 1) * K, n_frames) - ea.f0; ea.D = D; ea.n_clips = NC;
+        ea.nwp = h->ch_nwp; ea.nwaves = h->ngroups * (BLOCK / WAVE); ea.E = K;
+        ea.cnt = h->ch_cnt; ea.wmax = h->ch_wmax; ea.wtot = h->ch_wtot; ea.tsold = has_refr ? h->ch_tsold : nullptr;
+        ea.cf = h->ch_cf; ea.cT = h->ch_cT; ea.ckbase = h->ch_ckbase; ea.cperm = h->ch_cperm; ea.cpre = h->ch_cpre;
+        ea.events = (float4 *)events; ea.cap = cap;
+        ea.off_in = h->pipe_off + (size_t)(b & 1) * NC;
+        ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * NC;
+        constexpr int REC_LDS = 32000; // 4 waves x 2000 event records (a pass covers at most 64 x 31)
+        ea.capw = REC_LDS / 4 / (BLOCK / WAVE);
+        V2E_HIP(hipEventRecord(h->ev_fork[b], s));
+        V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
+        if (mark(ev_side, h->side)) return V2E_EHIP;
+        static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
+        if (!no_emit) {
+            k_cframe<<<dim3(1, NC, ea.nE), BLOCK, 0, h->side>>>(a, ea);
+            k_cemit<<<dim3(h->ngroups, NC, ea.nE), BLOCK, REC_LDS, h->side>>>(a, ea);
+        }
+        if (mark(ev_side, h->side)) return V2E_EHIP;
+        V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
+        (void)small_grid;
+        return 0;
+    };
+    // state planes: X[0] the caller's (bound) planes, X[1] the engine's second set; launch L reads X[L % 2], writes X[(L + 1) % 2]
+    void *xb[2] = {h->base, has_refr ? h->ch_base2 : h->base}, *xl[2] = {h->lp, has_refr ? h->ch_lp2 : h->lp};
+    float *xt[2] = {h->ts_mem, has_refr ? h->ch_ts2 : h->ts_mem};
+    for (int L = 0; L < nL; ++L) {
+        const bool tail = L >= nB;
+        ChainArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.frames = frames; ca.frame_stride = (unsigned long long)NC * h->npx * esz;
+        ca.ctl = h->run_ctl; ca.fidx_base = h->run_fidx;
+        ca.f0 = tail ? n_frames : L * K; ca.nf = tail ? 0 : std::min((L + 1) * K, n_frames) - L * K;
+        ca.pf0 = (L - 1) * K; ca.pnf = (has_refr && L > 0) ? std::min(L * K, n_frames) - (L - 1) * K : 0;
+        ca.D = D; ca.n_clips = NC; ca.nwp = h->ch_nwp; ca.K = K; ca.ngroups = h->ngroups;
+        ca.cnt = h->ch_cnt; ca.wmax = h->ch_wmax; ca.wtot = h->ch_wtot; ca.tsold = has_refr ? h->ch_tsold : nullptr;
+        if (has_refr) {
+            ca.gM_cur = h->ch_gM + (size_t)L * (K + 1) * NC * K;
+            ca.gM_prev = h->ch_gM + (size_t)(L > 0 ? L - 1 : 0) * (K + 1) * NC * K;
+            ca.bar_prev = h->ch_bar + (size_t)(L > 0 ? L - 1 : 0) * K * NC;
+        }
+        const int in = L % 2, out = tail ? 0 : (L + 1) % 2, pin = (L + 1) % 2;
+        ca.base_in = xb[in]; ca.lp_in = xl[in]; ca.ts_in = xt[in];
+        ca.base_fix = xb[in]; ca.lp_fix = xl[in]; ca.ts_fix = xt[in];
+        ca.base_out = xb[out]; ca.lp_out = xl[out]; ca.ts_out = xt[out];
+        ca.base_pin = xb[pin]; ca.lp_pin = xl[pin]; ca.ts_pin = xt[pin];
+        ca.recs = recs;
+        ca.store_out = tail && in != 0;
+        // ring slots of batch L were last read by the emission of batch L - 3
+        if (!tail && L >= 3) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[L - 3], 0));
+        if (L == 0 && mark(ev_main, s)) return V2E_EHIP;
+        DISPATCH_FT(dtype, {
+            const size_t px_lds = (size_t)K * BLOCK * sizeof(FT);
+            if (p->f64_state) k_chain<double, FT><<<grid, BLOCK, px_lds, s>>>(a, ca);
+            else k_chain<float, FT><<<grid, BLOCK, px_lds, s>>>(a, ca);
+        });
+        // what is final now: with a refractory period batch L - 1 (just validated), without one batch L itself
+        const int fin = has_refr ? L - 1 : L;
+        if (fin >= 0 && fin < nB && launch_emission(fin)) return V2E_EHIP;
+    }
+    if (mark(ev_main, s)) return V2E_EHIP;
+    V2E_HIP(hipStreamWaitEvent(s, h->ev_join[nB - 1], 0)); // join: the run is complete on `s`
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames, const double *t_prev,
                 const double *t_frame, uint32_t frame_idx0, float *events, uint64_t cap, v2e_frame_rec *recs_dev,
                 int use_graph, void *stream)
@@ -1436,13 +1651,22 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     // frame with emission on the chain once the grid is large enough to be throughput-bound (each pixel touched
     // once).  |32 / |64 force the one or the other.
     const bool small_grid = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu;
-    const bool fused = !legacy && ((use_graph & 32) != 0 || (!(use_graph & 64) && !small_grid));
-    const bool pipe = !legacy && !fused;
+    // K frames per launch with the state in registers (emu_chain.h) wherever it can run: |256 insists on it, |512 or any
+    // of the explicit pipeline bits (|16 |32 |64 |128) selects the earlier pipelines (kept for A/B and as the fallback)
+    const bool chain_ok = chain_eligible(h, p);
+    V2E_REQUIRE(!(use_graph & 256) || chain_ok, "k_chain cannot run this configuration (max_iters or a grid too large for the redo rendezvous)");
+    const bool chain = chain_ok && ((use_graph & 256) != 0 || (!(use_graph & (16 | 32 | 64 | 128 | 512)) && !getenv("V2E_AMD_NO_CHAIN")));
+    const bool fused = !legacy && !chain && ((use_graph & 32) != 0 || (!(use_graph & 64) && !small_grid));
+    const bool pipe = !legacy && !fused && !chain;
     // Two frames per launch (k_step2, second frame finalised speculatively) needs the grid co-resident for the
     // rare in-kernel rendezvous of its recovery path: grids of at most two workgroups per CU.  |128 forces one
     // frame per launch (also what a caller should pick for clips on which the refractory rule is mostly active).
     const int K = (pipe && h->pipe_E % 2 == 0 && (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu && !(use_graph & 128) &&
                    !getenv("V2E_AMD_NO_SPECULATION")) ? 2 : 1;
+    if (chain) {
+        rc = chain_alloc(h, p, n_frames);
+        if (rc) return rc;
+    }
     if (pipe) { // everything the capture must not allocate
         if (p->refractory_period_s > 0 && !h->pipe_tsold)
             V2E_HIP(hipMalloc(&h->pipe_tsold, sizeof(float) * (size_t)h->pipe_D * h->n_clips * h->npx_pad));
@@ -1465,9 +1689,31 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
             return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs);
         }
         if (fused) return enqueue_run_fused(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs, nm);
+        if (chain) return enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st);
         return enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, K);
     };
     if (mode == 0) return enqueue(s, nullptr, nullptr);
+    if (mode == 2 && chain) { // instrumented: chain time from events on `s`, emission batches from events on the side stream
+        std::vector<hipEvent_t> em, es;
+        rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, &em, &es);
+        if (rc == 0) {
+            V2E_HIP(hipStreamSynchronize(s));
+            for (int k = 0; k < 4; ++k) h->prof_ms[k] = 0.0;
+            float ms = 0.f;
+            V2E_HIP(hipEventElapsedTime(&ms, em.front(), em.back()));
+            h->prof_ms[0] = ms;
+            h->prof_step_launches = (n_frames + h->ch_K - 1) / h->ch_K + (p->refractory_period_s > 0 ? 1 : 0);
+            for (size_t i = 0; i + 1 < es.size(); i += 2) {
+                V2E_HIP(hipEventElapsedTime(&ms, es[i], es[i + 1]));
+                h->prof_ms[3] += ms;
+            }
+            h->prof_launches = n_frames;
+            h->prof_emit_batches = (int)(es.size() / 2);
+        }
+        for (hipEvent_t e : em) hipEventDestroy(e);
+        for (hipEvent_t e : es) hipEventDestroy(e);
+        return rc;
+    }
     if (mode == 2 && pipe) { // instrumented: step-chain time from events on `s`, emission batches from events on the side stream
         std::vector<hipEvent_t> em, es;
         rc = enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, K, &em, &es);
@@ -1519,7 +1765,8 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&a, sizeof(a)); push(&frames, sizeof(frames)); push(&dtype, sizeof(dtype)); push(&n_frames, sizeof(n_frames));
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
-    int lg = legacy ? 1 : (fused ? 2 : 0); push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
+    int lg = legacy ? 1 : (fused ? 2 : (chain ? 3 : 0)); push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
+    push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold));
     push(&h->pipe_tsold, sizeof(h->pipe_tsold)); push(&h->pipe_bck, sizeof(h->pipe_bck)); push(&K, sizeof(K));
     int nis = getenv("V2E_AMD_NO_INKERNEL_SYNC") ? 1 : 0; push(&nis, sizeof(nis));
     if (!h->graph || key != h->graph_key) {

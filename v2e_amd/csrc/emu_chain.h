@@ -1,0 +1,608 @@
+// emu_chain.h -- K frames per chain launch, per-pixel state in registers (included by emu.hip after emu_pipe.h).
+//
+// The frame-to-frame dependency of the DVS pixel model is per pixel, except for ONE global number per frame: the
+// frame's max event count M, and only through the refractory rule (emulator.py:830: the rule is applied iff
+// refractory_period_s > delta_time / M).  When the rule is off a pixel's pass count is its own count, so a pixel
+// can be advanced through any number of frames without looking at another pixel.  k_chain does exactly that:
+//
+//   one launch = K consecutive frames.  A thread owns a pixel: it loads base_log_frame / lp_log_frame /
+//   timestamp_mem / thresholds / noise rate ONCE, then per frame: lin-log (LDS table) -> IIR low-pass -> leak ->
+//   exact floor-division -> shot-noise decision -> count word to the frame's ring slot -> finalise (emulator.py:
+//   936-942) ASSUMING the rule is off -> next frame.  State goes back to HBM once per launch: the per-pixel state
+//   crosses HBM once per K frames, and a launch boundary (~4 us between dependent launches, longer than two
+//   frames of arithmetic) is paid once per K frames instead of once per frame (k_step) or two (k_step2).
+//
+//   What the event list needs beyond the count words is produced on the way, per WAVE (no workgroup barrier in the
+//   frame loop): the wave's max count and its (iteration, polarity) event totals (ballot/popcount), key-major u8
+//   rows [key][wave].  A prefix over waves (k_cframe) turns them into row offsets; k_cemit writes the rows, every
+//   wave on its own.  No per-workgroup totals pass (k_tot_multi), no second read of the count plane for it.
+//
+//   Speculation check: a wave whose max count reaches the frame's rule threshold (FrameCtl::refr_on_n, host-
+//   computed with the reference's own float64 predicate) publishes it with an atomicMax into the launch's gM row.
+//   The NEXT launch reads that row first.  All zero (almost always): the previous launch was right.  Otherwise the
+//   first flagged frame j was a rule-on frame and M(j) = gM[j] is exact (everything before j was right), and the
+//   previous launch is REDONE from its own input state (state planes ping-pong between launches, so it is still
+//   there) with j finalised by the rule -- ts_mem as it was goes to the frame's tsold slot for the emission side,
+//   the wave totals are the filtered ones -- frames after j speculated again, published into the next gM row,
+//   one grid rendezvous (clip_barrier, co-resident grids only), and the check repeats on the frames after j.
+//   lp_log_frame never depends on the speculation; everything is deterministic.
+//
+//   Clips (independent pixel arrays) beyond what is co-resident are walked by a loop inside the workgroup.
+#pragma once
+
+constexpr int CHAIN_K_MAX = 32;
+constexpr int CHAIN_MAX_ITERS = 1024; // k_cframe keeps one total per key in LDS
+
+struct ChainArgs {
+    const void *frames;               // frames of the run, frame f at frames + f * frame_stride
+    unsigned long long frame_stride;  // bytes
+    const FrameCtl *ctl;              // [n_frames][n_clips]
+    const uint32_t *fidx_base;
+    int f0, nf;                       // this launch advances frames [f0, f0 + nf) of the run (nf = 0: tail launch)
+    int pf0, pnf;                     // the previous launch's frames, to be validated (pnf = 0: nothing to validate)
+    int D, n_clips, nwp, K, ngroups;
+    uint32_t *cnt;                    // [D][n_clips][npx_pad] count words, slot = frame % D
+    uint16_t *wmax;                   // [D][n_clips][nwp] per-wave max count
+    uint8_t *wtot;                    // [D][n_clips][nkeys_cap][nwp] per-wave key totals (<= 64 each)
+    float *tsold;                     // [D][n_clips][npx_pad] ts_mem before a rule-on frame's update, or nullptr
+    uint32_t *gM_prev, *gM_cur;       // [K + 1][n_clips][K] rule-on maxima: row r = after r redo passes
+    unsigned *bar_prev;               // [K][n_clips] rendezvous counters of the redo passes on the previous launch
+    const void *base_in, *lp_in;      // state as the previous launch left it
+    const float *ts_in;
+    void *base_out, *lp_out;          // where this launch leaves it
+    float *ts_out;
+    const void *base_pin, *lp_pin;    // what the previous launch started from (redo)
+    const float *ts_pin;
+    void *base_fix, *lp_fix;          // == *_in, written after a redo so that the next launch can redo this one
+    float *ts_fix;
+    v2e_frame_rec *recs;              // [n_frames][n_clips]
+    int store_out;                    // tail launch: state must be copied to *_out even without a redo
+};
+
+// exact floor(a/b), a >= 0, b > 0, from a reciprocal computed once per launch: a*rb is within a few ulp of a/b, so
+// its floor is the true floor or one off, and the exactly rounded remainder a - q*b decides (same value as
+// floor_div_pos, which equals c10::div_floor_floating for these operands).  Anything unusual takes floor_div_pos.
+template <typename R> __device__ __forceinline__ R floor_div_rcp(R a, R b, R rb)
+{
+    if (a < b) return (R)0;
+    R q = floor(a * rb);
+    R r = fma(-q, b, a);
+    if (r < (R)0) { q -= (R)1; r += b; }
+    else if (r >= b) { q += (R)1; r -= b; }
+    if (!(r >= (R)0 && r < b)) return floor_div_pos<R>(a, b);
+    return q;
+}
+
+template <typename R, typename FT>
+__global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
+{
+    extern __shared__ unsigned char s_dyn[]; // [K][BLOCK] pixels of the pass
+    FT *s_px = (FT *)s_dyn;
+    __shared__ float s_lutL[256];
+    __shared__ double s_lutI[256];
+    __shared__ uint32_t s_exact[CHAIN_K_MAX]; // M of the previous launch's frames known to be rule-on (0: speculate)
+    __shared__ double s_dtau[CHAIN_K_MAX], s_shot[CHAIN_K_MAX]; // per frame of the pass: FrameCtl::dt_over_tau, shot_base,
+    __shared__ float s_dtime[CHAIN_K_MAX];                       // (float)delta_time,
+    __shared__ uint32_t s_mon[CHAIN_K_MAX];                      // refr_on_n
+    constexpr bool U8 = sizeof(FT) == 1;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int g = blockIdx.x;
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const int wave_g = g * (BLOCK / WAVE) + wave;
+    __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
+    if (U8) {
+        s_lutL[tid] = a.lut_L[tid];
+        s_lutI[tid] = a.lut_I[tid];
+    }
+    const uint32_t fbase = *ca.fidx_base;
+    const bool need_r = a.do_leak && a.jit_f != 0.f;
+    const bool need_draw = need_r || a.do_shot;
+    __syncthreads();
+
+    for (int clip = blockIdx.y; clip < ca.n_clips; clip += (int)gridDim.y) {
+        const size_t sp = (size_t)clip * a.npx_pad + p;
+        // ---- read-only planes and what follows from them for every frame of the launch
+        float thp = 1.f, thn = 1.f, nr = 0.f;
+        if (valid) {
+            thp = a.pos_thres[sp];
+            thn = a.neg_thres[sp];
+            if (a.do_leak) nr = a.noise_rate[sp];
+        }
+        const float lk = a.leak_hz_f * nr;                          // emulator_utils.py:126, left to right
+        const R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;       // emulator_utils.py:154-157 divisors
+        const R tnd = a.scalar_thres ? (R)a.neg_div : (R)thn;
+        const R rtp = (R)1 / tpd, rtn = (R)1 / tnd;
+        const float ppre = a.scalar_thres ? a.pos_pre_scalar : a.pos_nom_f / thp; // emulator.py:475-478
+        const float npre = a.scalar_thres ? a.neg_pre_scalar : a.neg_nom_f / thn;
+        // ---- state
+        R b = (R)0, lp = (R)0;
+        float tsm = 0.f;
+        if (valid) {
+            b = ((const R *)ca.base_in)[sp];
+            if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.lp_in)[sp];
+            if (a.has_refr) tsm = ca.ts_in[sp];
+        }
+        // every load above retires HERE, outside the frame loop: a wait for them inside the loop would, from the second
+        // frame on, be a wait for the previous frame's stores (vector memory operations retire in order)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(b), "+v"(lp), "+v"(tsm), "+v"(thp), "+v"(thn), "+v"(nr) : : "memory");
+        // ---- passes: [redo of the previous launch]* then this launch's own frames
+        bool own = !(a.has_refr && ca.pnf > 0);
+        bool redone = false;
+        int round = 0, last_exact = -1;
+        if (!own) {
+            __syncthreads();
+            if (tid < CHAIN_K_MAX) s_exact[tid] = 0u;
+            __syncthreads();
+        }
+        for (;;) {
+            int fs, fn;
+            uint32_t *gM_dst;
+            if (!own) {
+                // first frame after last_exact on which some wave reached the rule threshold (uniform: scalar loads)
+                const uint32_t *row = ca.gM_prev + ((size_t)round * ca.n_clips + clip) * ca.K;
+                int j = -1;
+                uint32_t Mj = 0;
+                for (int k = last_exact + 1; k < ca.pnf; ++k) {
+                    const uint32_t v = __builtin_amdgcn_readfirstlane(row[k]);
+                    if (v != 0u) { j = k; Mj = v; break; }
+                }
+                if (j < 0) {
+                    own = true;
+                } else {
+                    __syncthreads();
+                    if (tid == 0) s_exact[j] = Mj;
+                    __syncthreads();
+                    last_exact = j;
+                    ++round;
+                    redone = true;
+                    if (valid) { // the previous launch's input state
+                        b = ((const R *)ca.base_pin)[sp];
+                        if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.lp_pin)[sp];
+                        tsm = ca.ts_pin[sp];
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b), "+v"(lp), "+v"(tsm) : : "memory");
+                }
+            }
+            if (own) { fs = ca.f0; fn = ca.nf; gM_dst = ca.gM_cur + (size_t)clip * ca.K; }
+            else { fs = ca.pf0; fn = ca.pnf; gM_dst = ca.gM_prev + ((size_t)round * ca.n_clips + clip) * ca.K; }
+
+            // ------------------------------------------------------------ the frame loop
+            // per-frame scalars of this pass through LDS (a scalar load per frame would sit on the critical path)
+            __syncthreads();
+            if (tid < fn) {
+                const FrameCtl *c = ca.ctl + (size_t)(fs + tid) * ca.n_clips + clip;
+                s_dtau[tid] = c->dt_over_tau;
+                s_shot[tid] = c->shot_base;
+                s_dtime[tid] = (float)(c->t_frame - c->t_prev);
+                s_mon[tid] = c->refr_on_n;
+            }
+            __syncthreads();
+            float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f;
+            bool have_pair = false;
+            // The pass's pixels go through LDS, all loads in flight at once: vector memory operations retire in order, so a
+            // load issued inside the frame loop would wait for the write acknowledgements of the stores before it.
+            if (valid) {
+                const FT *fpx = (const FT *)((const char *)ca.frames + (size_t)fs * ca.frame_stride) + (size_t)clip * a.npx + p;
+                for (int k = 0; k < fn; ++k) s_px[(size_t)k * BLOCK + tid] = fpx[(size_t)k * (ca.frame_stride / sizeof(FT))];
+            }
+            auto frame_body = [&](const int k, const FT px) __attribute__((always_inline)) {
+                const int f = fs + k;
+                const int slot = f % ca.D;
+                const FrameCtl *c = ca.ctl + (size_t)f * ca.n_clips + clip; // rule-on frames only (timestamp tables)
+                const double dt_over_tau = s_dtau[k], shot_base = s_shot[k];
+                const float dtime_f = s_dtime[k];
+                const uint32_t Mon = s_mon[k];
+                const uint32_t exM = own ? 0u : s_exact[k];
+                // draws: one Philox call per pair of frames (v2e_detmath.h)
+                const uint32_t gf = fbase + (uint32_t)f;
+                float rr = 0.f, uu = 0.f;
+                if (need_draw) {
+                    if (!have_pair || v2e_frame_half(gf) == 0u)
+                        v2e_draw_pair(a.seed, (uint32_t)clip, v2e_frame_pair(gf), (uint32_t)p, need_r, &r_odd, &u_odd, &r_even, &u_even);
+                    have_pair = true;
+                    const bool even = v2e_frame_half(gf) != 0u;
+                    rr = even ? r_even : r_odd;
+                    uu = even ? u_even : u_odd;
+                }
+                // photoreceptor (emulator_utils.py:18-134)
+                double L, inten01;
+                if (U8) {
+                    L = a.log_input ? (double)px : (double)s_lutL[(int)px];
+                    inten01 = s_lutI[(int)px];
+                } else {
+                    const double x = (double)px;
+                    L = a.log_input ? x : (double)lin_log(x);
+                    inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
+                }
+                R lpn;
+                if (a.has_cutoff) {
+                    double eps = inten01 * dt_over_tau;
+                    if (eps > 1.0) eps = 1.0;
+                    lpn = (R)((1.0 - eps) * (double)lp + eps * (double)L);
+                } else {
+                    lpn = (R)L;
+                }
+                if (a.do_leak) {
+                    const float rate = lk * (1.0f - a.jit_f * rr);
+                    const float delta_leak = (dtime_f * rate) * thp;
+                    b = b - (R)delta_leak;
+                }
+                // counts (emulator_utils.py:137-173): diff has one sign, one exact floor division
+                const R diff = (lpn + (R)0.0f) - b;
+                const bool is_pos = diff > (R)0;
+                const R mg = is_pos ? diff : ((-diff) > (R)0 ? -diff : (R)0);
+                const int q = (int)floor_div_rcp<R>(mg, is_pos ? tpd : tnd, is_pos ? rtp : rtn);
+                const int mag = q > 0 ? q : 0;
+                const bool neg = !is_pos;
+                uint32_t cw = mag > 0 ? (((uint32_t)mag & CNT_MASK) | (neg ? CNT_NEG : 0u)) : 0u;
+                if (a.do_shot) { // emulator_utils.py:326-349
+                    const double F = shot_base * (a.inten_slope * inten01 + 1);
+                    if ((double)uu > 1 - F * (double)ppre) cw |= CNT_SHOT_ON;
+                    if ((double)uu < F * (double)npre) cw |= CNT_SHOT_OFF;
+                }
+                if (!valid) cw = 0u;
+                if (valid) ca.cnt[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p] = cw;
+                const int magv = valid ? mag : 0;
+                const int wm = wave_max_i32(magv);
+                if (lane == 0) {
+                    ca.wmax[((size_t)slot * ca.n_clips + clip) * ca.nwp + wave_g] = (uint16_t)min(wm, 65535);
+                    // speculation check: only a wave that reaches the rule threshold says so
+                    if (a.has_refr && k > (own ? -1 : last_exact) && (uint32_t)wm >= Mon) atomicMax(gM_dst + k, (uint32_t)wm);
+                }
+                // ---- finalise (emulator.py:830-842, 936-942) -- by the refractory rule where M is known to switch it on --
+                // and, in the same walk over the wave's iterations, this wave's (iteration, polarity) totals:
+                // key 0/1 shot ON/OFF, key 2+2i / 3+2i iteration i ON/OFF (after the rule).  The rule-on walk is its own
+                // copy of the loop: nothing it loads (timestamp tables) may be live in the common path, or the common
+                // path inherits a wait for every outstanding store.
+                int fcount = magv;
+                uint8_t *trow = ca.wtot + (((size_t)slot * ca.n_clips + clip) * a.nkeys_cap) * ca.nwp + wave_g;
+                const int wmc = min(wm, a.max_iters); // beyond max_iters the frame is flagged and not emitted
+                const int nkw = 2 + 2 * wmc;
+                const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
+                const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+                bool ruled = false;
+                if (exM != 0u) {
+                    const FrameTab ftb(c, lane);
+                    const TsGen tg = frame_tsgen(a, c, ftb, (int)exM, ruled);
+                    if (ruled) {
+                        if (valid) ca.tsold[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p] = tsm; // ts_mem as it was
+                        fcount = 0;
+                        for (int kb = 0; kb < nkw; kb += WAVE) {
+                            uint32_t mine = 0;
+                            const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
+                            const int i_hi = min((kb + WAVE - 2) / 2, wmc);
+                            for (int i = i_lo; i < i_hi; ++i) {
+                                bool pass = magv > i;
+                                if (pass) {
+                                    const float t = tg(i);
+                                    const float pt = 1.0f * t - tsm;
+                                    pass = pt > a.refr_f;
+                                    if (pass) { tsm = t; ++fcount; }
+                                }
+                                const unsigned long long bo = __ballot(pass && !neg);
+                                const unsigned long long bf = __ballot(pass && neg);
+                                const int kl = 2 + 2 * i - kb;
+                                if (lane == kl) mine = (uint32_t)__popcll(bo);
+                                if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+                            }
+                            if (kb == 0) {
+                                if (lane == 0) mine = (uint32_t)__popcll(so);
+                                if (lane == 1) mine = (uint32_t)__popcll(sf);
+                            }
+                            if (kb + lane < nkw) trow[(size_t)(kb + lane) * ca.nwp] = (uint8_t)mine;
+                        }
+                    }
+                }
+                if (!ruled) {
+                    for (int kb = 0; kb < nkw; kb += WAVE) {
+                        uint32_t mine = 0;
+                        const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
+                        const int i_hi = min((kb + WAVE - 2) / 2, wmc);
+                        for (int i = i_lo; i < i_hi; ++i) {
+                            const bool pass = magv > i;
+                            const unsigned long long bo = __ballot(pass && !neg);
+                            const unsigned long long bf = __ballot(pass && neg);
+                            const int kl = 2 + 2 * i - kb;
+                            if (lane == kl) mine = (uint32_t)__popcll(bo);
+                            if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+                        }
+                        if (kb == 0) {
+                            if (lane == 0) mine = (uint32_t)__popcll(so);
+                            if (lane == 1) mine = (uint32_t)__popcll(sf);
+                        }
+                        if (kb + lane < nkw) trow[(size_t)(kb + lane) * ca.nwp] = (uint8_t)mine;
+                    }
+                }
+                if (valid) {
+                    const bool shot = (cw & (CNT_SHOT_ON | CNT_SHOT_OFF)) != 0u;
+                    if (fcount > 0 || shot) {
+                        const float dp = (float)(neg ? 0 : fcount) * thp;
+                        const float dn = (float)(neg ? fcount : 0) * thn;
+                        b = b + (R)dp;
+                        b = b - (R)dn;
+                        if (shot) b = lpn;
+                    }
+                }
+                lp = lpn;
+            };
+            for (int k = 0; k < fn; ++k) frame_body(k, s_px[(size_t)k * BLOCK + tid]);
+            if (own) break;
+            // a redo pass: leave the corrected state where the next launch's own redo would look for it, and let every
+            // workgroup of the clip publish before the check is repeated
+            if (valid) {
+                ((R *)ca.base_fix)[sp] = b;
+                if (a.has_cutoff || a.do_shot) ((R *)ca.lp_fix)[sp] = lp;
+                ca.ts_fix[sp] = tsm;
+            }
+            const bool ok = clip_barrier(ca.bar_prev + (size_t)(round - 1) * ca.n_clips + clip, (unsigned)ca.ngroups);
+            if (!ok && tid == 0) atomicOr(&ca.recs[(size_t)ca.pf0 * ca.n_clips + clip].flags, V2E_FLAG_SYNC_TIMEOUT);
+        }
+        if (valid && (ca.nf > 0 || ca.store_out || redone)) {
+            ((R *)ca.base_out)[sp] = b;
+            if (ca.nf > 0 || a.has_cutoff || a.do_shot) ((R *)ca.lp_out)[sp] = lp;
+            if (a.has_refr) ca.ts_out[sp] = tsm;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ emission side of the chain
+struct CFrame { // per (batch frame, clip)
+    int M;
+    uint32_t n_events, n_signal, discarded;
+};
+
+struct CEmitArgs {
+    const FrameCtl *ctl;
+    v2e_frame_rec *recs;
+    const uint32_t *fidx_base;
+    int f0, nE, D, n_clips, nwp, nwaves, E;
+    const uint32_t *cnt;
+    const uint16_t *wmax;
+    const uint8_t *wtot;
+    const float *tsold;
+    CFrame *cf;          // [E][n_clips]
+    uint32_t *cT;        // [E][n_clips][nkeys_cap] events per key over all waves
+    uint32_t *ckbase;    // [E][n_clips][nkeys_cap] first row of the key's iteration within the frame (signal keys)
+    uint32_t *cperm;     // [E][n_clips][max_iters][8] shuffle round keys k0..k3, sh, a, amask, n per iteration
+    uint32_t *cpre;      // [E][n_clips][nkeys_cap][nwp] exclusive prefix over waves per key
+    float4 *events;
+    unsigned long long cap;
+    const unsigned long long *off_in;
+    unsigned long long *off_out;
+    int capw;
+};
+
+// One workgroup per (frame, clip): M, per key the prefix over waves and the total, prefix over keys, shuffle parameters.
+__global__ __launch_bounds__(BLOCK) void k_cframe(KArgs a, CEmitArgs ea)
+{
+    __shared__ int s_red[BLOCK / WAVE];
+    __shared__ uint32_t s_T[2 * CHAIN_MAX_ITERS + 2];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const uint16_t *wm = ea.wmax + ((size_t)slot * ea.n_clips + clip) * ea.nwp;
+    int m = 0;
+    for (int k = tid; k < ea.nwaves; k += BLOCK) m = max(m, (int)wm[k]);
+    const int M = block_max_finish(m, s_red, lane, wave);
+    CFrame *cf = ea.cf + (size_t)z * ea.n_clips + clip;
+    v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips + clip;
+    if (M > a.max_iters) { // the frame is not emitted; the caller sees the flag
+        if (tid == 0) {
+            cf->M = M; cf->n_events = 0u; cf->n_signal = 0u; cf->discarded = 1u;
+            rec->max_events = M;
+            atomicOr(&rec->flags, V2E_FLAG_ITERS_CLAMPED);
+        }
+        return;
+    }
+    const int nk = 2 + 2 * M;
+    const uint8_t *tot = ea.wtot + ((size_t)slot * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
+    uint32_t *pre = ea.cpre + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
+    for (int k = wave; k < nk; k += BLOCK / WAVE) { // one wave per key row, 16 waves' totals per lane and step
+        uint32_t carry = 0;
+        for (int w0 = 0; w0 < ea.nwp; w0 += 16 * WAVE) {
+            const int wi = w0 + lane * 16;
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = 0u;
+            if (wi < ea.nwp) {
+                const uint4 t4 = *(const uint4 *)(tot + (size_t)k * ea.nwp + wi);
+                const uint4 m0 = *(const uint4 *)(wm + wi), m1 = *(const uint4 *)(wm + wi + 8);
+                const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
+                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                    // a wave writes only the rows of its own iterations; above them the slot holds an older frame's bytes
+                    v[j] = (uint32_t)k < 2u + 2u * wmj ? ((tw[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 0u;
+                }
+            }
+            uint32_t lane_tot = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) lane_tot += v[j];
+            uint32_t run = carry + wave_excl_scan_u32(lane_tot, lane);
+            carry += wave_sum_u32(lane_tot);
+            if (wi < ea.nwp) {
+                uint32_t o[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { o[j] = run; run += v[j]; }
+                uint4 *dst = (uint4 *)(pre + (size_t)k * ea.nwp + wi);
+                dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+                dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
+            }
+        }
+        if (lane == 0) s_T[k] = carry;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t *cT = ea.cT + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap;
+    uint32_t *ckb = ea.ckbase + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap;
+    uint32_t carry = 0, sum_on = 0, sum_off = 0;
+    for (int kb = 0; kb < nk; kb += WAVE) {
+        const int key = kb + lane;
+        const uint32_t T_k = key < nk ? s_T[key] : 0u;
+        const uint32_t sig = key >= 2 ? T_k : 0u;
+        const uint32_t kbase = carry + wave_excl_scan_u32(sig, lane);
+        if (key < a.nkeys_cap) { cT[key] = T_k; ckb[key] = kbase; }
+        sum_on += wave_sum_u32((lane & 1) ? 0u : sig);
+        sum_off += wave_sum_u32((lane & 1) ? sig : 0u);
+        carry += wave_sum_u32(sig);
+    }
+    const uint32_t n_signal = carry;
+    uint32_t *perm = ea.cperm + ((size_t)z * ea.n_clips + clip) * a.max_iters * 8;
+    if (a.shuffle && a.rng_mode == V2E_RNG_PHILOX) {
+        const uint32_t fbase = ea.fidx_base ? *ea.fidx_base : 0u;
+        for (int i = lane; i < M; i += WAVE) {
+            uint32_t pk[4], sh, aa, amask;
+            const uint32_t n_i = s_T[2 + 2 * i] + s_T[3 + 2 * i];
+            v2e_perm_shape(n_i, &sh, &aa, &amask);
+            v2e_perm_keys(a.seed, (uint32_t)clip, fbase + (uint32_t)fe, (uint32_t)i, pk);
+            uint4 *pp = (uint4 *)(perm + (size_t)i * 8);
+            pp[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            pp[1] = make_uint4(sh, aa, amask, n_i);
+        }
+    }
+    if (lane == 0) {
+        const uint32_t son = a.do_shot ? s_T[0] : 0u, soff = a.do_shot ? s_T[1] : 0u;
+        cf->M = M; cf->n_signal = n_signal; cf->n_events = n_signal + son + soff; cf->discarded = 0u;
+        rec->max_events = M;
+        rec->n_signal = n_signal;
+        rec->n_events = n_signal + son + soff;
+        rec->n_on = sum_on + son;
+        rec->n_off = sum_off + soff;
+    }
+}
+
+// Event rows of one frame, every wave on its own: which of my iterations pass (the refractory recurrence against
+// tsold on rule-on frames), ballot ranks, one 4-byte record per event in LDS; then one event per lane: row =
+// frame offset + iteration base + shuffle(ON/OFF block offset + prefix over earlier waves + rank in wave).
+__global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
+{
+    extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw]
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const size_t zc = (size_t)z * ea.n_clips + clip;
+    const CFrame *cf = ea.cf + zc;
+    const int wave_g = g * (BLOCK / WAVE) + wave;
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
+    unsigned long long ev0 = ea.off_in[clip];
+    for (int j = 0; j < z; ++j) ev0 += ea.cf[(size_t)j * ea.n_clips + clip].n_events;
+    v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips;
+    const int M = __builtin_amdgcn_readfirstlane(cf->M);
+    const uint32_t n_signal = __builtin_amdgcn_readfirstlane((int)cf->n_signal);
+    const uint32_t n_events = __builtin_amdgcn_readfirstlane((int)cf->n_events);
+    if (g == 0 && tid == 0) {
+        rec[clip].ev_offset = ev0;
+        if (z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events;
+    }
+    if (cf->discarded) return;
+    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
+    const int wmw = __builtin_amdgcn_readfirstlane((int)ea.wmax[((size_t)slot * ea.n_clips + clip) * ea.nwp + wave_g]);
+    const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0), sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+    if (wmw == 0 && (so | sf) == 0ull) return; // nothing of this wave in the frame
+    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
+    const FrameTab ftb(c, lane);
+    const int n = M > 0 ? M : 1;
+    bool use_refr;
+    const TsGen tg = frame_tsgen(a, c, ftb, n, use_refr);
+    float tsm = (valid && use_refr && ea.tsold) ? ea.tsold[sp] : 0.f;
+    const int mag = (int)(cw & CNT_MASK);
+    const bool neg = (cw & CNT_NEG) != 0;
+    float4 *ev = ea.events + (size_t)clip * ea.cap;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float fx = (float)(p % a.W), fy = (float)(p / a.W);
+    const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
+    uint32_t *rec_w = s_crec + (size_t)wave * ea.capw;
+    const uint32_t *cT = ea.cT + zc * a.nkeys_cap, *ckb = ea.ckbase + zc * a.nkeys_cap;
+    const uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp + wave_g;
+    const uint32_t *perm = ea.cperm + zc * a.max_iters * 8;
+    bool dropped = false;
+    const int iters = min(wmw, M);
+    constexpr int ICH = 31; // iterations per pass: 62 keys in a wave's lanes, at most 64 * 31 records
+    for (int i0 = 0; i0 < iters; i0 += ICH) {
+        const int i1 = min(i0 + ICH, iters);
+        const int key = 2 + 2 * i0 + lane; // lanes 0..61: the ON / OFF keys of iterations i0 .. i0+30
+        uint32_t T_k = 0, kbase_k = 0, P_k = 0;
+        if (lane < 2 * ICH && key < 2 + 2 * i1) {
+            T_k = cT[key];
+            kbase_k = ckb[key];
+            P_k = pre[(size_t)key * ea.nwp];
+        }
+        uint4 pa = make_uint4(0u, 0u, 0u, 0u), pb = make_uint4(0u, 1u, 0u, 0u);
+        if (shuf && lane < ICH && i0 + lane < i1) {
+            pa = ((const uint4 *)(perm + (size_t)(i0 + lane) * 8))[0];
+            pb = ((const uint4 *)(perm + (size_t)(i0 + lane) * 8))[1];
+        }
+        // pass 1
+        uint32_t nrec = 0;
+        bool alive = true;
+        for (int i = i0; i < i1; ++i) {
+            const bool cand = mag > i;
+            if (__ballot(cand) == 0ull) { alive = false; break; }
+            bool pass = cand;
+            if (use_refr) {
+                const float t = tg(i);
+                const float pt = (cand ? 1.0f : 0.0f) * t - tsm;
+                pass = pt > a.refr_f;
+                if (pass) tsm = t;
+            }
+            const unsigned long long bo = __ballot(pass && !neg);
+            const unsigned long long bf = __ballot(pass && neg);
+            if (pass) {
+                const uint32_t rank = (uint32_t)__popcll((neg ? bf : bo) & lt);
+                const uint32_t pos = nrec + (uint32_t)__popcll((bo | bf) & lt);
+                rec_w[pos] = (uint32_t)lane | ((uint32_t)(i - i0) << 6) | ((neg ? 1u : 0u) << 11) | (rank << 12);
+            }
+            nrec += (uint32_t)__popcll(bo | bf);
+        }
+        // pass 2: one event per lane
+        for (uint32_t e0 = 0; e0 < nrec; e0 += WAVE) {
+            const bool has = e0 + lane < nrec;
+            const uint32_t r = has ? rec_w[e0 + lane] : 0u;
+            const int src = (int)(r & 63u), il = (int)((r >> 6) & 31u);
+            const bool eneg = (r >> 11) & 1u;
+            const uint32_t rank = r >> 12;
+            const int kl = 2 * il;
+            const uint32_t it_base = (uint32_t)__shfl((int)kbase_k, kl);
+            const uint32_t tot_on = (uint32_t)__shfl((int)T_k, kl);
+            const uint32_t off = (uint32_t)__shfl((int)P_k, kl + (eneg ? 1 : 0));
+            const float ex = __shfl(fx, src), ey = __shfl(fy, src);
+            uint32_t cidx = (eneg ? tot_on : 0u) + off + rank;
+            if (shuf) {
+                v2e_perm_t pm;
+                pm.k[0] = (uint32_t)__shfl((int)pa.x, il); pm.k[1] = (uint32_t)__shfl((int)pa.y, il);
+                pm.k[2] = (uint32_t)__shfl((int)pa.z, il); pm.k[3] = (uint32_t)__shfl((int)pa.w, il);
+                pm.sh = (uint32_t)__shfl((int)pb.x, il); pm.a = (uint32_t)__shfl((int)pb.y, il);
+                pm.amask = (uint32_t)__shfl((int)pb.z, il); pm.n = (uint32_t)__shfl((int)pb.w, il);
+                pm.rmask = (1u << pm.sh) - 1u;
+                if (has) cidx = v2e_perm_apply(&pm, cidx);
+            }
+            if (has) {
+                const unsigned long long row = ev0 + it_base + cidx;
+                if (row < ea.cap) store_event_wt(ev, row, tg(i0 + il), ex, ey, eneg ? -1.0f : 1.0f);
+                else dropped = true;
+            }
+        }
+        if (!alive) break;
+    }
+    // shot-noise events after all signal events (ON block, OFF block), ts[-1], unshuffled
+    if (a.do_shot && (so | sf)) {
+        const uint32_t son_tot = cT[0];
+        const uint32_t son_off = pre[0], soff_off = pre[(size_t)ea.nwp];
+        const float tl = tg(n - 1);
+        if (cw & CNT_SHOT_ON) {
+            const unsigned long long row = ev0 + n_signal + son_off + (uint32_t)__popcll(so & lt);
+            if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, 1.0f);
+            else dropped = true;
+        }
+        if (cw & CNT_SHOT_OFF) {
+            const unsigned long long row = ev0 + n_signal + son_tot + soff_off + (uint32_t)__popcll(sf & lt);
+            if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, -1.0f);
+            else dropped = true;
+        }
+    }
+    if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
+}
