@@ -111,7 +111,7 @@ def test_step_chain_pipeline_ring_wraps(name, pipe_e, monkeypatch):
             assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
 
 
-@pytest.mark.parametrize("chain_k", [1, 2, 3, 5, 8, 32])
+@pytest.mark.parametrize("chain_k", [1, 2, 3, 5, 8, 11, 16, 32])
 @pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260", "philox_defaults_346x260"])
 def test_chain_launch_lengths_and_ring_wrap(name, chain_k, monkeypatch):
     """k_chain with few frames per launch: the ring of 3 K frame slots wraps several times within the fixture clip,

@@ -728,6 +728,10 @@ struct v2e_emu {
     uint16_t *ch_wmax = nullptr;    // [ch_D][n_clips][ch_nwp]
     uint8_t *ch_wtot = nullptr;     // [ch_D][n_clips][nkeys_cap][ch_nwp]
     float *ch_tsold = nullptr;      // [ch_D][n_clips][npx_pad] (refractory runs)
+    uint4 *ch_rec = nullptr;        // [ch_D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
+    hipStream_t ahead = nullptr, tables = nullptr; // k_ahead / k_cframe run beside the chain and the event writer
+    std::vector<hipEvent_t> ev_ahead, ev_chain, ev_tables;
+    int ch_E = 0;                   // frames per k_ahead launch / emission batch (a multiple of ch_K)
     uint32_t *ch_gM = nullptr;      // [ch_launch_cap][ch_K + 1][n_clips][ch_K]
     unsigned *ch_bar = nullptr;     // [ch_launch_cap][ch_K][n_clips]
     void *ch_base2 = nullptr, *ch_lp2 = nullptr; // second set of state planes (ping-pong between launches)
@@ -924,6 +928,12 @@ int v2e_emu_destroy(v2e_emu *h)
     for (hipEvent_t e : h->ev_join) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
     hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_gM); hipFree(h->ch_bar);
+    hipFree(h->ch_rec);
+    for (hipEvent_t e : h->ev_ahead) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_chain) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_tables) hipEventDestroy(e);
+    if (h->ahead) hipStreamDestroy(h->ahead);
+    if (h->tables) hipStreamDestroy(h->tables);
     hipFree(h->ch_base2); hipFree(h->ch_lp2); hipFree(h->ch_ts2); hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase);
     hipFree(h->ch_cperm); hipFree(h->ch_cpre);
     hipFree(h->cnt_b); hipFree(h->gtot[0]); hipFree(h->gtot[1]); hipFree(h->gmaxv[0]); hipFree(h->gmaxv[1]);
@@ -1430,28 +1440,60 @@ static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a,
 }
 
 // ------------------------------------------------------------------ K frames per launch (emu_chain.h)
-static int chain_frames_per_launch(const v2e_emu *h)
+static bool chain_small_grid(const v2e_emu *h) { return (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu; }
+
+static int chain_frames_per_launch(const v2e_emu *h, bool has_refr)
 {
-    // the launch boundary (~4 us) is paid once per K frames; a redo (rule-on frame: ~1 % of the frames of the benchmark
-    // clip) repeats a whole launch, and the ring is 3 K frame slots: 16 frames keep both small
-    int K = 16;
+    // The launch boundary (~4 us) and the prologue are paid once per K frames; a redo (rule-on frame: ~1 % of the frames of
+    // the benchmark clip) repeats a whole launch.  Small grids (bounded by latency): 32 frames, records through LDS 8 frames
+    // = 32 KB at a time, so that two chain workgroups (64 KB) always fit a CU beside the parallel kernels, which are capped
+    // at 4 x 24 KB (the redo rendezvous needs every chain workgroup resident).  Large grids (bounded by throughput, records
+    // built in the chain): 16 frames, 8 where a redo is possible.
+    int K = chain_small_grid(h) ? 32 : (has_refr ? 8 : 16);
     if (const char *ev = getenv("V2E_AMD_CHAIN_K")) { const int v = atoi(ev); if (v >= 1 && v <= CHAIN_K_MAX) K = v; }
     return K;
+}
+
+// workgroups of k_chain a CU holds (the redo rendezvous needs a clip's workgroups co-resident); the occupancy API can
+// over-report by one per CU (MI355X guide), hence the margin
+static int chain_blocks_per_cu(int K, bool fused)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *)k_chain<double, uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        hipFuncSetAttribute((const void *)k_chain<float, uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        attr_set = true;
+    }
+    int per_cu = 0;
+    hipError_t e;
+    if (fused) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<double, double, true>, BLOCK, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<double, uint8_t, false>, BLOCK, (size_t)std::min(K, CHAIN_SUB) * BLOCK * sizeof(uint4));
+    if (e != hipSuccess) return 0;
+    if (per_cu <= 2) return per_cu; // LDS-bound counts are exact
+    return std::min(per_cu - 1, 6);
 }
 
 // scratch of the chain pipeline: everything a captured run must not allocate
 static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
 {
-    const int K = chain_frames_per_launch(h);
     const bool has_refr = p->refractory_period_s > 0;
-    if (h->ch_K != K || h->ch_nkeys_cap != h->nkeys_cap) {
+    const int K = chain_frames_per_launch(h, has_refr);
+    // frames per k_ahead launch and per emission batch: a multiple of K (measured at 346x260: K = 32 with batches of 32
+    // frames 4.86 us/frame, of 64 frames 5.18; K = 16 with 64: 5.27)
+    int m = 1;
+    if (const char *ev = getenv("V2E_AMD_CHAIN_M")) { const int v = atoi(ev); if (v >= 1 && v <= 64) m = v; }
+    const int E = m * K;
+    if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap) {
         hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_cf); hipFree(h->ch_cT);
         hipFree(h->ch_ckbase); hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_gM); hipFree(h->ch_bar);
+        hipFree(h->ch_rec);
+        h->ch_rec = nullptr;
         h->ch_cnt = nullptr; h->ch_wmax = nullptr; h->ch_wtot = nullptr; h->ch_tsold = nullptr; h->ch_cf = nullptr; h->ch_cT = nullptr;
         h->ch_ckbase = nullptr; h->ch_cperm = nullptr; h->ch_cpre = nullptr; h->ch_gM = nullptr; h->ch_bar = nullptr;
         h->ch_launch_cap = 0;
         h->ch_K = K;
-        h->ch_D = 3 * K; // batch b is read by its emission while launch b + 1 validates it and launch b + 2 writes its own slots
+        h->ch_E = E;
+        h->ch_D = 3 * E; // batch b is read by its emission while the chain is in batch b + 1 and k_ahead fills batch b + 2
         h->ch_nwp = (h->ngroups * (BLOCK / WAVE) + 15) / 16 * 16;
         h->ch_nkeys_cap = h->nkeys_cap;
         const size_t nc = (size_t)h->n_clips;
@@ -1460,19 +1502,29 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
         V2E_HIP(hipMemset(h->ch_wmax, 0, sizeof(uint16_t) * h->ch_D * nc * h->ch_nwp));
         V2E_HIP(hipMalloc(&h->ch_wtot, (size_t)h->ch_D * nc * h->nkeys_cap * h->ch_nwp));
         V2E_HIP(hipMemset(h->ch_wtot, 0, (size_t)h->ch_D * nc * h->nkeys_cap * h->ch_nwp));
-        V2E_HIP(hipMalloc(&h->ch_cf, sizeof(CFrame) * K * nc));
-        V2E_HIP(hipMemset(h->ch_cf, 0, sizeof(CFrame) * K * nc));
-        V2E_HIP(hipMalloc(&h->ch_cT, sizeof(uint32_t) * K * nc * h->nkeys_cap));
-        V2E_HIP(hipMalloc(&h->ch_ckbase, sizeof(uint32_t) * K * nc * h->nkeys_cap));
-        V2E_HIP(hipMalloc(&h->ch_cperm, sizeof(uint32_t) * K * nc * h->max_iters * 8));
-        V2E_HIP(hipMalloc(&h->ch_cpre, sizeof(uint32_t) * K * nc * h->nkeys_cap * h->ch_nwp));
-        int per_cu = 0;
-        V2E_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<double, uint8_t>, BLOCK, 0));
-        per_cu = per_cu > 4 ? 4 : (per_cu > 1 ? per_cu - 1 : 0); // the API can over-report by one per CU (MI355X guide)
-        h->ch_max_blocks = per_cu * h->n_cu;
+        V2E_HIP(hipMalloc(&h->ch_cf, 2 * sizeof(CFrame) * E * nc)); // two sets: k_cframe(b + 1) beside k_cemit(b)
+        V2E_HIP(hipMemset(h->ch_cf, 0, 2 * sizeof(CFrame) * E * nc));
+        V2E_HIP(hipMalloc(&h->ch_cT, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap)); // two sets: k_cframe(b + 1) beside k_cemit(b)
+        V2E_HIP(hipMalloc(&h->ch_ckbase, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap)); // two sets: k_cframe(b + 1) beside k_cemit(b)
+        V2E_HIP(hipMalloc(&h->ch_cperm, 2 * sizeof(uint32_t) * E * nc * h->max_iters * 8)); // two sets: k_cframe(b + 1) beside k_cemit(b)
+        V2E_HIP(hipMalloc(&h->ch_cpre, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp)); // two sets: k_cframe(b + 1) beside k_cemit(b)
+        V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
+        h->ch_max_blocks = chain_blocks_per_cu(K, !chain_small_grid(h)) * h->n_cu;
         if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
     }
     const int n_launch = (n_frames + K - 1) / K + 1;
+    if (!h->ahead) V2E_HIP(hipStreamCreateWithFlags(&h->ahead, hipStreamNonBlocking));
+    if (!h->tables) V2E_HIP(hipStreamCreateWithFlags(&h->tables, hipStreamNonBlocking));
+    auto grow = [&](std::vector<hipEvent_t> &v, size_t n) -> int {
+        while (v.size() < n) {
+            hipEvent_t e;
+            V2E_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            v.push_back(e);
+        }
+        return 0;
+    };
+    if (grow(h->ev_ahead, n_launch + 1) || grow(h->ev_chain, n_launch + 1) || grow(h->ev_fork, n_launch + 1) ||
+        grow(h->ev_join, n_launch + 1) || grow(h->ev_tables, n_launch + 1)) return V2E_EHIP;
     if (has_refr) {
         if (!h->ch_tsold) V2E_HIP(hipMalloc(&h->ch_tsold, sizeof(float) * (size_t)h->ch_D * h->n_clips * h->npx_pad));
         if (!h->ch_base2) {
@@ -1492,26 +1544,19 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
             if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
         }
     }
-    const size_t nb = (size_t)n_launch;
-    while (h->ev_fork.size() < nb) {
-        hipEvent_t e0, e1;
-        V2E_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        V2E_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        h->ev_fork.push_back(e0);
-        h->ev_join.push_back(e1);
-    }
     return 0;
 }
 
 // can this run go through k_chain?  (the redo path needs the grid co-resident for its rendezvous)
-static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p)
+static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p, int dtype, bool force)
 {
     if (h->max_iters > CHAIN_MAX_ITERS) return false;
+    if (dtype == V2E_DT_F64 && p->log_input) return false; // k_ahead's records carry the lin-log value as float32
     if (p->refractory_period_s > 0) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<double, uint8_t>, BLOCK, 0) != hipSuccess) return false;
-        per_cu = per_cu > 4 ? 4 : (per_cu > 1 ? per_cu - 1 : 0);
-        if ((long long)h->ngroups > (long long)per_cu * h->n_cu) return false;
+        // the redo rendezvous needs a clip's workgroups co-resident; and where only a few clips of a large multi-clip grid
+        // are, the clip loop inside the workgroup serialises them: k_main per frame is faster there (64 clips: 10.3 vs 8.9 Gev/s)
+        if ((long long)h->ngroups > (long long)chain_blocks_per_cu(chain_frames_per_launch(h, true), !chain_small_grid(h)) * h->n_cu) return false;
+        if (!chain_small_grid(h) && !force) return false;
     }
     return true;
 }
@@ -1520,11 +1565,18 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
                              float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, std::vector<hipEvent_t> *ev_main = nullptr,
                              std::vector<hipEvent_t> *ev_side = nullptr)
 {
+    // Four streams: `s` the chain (k_chain, K frames per launch); h->ahead k_ahead, h->tables k_cframe, h->side k_cemit, the
+    // last three in batches of E = m K frames (batch b = frames [b E, (b + 1) E) = chain launches [b m, (b + 1) m)).
+    //   k_ahead(b)  before chain launch b m; overwrites the records of batch b - 3, last read by launch (b - 2) m (its redo)
+    //   k_cframe(b) once batch b is final: after the launch that validated its last K frames (or, without a refractory
+    //               period, after its last launch); k_cemit(b) after k_cframe(b)
+    //   chain launch b m overwrites the ring slots of batch b - 3: after k_cemit(b - 3)
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
     const bool has_refr = p->refractory_period_s > 0;
-    const int K = h->ch_K, D = h->ch_D, NC = h->n_clips;
-    const int nB = (n_frames + K - 1) / K;           // batches = chain launches with frames
-    const int nL = has_refr ? nB + 1 : nB;           // + the tail launch that validates the last batch
+    const int K = h->ch_K, E = h->ch_E, m = E / K, D = h->ch_D, NC = h->n_clips;
+    const int nB = (n_frames + K - 1) / K;           // chain launches with frames
+    const int nL = has_refr ? nB + 1 : nB;           // + the tail launch that validates the last K frames
+    const int nEB = (n_frames + E - 1) / E;          // batches of the parallel kernels
     V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * NC, s));
     V2E_HIP(zero_async(h->pipe_off, sizeof(unsigned long long) * 2 * NC, s));
     if (has_refr) {
@@ -1543,46 +1595,80 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     int gy = NC;
     if (has_refr) gy = std::max(1, std::min(NC, h->ch_max_blocks / std::max(h->ngroups, 1)));
     dim3 grid(h->ngroups, gy);
-    const bool small_grid = (long long)h->ngroups * gy <= 4ll * h->n_cu;
-    auto launch_emission = [&](int b) -> int {
+    // large grids build the records inside the chain (no k_ahead, no record traffic): see k_chain
+    static const int fused_env = getenv("V2E_AMD_CHAIN_FUSED") ? atoi(getenv("V2E_AMD_CHAIN_FUSED")) : -1;
+    const bool fused_rec = fused_env >= 0 ? fused_env != 0 : !chain_small_grid(h);
+    static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
+    static const int par_lds_env = getenv("V2E_AMD_PAR_LDS") ? atoi(getenv("V2E_AMD_PAR_LDS")) : -1;
+    const int par_lds = par_lds_env >= 0 ? par_lds_env : 0; // dev: LDS reservation capping the parallel kernels' occupancy (measured: no gain)
+    auto launch_emission = [&](int b) -> int { // fork event ev_fork[b] has been recorded on `s`
         CEmitArgs ea;
         memset(&ea, 0, sizeof(ea));
         ea.ctl = h->run_ctl; ea.recs = recs; ea.fidx_base = h->run_fidx;
-        ea.f0 = b * K; ea.nE = std::min((b + 1) * K, n_frames) - ea.f0; ea.D = D; ea.n_clips = NC;
-        ea.nwp = h->ch_nwp; ea.nwaves = h->ngroups * (BLOCK / WAVE); ea.E = K;
+        ea.f0 = b * E; ea.nE = std::min((b + 1) * E, n_frames) - ea.f0; ea.D = D; ea.n_clips = NC;
+        ea.nwp = h->ch_nwp; ea.nwaves = h->ngroups * (BLOCK / WAVE); ea.E = E;
         ea.cnt = h->ch_cnt; ea.wmax = h->ch_wmax; ea.wtot = h->ch_wtot; ea.tsold = has_refr ? h->ch_tsold : nullptr;
-        ea.cf = h->ch_cf; ea.cT = h->ch_cT; ea.ckbase = h->ch_ckbase; ea.cperm = h->ch_cperm; ea.cpre = h->ch_cpre;
+        const size_t set = (size_t)(b & 1) * E * NC; // table set of this batch
+        ea.cf = h->ch_cf + set; ea.cT = h->ch_cT + set * h->nkeys_cap; ea.ckbase = h->ch_ckbase + set * h->nkeys_cap;
+        ea.cperm = h->ch_cperm + set * h->max_iters * 8; ea.cpre = h->ch_cpre + set * h->nkeys_cap * h->ch_nwp;
         ea.events = (float4 *)events; ea.cap = cap;
         ea.off_in = h->pipe_off + (size_t)(b & 1) * NC;
         ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * NC;
-        constexpr int REC_LDS = 32000; // 4 waves x 2000 event records (a pass covers at most 64 x 31)
-        ea.capw = REC_LDS / 4 / (BLOCK / WAVE);
-        V2E_HIP(hipEventRecord(h->ev_fork[b], s));
+        // event records of k_cemit: 64 x ich per wave and pass.  The chain's workgroups need their LDS (4 KB per frame) on
+        // every CU: 15 iterations per pass (most frames have fewer) keep an emission workgroup at 15 KB
+        static const int ich_env = getenv("V2E_AMD_CEMIT_ICH") ? atoi(getenv("V2E_AMD_CEMIT_ICH")) : 0;
+        ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 15;
+        ea.capw = 64 * ea.ich;
+        // small grids: k_cemit and k_ahead reserve 24 KB of LDS per workgroup, i.e. at most four of them per CU beside the chain
+        const int REC_LDS = std::max(ea.capw * 4 * (BLOCK / WAVE), par_lds);
+        // (k_cframe on a stream of its own, beside k_cemit of the previous batch, crashed hipStreamEndCapture on ROCm 7.0:
+        // both stay on h->side, in order)
         V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
         if (mark(ev_side, h->side)) return V2E_EHIP;
-        static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
         if (!no_emit) {
             k_cframe<<<dim3(1, NC, ea.nE), BLOCK, 0, h->side>>>(a, ea);
             k_cemit<<<dim3(h->ngroups, NC, ea.nE), BLOCK, REC_LDS, h->side>>>(a, ea);
         }
         if (mark(ev_side, h->side)) return V2E_EHIP;
         V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
-        (void)small_grid;
+        return 0;
+    };
+    auto launch_ahead = [&](int b) -> int {
+        AheadArgs aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.frames = frames; aa.frame_stride = (unsigned long long)NC * h->npx * esz;
+        aa.ctl = h->run_ctl; aa.fidx_base = h->run_fidx;
+        aa.f0 = b * E; aa.nf = std::min((b + 1) * E, n_frames) - b * E; aa.D = D; aa.n_clips = NC;
+        aa.rec = h->ch_rec;
+        if (b >= 3) V2E_HIP(hipStreamWaitEvent(h->ahead, h->ev_chain[(b - 2) * m], 0));
+        // frame pairs touched by the batch: at most nf / 2 + 1 (the device knows the run's first frame index, the host's
+        // capture does not: one extra pair covers either alignment; threads of a pair outside the batch return)
+        dim3 ga(h->ngroups, NC, aa.nf / 2 + 1);
+        DISPATCH_FT(dtype, { k_ahead<FT><<<ga, BLOCK, par_lds, h->ahead>>>(a, aa); });
+        V2E_HIP(hipEventRecord(h->ev_ahead[b], h->ahead));
         return 0;
     };
     // state planes: X[0] the caller's (bound) planes, X[1] the engine's second set; launch L reads X[L % 2], writes X[(L + 1) % 2]
     void *xb[2] = {h->base, has_refr ? h->ch_base2 : h->base}, *xl[2] = {h->lp, has_refr ? h->ch_lp2 : h->lp};
     float *xt[2] = {h->ts_mem, has_refr ? h->ch_ts2 : h->ts_mem};
+    if (!fused_rec) {
+        V2E_HIP(hipEventRecord(h->ev_fork[nL], s)); // the run's uploads (frame times, first frame index) precede everything
+        V2E_HIP(hipStreamWaitEvent(h->ahead, h->ev_fork[nL], 0));
+    }
+    for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b)
+        if (launch_ahead(b)) return V2E_EHIP;
     for (int L = 0; L < nL; ++L) {
+        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] chain launch %d / %d (nEB %d m %d)\n", L, nL, nEB, m);
         const bool tail = L >= nB;
         ChainArgs ca;
         memset(&ca, 0, sizeof(ca));
-        ca.frames = frames; ca.frame_stride = (unsigned long long)NC * h->npx * esz;
-        ca.ctl = h->run_ctl; ca.fidx_base = h->run_fidx;
+        ca.frames = frames; ca.frame_stride = (unsigned long long)NC * h->npx * esz; ca.fidx_base = h->run_fidx;
+        ca.ctl = h->run_ctl;
         ca.f0 = tail ? n_frames : L * K; ca.nf = tail ? 0 : std::min((L + 1) * K, n_frames) - L * K;
         ca.pf0 = (L - 1) * K; ca.pnf = (has_refr && L > 0) ? std::min(L * K, n_frames) - (L - 1) * K : 0;
         ca.D = D; ca.n_clips = NC; ca.nwp = h->ch_nwp; ca.K = K; ca.ngroups = h->ngroups;
         ca.cnt = h->ch_cnt; ca.wmax = h->ch_wmax; ca.wtot = h->ch_wtot; ca.tsold = has_refr ? h->ch_tsold : nullptr;
+        ca.rec = h->ch_rec;
         if (has_refr) {
             ca.gM_cur = h->ch_gM + (size_t)L * (K + 1) * NC * K;
             ca.gM_prev = h->ch_gM + (size_t)(L > 0 ? L - 1 : 0) * (K + 1) * NC * K;
@@ -1595,20 +1681,42 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.base_pin = xb[pin]; ca.lp_pin = xl[pin]; ca.ts_pin = xt[pin];
         ca.recs = recs;
         ca.store_out = tail && in != 0;
-        // ring slots of batch L were last read by the emission of batch L - 3
-        if (!tail && L >= 3) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[L - 3], 0));
+        ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
+        if (!tail && L % m == 0) {
+            const int b = L / m;
+            if (b >= 3) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[b - 3], 0)); // ring slots of batch b: read by k_cemit(b - 3)
+            if (!fused_rec) V2E_HIP(hipStreamWaitEvent(s, h->ev_ahead[b], 0));
+        }
         if (L == 0 && mark(ev_main, s)) return V2E_EHIP;
-        DISPATCH_FT(dtype, {
-            const size_t px_lds = (size_t)K * BLOCK * sizeof(FT);
-            if (p->f64_state) k_chain<double, FT><<<grid, BLOCK, px_lds, s>>>(a, ca);
-            else k_chain<float, FT><<<grid, BLOCK, px_lds, s>>>(a, ca);
-        });
-        // what is final now: with a refractory period batch L - 1 (just validated), without one batch L itself
-        const int fin = has_refr ? L - 1 : L;
-        if (fin >= 0 && fin < nB && launch_emission(fin)) return V2E_EHIP;
+        if (fused_rec) {
+            DISPATCH_FT(dtype, {
+                if (p->f64_state) k_chain<double, FT, true><<<grid, BLOCK, 0, s>>>(a, ca);
+                else k_chain<float, FT, true><<<grid, BLOCK, 0, s>>>(a, ca);
+            });
+        } else {
+            const size_t rec_lds = (size_t)std::min(K, CHAIN_SUB) * BLOCK * sizeof(uint4);
+            if (p->f64_state) k_chain<double, uint8_t, false><<<grid, BLOCK, rec_lds, s>>>(a, ca);
+            else k_chain<float, uint8_t, false><<<grid, BLOCK, rec_lds, s>>>(a, ca);
+        }
+        if (L % m == 0) {
+            V2E_HIP(hipEventRecord(h->ev_chain[L], s));
+            const int b = L / m;
+            if (!fused_rec && b + 2 < nEB && launch_ahead(b + 2)) return V2E_EHIP;
+        }
+        // what is final now: with a refractory period the frames up to launch L - 1's (just validated), without one up to L's
+        const int fin_launch = has_refr ? L - 1 : L;
+        if (fin_launch >= 0) {
+            const bool last = fin_launch == nB - 1;
+            if ((fin_launch + 1) % m == 0 || last) {
+                const int b = fin_launch / m;
+                V2E_HIP(hipEventRecord(h->ev_fork[b], s));
+                if (launch_emission(b)) return V2E_EHIP;
+            }
+        }
     }
     if (mark(ev_main, s)) return V2E_EHIP;
-    V2E_HIP(hipStreamWaitEvent(s, h->ev_join[nB - 1], 0)); // join: the run is complete on `s`
+    V2E_HIP(hipStreamWaitEvent(s, h->ev_join[nEB - 1], 0)); // join: the run is complete on `s`
+    if (!fused_rec) V2E_HIP(hipStreamWaitEvent(s, h->ev_ahead[nEB - 1], 0));
     V2E_HIP(hipGetLastError());
     return 0;
 }
@@ -1653,7 +1761,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     const bool small_grid = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu;
     // K frames per launch with the state in registers (emu_chain.h) wherever it can run: |256 insists on it, |512 or any
     // of the explicit pipeline bits (|16 |32 |64 |128) selects the earlier pipelines (kept for A/B and as the fallback)
-    const bool chain_ok = chain_eligible(h, p);
+    const bool chain_ok = chain_eligible(h, p, dtype, (use_graph & 256) != 0);
     V2E_REQUIRE(!(use_graph & 256) || chain_ok, "k_chain cannot run this configuration (max_iters or a grid too large for the redo rendezvous)");
     const bool chain = chain_ok && ((use_graph & 256) != 0 || (!(use_graph & (16 | 32 | 64 | 128 | 512)) && !getenv("V2E_AMD_NO_CHAIN")));
     const bool fused = !legacy && !chain && ((use_graph & 32) != 0 || (!(use_graph & 64) && !small_grid));
@@ -1664,7 +1772,9 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     const int K = (pipe && h->pipe_E % 2 == 0 && (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu && !(use_graph & 128) &&
                    !getenv("V2E_AMD_NO_SPECULATION")) ? 2 : 1;
     if (chain) {
+        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] chain_alloc n_frames=%d\n", n_frames);
         rc = chain_alloc(h, p, n_frames);
+        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] chain_alloc rc=%d K=%d E=%d D=%d\n", rc, h->ch_K, h->ch_E, h->ch_D);
         if (rc) return rc;
     }
     if (pipe) { // everything the capture must not allocate
@@ -1766,7 +1876,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
     int lg = legacy ? 1 : (fused ? 2 : (chain ? 3 : 0)); push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
-    push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold));
+    push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_E, sizeof(h->ch_E)); push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold));
     push(&h->pipe_tsold, sizeof(h->pipe_tsold)); push(&h->pipe_bck, sizeof(h->pipe_bck)); push(&K, sizeof(K));
     int nis = getenv("V2E_AMD_NO_INKERNEL_SYNC") ? 1 : 0; push(&nis, sizeof(nis));
     if (!h->graph || key != h->graph_key) {
@@ -1775,12 +1885,15 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         rc = enqueue(cs, nullptr, nullptr);
+        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] enqueue rc=%d, ending capture\n", rc);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
+        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] capture ended: %d\n", (int)e);
         hipStreamDestroy(cs);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         V2E_HIP(e);
         V2E_HIP(hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0));
+        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] instantiated\n");
         V2E_HIP(hipGraphDestroy(g));
         h->graph_key = key;
     }

@@ -31,13 +31,14 @@
 #pragma once
 
 constexpr int CHAIN_K_MAX = 32;
+constexpr int CHAIN_SUB = 8; // frames whose records are in LDS at a time (4 KB per frame and workgroup)
 constexpr int CHAIN_MAX_ITERS = 1024; // k_cframe keeps one total per key in LDS
 
 struct ChainArgs {
-    const void *frames;               // frames of the run, frame f at frames + f * frame_stride
-    unsigned long long frame_stride;  // bytes
+    const void *frames;               // FUSED: frames of the run, frame f at frames + f * frame_stride (bytes)
+    unsigned long long frame_stride;
+    const uint32_t *fidx_base;        // FUSED: the run's first frame index
     const FrameCtl *ctl;              // [n_frames][n_clips]
-    const uint32_t *fidx_base;
     int f0, nf;                       // this launch advances frames [f0, f0 + nf) of the run (nf = 0: tail launch)
     int pf0, pnf;                     // the previous launch's frames, to be validated (pnf = 0: nothing to validate)
     int D, n_clips, nwp, K, ngroups;
@@ -45,6 +46,7 @@ struct ChainArgs {
     uint16_t *wmax;                   // [D][n_clips][nwp] per-wave max count
     uint8_t *wtot;                    // [D][n_clips][nkeys_cap][nwp] per-wave key totals (<= 64 each)
     float *tsold;                     // [D][n_clips][npx_pad] ts_mem before a rule-on frame's update, or nullptr
+    const uint4 *rec;                 // [D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
     uint32_t *gM_prev, *gM_cur;       // [K + 1][n_clips][K] rule-on maxima: row r = after r redo passes
     unsigned *bar_prev;               // [K][n_clips] rendezvous counters of the redo passes on the previous launch
     const void *base_in, *lp_in;      // state as the previous launch left it
@@ -57,7 +59,120 @@ struct ChainArgs {
     float *ts_fix;
     v2e_frame_rec *recs;              // [n_frames][n_clips]
     int store_out;                    // tail launch: state must be copied to *_out even without a redo
+    unsigned long long *dbg;          // dev tool: [ngroups][16] wall-clock stamps of one launch, or nullptr
 };
+
+// Per-frame outputs of the chain are written through to memory: as dirty L2 lines they would all be written back by the
+// release at the end of the launch, on the critical path between two dependent launches.
+#ifndef V2E_CHAIN_WT
+#define V2E_CHAIN_WT 1
+#endif
+#if V2E_CHAIN_WT
+#define WT_STORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#else
+#define WT_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
+#define V2E_STAMP_C(i) do { if (ca.dbg && tid == 0) ca.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
+
+// One frame's state-independent quantities of a pixel as a 16-byte record (layout: see k_ahead):
+// lin-log / eps (emulator_utils.py:18-45, 80-96), leak step (:126-129, float32 left to right), shot decisions (:326-349).
+template <typename FT>
+__device__ __forceinline__ uint4 make_frame_record(const KArgs &a, FT px, const float *s_lutL, const double *s_lutI, double dt_over_tau,
+                                                   double shot_base, float dtime_f, float lk, float thp, float ppre, float npre, float rr,
+                                                   float uu)
+{
+    constexpr bool U8 = sizeof(FT) == 1;
+    double L, inten01;
+    if (U8) {
+        L = a.log_input ? (double)px : (double)s_lutL[(int)px];
+        inten01 = s_lutI[(int)px];
+    } else {
+        const double x = (double)px;
+        L = a.log_input ? x : (double)lin_log(x);
+        inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
+    }
+    double eps = 0.0;
+    if (a.has_cutoff) {
+        eps = inten01 * dt_over_tau;
+        if (eps > 1.0) eps = 1.0;
+    }
+    float dl = 0.f;
+    if (a.do_leak) {
+        const float rate = lk * (1.0f - a.jit_f * rr);
+        dl = (dtime_f * rate) * thp;
+    }
+    uint32_t sb = 0;
+    if (a.do_shot) {
+        const double F = shot_base * (a.inten_slope * inten01 + 1);
+        if ((double)uu > 1 - F * (double)ppre) sb |= 1u; // ON -> bit 30 of the high word
+        if ((double)uu < F * (double)npre) sb |= 2u;     // OFF -> bit 31
+    }
+    const unsigned long long eb = (unsigned long long)__double_as_longlong(eps);
+    uint4 r;
+    r.x = (uint32_t)eb;
+    r.y = (uint32_t)(eb >> 32) | (sb << 30);
+    r.z = __float_as_uint((float)L);
+    r.w = __float_as_uint(dl);
+    return r;
+}
+
+// Everything about a frame that depends on no state, for all frames of a chain launch at once: lin-log of the pixel,
+// the low-pass coefficient eps (emulator_utils.py:80-96), the Philox draws, the leak step delta_leak
+// (emulator_utils.py:126-129, float32 left to right) and the shot-noise decisions (emulator_utils.py:326-349).  One thread per
+// (pixel, frame pair), so the draws of a pair cost one Philox call and the work runs at full occupancy beside the chain
+// instead of inside its one-wave-per-SIMD dependency chain.  Result: one 16-byte record per (frame, pixel)
+//   .x .y  eps (float64, in [0,1]: top exponent bit and sign bit are free and carry the shot ON / OFF decisions)
+//   .z     lin-log value L (float32; the frame itself when it is log-encoded already)
+//   .w     delta_leak (float32)
+struct AheadArgs {
+    const void *frames;
+    unsigned long long frame_stride;
+    const FrameCtl *ctl;
+    const uint32_t *fidx_base;
+    int f0, nf, D, n_clips;
+    uint4 *rec; // [D][n_clips][npx_pad]
+};
+
+template <typename FT>
+__global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
+{
+    __shared__ float s_lutL[256];
+    __shared__ double s_lutI[256];
+    constexpr bool U8 = sizeof(FT) == 1;
+    const int tid = threadIdx.x;
+    if (U8) {
+        s_lutL[tid] = a.lut_L[tid];
+        s_lutI[tid] = a.lut_I[tid];
+    }
+    __syncthreads();
+    const int clip = blockIdx.y, p = blockIdx.x * BLOCK + tid;
+    if (p >= a.npx) return;
+    const uint32_t fbase = *aa.fidx_base;
+    // pair z of the launch: global frames 2q-1 (odd) and 2q (even), q = pair of the launch's first frame + z
+    const uint32_t q = v2e_frame_pair(fbase + (uint32_t)aa.f0) + blockIdx.z;
+    const long long f_odd = 2ll * q - 1 - (long long)fbase; // run-relative
+    const bool in0 = f_odd >= aa.f0 && f_odd < aa.f0 + aa.nf, in1 = f_odd + 1 >= aa.f0 && f_odd + 1 < aa.f0 + aa.nf;
+    if (!in0 && !in1) return;
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const bool need_r = a.do_leak && a.jit_f != 0.f;
+    float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f;
+    if (need_r || a.do_shot) v2e_draw_pair(a.seed, (uint32_t)clip, q, (uint32_t)p, need_r, &r_odd, &u_odd, &r_even, &u_even);
+    const float thp = a.pos_thres[sp], thn = a.neg_thres[sp];
+    const float lk = a.do_leak ? a.leak_hz_f * a.noise_rate[sp] : 0.f;
+    const float ppre = a.scalar_thres ? a.pos_pre_scalar : a.pos_nom_f / thp; // emulator.py:475-478
+    const float npre = a.scalar_thres ? a.neg_pre_scalar : a.neg_nom_f / thn;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (!(half ? in1 : in0)) continue;
+        const long long f = f_odd + half;
+        const FrameCtl *c = aa.ctl + (size_t)f * aa.n_clips + clip;
+        const FT px = ((const FT *)((const char *)aa.frames + (size_t)f * aa.frame_stride))[(size_t)clip * a.npx + p];
+        const uint4 r = make_frame_record<FT>(a, px, s_lutL, s_lutI, c->dt_over_tau, c->shot_base, (float)(c->t_frame - c->t_prev), lk, thp,
+                                              ppre, npre, half ? r_even : r_odd, half ? u_even : u_odd);
+        aa.rec[((size_t)(f % aa.D) * aa.n_clips + clip) * a.npx_pad + p] = r;
+    }
+}
 
 // exact floor(a/b), a >= 0, b > 0, from a reciprocal computed once per launch: a*rb is within a few ulp of a/b, so
 // its floor is the true floor or one off, and the exactly rounded remainder a - q*b decides (same value as
@@ -73,17 +188,19 @@ template <typename R> __device__ __forceinline__ R floor_div_rcp(R a, R b, R rb)
     return q;
 }
 
-template <typename R, typename FT>
+// FUSED = false: the frames' records come from k_ahead through LDS (small grids: the chain is one wave per SIMD and every
+// instruction in it is latency).  FUSED = true: the chain builds each record itself (large grids: the occupancy hides
+// latencies, and the records' 32 B per pixel and frame of extra HBM traffic would be what bounds the run).
+template <typename R, typename FT, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
 {
-    extern __shared__ unsigned char s_dyn[]; // [K][BLOCK] pixels of the pass
-    FT *s_px = (FT *)s_dyn;
-    __shared__ float s_lutL[256];
-    __shared__ double s_lutI[256];
+    extern __shared__ uint4 s_arec[];         // [CHAIN_SUB][BLOCK] k_ahead's records of the frames in flight
     __shared__ uint32_t s_exact[CHAIN_K_MAX]; // M of the previous launch's frames known to be rule-on (0: speculate)
-    __shared__ double s_dtau[CHAIN_K_MAX], s_shot[CHAIN_K_MAX]; // per frame of the pass: FrameCtl::dt_over_tau, shot_base,
-    __shared__ float s_dtime[CHAIN_K_MAX];                       // (float)delta_time,
-    __shared__ uint32_t s_mon[CHAIN_K_MAX];                      // refr_on_n
+    __shared__ uint32_t s_mon[CHAIN_K_MAX];   // per frame of the pass: FrameCtl::refr_on_n
+    __shared__ float s_lutL[FUSED ? 256 : 1]; // FUSED: lin-log tables and the pass's frame scalars
+    __shared__ double s_lutI[FUSED ? 256 : 1];
+    __shared__ double s_dtau[FUSED ? CHAIN_K_MAX : 1], s_shot[FUSED ? CHAIN_K_MAX : 1];
+    __shared__ float s_dtime[FUSED ? CHAIN_K_MAX : 1];
     constexpr bool U8 = sizeof(FT) == 1;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int g = blockIdx.x;
@@ -91,62 +208,113 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
     const bool valid = p < a.npx;
     const int wave_g = g * (BLOCK / WAVE) + wave;
     __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
-    if (U8) {
-        s_lutL[tid] = a.lut_L[tid];
-        s_lutI[tid] = a.lut_I[tid];
+    V2E_STAMP_C(0);
+    uint32_t fbase = 0u;
+    if (FUSED) {
+        fbase = *ca.fidx_base;
+        if (U8) {
+            s_lutL[tid] = a.lut_L[tid];
+            s_lutI[tid] = a.lut_I[tid];
+        }
     }
-    const uint32_t fbase = *ca.fidx_base;
     const bool need_r = a.do_leak && a.jit_f != 0.f;
-    const bool need_draw = need_r || a.do_shot;
-    __syncthreads();
 
     for (int clip = blockIdx.y; clip < ca.n_clips; clip += (int)gridDim.y) {
+        if (clip != (int)blockIdx.y) __syncthreads(); // the LDS tables of the previous clip are no longer read
         const size_t sp = (size_t)clip * a.npx_pad + p;
-        // ---- read-only planes and what follows from them for every frame of the launch
-        float thp = 1.f, thn = 1.f, nr = 0.f;
-        if (valid) {
-            thp = a.pos_thres[sp];
-            thn = a.neg_thres[sp];
-            if (a.do_leak) nr = a.noise_rate[sp];
-        }
-        const float lk = a.leak_hz_f * nr;                          // emulator_utils.py:126, left to right
-        const R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;       // emulator_utils.py:154-157 divisors
-        const R tnd = a.scalar_thres ? (R)a.neg_div : (R)thn;
-        const R rtp = (R)1 / tpd, rtn = (R)1 / tnd;
-        const float ppre = a.scalar_thres ? a.pos_pre_scalar : a.pos_nom_f / thp; // emulator.py:475-478
-        const float npre = a.scalar_thres ? a.neg_pre_scalar : a.neg_nom_f / thn;
-        // ---- state
+        // A pass's records go through LDS, CHAIN_SUB frames at a time, their loads in flight at once: vector memory
+        // operations retire in order, so a load issued inside the frame loop would wait for the write acknowledgements of
+        // the stores before it.  The next CHAIN_SUB frames' records are fetched into registers BEFORE the current ones are
+        // processed (older than those frames' stores) and moved to LDS after them.  Every thread reads back only what it
+        // wrote: no barrier.
+        auto stage = [&](const int fs, const int fn) __attribute__((always_inline)) { // the first CHAIN_SUB frames of a pass
+            if (FUSED || !valid) return;
+            uint4 t[CHAIN_SUB];
+#pragma unroll
+            for (int j = 0; j < CHAIN_SUB; ++j) {
+                t[j] = make_uint4(0u, 0u, 0u, 0u);
+                if (j < fn) t[j] = ca.rec[((size_t)((fs + j) % ca.D) * ca.n_clips + clip) * a.npx_pad + p];
+            }
+#pragma unroll
+            for (int j = 0; j < CHAIN_SUB; ++j)
+                if (j < fn) s_arec[(size_t)j * BLOCK + tid] = t[j];
+        };
+        auto fill_scalars = [&](const int fs, const int fn) __attribute__((always_inline)) {
+            __syncthreads();
+            if (tid < fn) {
+                const FrameCtl *c = ca.ctl + (size_t)(fs + tid) * ca.n_clips + clip;
+                s_mon[tid] = c->refr_on_n;
+                if (FUSED) {
+                    s_dtau[tid] = c->dt_over_tau;
+                    s_shot[tid] = c->shot_base;
+                    s_dtime[tid] = (float)(c->t_frame - c->t_prev);
+                }
+            }
+            __syncthreads();
+        };
+        // ---- every load of the prologue is issued before the first one is consumed (one memory round trip, not one per
+        // item): read-only planes, state, the previous launch's rule-on row, this launch's frame scalars, and last the
+        // staged records, whose arrival (in-order retirement) means everything before them has arrived too
+        float thp = 1.f, thn = 1.f;
         R b = (R)0, lp = (R)0;
         float tsm = 0.f;
         if (valid) {
+            thp = a.pos_thres[sp];
+            thn = a.neg_thres[sp];
             b = ((const R *)ca.base_in)[sp];
             if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.lp_in)[sp];
             if (a.has_refr) tsm = ca.ts_in[sp];
         }
-        // every load above retires HERE, outside the frame loop: a wait for them inside the loop would, from the second
-        // frame on, be a wait for the previous frame's stores (vector memory operations retire in order)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(b), "+v"(lp), "+v"(tsm), "+v"(thp), "+v"(thn), "+v"(nr) : : "memory");
-        // ---- passes: [redo of the previous launch]* then this launch's own frames
         bool own = !(a.has_refr && ca.pnf > 0);
+        uint32_t gM_v = 0u; // lane k: rule-on max of the previous launch's frame k as its own pass left it
+        if (!own && lane < ca.pnf) gM_v = ca.gM_prev[(size_t)clip * ca.K + lane];
+        uint32_t mon_r = 0xFFFFFFFFu;
+        double dtau_r = 0.0, shot_r = 0.0;
+        float dtime_r = 0.f, nr = 0.f;
+        if (tid < ca.nf) {
+            const FrameCtl *c = ca.ctl + (size_t)(ca.f0 + tid) * ca.n_clips + clip;
+            mon_r = c->refr_on_n;
+            if (FUSED) {
+                dtau_r = c->dt_over_tau;
+                shot_r = c->shot_base;
+                dtime_r = (float)(c->t_frame - c->t_prev);
+            }
+        }
+        if (FUSED && valid && a.do_leak) nr = a.noise_rate[sp];
+        stage(ca.f0, ca.nf); // this launch's own frames (almost always the only pass)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(b), "+v"(lp), "+v"(tsm), "+v"(thp), "+v"(thn), "+v"(gM_v), "+v"(mon_r) : : "memory");
+        if (tid < CHAIN_K_MAX) {
+            s_exact[tid] = 0u;
+            s_mon[tid] = mon_r;
+            if (FUSED) {
+                s_dtau[tid] = dtau_r;
+                s_shot[tid] = shot_r;
+                s_dtime[tid] = dtime_r;
+            }
+        }
+        __syncthreads();
+        const float lk = a.leak_hz_f * nr;                                          // FUSED: emulator_utils.py:126
+        const float ppre = a.scalar_thres ? a.pos_pre_scalar : a.pos_nom_f / thp;   // FUSED: emulator.py:475-478
+        const float npre = a.scalar_thres ? a.neg_pre_scalar : a.neg_nom_f / thn;
+        const R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;       // emulator_utils.py:154-157 divisors
+        const R tnd = a.scalar_thres ? (R)a.neg_div : (R)thn;
+        const R rtp = (R)1 / tpd, rtn = (R)1 / tnd;
+        V2E_STAMP_C(1);
+        // ---- passes: [redo of the previous launch]* then this launch's own frames
         bool redone = false;
         int round = 0, last_exact = -1;
-        if (!own) {
-            __syncthreads();
-            if (tid < CHAIN_K_MAX) s_exact[tid] = 0u;
-            __syncthreads();
-        }
         for (;;) {
             int fs, fn;
             uint32_t *gM_dst;
             if (!own) {
-                // first frame after last_exact on which some wave reached the rule threshold (uniform: scalar loads)
-                const uint32_t *row = ca.gM_prev + ((size_t)round * ca.n_clips + clip) * ca.K;
-                int j = -1;
-                uint32_t Mj = 0;
-                for (int k = last_exact + 1; k < ca.pnf; ++k) {
-                    const uint32_t v = __builtin_amdgcn_readfirstlane(row[k]);
-                    if (v != 0u) { j = k; Mj = v; break; }
+                // first frame after last_exact on which some wave reached the rule threshold: lane k = frame k
+                if (round > 0) {
+                    gM_v = 0u;
+                    if (lane < ca.pnf) gM_v = ca.gM_prev[((size_t)round * ca.n_clips + clip) * ca.K + lane];
                 }
+                const unsigned long long hit = __ballot(gM_v != 0u && lane > last_exact);
+                const int j = hit ? (int)__builtin_ctzll(hit) : -1;
+                const uint32_t Mj = hit ? lane_value(gM_v, j) : 0u;
                 if (j < 0) {
                     own = true;
                 } else {
@@ -166,68 +334,42 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             }
             if (own) { fs = ca.f0; fn = ca.nf; gM_dst = ca.gM_cur + (size_t)clip * ca.K; }
             else { fs = ca.pf0; fn = ca.pnf; gM_dst = ca.gM_prev + ((size_t)round * ca.n_clips + clip) * ca.K; }
-
-            // ------------------------------------------------------------ the frame loop
-            // per-frame scalars of this pass through LDS (a scalar load per frame would sit on the critical path)
-            __syncthreads();
-            if (tid < fn) {
-                const FrameCtl *c = ca.ctl + (size_t)(fs + tid) * ca.n_clips + clip;
-                s_dtau[tid] = c->dt_over_tau;
-                s_shot[tid] = c->shot_base;
-                s_dtime[tid] = (float)(c->t_frame - c->t_prev);
-                s_mon[tid] = c->refr_on_n;
+            if (redone) { // a redo pass, or the own pass after one: its inputs replace what the prologue staged
+                fill_scalars(fs, fn);
+                stage(fs, fn);
             }
-            __syncthreads();
-            float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f;
+            if (own) V2E_STAMP_C(2);
+            float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f; // FUSED: the draws of the current frame pair
             bool have_pair = false;
-            // The pass's pixels go through LDS, all loads in flight at once: vector memory operations retire in order, so a
-            // load issued inside the frame loop would wait for the write acknowledgements of the stores before it.
-            if (valid) {
-                const FT *fpx = (const FT *)((const char *)ca.frames + (size_t)fs * ca.frame_stride) + (size_t)clip * a.npx + p;
-                for (int k = 0; k < fn; ++k) s_px[(size_t)k * BLOCK + tid] = fpx[(size_t)k * (ca.frame_stride / sizeof(FT))];
-            }
-            auto frame_body = [&](const int k, const FT px) __attribute__((always_inline)) {
+            auto frame_body = [&](const int k) __attribute__((always_inline)) {
                 const int f = fs + k;
                 const int slot = f % ca.D;
                 const FrameCtl *c = ca.ctl + (size_t)f * ca.n_clips + clip; // rule-on frames only (timestamp tables)
-                const double dt_over_tau = s_dtau[k], shot_base = s_shot[k];
-                const float dtime_f = s_dtime[k];
                 const uint32_t Mon = s_mon[k];
                 const uint32_t exM = own ? 0u : s_exact[k];
-                // draws: one Philox call per pair of frames (v2e_detmath.h)
-                const uint32_t gf = fbase + (uint32_t)f;
-                float rr = 0.f, uu = 0.f;
-                if (need_draw) {
-                    if (!have_pair || v2e_frame_half(gf) == 0u)
-                        v2e_draw_pair(a.seed, (uint32_t)clip, v2e_frame_pair(gf), (uint32_t)p, need_r, &r_odd, &u_odd, &r_even, &u_even);
-                    have_pair = true;
+                // k_ahead's record: eps (+ shot decisions in its two free bits), lin-log value, leak step
+                uint4 rc;
+                if (FUSED) {
+                    FT px = (FT)0;
+                    if (valid) px = ((const FT *)((const char *)ca.frames + (size_t)f * ca.frame_stride))[(size_t)clip * a.npx + p];
+                    const uint32_t gf = fbase + (uint32_t)f;
+                    if (need_r || a.do_shot) { // one Philox call per pair of frames (v2e_detmath.h)
+                        if (!have_pair || v2e_frame_half(gf) == 0u)
+                            v2e_draw_pair(a.seed, (uint32_t)clip, v2e_frame_pair(gf), (uint32_t)p, need_r, &r_odd, &u_odd, &r_even, &u_even);
+                        have_pair = true;
+                    }
                     const bool even = v2e_frame_half(gf) != 0u;
-                    rr = even ? r_even : r_odd;
-                    uu = even ? u_even : u_odd;
-                }
-                // photoreceptor (emulator_utils.py:18-134)
-                double L, inten01;
-                if (U8) {
-                    L = a.log_input ? (double)px : (double)s_lutL[(int)px];
-                    inten01 = s_lutI[(int)px];
+                    rc = make_frame_record<FT>(a, px, s_lutL, s_lutI, s_dtau[k], s_shot[k], s_dtime[k], lk, thp, ppre, npre,
+                                               even ? r_even : r_odd, even ? u_even : u_odd);
                 } else {
-                    const double x = (double)px;
-                    L = a.log_input ? x : (double)lin_log(x);
-                    inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
+                    rc = s_arec[(size_t)(k % CHAIN_SUB) * BLOCK + tid];
                 }
-                R lpn;
-                if (a.has_cutoff) {
-                    double eps = inten01 * dt_over_tau;
-                    if (eps > 1.0) eps = 1.0;
-                    lpn = (R)((1.0 - eps) * (double)lp + eps * (double)L);
-                } else {
-                    lpn = (R)L;
-                }
-                if (a.do_leak) {
-                    const float rate = lk * (1.0f - a.jit_f * rr);
-                    const float delta_leak = (dtime_f * rate) * thp;
-                    b = b - (R)delta_leak;
-                }
+                const double eps = __longlong_as_double((long long)(((unsigned long long)(rc.y & 0x3FFFFFFFu) << 32) | rc.x));
+                const double L = (double)__uint_as_float(rc.z);
+                R lpn; // emulator_utils.py:96
+                if (a.has_cutoff) lpn = (R)((1.0 - eps) * (double)lp + eps * L);
+                else lpn = (R)L;
+                if (a.do_leak) b = b - (R)__uint_as_float(rc.w); // emulator_utils.py:131
                 // counts (emulator_utils.py:137-173): diff has one sign, one exact floor division
                 const R diff = (lpn + (R)0.0f) - b;
                 const bool is_pos = diff > (R)0;
@@ -236,17 +378,13 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 const int mag = q > 0 ? q : 0;
                 const bool neg = !is_pos;
                 uint32_t cw = mag > 0 ? (((uint32_t)mag & CNT_MASK) | (neg ? CNT_NEG : 0u)) : 0u;
-                if (a.do_shot) { // emulator_utils.py:326-349
-                    const double F = shot_base * (a.inten_slope * inten01 + 1);
-                    if ((double)uu > 1 - F * (double)ppre) cw |= CNT_SHOT_ON;
-                    if ((double)uu < F * (double)npre) cw |= CNT_SHOT_OFF;
-                }
+                if (a.do_shot) cw |= (rc.y >> 30) << 25; // CNT_SHOT_ON / CNT_SHOT_OFF
                 if (!valid) cw = 0u;
-                if (valid) ca.cnt[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p] = cw;
+                if (valid) WT_STORE(&ca.cnt[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p], cw);
                 const int magv = valid ? mag : 0;
                 const int wm = wave_max_i32(magv);
                 if (lane == 0) {
-                    ca.wmax[((size_t)slot * ca.n_clips + clip) * ca.nwp + wave_g] = (uint16_t)min(wm, 65535);
+                    WT_STORE(&ca.wmax[((size_t)slot * ca.n_clips + clip) * ca.nwp + wave_g], (uint16_t)min(wm, 65535));
                     // speculation check: only a wave that reaches the rule threshold says so
                     if (a.has_refr && k > (own ? -1 : last_exact) && (uint32_t)wm >= Mon) atomicMax(gM_dst + k, (uint32_t)wm);
                 }
@@ -290,7 +428,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                                 if (lane == 0) mine = (uint32_t)__popcll(so);
                                 if (lane == 1) mine = (uint32_t)__popcll(sf);
                             }
-                            if (kb + lane < nkw) trow[(size_t)(kb + lane) * ca.nwp] = (uint8_t)mine;
+                            if (kb + lane < nkw) WT_STORE(&trow[(size_t)(kb + lane) * ca.nwp], (uint8_t)mine);
                         }
                     }
                 }
@@ -311,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                             if (lane == 0) mine = (uint32_t)__popcll(so);
                             if (lane == 1) mine = (uint32_t)__popcll(sf);
                         }
-                        if (kb + lane < nkw) trow[(size_t)(kb + lane) * ca.nwp] = (uint8_t)mine;
+                        if (kb + lane < nkw) WT_STORE(&trow[(size_t)(kb + lane) * ca.nwp], (uint8_t)mine);
                     }
                 }
                 if (valid) {
@@ -325,8 +463,26 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     }
                 }
                 lp = lpn;
+                if (own && k < 12) V2E_STAMP_C(3 + k);
             };
-            for (int k = 0; k < fn; ++k) frame_body(k, s_px[(size_t)k * BLOCK + tid]);
+            for (int k0 = 0; k0 < fn; k0 += CHAIN_SUB) {
+                uint4 nx[CHAIN_SUB];
+                const int nnext = min(CHAIN_SUB, fn - k0 - CHAIN_SUB); // frames of the next sub-pass (<= 0: none)
+#pragma unroll
+                for (int j = 0; j < CHAIN_SUB; ++j) {
+                    nx[j] = make_uint4(0u, 0u, 0u, 0u);
+                    if (!FUSED && valid && j < nnext)
+                        nx[j] = ca.rec[((size_t)((fs + k0 + CHAIN_SUB + j) % ca.D) * ca.n_clips + clip) * a.npx_pad + p];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int kend = min(k0 + CHAIN_SUB, fn);
+                for (int k = k0; k < kend; ++k) frame_body(k);
+                if (!FUSED && valid) {
+#pragma unroll
+                    for (int j = 0; j < CHAIN_SUB; ++j)
+                        if (j < nnext) s_arec[(size_t)j * BLOCK + tid] = nx[j];
+                }
+            }
             if (own) break;
             // a redo pass: leave the corrected state where the next launch's own redo would look for it, and let every
             // workgroup of the clip publish before the check is repeated
@@ -335,7 +491,11 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 if (a.has_cutoff || a.do_shot) ((R *)ca.lp_fix)[sp] = lp;
                 ca.ts_fix[sp] = tsm;
             }
+            // (not at raised priority: a spinning wave that outranks the other kernels' waves on its SIMD keeps them from
+            // finishing, and the workgroups this one waits for may need their slots)
+            __builtin_amdgcn_s_setprio(0);
             const bool ok = clip_barrier(ca.bar_prev + (size_t)(round - 1) * ca.n_clips + clip, (unsigned)ca.ngroups);
+            __builtin_amdgcn_s_setprio(3);
             if (!ok && tid == 0) atomicOr(&ca.recs[(size_t)ca.pf0 * ca.n_clips + clip].flags, V2E_FLAG_SYNC_TIMEOUT);
         }
         if (valid && (ca.nf > 0 || ca.store_out || redone)) {
@@ -343,6 +503,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             if (ca.nf > 0 || a.has_cutoff || a.do_shot) ((R *)ca.lp_out)[sp] = lp;
             if (a.has_refr) ca.ts_out[sp] = tsm;
         }
+        V2E_STAMP_C(15);
     }
 }
 
@@ -370,7 +531,7 @@ struct CEmitArgs {
     unsigned long long cap;
     const unsigned long long *off_in;
     unsigned long long *off_out;
-    int capw;
+    int capw, ich; // event records per wave in LDS; iterations per pass of k_cemit (64 * ich <= capw, 2 * ich <= 62)
 };
 
 // One workgroup per (frame, clip): M, per key the prefix over waves and the total, prefix over keys, shuffle parameters.
@@ -521,7 +682,7 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
     const uint32_t *perm = ea.cperm + zc * a.max_iters * 8;
     bool dropped = false;
     const int iters = min(wmw, M);
-    constexpr int ICH = 31; // iterations per pass: 62 keys in a wave's lanes, at most 64 * 31 records
+    const int ICH = ea.ich; // iterations per pass: their 2 * ICH keys in the wave's lanes, at most 64 * ICH records
     for (int i0 = 0; i0 < iters; i0 += ICH) {
         const int i1 = min(i0 + ICH, iters);
         const int key = 2 + 2 * i0 + lane; // lanes 0..61: the ON / OFF keys of iterations i0 .. i0+30
