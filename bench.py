@@ -6,15 +6,20 @@ Workload (BASELINE.json configs[1]): a 346x260
 EventEmulator.generate_events path (v2ecore/emulator.py:619-1022) as HIP kernels, CLI
 default DVS parameters (v2e_args.py:150-204), Philox RNG, frames resident in HBM.
 One *step* = one second of source video = 300 emulator frames advanced on device with no
-host synchronisation in between.  value = events emitted / wall time (Mevents/s), whole job.
+host synchronisation in between; the host prepares and enqueues step s+1 while step s
+executes (EventEmulator.generate_events_batch_async) and then reads step s's records.
+value = events emitted / wall time (Mevents/s), whole job.
 
 N > 1 (driver: python -m torch.distributed.run ...): one independent clip per GPU
 (BASELINE.json configs[4]); every step ends with an RCCL all-gather of the ranks' event
-streams, overlapped with the next step's kernels on a side stream.
+streams, overlapped with the next step's kernels on a side stream.  The line then also
+carries `compute_only` (the same loop without the exchange) and `bytes_gathered`.
 
 Extra objects on the JSON line: roofline (dominant emulator kernel, HIP-event timed),
-cpu_baseline (CPU oracle on this host, rank 0, N=1), slomo (interpolated frames/s of the
-SuperSloMo HIP path with its own MFMA roofline), batched (many clips per launch).
+cpu_baseline (CPU oracle on this host, rank 0, N=1; + the recorded reference torch-CPU run),
+frame_api / delivered_to_host (what a v2e.py caller of the drop-in class gets), slomo
+(interpolated frames/s of the SuperSloMo HIP path with its own MFMA roofline), batched,
+hd_noisy, end_to_end.
 """
 import argparse
 import json
@@ -35,6 +40,7 @@ DEFAULT_KW = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, le
                   shot_noise_rate_hz=.001, refractory_period_s=.0005)
 HBM_PEAK = 8.0e12        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: f32-input MFMA peak
+CLIP_STEPS = 24           # distinct seconds of synthetic video generated; longer runs cycle through them
 
 
 def gen_frames_device(n, seed, device, h=H, w=W, sigma=3.0, i0=0):
@@ -67,20 +73,28 @@ def emulator_bytes_per_pixel(kw):
     return b
 
 
-def pmc_traffic_per_launch(kernel="k_step2"):
+def pmc_traffic_per_launch(kernel):
     """HBM bytes per chain-kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE
-    uncorrected -- our loads are 1-8 B per lane, for which the guide's x2 factor is uncalibrated).
-    Counters cannot be read from inside this process, so the value is the recorded one or null."""
-    path = os.path.join(ROOT, "profiles", "r01_emulator_pmc_hbm.txt")
-    try:
-        for line in open(path):
-            if line.startswith("# " + kernel + "<"):
-                parts = line.split()
-                return int((float(parts[-2]) + float(parts[-1])) * 1024)
-    except Exception:
-        pass
+    (profiles/r02_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs).  Counters cannot
+    be read from inside this process, so the value is the recorded one or null."""
+    for name in ("r02_emulator_pmc_hbm.txt", "r01_emulator_pmc_hbm.txt"):
+        try:
+            for line in open(os.path.join(ROOT, "profiles", name)):
+                if line.startswith("# " + kernel + "<") or line.startswith("# " + kernel + " "):
+                    parts = line.split()
+                    return int((float(parts[-2]) + float(parts[-1])) * 1024)
+        except Exception:
+            pass
     return None
+
+
+def recorded_reference():
+    """The unmodified reference timed on the build container's CPU (scripts/cpu_reference_baseline.py): recorded,
+    because /root/reference does not exist on the GPU box."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_reference.json")))
+    except Exception:
+        return None
 
 
 def cpu_baseline(frames_host, budget_s=15.0):
@@ -97,18 +111,95 @@ def cpu_baseline(frames_host, budget_s=15.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(n_ev / dt / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
-            "frames_per_s": round(n_fr / dt, 1),
-            "sample": "first %d frames of the same 346x260 clip, C oracle (oracle/emu_oracle.c), Philox RNG, %.1f s" % (n_fr, dt)}
+    out = {"value": round(n_ev / dt / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
+           "frames_per_s": round(n_fr / dt, 1),
+           "sample": "first %d frames of the same 346x260 clip, C oracle (oracle/emu_oracle.c), Philox RNG, %.1f s" % (n_fr, dt)}
+    ref = recorded_reference()
+    if ref:
+        runs = ref["emulator"]["runs"]
+        out["reference"] = {"kind": "reference, recorded (the reference tree exists only in the build container)",
+                            "host": ref["host"], "script": "scripts/cpu_reference_baseline.py -> profiles/r02_cpu_reference.json",
+                            "runs": [{"cores": r["threads"], "value": r["Mevents_per_s"], "unit": "Mevents/s",
+                                      "frames_per_s": r["frames_per_s"]} for r in runs]}
+    return out
+
+
+def frame_api_bench(frames_all, budget_frames=600):
+    """What a v2e.py caller of the drop-in gets: generate_events(frame, t) one frame at a time, host numpy in, host
+    numpy out (PCIe inclusive), in the default tape mode (the reference's own MT19937 stream) and in Philox mode."""
+    from v2e_amd import EventEmulator
+    host = frames_all[:budget_frames + 1].cpu().numpy()
+    out = {}
+    for mode in ("tape", "philox"):
+        emu = EventEmulator(device="cuda", seed=1, rng_mode=mode, **DEFAULT_KW)
+        emu.generate_events(host[0], 0.0)
+        for i in range(1, 21):
+            emu.generate_events(host[i], i * DT)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_ev = 0
+        for i in range(21, len(host)):
+            e = emu.generate_events(host[i], i * DT)
+            n_ev += 0 if e is None else len(e)
+        sec = time.perf_counter() - t0
+        out[mode] = {"frames_per_s": round((len(host) - 21) / sec, 1), "Mevents_per_s": round(n_ev / sec / 1e6, 2)}
+    out["note"] = "EventEmulator.generate_events per frame, host ndarray in / host ndarray out (PCIe inclusive), 346x260"
+    return out
+
+
+def delivered_to_host_bench(device, frames_all, steps=6):
+    """The device-resident run with its event rows delivered to pinned host memory: the D2H copy of step s on a side
+    stream overlaps step s + 1 (two event buffers alternate)."""
+    from v2e_amd import EventEmulator
+    F = FRAMES_PER_STEP
+    emu = EventEmulator(device=device, seed=1, rng_mode="philox", **DEFAULT_KW)
+    emu.generate_events(frames_all[0], 0.0)
+    buf = torch.empty((F, H, W), dtype=torch.uint8, device=device)
+    copy_stream = torch.cuda.Stream(device)
+    host = [None, None]
+
+    def enqueue(s):
+        lo = 1 + (s % CLIP_STEPS) * F
+        buf.copy_(frames_all[lo:lo + F])
+        return emu.generate_events_batch_async(buf, [(1 + s * F + i) * DT for i in range(F)], return_device=True)
+
+    def deliver(pend, slot):
+        ev, counts = pend.result()
+        n = int(counts.sum())
+        if host[slot] is None or host[slot].shape[0] < n:
+            host[slot] = torch.empty((int(n * 1.2) + 1024, 4), dtype=torch.float32).pin_memory()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(pend.done)
+            host[slot][:n].copy_(ev, non_blocking=True)
+        return n
+
+    pend = enqueue(0)
+    deliver(pend, 0)
+    copy_stream.synchronize()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    n_ev = 0
+    pend = enqueue(1)
+    for s in range(2, 2 + steps):
+        nxt = enqueue(s)
+        n_ev += deliver(pend, s & 1)
+        pend = nxt
+    n_ev += deliver(pend, (2 + steps) & 1)
+    copy_stream.synchronize()
+    torch.cuda.synchronize(device)
+    sec = time.perf_counter() - t0
+    return {"value": round(n_ev / sec / 1e6, 1), "unit": "Mevents/s", "GB_per_s_over_pcie": round(n_ev * 16 / sec / 1e9, 2),
+            "note": "same device-resident run, event rows (16 B each) copied to pinned host memory on a side stream while the "
+                    "next step executes"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the slomo / batched side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the slomo / batched / frame-API side measurements")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--force-allgather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
     args = ap.parse_args()
@@ -130,57 +221,40 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from v2e_amd import EventEmulator
+    from v2e_amd.benchutil import run_steps
     from v2e_amd.dist import EventStreamGatherer
 
     K, Wm = args.steps, args.warmup
     F = FRAMES_PER_STEP
-    n_total = (K + Wm) * F + 1
     # one independent clip per rank (configs[4]: seeds 10..17); rank 0 at N=1 uses seed 1 (configs[1])
     clip_seed = 1 if world == 1 else 10 + rank
-    frames_all = gen_frames_device(n_total, clip_seed, device)
-    emu = EventEmulator(device=device, seed=clip_seed, rng_mode="philox", **DEFAULT_KW)
-    emu.generate_events(frames_all[0], 0.0)  # first frame: state init, no events
-    buf = torch.empty((F, H, W), dtype=torch.uint8, device=device)
-    gather = EventStreamGatherer(device, world) if ((world > 1 or args.force_allgather) and not args.no_allgather) else None
+    frames_all = gen_frames_device(min(K + Wm, CLIP_STEPS) * F + 1, clip_seed, device)
 
-    def step(s):
-        lo = 1 + s * F
-        buf.copy_(frames_all[lo:lo + F])
-        times = [(lo + i) * DT for i in range(F)]
-        ev, counts = emu.generate_events_batch(buf, times, return_device=True, use_graph=True)
-        n = int(counts.sum())
-        if gather is not None:
-            gather.submit(ev, n)  # all-gather of this step's stream overlaps the next step
-        return n
+    def make_emu():
+        emu = EventEmulator(device=device, seed=clip_seed, rng_mode="philox", **DEFAULT_KW)
+        emu.generate_events(frames_all[0], 0.0)  # first frame: state init, no events
+        return emu
 
-    for s in range(Wm):
-        step(s)
-    if gather is not None:
-        gather.wait()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n_events = 0
-    for s in range(Wm, Wm + K):
-        n_events += step(s)
-    if gather is not None:
-        gather.wait()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    use_gather = (world > 1 or args.force_allgather) and not args.no_allgather
+    emu = make_emu()
+    gather = EventStreamGatherer(device, world) if use_gather else None
+    elapsed, n_events = run_steps(emu, frames_all, F, DT, K, Wm, gather, dist, device)
+    compute_only = None
+    if use_gather:  # the same loop without the exchange: how much of the N-GPU number the interconnect decides
+        emu_c = make_emu()
+        el_c, n_c = run_steps(emu_c, frames_all, F, DT, K, Wm, None, dist, device)
+        compute_only = (el_c, n_c)
 
     tot_events = n_events
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, compute_only[0] if compute_only else 0.0], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        ne = torch.tensor([n_events], dtype=torch.float64, device=device)
+        elapsed = float(t[0].item())
+        ne = torch.tensor([n_events, compute_only[1] if compute_only else 0], dtype=torch.float64, device=device)
         dist.all_reduce(ne, op=dist.ReduceOp.SUM)
-        tot_events = int(ne.item())
+        tot_events = int(ne[0].item())
+        if compute_only:
+            compute_only = (float(t[1].item()), int(ne[1].item()))
 
     out = None
     if rank == 0:
@@ -197,63 +271,78 @@ def main():
                                    "dt=1/300 s, emulator-only, v2e CLI default DVS params, Philox RNG, "
                                    "%d frames/step device-resident, one clip per GPU" % F,
                        "frames_per_step": F, "clips_per_gpu": 1,
-                       "event_stream_allgather": bool(gather is not None)},
+                       "event_stream_allgather": bool(use_gather)},
             "emulator_frames_per_s": round(world * K * F / elapsed, 1),
             "events_per_frame": round(tot_events / (world * K * F), 1),
         }
+        if compute_only:
+            out["compute_only"] = {"value": round(compute_only[1] / compute_only[0] / 1e6, 3), "unit": "Mevents/s",
+                                   "ms_per_step": round(compute_only[0] / K * 1e3, 4),
+                                   "note": "same loop, no event-stream exchange"}
+            out["with_allgather"] = {"value": out["value"], "unit": "Mevents/s",
+                                     "bytes_gathered_per_rank_per_step": int(gather.bytes_gathered / max(K + Wm, 1)),
+                                     "wire_format": "8 B per event (v2e_events_pack64)"}
 
     # ---------------- roofline of the dominant emulator kernel (rank 0, HIP events, same workload)
     if rank == 0:
         eng = emu._engine
         P = emu._params()
-        lo = 1 + (Wm + K - 1) * F
+        buf = torch.empty((F, H, W), dtype=torch.uint8, device=device)
+        lo = 1 + ((Wm + K - 1) % CLIP_STEPS) * F
         buf.copy_(frames_all[lo:lo + F])
-        # re-run the last step's frames instrumented (state keeps advancing; timing only)
-        t_prev = [(lo + F - 1 + i) * DT for i in range(F)]
-        t_frame = [(lo + F + i) * DT for i in range(F)]
+        # re-run one step's frames instrumented (state keeps advancing; timing only)
+        t_prev = [emu.t_previous + i * DT for i in range(F)]
+        t_frame = [emu.t_previous + (i + 1) * DT for i in range(F)]
         ev = eng.event_buffer(1)
         recs = eng.alloc_recs(F)
         eng.run(P, buf, t_prev, t_frame, emu.frame_counter, ev, recs, use_graph=2)
         prof = eng.last_profile()
+        kname, fpl, fpb = eng.last_pipeline()
         r = eng.recs_to_numpy(recs)[:, 0]
         ev_per_frame = float(r["n_events"].mean())
         npx = H * W
-        # decoupled pipeline: k_step(f) = finalise(f-1) + count(f) is the frame-to-frame
-        # dependency chain and owns the per-pixel state traffic (53 B/pixel + the 4-byte count word written for
-        # the emission side); the emission batches (k_tot_multi + k_emit_multi, 16 B/event + 4 B/pixel re-read)
-        # run behind it on a second stream.
+        # The dependency chain owns the per-pixel state traffic: SURVEY 8(d) prices a frame at 53 B/pixel (frame 1 + lp 16 +
+        # base 16 + thresholds 8 + noise rate 4 + ts_mem 8) + 16 B/event; the chain kernel also writes the 4-byte count word the
+        # event writer reads.  A launch covers `fpl` frames.
         n_step = max(prof.get("step_launches", 0), 1)
-        fpl = 2 if n_step < prof["launches"] else 1   # frames counted per chain launch (k_step2 : k_step)
-        kname = "k_step2" if fpl == 2 else "k_step"
         step_us = prof["count"] / n_step * 1e3
         step_bytes = (bpp + 4) * npx * fpl
-        emit_bytes = 16 * ev_per_frame + 2 * 4 * npx
+        emit_bytes = 16 * ev_per_frame + 4 * npx
         ach = step_bytes / (step_us * 1e-6)
         whole = (bpp * npx + 16 * ev_per_frame)
         out["roofline"] = {
-            "bound": "hbm", "kernel": kname,
+            "bound": "hbm", "kernel": kname.split("(")[0],
             "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK, 5), "traffic": pmc_traffic_per_launch(kname),
+            "frac": round(ach / HBM_PEAK, 5), "traffic": pmc_traffic_per_launch(kname.split("(")[0]),
             "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
             "avg_launch_us": {kname: round(step_us, 3),
-                              "emission_batch(k_tot_multi+k_frame_multi+k_emit2_multi)": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3)},
-            "emission": {"frames_per_batch": prof.get("frames_per_batch"), "algorithmic_bytes_per_frame": int(emit_bytes)},
+                              "event_batch(k_cframe+k_cemit)": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3)},
+            "emission": {"frames_per_batch": fpb, "algorithmic_bytes_per_frame": int(emit_bytes)},
             "whole_step": {"algorithmic_bytes_per_frame": int(whole),
                            "achieved_GBps": round(whole * K * F / elapsed / 1e9, 2),
                            "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
-            "note": "avg_launch_us: HIP events before the first and after the last chain launch on its stream (includes "
-                    "the inter-kernel gaps) and around every emission batch on the emission stream; 346x260 state (2.9 MB) is "
-                    "L2/MALL resident and one frame is only 1406 waves, so the chain is bounded by per-launch latency, "
-                    "not HBM (DESIGN.md section 3)",
+            "note": "avg_launch_us: HIP events before the first and after the last chain launch on its stream (includes the "
+                    "inter-launch gaps and the rare redo passes) and around every event batch on its stream; the per-pixel state "
+                    "(2.9 MB at 346x260) stays in registers for the launch's frames and is L2/MALL resident between launches, "
+                    "and one frame is only 1408 waves, so the chain is bounded by launch and instruction latency, not HBM "
+                    "(DESIGN.md section 3); whole_step prices the complete frame against the driver-timed region",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())
         if not args.no_extras and world == 1:
             try:
                 from v2e_amd.benchutil import batched_emulator_bench, e2e_bench, hd_noisy_emulator_bench, slomo_bench
+                out["frame_api"] = frame_api_bench(frames_all)
+                out["delivered_to_host"] = delivered_to_host_bench(device, frames_all)
                 out["batched"] = batched_emulator_bench(device)
                 out["hd_noisy"] = hd_noisy_emulator_bench(device)
                 out["slomo"] = slomo_bench(device)
+                ref = recorded_reference()
+                if ref:
+                    out["slomo"]["cpu_baseline"] = {
+                        "kind": "reference, recorded (scripts/cpu_reference_baseline.py)", "host": ref["host"]["cpu"],
+                        "runs": [{"cores": q["threads"], "batch_pairs": q["batch_pairs"], "value": q["interpolated_frames_per_s"],
+                                  "unit": "frames/s"} for q in ref["slomo"]["runs"]]}
                 out["end_to_end"] = e2e_bench(device)
             except Exception as e:  # side measurements must never hide the headline number
                 out["extras_error"] = repr(e)[:300]

@@ -217,6 +217,11 @@ int v2e_emu_pipe_plan(int n_frames, int frames_per_batch, int frames_per_launch,
  * the number of chain launches ms_count covers (step_launches may be NULL). */
 int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch, int *step_launches);
 
+/* Which pipeline the last v2e_emu_run on this handle used: kind 0 = unfused count/rank/scan/emit, 1 = k_step / k_step2
+ * chain + deferred emission, 2 = k_main per frame, 3 = k_chain (K frames per launch, state in registers; 4 = the same with
+ * the per-frame records built inside the chain); frames_per_launch of the dependency chain and frames per emission batch. */
+int v2e_emu_last_pipeline(v2e_emu *h, int *kind, int *frames_per_launch, int *frames_per_batch);
+
 /* ------------------------------------------------------------- SuperSloMo */
 
 /* one 2-D convolution layer of the UNet (model.py: nn.Conv2d + leaky_relu 0.1) */

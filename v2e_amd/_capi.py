@@ -93,6 +93,7 @@ SIGNATURES = {
                                   C.POINTER(_i)]),
     "v2e_emu_pipe_plan": (_i, [_i, _i, _i, _vp, _i]),
     "v2e_emu_last_profile_pipe": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "v2e_emu_last_pipeline": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "v2e_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_conv2d_lrelu": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(ConvDesc), _vp, _i, _i, _i, _vp]),
     "v2e_unet_workspace_bytes": (_i64, [_i, _i, _i, _i]),

@@ -10,6 +10,57 @@ F32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: f32-input MFMA, dense
 HBM_PEAK = 8.0e12
 
 
+def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device):
+    """The timed loop of bench.py: `warmup` untimed steps, then `steps` steps of F frames bracketed by a barrier and a
+    device synchronisation on both sides; returns (seconds, events of this rank).  Step s + 1 is prepared and enqueued
+    while step s executes; the event stream of step s goes to `gather` (all-gather over the ranks) when there is one.
+    Works on any object with EventEmulator's generate_events_batch_async (the CPU tests pass a stub)."""
+    device = torch.device(device)
+    cuda = device.type == "cuda"
+    buf = torch.empty((F,) + tuple(frames_all.shape[1:]), dtype=frames_all.dtype, device=device)
+    nclip = max((int(frames_all.shape[0]) - 1) // F, 1)
+
+    def enqueue(s):
+        lo = 1 + (s % nclip) * F  # the synthetic clip is cycled through; time keeps running
+        buf.copy_(frames_all[lo:lo + F])  # fixed buffer: the run's hipGraph bakes the pointer in
+        return emu.generate_events_batch_async(buf, [(1 + s * F + i) * dt for i in range(F)], return_device=True, use_graph=True)
+
+    def finish(pend):
+        ev, counts = pend.result()
+        n = int(counts.sum())
+        if gather is not None:
+            gather.submit(ev, n)  # all-gather of this step's stream overlaps the next step
+        return n
+
+    def sync():
+        if gather is not None:
+            gather.wait()
+        if cuda:
+            torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        if cuda:
+            torch.cuda.synchronize(device)
+
+    def loop(first, count):
+        n, pend = 0, None
+        for s in range(first, first + count):
+            nxt = enqueue(s)
+            if pend is not None:
+                n += finish(pend)
+            pend = nxt
+        if pend is not None:
+            n += finish(pend)
+        return n
+
+    loop(0, warmup)
+    sync()
+    t0 = time.perf_counter()
+    n_events = loop(warmup, steps)
+    sync()
+    return time.perf_counter() - t0, n_events
+
+
 def unet_flops(cin, cout, h, w):
     """2*MACs of model.UNet on one [cin,h,w] sample."""
     from .synth import unet_layer_shapes

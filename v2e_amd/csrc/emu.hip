@@ -691,12 +691,18 @@ struct v2e_emu {
     unsigned long long *off_dev = nullptr, *off_host = nullptr; // [n_clips] explicit event offsets
     // multi-frame run
     FrameCtl *run_ctl = nullptr;       // device [run_cap][n_clips]
-    FrameCtl *run_ctl_host = nullptr;  // pinned
+    FrameCtl *run_ctl_host2[2] = {nullptr, nullptr}; // pinned staging, two sets
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    int run_stage = 0;
     int run_cap = 0;
     uint32_t *run_fidx = nullptr;      // device: frame_idx0 of the current run
     uint32_t *run_fidx_host = nullptr; // pinned
-    hipGraphExec_t graph = nullptr;
-    std::vector<unsigned char> graph_key;
+    // captured runs, keyed by everything baked into them (buffers, sizes, parameters): a caller that alternates between two
+    // sets of frame / event / record buffers (the asynchronous API) replays two graphs
+    struct CachedGraph { std::vector<unsigned char> key; hipGraphExec_t exec; unsigned long long used; };
+    std::vector<CachedGraph> graphs;
+    unsigned long long graph_clock = 0;
+    void drop_graphs() { for (auto &g : graphs) hipGraphExecDestroy(g.exec); graphs.clear(); }
     unsigned long long *dbg = nullptr; // dev tool (v2e_emu_debug_timeline)
     unsigned *run_bar = nullptr;       // [run_cap + 1][n_clips] rendezvous counters of the fused pipeline
     uint32_t *pre32 = nullptr, *tot32 = nullptr; // k_scan2 outputs (large grids only)
@@ -732,6 +738,7 @@ struct v2e_emu {
     hipStream_t ahead = nullptr, tables = nullptr; // k_ahead / k_cframe run beside the chain and the event writer
     std::vector<hipEvent_t> ev_ahead, ev_chain, ev_tables;
     int ch_E = 0;                   // frames per k_ahead launch / emission batch (a multiple of ch_K)
+    int last_kind = -1, last_fpl = 0, last_fpb = 0; // v2e_emu_last_pipeline
     uint32_t *ch_gM = nullptr;      // [ch_launch_cap][ch_K + 1][n_clips][ch_K]
     unsigned *ch_bar = nullptr;     // [ch_launch_cap][ch_K][n_clips]
     void *ch_base2 = nullptr, *ch_lp2 = nullptr; // second set of state planes (ping-pong between launches)
@@ -843,7 +850,7 @@ static int alloc_iter_scratch(v2e_emu *h, int max_iters)
         V2E_HIP(hipMemset(h->pre32, 0, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap * h->ngp));
         V2E_HIP(hipMemset(h->tot32, 0, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap));
     }
-    if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+    h->drop_graphs();
     return 0;
 }
 
@@ -910,7 +917,7 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
     V2E_HIP(hipMalloc(&h->off_dev, sizeof(unsigned long long) * n_clips));
     V2E_HIP(hipHostMalloc(&h->off_host, sizeof(unsigned long long) * n_clips));
     V2E_HIP(hipMalloc(&h->run_fidx, sizeof(uint32_t)));
-    V2E_HIP(hipHostMalloc(&h->run_fidx_host, sizeof(uint32_t)));
+    V2E_HIP(hipHostMalloc(&h->run_fidx_host, 2 * sizeof(uint32_t)));
     *out = h;
     return 0;
 }
@@ -919,7 +926,7 @@ int v2e_emu_destroy(v2e_emu *h)
 {
     if (!h) return 0;
     hipSetDevice(h->device);
-    if (h->graph) hipGraphExecDestroy(h->graph);
+    h->drop_graphs();
     hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
     hipFree(h->lut_L); hipFree(h->lut_I); hipFree(h->pre32); hipFree(h->tot32);
     hipFree(h->pipe_cnt); hipFree(h->pipe_gmax); hipFree(h->pipe_tsold); hipFree(h->pipe_gtT); hipFree(h->pipe_rowext);
@@ -942,7 +949,7 @@ int v2e_emu_destroy(v2e_emu *h)
     if (h->off_host) hipHostFree(h->off_host);
     if (h->run_ctl) hipFree(h->run_ctl);
     if (h->run_bar) hipFree(h->run_bar);
-    if (h->run_ctl_host) hipHostFree(h->run_ctl_host);
+    for (int q = 0; q < 2; ++q) { if (h->run_ctl_host2[q]) hipHostFree(h->run_ctl_host2[q]); if (h->ev_stage[q]) hipEventDestroy(h->ev_stage[q]); }
     hipFree(h->run_fidx);
     if (h->run_fidx_host) hipHostFree(h->run_fidx_host);
     delete h;
@@ -955,7 +962,7 @@ int v2e_emu_bind_state(v2e_emu *h, void *lp, void *base, float *ts_mem, float *p
     V2E_REQUIRE(h && lp && base && pos_thres && neg_thres, "bind_state: null plane");
     h->lp = lp; h->base = base; h->ts_mem = ts_mem;
     h->pos_thres = pos_thres; h->neg_thres = neg_thres; h->noise_rate = noise_rate;
-    if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+    h->drop_graphs();
     return 0;
 }
 
@@ -1510,7 +1517,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
         V2E_HIP(hipMalloc(&h->ch_cpre, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp)); // two sets: k_cframe(b + 1) beside k_cemit(b)
         V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
         h->ch_max_blocks = chain_blocks_per_cu(K, !chain_small_grid(h)) * h->n_cu;
-        if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+        h->drop_graphs();
     }
     const int n_launch = (n_frames + K - 1) / K + 1;
     if (!h->ahead) V2E_HIP(hipStreamCreateWithFlags(&h->ahead, hipStreamNonBlocking));
@@ -1541,7 +1548,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
             h->ch_launch_cap = n_launch;
             V2E_HIP(hipMalloc(&h->ch_gM, sizeof(uint32_t) * (size_t)n_launch * (K + 1) * h->n_clips * K));
             V2E_HIP(hipMalloc(&h->ch_bar, sizeof(unsigned) * (size_t)n_launch * K * h->n_clips));
-            if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+            h->drop_graphs();
         }
     }
     return 0;
@@ -1735,22 +1742,27 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     if (n_frames > h->run_cap) {
         V2E_HIP(hipStreamSynchronize(s));
         if (h->run_ctl) V2E_HIP(hipFree(h->run_ctl));
-        if (h->run_ctl_host) V2E_HIP(hipHostFree(h->run_ctl_host));
+        for (int q = 0; q < 2; ++q) if (h->run_ctl_host2[q]) V2E_HIP(hipHostFree(h->run_ctl_host2[q]));
         h->run_cap = n_frames;
         V2E_HIP(hipMalloc(&h->run_ctl, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
-        V2E_HIP(hipHostMalloc(&h->run_ctl_host, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
+        for (int q = 0; q < 2; ++q) V2E_HIP(hipHostMalloc(&h->run_ctl_host2[q], sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
         if (h->run_bar) V2E_HIP(hipFree(h->run_bar));
         V2E_HIP(hipMalloc(&h->run_bar, sizeof(unsigned) * (size_t)(h->run_cap + 1) * h->n_clips));
-        if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
-    } else {
-        // the pinned staging buffers are reused: make sure the previous upload finished
-        V2E_HIP(hipStreamSynchronize(s));
+        h->drop_graphs();
     }
+    // two pinned staging sets, each guarded by the event of the upload that last read it: the host prepares run n + 1
+    // while run n executes
+    const int sq = h->run_stage ^= 1;
+    if (!h->ev_stage[sq]) V2E_HIP(hipEventCreateWithFlags(&h->ev_stage[sq], hipEventDisableTiming));
+    else V2E_HIP(hipEventSynchronize(h->ev_stage[sq]));
+    FrameCtl *ctl_host = h->run_ctl_host2[sq];
+    uint32_t *fidx_host = h->run_fidx_host + sq;
     const size_t nct = (size_t)n_frames * h->n_clips;
-    for (size_t i = 0; i < nct; ++i) h->run_ctl_host[i] = make_ctl(t_prev[i], t_frame[i], p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
-    *h->run_fidx_host = frame_idx0;
-    V2E_HIP(hipMemcpyAsync(h->run_ctl, h->run_ctl_host, sizeof(FrameCtl) * nct, hipMemcpyHostToDevice, s));
-    V2E_HIP(hipMemcpyAsync(h->run_fidx, h->run_fidx_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    for (size_t i = 0; i < nct; ++i) ctl_host[i] = make_ctl(t_prev[i], t_frame[i], p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
+    *fidx_host = frame_idx0;
+    V2E_HIP(hipMemcpyAsync(h->run_ctl, ctl_host, sizeof(FrameCtl) * nct, hipMemcpyHostToDevice, s));
+    V2E_HIP(hipMemcpyAsync(h->run_fidx, fidx_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    V2E_HIP(hipEventRecord(h->ev_stage[sq], s));
     KArgs a = make_kargs(h, p);
     const int mode = use_graph & 3;          // 0 plain launches, 1 hipGraph, 2 instrumented
     const bool legacy = (use_graph & 16) != 0; // 4-kernel count/rank/scan/emit pipeline (kept for A/B)
@@ -1793,6 +1805,9 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
             h->ev_join.push_back(e1);
         }
     }
+    h->last_kind = legacy ? 0 : (fused ? 2 : (chain ? (chain_small_grid(h) && !getenv("V2E_AMD_CHAIN_FUSED") ? 3 : 4) : 1));
+    h->last_fpl = chain ? h->ch_K : (pipe ? K : 1);
+    h->last_fpb = chain ? h->ch_E : (pipe ? h->pipe_E : 1);
     auto enqueue = [&](hipStream_t st, hipEvent_t *evs, int *nm) -> int {
         if (legacy) {
             if (nm) *nm = 4 * n_frames + 1;
@@ -1879,25 +1894,30 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_E, sizeof(h->ch_E)); push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold));
     push(&h->pipe_tsold, sizeof(h->pipe_tsold)); push(&h->pipe_bck, sizeof(h->pipe_bck)); push(&K, sizeof(K));
     int nis = getenv("V2E_AMD_NO_INKERNEL_SYNC") ? 1 : 0; push(&nis, sizeof(nis));
-    if (!h->graph || key != h->graph_key) {
-        if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; }
+    hipGraphExec_t exec = nullptr;
+    for (auto &cg : h->graphs)
+        if (cg.key == key) { exec = cg.exec; cg.used = ++h->graph_clock; break; }
+    if (!exec) {
+        if (h->graphs.size() >= 4) { // drop the least recently used one
+            size_t lru = 0;
+            for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
+            hipGraphExecDestroy(h->graphs[lru].exec);
+            h->graphs.erase(h->graphs.begin() + lru);
+        }
         hipStream_t cs;
         V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         rc = enqueue(cs, nullptr, nullptr);
-        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] enqueue rc=%d, ending capture\n", rc);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
-        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] capture ended: %d\n", (int)e);
         hipStreamDestroy(cs);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         V2E_HIP(e);
-        V2E_HIP(hipGraphInstantiate(&h->graph, g, nullptr, nullptr, 0));
-        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] instantiated\n");
+        V2E_HIP(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
         V2E_HIP(hipGraphDestroy(g));
-        h->graph_key = key;
+        h->graphs.push_back({key, exec, ++h->graph_clock});
     }
-    V2E_HIP(hipGraphLaunch(h->graph, s));
+    V2E_HIP(hipGraphLaunch(exec, s));
     return 0;
 }
 
@@ -1909,7 +1929,7 @@ int v2e_emu_debug_timeline(v2e_emu *h, unsigned long long *out_host /* [ngroups]
     if (!h->dbg) {
         V2E_HIP(hipMalloc(&h->dbg, sizeof(unsigned long long) * 16 * h->ngroups));
         V2E_HIP(hipMemset(h->dbg, 0, sizeof(unsigned long long) * 16 * h->ngroups));
-        if (h->graph) { hipGraphExecDestroy(h->graph); h->graph = nullptr; h->graph_key.clear(); }
+        h->drop_graphs();
     }
     if (ngroups) *ngroups = h->ngroups;
     if (out_host) {
@@ -1943,11 +1963,18 @@ int v2e_emu_pipe_plan(int n_frames, int frames_per_batch, int frames_per_launch,
     return (int)plan.size();
 }
 
+int v2e_emu_last_pipeline(v2e_emu *h, int *kind, int *frames_per_launch, int *frames_per_batch)
+{
+    V2E_REQUIRE(h && kind && frames_per_launch && frames_per_batch, "null");
+    *kind = h->last_kind; *frames_per_launch = h->last_fpl; *frames_per_batch = h->last_fpb;
+    return 0;
+}
+
 int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch, int *step_launches)
 {
     V2E_REQUIRE(h && emit_batches && frames_per_batch, "null");
     *emit_batches = h->prof_emit_batches;
-    *frames_per_batch = h->pipe_E;
+    *frames_per_batch = h->last_kind >= 3 ? h->ch_E : h->pipe_E;
     if (step_launches) *step_launches = h->prof_step_launches;
     return 0;
 }

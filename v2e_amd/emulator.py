@@ -104,6 +104,23 @@ def _as_f32_tensor(a):
     return a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
 
 
+class _PendingRun:
+    """Handle of an enqueued device-resident run (EventEmulator.generate_events_batch_async)."""
+
+    def __init__(self, emu, ev, recs, done, counts, start, return_device, empty, dts=None):
+        self.emu, self.ev, self.recs, self.done = emu, ev, recs, done
+        self.counts, self.start, self.return_device, self.empty, self.dts = counts, start, return_device, empty, dts
+        self._res = None
+
+    def result(self):
+        if self._res is None:
+            if self.recs is None:
+                self._res = ((self.empty if self.return_device else None), self.counts)
+            else:
+                self._res = self.emu._finish_run(self)
+        return self._res
+
+
 class EventEmulator(object):
     """compute events based on the input frame (MI355X implementation)."""
 
@@ -560,6 +577,17 @@ class EventEmulator(object):
         an [N,4] float32 array (or device tensor) of all frames' events concatenated,
         counts[f] the number of events of frame f (0 for the very first frame).
         """
+        return self.generate_events_batch_async(frames, t_frames, return_device=return_device, use_graph=use_graph,
+                                                cap=cap, _single_buffer=True).result()
+
+    def generate_events_batch_async(self, frames, t_frames, return_device=False, use_graph=True, cap=None,
+                                    _single_buffer=False):
+        """generate_events_batch without waiting for the device: enqueues the run and returns a handle whose
+        result() gives (events, counts).  The host can prepare and enqueue the next run (it executes behind this one
+        on the same stream) before reading this one's result: two sets of event / record buffers alternate, so a
+        result stays valid until the second-next call.  Pixel state, frame counter and t_previous advance at enqueue
+        time; the event counters (num_events_*) when result() is called; errors (capacity, max_iters) are raised there.
+        """
         if self.rng_mode != "philox":
             raise ValueError("generate_events_batch needs rng_mode='philox' (tape mode needs the host per frame)")
         if self.photoreceptor_noise:
@@ -585,7 +613,7 @@ class EventEmulator(object):
         nrun = F - start
         if nrun <= 0:
             empty = torch.empty((0, 4), dtype=torch.float32, device=eng.device)
-            return (empty if return_device else None), counts
+            return _PendingRun(self, None, None, None, counts, start, return_device, empty)
         t_prev = []
         tp = float(self.t_previous)
         for f in range(start, F):
@@ -597,17 +625,28 @@ class EventEmulator(object):
         P = self._params()
         if cap is None:
             cap = max(4 * H * W, 1 << 16) * min(nrun, 64)
-        ev = eng.event_buffer(cap)
-        recs = eng.alloc_recs(nrun)
+        which = 0 if _single_buffer else self.__dict__.setdefault("_async_flip", 0)
+        if not _single_buffer:
+            self._async_flip = which ^ 1
+        ev = eng.event_buffer(cap, which)
+        recs = eng.alloc_recs(nrun, which)
         ug = int(use_graph)
         if getattr(self, "_refr_mostly_on", False):
-            ug |= 128  # one frame per launch: the two-frame chain would repair its speculation on most launches
+            ug |= 128  # one frame per launch: the speculating chains would repair their speculation on most launches
         eng.run(P, frames_dev[start:], t_prev, t_frames[start:], self.frame_counter, ev, recs, use_graph=ug)
-        r = eng.recs_to_numpy(recs)[:, 0]
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(eng.device))
+        self.frame_counter += nrun
+        self.t_previous = t_frames[-1]
+        dts = np.asarray(t_frames[start:]) - np.asarray(t_prev)
+        return _PendingRun(self, ev, recs, done, counts, start, return_device, None, dts)
+
+    def _finish_run(self, pend):
+        eng = self._engine
+        r = eng.read_recs_after(pend.recs, pend.done)[:, 0]
         if self.refractory_period_s > 0:  # emulator.py:830 on the frames just run: how often was the rule active?
-            dts = np.asarray(t_frames[start:]) - np.asarray(t_prev)
             m = np.maximum(r["max_events"], 1)
-            self._refr_mostly_on = bool(np.mean(self.refractory_period_s > dts / m) > 0.05)
+            self._refr_mostly_on = bool(np.mean(self.refractory_period_s > pend.dts / m) > 0.05)
         if (r["flags"] & _capi.FLAG_ITERS_CLAMPED).any():
             raise _capi.V2EAmdError("a pixel produced more than max_iters=%d events in one frame; "
                                     "construct with a larger max_iters" % eng.max_iters)
@@ -616,15 +655,13 @@ class EventEmulator(object):
                                     "set V2E_AMD_NO_INKERNEL_SYNC=1 to use the two-launch pipeline")
         if (r["flags"] & _capi.FLAG_EVENTS_DROPPED).any():
             raise _capi.V2EAmdError("event buffer capacity %d exceeded (needed %d); pass a larger cap" % (
-                ev.shape[1], int(r["n_events"].sum())))
-        counts[start:] = r["n_events"]
+                pend.ev.shape[1], int(r["n_events"].sum())))
+        pend.counts[pend.start:] = r["n_events"]
         total = int(r["n_events"].sum())
-        self.frame_counter += nrun
         self.num_events_total += total
         self.num_events_on += int(r["n_on"].sum())
         self.num_events_off += int(r["n_off"].sum())
-        self.t_previous = t_frames[-1]
-        out = ev[0, :total]
-        if return_device:
-            return out, counts
-        return (out.cpu().numpy() if total > 0 else None), counts
+        out = pend.ev[0, :total]
+        if pend.return_device:
+            return out, pend.counts
+        return (out.cpu().numpy() if total > 0 else None), pend.counts

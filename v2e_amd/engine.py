@@ -152,8 +152,15 @@ class EmuEngine:
               "v2e_emu_read_iter_counts")
         return np.frombuffer(out, dtype=np.uint32).reshape(self.n_clips, n_iters + 1, 2).copy()
 
-    def event_buffer(self, cap):
-        """Device [n_clips][cap][4] float32 buffer, grown geometrically."""
+    def event_buffer(self, cap, which=0):
+        """Device [n_clips][cap][4] float32 buffer, grown geometrically (`which`: one of two sets, so that the events of a
+        run can still be read while the next run writes the other set)."""
+        if which:
+            cur = self.__dict__.get("_events_b")
+            if cur is None or cur.shape[1] < cap:
+                ncap = max(int(cap), 1024) if cur is None else max(int(cap), 2 * cur.shape[1])
+                self._events_b = torch.empty((self.n_clips, ncap, 4), dtype=torch.float32, device=self.device)
+            return self._events_b
         if self._events is None or self._events.shape[1] < cap:
             ncap = max(int(cap), 1024)
             if self._events is not None:
@@ -196,16 +203,43 @@ class EmuEngine:
         return dict(count=v[0].value, rank=v[1].value, scan=v[2].value, emit=v[3].value, launches=n.value,
                     emit_batches=nb.value, frames_per_batch=fpb.value, step_launches=nsl.value)
 
-    def alloc_recs(self, n_frames):
-        """Device record array [F][n_clips] (struct v2e_frame_rec = 32 bytes), cached per F so that
+    def last_pipeline(self):
+        """(kind, frames per chain launch, frames per emission batch) of the last run(); see v2e_emu_last_pipeline."""
+        k, a, b = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.v2e_emu_last_pipeline(self._h, C.byref(k), C.byref(a), C.byref(b)), "v2e_emu_last_pipeline")
+        names = {0: "k_count/k_rank/k_scan/k_emit", 1: "k_step", 2: "k_main", 3: "k_chain", 4: "k_chain(fused records)"}
+        return names.get(k.value, "?"), a.value, b.value
+
+    def alloc_recs(self, n_frames, which=0):
+        """Device record array [F][n_clips] (struct v2e_frame_rec = 32 bytes), cached per (F, set) so that
         the hipGraph of run() (which bakes the pointer in) stays valid across calls."""
         cache = self.__dict__.setdefault("_recs_cache", {})
-        if n_frames not in cache:
+        key = (n_frames, which)
+        if key not in cache:
             if len(cache) > 8:
                 cache.clear()
-            cache[n_frames] = torch.zeros((n_frames, self.n_clips, C.sizeof(FrameRec)), dtype=torch.uint8,
-                                          device=self.device)
-        return cache[n_frames]
+            cache[key] = torch.zeros((n_frames, self.n_clips, C.sizeof(FrameRec)), dtype=torch.uint8,
+                                     device=self.device)
+        return cache[key]
+
+    def read_recs_after(self, recs_dev, done_event):
+        """Records of a run as a structured numpy array, copied on a side stream once `done_event` (recorded behind the run)
+        has completed: later runs already enqueued on the main stream are not waited for."""
+        cs = self.__dict__.get("_copy_stream")
+        if cs is None:
+            cs = self._copy_stream = torch.cuda.Stream(self.device)
+        host = self.__dict__.setdefault("_recs_host", {})
+        key = tuple(recs_dev.shape)
+        if key not in host:
+            host[key] = torch.empty(recs_dev.shape, dtype=torch.uint8).pin_memory()
+        with torch.cuda.stream(cs):
+            cs.wait_event(done_event)
+            host[key].copy_(recs_dev, non_blocking=True)
+            cs.synchronize()
+        dt = np.dtype([("max_events", "<i4"), ("flags", "<u4"), ("n_signal", "<u4"), ("n_events", "<u4"),
+                       ("n_on", "<u4"), ("n_off", "<u4"), ("ev_offset", "<u8")])
+        a = host[key].numpy().copy()
+        return a.view(dt).reshape(a.shape[0], a.shape[1])
 
     @staticmethod
     def recs_to_numpy(recs_dev):
