@@ -73,6 +73,43 @@ class PhiloxFixture:
             self.events = [z["ev_%04d" % i] for i in range(len(self.times))]
 
 
+TAPE_LIVE_FIXTURES = ["tape_live_defaults_346x260", "tape_live_noisy_346x260", "tape_live_noisy_1280x720",
+                      "tape_live_moving_dot_64x64"]  # tests/golden/make_golden_tape_live.py
+
+
+class LiveTapeFixture(PhiloxFixture):
+    """Digest-only fixture of the reference run with its own seeded torch generator (the drop-in's default mode)."""
+
+    def __init__(self, name):
+        super().__init__(name)
+        z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        self.draw_probe = str(z["draw_probe"])
+        self.exp_probe = str(z["exp_probe"])
+        self.torch_version = str(z["torch_version"])
+
+    def generator_matches(self):
+        """True iff this host's torch produces the draws the fixture was generated with (same MT19937 consumption by
+        normal / randn / rand / randperm / linspace); otherwise the replay cannot be compared and the test is skipped."""
+        import hashlib
+        import torch
+        torch.manual_seed(self.seed)
+        h = hashlib.sha256()
+        for a in (torch.normal(0.2, 0.03, size=(7, 11), dtype=torch.float32), torch.randn((5, 13), dtype=torch.float32),
+                  torch.rand(size=(3, 17), dtype=torch.float32), torch.randperm(1000), torch.randperm(70000),
+                  torch.linspace(start=0.0123, end=0.0456, steps=7, dtype=torch.float32)):
+            h.update(np.ascontiguousarray(a.numpy()).tobytes())
+        return h.hexdigest() == self.draw_probe
+
+    def host_exp_matches(self):
+        """torch.exp (float32, CPU: noise_rate_array, emulator.py:504) gives the fixture host's bits on this host; where it
+        does not (its last bit depends on the CPU), base_log_frame differs in the last bits from the stored digest."""
+        import hashlib
+        import torch
+        torch.manual_seed(5)
+        r = torch.randn((64, 64), dtype=torch.float32)
+        return hashlib.sha256(torch.exp(0.23025850929940458 * r).numpy().tobytes()).hexdigest() == self.exp_probe
+
+
 def events_equal(a, b):
     if a is None:
         a = np.zeros((0, 4), np.float32)

@@ -116,3 +116,85 @@ def test_event_stream_allgather_nccl_world2_unequal_counts():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: True, 1: True}
+
+
+class _StubPending:
+    def __init__(self, ev, counts):
+        self.ev, self.counts = ev, counts
+
+    def result(self):
+        return self.ev, self.counts
+
+
+class _StubEmulator:
+    """Stands in for v2e_amd.EventEmulator in bench.py's step loop: `generate_events_batch_async(frames, times)` returns
+    a handle whose result() is (event rows, per-frame counts); here a deterministic function of (rank, step)."""
+
+    def __init__(self, rank):
+        self.rank, self.step, self.calls = rank, 0, []
+
+    def generate_events_batch_async(self, frames, times, return_device=True, use_graph=True):
+        F = len(times)
+        counts = np.asarray([(3 + self.rank + (self.step + f) % 5) for f in range(F)], dtype=np.int64)
+        counts[0] += int(frames[0, 0, 0])            # depends on the frames the loop copied into its buffer
+        ev = _rows(int(counts.sum()), self.rank, self.step)
+        self.calls.append((float(times[0]), float(times[-1]), int(frames[0, 0, 0])))
+        self.step += 1
+        return _StubPending(ev, counts)
+
+
+def _bench_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from v2e_amd.benchutil import run_steps
+    from v2e_amd.dist import EventStreamGatherer
+    F, K, Wm, dt = 4, 5, 2, 0.25
+    clip_seed = 10 + rank                               # bench.py: one independent clip per rank, seeds 10..17
+    frames_all = torch.full((3 * F + 1, 2, 3), 0, dtype=torch.uint8)
+    for i in range(frames_all.shape[0]):
+        frames_all[i] = (clip_seed + i) % 7
+    emu = _StubEmulator(rank)
+    gather = EventStreamGatherer("cpu", world)
+    elapsed, n_events = run_steps(emu, frames_all, F, dt, K, Wm, gather, dist, "cpu")
+    ok = elapsed > 0 and len(emu.calls) == K + Wm
+    # frames: the synthetic clip is cycled through (3 steps of frames), time keeps increasing step after step
+    for s, (t0, t1, px) in enumerate(emu.calls):
+        ok &= abs(t0 - (1 + s * F) * dt) < 1e-12 and abs(t1 - (s * F + F) * dt) < 1e-12
+        ok &= px == (clip_seed + 1 + (s % 3) * F) % 7
+    # events counted = the timed steps only
+    exp = 0
+    for s in range(Wm, Wm + K):
+        c = sum(3 + rank + (s + f) % 5 for f in range(F)) + (clip_seed + 1 + (s % 3) * F) % 7
+        exp += c
+    ok &= n_events == exp
+    # the reduction bench.py does over the ranks
+    t = torch.tensor([float(n_events)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    # the last step's streams of every rank arrived everywhere, in rank order
+    parts = gather.result()
+    last = Wm + K - 1
+    for r in range(world):
+        n_r = sum(3 + r + (last + f) % 5 for f in range(F)) + (10 + r + 1 + (last % 3) * F) % 7
+        ok &= parts[r].shape == (n_r, 4) and torch.equal(parts[r], _rows(n_r, r, last))
+    ok &= gather.bytes_gathered > 0
+    q.put((rank, bool(ok), float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_loop_gloo_world2():
+    """bench.py's timed loop (v2e_amd.benchutil.run_steps: clip per rank, pipelined steps, event-stream all-gather of
+    every step, barrier-bracketed timing, totals reduced over ranks) on CPU tensors, two gloo ranks, engine stubbed."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)]
+    assert res[0][2] == res[1][2] > 0

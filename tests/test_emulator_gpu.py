@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from fixtures import PHILOX_FIXTURES, TAPE_FIXTURES, PhiloxFixture, TapeFixture, events_equal, sha
+from fixtures import (PHILOX_FIXTURES, TAPE_FIXTURES, TAPE_LIVE_FIXTURES, LiveTapeFixture, PhiloxFixture, TapeFixture,
+                      events_equal, sha)
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +41,41 @@ def test_hip_replays_reference_tape(name, oracle_lib):
     if fx.ts_mem_final is not None:
         assert np.array_equal(st["timestamp_mem"], fx.ts_mem_final)
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
+@pytest.mark.parametrize("name", TAPE_LIVE_FIXTURES)
+def test_hip_default_mode_at_sensor_size(name, oracle_lib):
+    """The drop-in exactly as v2e.py would construct it (rng_mode default = tape, the reference's seeded MT19937
+    stream drawn live on the host) at 346x260 and 1280x720 -- multi-workgroup scans, k_permute and the host randperm
+    gather at full size -- and BASELINE configs[0] in full (500 frames, 8 435 events): the reference's events, frame by
+    frame.  Final state: bit-equal to the oracle run on this host with the same seed, and to the reference's digest
+    where this host's torch.exp (noise_rate_array, emulator.py:504) has the fixture host's last bits."""
+    fx = LiveTapeFixture(name)
+    if not fx.generator_matches():
+        pytest.skip("torch %s draws differently from the fixture's torch %s" % (torch.__version__, fx.torch_version))
+    emu = _mk(fx, seed=fx.seed)
+    assert emu.rng_mode == "tape"
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        ev = emu.generate_events(f, float(t))
+        n = 0 if ev is None else len(ev)
+        assert n == fx.n_events[k], "frame %d: %d events, reference %d" % (k, n, fx.n_events[k])
+        if n:
+            assert sha(ev) == fx.ev_sha[k], "frame %d event digest differs" % k
+    st = _state(emu)
+    ora = oracle_lib.OracleEmulator(seed=fx.seed, rng_mode="tape", **fx.kw)
+    if fx.preset:
+        ora.set_dvs_params(fx.preset)
+    for f, t in zip(fx.frames, fx.times):
+        ora.generate_events(f, float(t))
+    assert np.array_equal(st["base_log_frame"].view(np.uint64), ora.base_log_frame.view(np.uint64))
+    if fx.host_exp_matches():
+        assert sha(st["base_log_frame"]) == fx.base_sha
+    assert sha(st["lp_log_frame"]) == fx.lp_sha
+    if fx.ts_mem_sha:
+        assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
+    assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+    if "moving_dot" in name:
+        assert emu.num_events_total == 8435
 
 
 @pytest.mark.parametrize("name", PHILOX_FIXTURES)

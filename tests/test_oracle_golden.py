@@ -4,7 +4,8 @@ rows, final float64/float32 state planes."""
 import numpy as np
 import pytest
 
-from fixtures import PHILOX_FIXTURES, TAPE_FIXTURES, PhiloxFixture, TapeFixture, events_equal, sha
+from fixtures import (PHILOX_FIXTURES, TAPE_FIXTURES, TAPE_LIVE_FIXTURES, LiveTapeFixture, PhiloxFixture, TapeFixture,
+                      events_equal, sha)
 
 
 @pytest.mark.parametrize("name", TAPE_FIXTURES)
@@ -42,3 +43,31 @@ def test_oracle_philox_matches_reference_with_philox_source(name, oracle_lib):
     if fx.ts_mem_sha:
         assert sha(emu.timestamp_mem) == fx.ts_mem_sha
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
+@pytest.mark.parametrize("name", TAPE_LIVE_FIXTURES)
+def test_oracle_live_tape_at_sensor_size(name, oracle_lib):
+    """The reference's own seeded MT19937 stream at 346x260 / 1280x720 and BASELINE configs[0] in full (500 frames,
+    8 435 events): the oracle draws live from torch with the same seed and must give the reference's events."""
+    import torch
+    fx = LiveTapeFixture(name)
+    if not fx.generator_matches():
+        pytest.skip("torch %s draws differently from the fixture's torch %s" % (torch.__version__, fx.torch_version))
+    torch.set_num_threads(1)
+    emu = oracle_lib.OracleEmulator(seed=fx.seed, rng_mode="tape", **fx.kw)
+    if fx.preset:
+        emu.set_dvs_params(fx.preset)
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        ev = emu.generate_events(f, float(t))
+        n = 0 if ev is None else len(ev)
+        assert n == fx.n_events[k], "frame %d: %d events, reference %d" % (k, n, fx.n_events[k])
+        if n:
+            assert sha(ev) == fx.ev_sha[k], "frame %d event digest differs" % k
+    if fx.host_exp_matches():
+        assert sha(emu.base_log_frame) == fx.base_sha
+    assert sha(emu.lp_log_frame) == fx.lp_sha
+    if fx.ts_mem_sha:
+        assert sha(emu.timestamp_mem) == fx.ts_mem_sha
+    assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+    if "moving_dot" in name:
+        assert emu.num_events_total == 8435

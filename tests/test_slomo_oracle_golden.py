@@ -104,3 +104,38 @@ def test_oracle_matches_reference_at_trained_scale(oracle_lib):
     assert close_scaled(o["flow"], z["flow"]) < TOL
     assert close_scaled(o["intrp"].reshape(len(ts), I0.shape[0], 5, 64, 96), z["intrp"]) < TOL
     assert np.max(np.abs(o["Ft"].astype(np.float64) - z["Ft"])) < TRAINED_SCALE_FT_TOL
+
+
+def test_oracle_pipeline_matches_reference_class_pngs(oracle_lib):
+    """The reference CLASS end to end (v2ecore.slomo.SuperSloMo.interpolate on a 40x70 clip, PNG files out;
+    tests/golden/make_golden_slomo_class.py) against the oracle driven the same way: PIL LANCZOS in, ToTensor /
+    Normalize, UNets + warps, revNormalize / ToPILImage truncation, PIL BILINEAR out.  uint8 frames: a float
+    difference of 1e-7 can move a value across a truncation boundary, so at most one grey level on < 1 % of pixels."""
+    from PIL import Image
+    import torch
+    from v2e_amd.synth import portable_unet_state_dict
+    z = np.load(os.path.join(GOLDEN, "slomo_class_40x70.npz"))
+    fr, pngs, U = z["frames"], z["pngs"], int(z["U"])
+    n, Hs, Ws = fr.shape
+    assert np.allclose(z["times"], np.arange((n - 1) * U) / U) and float(z["avg"]) == U
+    dim = (int(Ws / 32) * 32, int(Hs / 32) * 32)
+
+    def prep(a):
+        im = np.asarray(Image.fromarray(a).resize(dim, Image.LANCZOS)).astype(np.float32) / np.float32(255.0)
+        return (im - np.float32(0.428))[None, None]
+
+    sf, si = (int(v) for v in z["seeds"])
+    sd_f, sd_i = portable_unet_state_dict(2, 4, sf), portable_unet_state_dict(12, 5, si)
+    ts = [(k + 0.5) / U for k in range(U)]
+    for norm, ref in ((True, pngs), (False, z["pngs_cpu_branch"])):  # slomo.py:154-161: GPU branch / CPU branch
+        mean = np.float32(0.428) if norm else np.float32(0.0)
+        worst, nbad = 0, 0
+        for pair in range(n - 1):
+            Ft = oracle_lib.slomo_interpolate(prep(fr[pair]) + (np.float32(0.428) - mean), prep(fr[pair + 1]) + (np.float32(0.428) - mean),
+                                              ts, sd_f, sd_i)["Ft"]
+            for k in range(U):
+                u8 = (torch.from_numpy(Ft[k, 0]) + float(mean)).mul(255).byte().numpy()[0]      # revNormalize, ToPILImage
+                img = np.asarray(Image.fromarray(u8, mode="L").resize((Ws, Hs), Image.BILINEAR))
+                d = np.abs(img.astype(int) - ref[pair * U + k].astype(int))
+                worst, nbad = max(worst, int(d.max())), nbad + int((d > 0).sum())
+        assert worst <= 1 and nbad < 0.01 * ref.size, (norm, worst, nbad)

@@ -240,8 +240,14 @@ class SuperSloMo(object):
             interpTimes = interframeTimes if interpTimes is None else np.concatenate((interpTimes, interframeTimes))
             ts = [(k + 0.5) / upsampling_factor for k in range(upsampling_factor)]  # slomo.py:405
             Ft = self.engine.interpolate(I0, I1, ts, flow=flowOut)  # [U,B,1,H,W]
-            # ToPILImage after revNormalize (slomo.py:153-161, 437): x*255 -> byte (truncation)
-            img_u8 = ((Ft + self.mean) * 255.0).to(torch.uint8).cpu().numpy()
+            # ToPILImage after revNormalize (slomo.py:153-161, 437): (x + mean) * 255 -> byte, the CPU conversion the
+            # reference performs (truncation, low byte): same kernel as the PNG-free pipeline uses
+            import ctypes as C
+            q = torch.empty(tuple(Ft.shape), dtype=torch.uint8, device=dev)
+            check(self.engine.lib.v2e_f32_to_u8_trunc(_ptr(Ft.contiguous()), _ptr(q), upsampling_factor, num_batch_frames,
+                                                      int(Ft.shape[-1] * Ft.shape[-2]), float(self.mean), 0,
+                                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "v2e_f32_to_u8_trunc")
+            img_u8 = q.cpu().numpy()
             for k in range(upsampling_factor):
                 for batchIndex in range(num_batch_frames):
                     img = Image.fromarray(img_u8[k, batchIndex, 0], mode="L")
