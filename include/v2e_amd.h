@@ -307,6 +307,9 @@ int v2e_events_accumulate_frame(const float *events, int64_t n, double *current_
                                 int bins_y, int bins_x, double y_lo, double y_hi, double x_lo, double x_hi,
                                 double full_scale, void *stream);
 
+/* Finished DVS frame in 0..1: (current_frame + full_scale) / (2 full_scale) in float64 (renderer.py:245-247, normalize_frame). */
+int v2e_frame_normalize(const double *current_frame, double *out, int n, double full_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

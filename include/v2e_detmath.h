@@ -221,7 +221,7 @@ V2E_HD void v2e_draw_init(uint64_t seed, uint32_t clip, uint32_t pixel,
  * domains") on [0,a) x [0,2^k), k ~ half the bits of n, a = ceil(n / 2^k), 4 rounds, plus
  * cycle walking for the < 2^k ~ sqrt(n) values of [n, a*2^k).  The domain is within
  * 1/sqrt(n) of n, so a walk is rare (a wave waits for its slowest lane), and splitting by a
- * power of two makes init and apply shifts, masks, adds and two conditional subtractions: no
+ * power of two makes init and apply shifts, masks, adds, a multiply-high and a conditional subtraction: no
  * division, no loops.  Integer arithmetic only, so host and device agree bit for bit.
  */
 V2E_HD uint32_t v2e_mix32(uint32_t x)
@@ -275,9 +275,9 @@ V2E_HD uint32_t v2e_perm_apply(const v2e_perm_t *p, uint32_t c)
     do {
         uint32_t l = x >> p->sh, r = x & p->rmask; /* l in [0,a), r in [0,2^sh) */
         for (int round = 0; round < 4; ++round) {
-            if ((round & 1) == 0) { /* add a value <= amask < 2a, reduce with two subtractions */
-                l += v2e_mix32(r + p->k[round]) & p->amask;
-                if (l >= p->a) l -= p->a;
+            if ((round & 1) == 0) { /* add a value uniform on [0,a): high word of hash * a (a mask-and-subtract
+                                       reduction is measurably biased: chi-square of 6 000 shuffles of 24 elements) */
+                l += (uint32_t)(((uint64_t)v2e_mix32(r + p->k[round]) * p->a) >> 32);
                 if (l >= p->a) l -= p->a;
             } else {
                 r = (r + v2e_mix32(l + p->k[round])) & p->rmask;

@@ -1,0 +1,83 @@
+"""Statistical validation of Philox mode: its streams are NOT the reference's MT19937 stream, so what has to
+hold is that they are statistically the same inputs -- standard normals, 24-bit uniforms, uniform random permutations --
+and that the emulator driven by them emits what it emits when driven by torch's generator.  The functions checked are
+the ones the kernels execute (include/v2e_detmath.h, through the oracle library)."""
+import numpy as np
+import pytest
+
+
+def test_philox_draws_are_standard_normal_and_uniform(oracle_lib):
+    from scipy import stats
+    n = 1 << 20
+    r0, u0 = oracle_lib.philox_frame(12345, 0, 1, n)   # frame 1 and 2: the two halves of one Philox call per pixel
+    r1, u1 = oracle_lib.philox_frame(12345, 0, 2, n)
+    for r in (r0, r1):
+        assert abs(r.mean()) < 4 / np.sqrt(n) and abs(r.std() - 1) < 4 / np.sqrt(2 * n)
+        assert abs(stats.skew(r)) < 0.01 and abs(stats.kurtosis(r)) < 0.02
+        assert stats.kstest(r[::16].astype(np.float64), "norm").pvalue > 1e-3
+    for u in (u0, u1):
+        assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 4 / np.sqrt(12 * n)
+        assert stats.kstest(u[::16].astype(np.float64), "uniform").pvalue > 1e-3
+    # the cosine and sine branches of one Box-Muller transform, and consecutive pixels / frames, are uncorrelated
+    lim = 5 / np.sqrt(n)
+    assert abs(np.corrcoef(r0, r1)[0, 1]) < lim and abs(np.corrcoef(u0, u1)[0, 1]) < lim
+    assert abs(np.corrcoef(r0[:-1], r0[1:])[0, 1]) < lim and abs(np.corrcoef(r0, u0)[0, 1]) < lim
+    r3, _ = oracle_lib.philox_frame(12345, 0, 3, n)
+    assert abs(np.corrcoef(r1, r3)[0, 1]) < lim
+    n_pos, n_neg, n_rate = oracle_lib.philox_init(7, 0, n)
+    for r in (n_pos, n_neg, n_rate):
+        assert abs(r.mean()) < 4 / np.sqrt(n) and abs(r.std() - 1) < 4 / np.sqrt(2 * n)
+
+
+def test_keyed_bijection_is_a_uniform_shuffle(oracle_lib):
+    """v2e_perm_apply (the stand-in for torch.randperm, emulator.py:868): a bijection for every n, and over many keys
+    every element lands on every position equally often (chi-square), with ~1 fixed point like a random permutation."""
+    from scipy import stats
+    for n in (1, 2, 3, 5, 64, 100, 257, 4096, 35000):
+        idx = oracle_lib.perm_idx(3, 0, 17, 2, n)
+        assert sorted(idx.tolist()) == list(range(n))
+    n, trials = 24, 6000
+    pos = np.zeros((n, n))
+    fixed = 0
+    for k in range(trials):
+        idx = oracle_lib.perm_idx(99, 0, k, k % 7, n)
+        pos[np.arange(n), idx] += 1
+        fixed += int((idx == np.arange(n)).sum())
+    chi2 = ((pos - trials / n) ** 2 / (trials / n)).sum()
+    assert stats.chi2.sf(chi2, (n - 1) * (n - 1)) > 1e-4, chi2
+    assert abs(fixed / trials - 1.0) < 0.1
+    # large n: displacement is uncorrelated with the canonical (row-major) index
+    idx = oracle_lib.perm_idx(5, 0, 3, 0, 30000).astype(np.float64)
+    assert abs(np.corrcoef(np.arange(30000), idx)[0, 1]) < 0.03
+
+
+@pytest.mark.gpu
+def test_philox_mode_emits_like_the_reference_stream():
+    """BASELINE configs[1] pattern, 346x260, 10x slowdown, 80 frames, `noisy` preset (leak and 5 Hz shot noise: the
+    random inputs matter): Philox mode against the default mode (the reference's seeded MT19937 stream), several seeds each.
+    Events per frame, ON fraction and shot-noise share agree within the seed-to-seed spread."""
+    from v2e_amd import EventEmulator
+    from v2e_amd.synth import sincos_gradient_frames
+    frames = sincos_gradient_frames(81, 260, 346, seed=1)
+    times = [i / 300 for i in range(81)]
+    kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak_rate_hz=.01, shot_noise_rate_hz=.001,
+              refractory_period_s=.0005)
+
+    def run(mode, seed):
+        emu = EventEmulator(device="cuda", seed=seed, rng_mode=mode, **kw)
+        emu.set_dvs_params("noisy")
+        per_frame = []
+        for f, t in zip(frames, times):
+            e = emu.generate_events(f, t)
+            per_frame.append(0 if e is None else len(e))
+        return np.asarray(per_frame[1:], np.float64), emu.num_events_on / max(emu.num_events_total, 1)
+
+    tape = [run("tape", s) for s in (11, 12, 13)]
+    phil = [run("philox", s) for s in (21, 22, 23)]
+    t_tot = np.array([a.sum() for a, _ in tape]); p_tot = np.array([a.sum() for a, _ in phil])
+    assert abs(p_tot.mean() / t_tot.mean() - 1) < 0.01, (p_tot, t_tot)
+    t_on = np.array([b for _, b in tape]); p_on = np.array([b for _, b in phil])
+    assert abs(p_on.mean() - t_on.mean()) < 0.005, (p_on, t_on)
+    # frame by frame the two modes track each other (same video, same physics; different noise)
+    rel = np.abs(np.mean([a for a, _ in phil], axis=0) / np.mean([a for a, _ in tape], axis=0) - 1)
+    assert np.median(rel) < 0.02 and rel.max() < 0.15

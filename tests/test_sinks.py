@@ -61,3 +61,101 @@ def test_event_frame_accumulator_matches_renderer_math():
                 np.add.at(H, (i[ok].astype(int), j[ok].astype(int)), sgn)
             cur = np.clip(cur + H, -3, 3)
             assert np.array_equal(got, cur)
+
+
+RENDER_CASES = [("duration", 0.5, None), ("duration", 2.0, None), ("count", 700, None), ("source", None, None), ("area_count", 40, 32)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("as_tensor", [False, True])
+@pytest.mark.parametrize("case", RENDER_CASES)
+def test_event_renderer_matches_reference(case, as_tensor):
+    """v2e_amd.EventRenderer against frames produced by the reference's EventRenderer.render_events_to_frames
+    (tests/golden/make_golden_renderer.py): three packets, every exposure mode, sensor resolution and down-scaled;
+    float64 frames bit-equal, as is the accumulator left behind after each run."""
+    import torch
+    from v2e_amd.renderer import EventRenderer, ExposureMode
+    mode, val, area = case
+    modes = {"duration": ExposureMode.DURATION, "count": ExposureMode.COUNT, "source": ExposureMode.SOURCE,
+             "area_count": ExposureMode.AREA_COUNT}
+    z = np.load(os.path.join(GOLDEN, "renderer.npz"))
+    ev = np.load(os.path.join(GOLDEN, "sinks.npz"))["ev_346x260"]
+    for (h, w) in ((260, 346), (130, 173)):
+        if mode == "area_count" and (h, w) != (260, 346):
+            continue
+        r = EventRenderer(full_scale_count=3, exposure_mode=modes[mode], exposure_value=val if val is not None else 1 / 300.0,
+                          area_dimension=area)
+        key = "%s_%s_%dx%d" % (mode, str(val).replace(".", "p"), h, w)
+        for k, (a, b) in enumerate(((0, 1800), (1800, 1801), (1801, 5000))):
+            pkt = ev[a:b].copy()
+            fr = r.render_events_to_frames(torch.from_numpy(pkt).cuda() if as_tensor else pkt, height=h, width=w, return_frames=True)
+            name = key + "_p%d" % k
+            if name in z.files:
+                assert fr is not None and fr.dtype == np.float64 and np.array_equal(fr, z[name]), name
+            else:
+                assert fr is None, name
+        if key + "_cur" in z.files:
+            assert np.array_equal(r.currentFrame.cpu().numpy(), z[key + "_cur"])
+        else:
+            assert r.currentFrame is None
+
+
+@pytest.mark.gpu
+def test_emulator_file_sinks_are_fed_from_the_device(tmp_path):
+    """dvs_aedat2 / dvs_text of the drop-in: the bytes after the header are what the reference's AEDat2Output wrote for
+    the same events (golden, label_signal_noise on), frame packets appended one after the other; the text file's rows are
+    `repr(float64(t)) x y p label`."""
+    import torch
+    from v2e_amd.sinks import DeviceAEDat2Output, DeviceTextOutput
+    z = np.load(os.path.join(GOLDEN, "sinks.npz"))
+    ev = z["ev_346x260"]
+    path = str(tmp_path / "x.aedat")
+    wr = DeviceAEDat2Output(path, output_width=346, output_height=260, label_signal_noise=True)
+    wr.file.flush()
+    hdr = os.path.getsize(path)
+    head = open(path, "rb").read()
+    assert head.startswith(b"#!AER-DAT2.0\r\n") and head.count(b"\r\n") == 8
+    dev = torch.from_numpy(ev).cuda()
+    wr.appendEvents(dev[:4000], n_signal=4000)          # a packet of signal events only
+    label = np.zeros(1000, bool)
+    wr.appendEvents(ev[4000:], signnoise_label=label)   # host rows, the reference's label array: all noise
+    wr.close()
+    assert np.array_equal(np.frombuffer(open(path, "rb").read()[hdr:], dtype=np.uint8), z["aedat2_346x260"])
+    assert wr.numEventsWritten == 5000 and wr.numOnEvents == int((ev[:, 3] > 0).sum())
+    tp = str(tmp_path / "x.txt")
+    tw = DeviceTextOutput(tp, label_signal_noise=True)
+    tw.appendEvents(dev[:300], n_signal=250)
+    tw.close()
+    rows = [l for l in open(tp).read().splitlines() if not l.startswith("#")]
+    assert len(rows) == 300
+    for i in (0, 17, 249, 250, 299):
+        t, x, y, p, lab = rows[i].split()
+        assert t == repr(float(np.float64(ev[i, 0]))) and int(x) == int(ev[i, 1]) and int(y) == int(ev[i, 2])
+        assert int(p) == (1 if ev[i, 3] > 0 else 0) and int(lab) == (1 if i < 250 else 0)
+
+
+@pytest.mark.gpu
+def test_emulator_writes_aedat2_while_generating(tmp_path):
+    """EventEmulator(dvs_aedat2=..., dvs_text=...): the files hold exactly the events generate_events returned."""
+    from v2e_amd import EventEmulator
+    from v2e_amd.synth import int_gradient_frames
+    frames = int_gradient_frames(5, 260, 346, seed=2, noise=6)
+    emu = EventEmulator(device="cuda", seed=3, rng_mode="philox", output_folder=str(tmp_path), dvs_aedat2="ev", dvs_text="ev",
+                        output_width=346, output_height=260, shot_noise_rate_hz=5.0, leak_rate_hz=0.1, cutoff_hz=200)
+    evs = [emu.generate_events(f, i / 300) for i, f in enumerate(frames)]
+    emu.cleanup()
+    allev = np.concatenate([e for e in evs if e is not None])
+    data = open(str(tmp_path / "ev.aedat"), "rb").read()
+    pos = 0
+    for _ in range(7):  # seven header lines, each ending in CRLF (no signal/noise comment line)
+        pos = data.index(b"\r\n", pos) + 2
+    body = data[pos:]
+    words = np.frombuffer(body, dtype=">i4").reshape(-1, 2)
+    assert len(words) == len(allev)
+    assert np.array_equal(words[:, 1], (np.float32(1e6) * allev[:, 0]).astype(np.int32))
+    x = 345 - allev[:, 1].astype(np.int32)
+    y = 259 - allev[:, 2].astype(np.int32)
+    p = ((allev[:, 3] + 1) / 2).astype(np.int32)
+    assert np.array_equal(words[:, 0], (x << 12) | (y << 22) | (p << 11))
+    rows = [l for l in open(str(tmp_path / "ev.txt")).read().splitlines() if not l.startswith("#")]
+    assert len(rows) == len(allev)

@@ -60,6 +60,13 @@ __global__ __launch_bounds__(256) void k_frame_clip_add(double *__restrict__ cur
     diff[i] = 0; // ready for the next slice
 }
 
+// img = (currentFrame + full_scale_count) / float(full_scale_count * 2)   (renderer.py:245-247): a true float64 division
+__global__ __launch_bounds__(256) void k_frame_normalize(const double *__restrict__ cur, double *__restrict__ out, int n, double full_scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (cur[i] + full_scale) / (full_scale * 2);
+}
+
 // 8-byte wire format of an event row (include/v2e_amd.h)
 __global__ __launch_bounds__(256) void k_pack64(const float4 *__restrict__ ev, unsigned long long *__restrict__ out, int64_t n)
 {
@@ -130,6 +137,14 @@ int v2e_events_accumulate_frame(const float *events, int64_t n, double *current_
     if (n > 0)
         k_hist_events<<<v2e_cdiv(n, 256), 256, 0, s>>>((const float4 *)events, n, scratch_diff, bins_y, bins_x, y_lo, x_lo, delta_y, delta_x);
     k_frame_clip_add<<<v2e_cdiv((int64_t)bins_y * bins_x, 256), 256, 0, s>>>(current_frame, scratch_diff, bins_y * bins_x, full_scale);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_frame_normalize(const double *current_frame, double *out, int n, double full_scale, void *stream)
+{
+    V2E_REQUIRE(current_frame && out && n > 0 && full_scale > 0, "bad args");
+    k_frame_normalize<<<v2e_cdiv((int64_t)n, 256), 256, 0, (hipStream_t)stream>>>(current_frame, out, n, full_scale);
     V2E_HIP(hipGetLastError());
     return 0;
 }

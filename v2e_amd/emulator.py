@@ -84,20 +84,14 @@ def photoreceptor_noise_vrms(shot_noise_rate_hz, f3db, sample_rate_hz, pos_thr, 
     return float(np.std(rin) / np.std(rout) * vn)
 
 
-class _OneHostThread:
+def _limit_host_threads(n):
     """Tape mode issues a handful of small torch CPU ops per frame (randn / rand of one frame, a randperm per
     iteration).  Their values do not depend on the intra-op thread count, but on a many-core host fanning each of
-    them out over the OpenMP pool costs milliseconds: 250 -> 1 170 frames/s on the MI355X box with one thread."""
-
-    def __enter__(self):
-        self.n = torch.get_num_threads()
-        if self.n != 1:
-            torch.set_num_threads(1)
-
-    def __exit__(self, *exc):
-        if self.n != 1:
-            torch.set_num_threads(self.n)
-        return False
+    them out over the OpenMP pool costs milliseconds: 250 -> 1 170 frames/s on the MI355X box with one thread.
+    The setting is process-global in torch, so it is applied ONCE, when a tape-mode emulator is constructed
+    (`tape_host_threads`, default 1; None leaves torch alone), not toggled around calls."""
+    if n is not None and torch.get_num_threads() != int(n):
+        torch.set_num_threads(int(n))
 
 
 def _as_f32_tensor(a):
@@ -174,6 +168,7 @@ class EventEmulator(object):
             tape=None,
             max_iters: int = 64,
             photoreceptor_noise_vrms: Optional[float] = None,
+            tape_host_threads: Optional[int] = 1,
     ):
         unsupported = []
         if cs_lambda_pixels is not None: unsupported.append("cs_lambda_pixels (CSDVS)")
@@ -226,6 +221,8 @@ class EventEmulator(object):
             raise ValueError("rng_mode must be 'tape' or 'philox', got %r" % (self.rng_mode,))
         self.shuffle = bool(shuffle)
         self._tape = tape if tape is not None else _TorchTape()
+        if self.rng_mode == "tape":
+            _limit_host_threads(tape_host_threads)
         self._max_iters = max_iters
         if seed != 0:  # emulator.py:221-224
             torch.manual_seed(seed)
@@ -244,34 +241,41 @@ class EventEmulator(object):
 
     # ------------------------------------------------------------- plumbing
     def _open_writers(self, dvs_h5, dvs_aedat2, dvs_aedat4, dvs_text):
+        """Event file sinks (emulator.py:312-346).  AEDAT-2.0 and text: v2e_amd.sinks writers fed from the device-resident
+        event buffer (integer conversion on the GPU, byte-identical to the reference writers).  HDF5: the reference's own
+        layout through h5py (rows converted on the GPU).  AEDAT-4: delegated to the reference's AEDat4Output (dv_processing),
+        where importable."""
         if not (dvs_h5 or dvs_aedat2 or dvs_aedat4 or dvs_text):
             return
-        try:
-            from v2ecore.v2e_utils import checkAddSuffix
-            if dvs_h5:
+
+        def suffixed(name, suffix):  # v2e_utils.checkAddSuffix
+            return name if name.endswith(suffix) else name + suffix
+
+        folder = self.output_folder or ""
+        if dvs_h5:
+            try:
                 import h5py
-                path = checkAddSuffix(os.path.join(self.output_folder, dvs_h5), '.h5')
-                self.dvs_h5 = h5py.File(path, "w")
-                self.dvs_h5_dataset = self.dvs_h5.create_dataset(
-                    name="events", shape=(0, 4), maxshape=(None, 4), dtype="uint32", compression="gzip")
-            if dvs_aedat2:
-                from v2ecore.output.aedat2_output import AEDat2Output
-                path = checkAddSuffix(os.path.join(self.output_folder, dvs_aedat2), '.aedat')
-                self.dvs_aedat2 = AEDat2Output(path, output_width=self.output_width,
-                                               output_height=self.output_height,
-                                               label_signal_noise=self.label_signal_noise)
-            if dvs_aedat4:
+            except ImportError as e:
+                raise NotImplementedError("dvs_h5 needs h5py: %s" % e)
+            self.dvs_h5 = h5py.File(suffixed(os.path.join(folder, dvs_h5), '.h5'), "w")
+            self.dvs_h5_dataset = self.dvs_h5.create_dataset(
+                name="events", shape=(0, 4), maxshape=(None, 4), dtype="uint32", compression="gzip")
+        if dvs_aedat2:
+            from .sinks import DeviceAEDat2Output
+            self.dvs_aedat2 = DeviceAEDat2Output(suffixed(os.path.join(folder, dvs_aedat2), '.aedat'),
+                                                 output_width=self.output_width, output_height=self.output_height,
+                                                 label_signal_noise=self.label_signal_noise)
+        if dvs_text:
+            from .sinks import DeviceTextOutput
+            self.dvs_text = DeviceTextOutput(suffixed(os.path.join(folder, dvs_text), '.txt'),
+                                             label_signal_noise=self.label_signal_noise)
+        if dvs_aedat4:
+            try:
                 from v2ecore.output.aedat4_output import AEDat4Output
-                path = checkAddSuffix(os.path.join(self.output_folder, dvs_aedat4), '.aedat4')
-                self.dvs_aedat4 = AEDat4Output(path)
-            if dvs_text:
-                from v2ecore.output.ae_text_output import DVSTextOutput
-                path = checkAddSuffix(os.path.join(self.output_folder, dvs_text), '.txt')
-                self.dvs_text = DVSTextOutput(path, label_signal_noise=self.label_signal_noise)
-        except ImportError as e:
-            raise NotImplementedError(
-                "event file output (dvs_h5/dvs_aedat2/dvs_aedat4/dvs_text) is delegated to the reference's "
-                "writer classes, which are not importable here: %s" % e)
+            except ImportError as e:
+                raise NotImplementedError("dvs_aedat4 is delegated to the reference's AEDat4Output (dv_processing), which "
+                                          "is not importable here: %s" % e)
+            self.dvs_aedat4 = AEDat4Output(suffixed(os.path.join(folder, dvs_aedat4), '.aedat4'))
 
     def prepare_storage(self, n_frames, frame_ts):  # emulator.py:374-400
         if self.dvs_h5:
@@ -366,7 +370,12 @@ class EventEmulator(object):
         return P
 
     def _ensure_engine(self, H, W):
-        if self._engine is None or (self._engine.H, self._engine.W) != (H, W):
+        if self._engine is not None and (self._engine.H, self._engine.W) != (H, W):
+            if self._initialized:
+                raise ValueError("frame shape changed from %dx%d to %dx%d after the first frame; call reset() first" % (
+                    self._engine.H, self._engine.W, H, W))
+            self._engine = None
+        if self._engine is None:
             self._engine = EmuEngine(H, W, n_clips=1, device=self.device, max_iters=self._max_iters)
         return self._engine
 
@@ -415,14 +424,12 @@ class EventEmulator(object):
         new_frame: np.ndarray or torch tensor [height, width]; t_frame: seconds.
         Returns np.ndarray [N,4] float32 rows [t, x, y, p(+1/-1)] or None.
         """
-        if self.rng_mode == "tape":
-            with _OneHostThread():
-                return self._generate_events(new_frame, t_frame)
         return self._generate_events(new_frame, t_frame)
 
     def _generate_events(self, new_frame, t_frame):
         if self.frame_h5_dataset is not None:
-            self.frame_h5_dataset[self.frame_counter] = np.asarray(new_frame).astype(np.uint8)
+            fr = new_frame.detach().cpu().numpy() if torch.is_tensor(new_frame) else np.asarray(new_frame)
+            self.frame_h5_dataset[self.frame_counter] = fr.astype(np.uint8)
         self.frame_counter += 1
         if t_frame < self.t_previous:
             raise ValueError("this frame time={} must be later than previous frame time={}".format(
@@ -539,34 +546,35 @@ class EventEmulator(object):
         self.num_events_total += n_events
 
         if events is not None:
-            self._write_events(events, n_signal)
+            self._write_events(events, n_signal, events_dev=ev[0, :n_events])
         if self.frame_ev_idx_dataset is not None:
             self.frame_ev_idx_dataset[self.frame_counter - 1] = self.dvs_h5_dataset.shape[0]
         self.t_previous = t_frame
         return events
 
-    def _write_events(self, events, n_signal):
-        """emulator.py:953-977 (file sinks; not part of the hot path)."""
-        label = None
-        if self.label_signal_noise:
-            label = np.zeros(len(events), dtype=bool)
-            label[:n_signal] = True
+    def _write_events(self, events, n_signal, events_dev=None):
+        """emulator.py:953-977: append this frame's events to the open sinks.  The integer conversions of the HDF5 rows
+        (emulator.py:957-960), the AEDAT-2.0 words and the text columns run on the GPU on the device-resident rows."""
+        if not (self.dvs_h5 is not None or self.dvs_aedat2 is not None or self.dvs_aedat4 is not None or self.dvs_text is not None):
+            return
+        ev_dev = events_dev if events_dev is not None else torch.from_numpy(np.ascontiguousarray(events, dtype=np.float32)).to(
+            self._engine.device)
+        sig = n_signal if self.label_signal_noise else None
         if self.dvs_h5 is not None:
-            temp = np.array(events, dtype=np.float32)
-            temp[:, 0] = temp[:, 0] * 1e6
-            temp[temp[:, 3] == -1, 3] = 0
-            temp = temp.astype(np.uint32)
+            from .sinks import pack_h5
+            temp = pack_h5(ev_dev).cpu().numpy().view(np.uint32)
             self.dvs_h5_dataset.resize(self.dvs_h5_dataset.shape[0] + temp.shape[0], axis=0)
             self.dvs_h5_dataset[-temp.shape[0]:] = temp
         if self.dvs_aedat2 is not None:
-            self.dvs_aedat2.appendEvents(events, signnoise_label=label)
+            self.dvs_aedat2.appendEvents(ev_dev, n_signal=sig)
         if self.dvs_aedat4 is not None:
+            label = None
+            if self.label_signal_noise:
+                label = np.zeros(len(events), dtype=bool)
+                label[:n_signal] = True
             self.dvs_aedat4.appendEvents(events, signnoise_label=label)
         if self.dvs_text is not None:
-            if self.label_signal_noise:
-                self.dvs_text.appendEvents(events, signnoise_label=label)
-            else:
-                self.dvs_text.appendEvents(events)
+            self.dvs_text.appendEvents(ev_dev, n_signal=sig)
 
     # ------------------------------------------------------------- device-resident clip
     def generate_events_batch(self, frames, t_frames, return_device=False, use_graph=True, cap=None):

@@ -36,6 +36,154 @@ def pack_h5(events_dev):
     return out
 
 
+class DeviceAEDat2Output:
+    """AEDAT-2.0 file sink fed from the device-resident event buffer (mirrors v2ecore/output/aedat2_output.py: same
+    header lines, same address layout per sensor size, big-endian (address, timestamp) int32 pairs, noise events marked
+    as special events with label_signal_noise).  The integer conversion and the byte order are done on the GPU
+    (v2e_events_pack_aedat2, byte-identical to the reference writer: tests/test_sinks.py); the host only moves bytes."""
+
+    def __init__(self, filepath, output_width=346, output_height=260, label_signal_noise=False):
+        import atexit
+        if (output_width, output_height) not in _AEDAT2_LAYOUT:
+            raise ValueError(f'AEDAT-2.0 output width={output_width} height={output_height} not supported')  # aedat2_output.py:78-80
+        self.filepath = filepath
+        self.width, self.height = output_width, output_height
+        self.label_signal_noise = label_signal_noise
+        self.numEventsWritten = self.numOnEvents = self.numOffEvents = 0
+        self.file = open(filepath, 'wb')
+        self._writeHeader()
+        atexit.register(self.cleanup)
+
+    def cleanup(self):
+        self.close()
+
+    def close(self):
+        if self.file:
+            self.file.close()
+            self.file = None
+
+    def _writeHeader(self):  # aedat2_output.py:111-133, CRLF line ends (jAER)
+        import datetime
+        import getpass
+        import time
+        date = datetime.datetime.now().strftime('# Creation time: %I:%M%p %B %d %Y\r\n')
+        tms = '# Creation time: System.currentTimeMillis() {}\r\n'.format(int(time.time() * 1000.))
+        user = '# User name: {}\r\n'.format(getpass.getuser())
+        sn_comment = ('# noise events are labeled as addressed external input events when the --label_signal_noise option is '
+                      'selected for output\r\n') if self.label_signal_noise else ''
+        header = ('#!AER-DAT2.0\r\n',
+                  '# This is a raw AE data file created by AEDat2Output in v2e (see https://github.com/SensorsINI/v2e) as '
+                  'specified at https://inivation.com/support/software/fileformat/#aedat-20\r\n',
+                  '# Data format is int32 address, int32 timestamp (8 bytes total), repeated for each event\r\n',
+                  '# Timestamps tick is 1 us\r\n', sn_comment, date, tms, user)
+        for line in header:
+            self.file.write(line.encode('UTF-8'))
+
+    def appendEvents(self, events, signnoise_label=None, n_signal=None):
+        """events: [N,4] float32 rows (t, x, y, p) as a device tensor or a host array; noise labelling either by the
+        reference's boolean array (True = signal) or by `n_signal` (rows from n_signal on are noise, how the emulator
+        orders a frame's events)."""
+        if self.file is None or events is None or len(events) == 0:
+            return
+        ev = events if torch.is_tensor(events) else torch.from_numpy(events.astype('float32', copy=False))
+        if not ev.is_cuda:
+            ev = ev.cuda()
+        n = int(ev.shape[0])
+        noise_from = -1
+        if self.label_signal_noise:
+            if n_signal is not None:
+                noise_from = int(n_signal)
+            elif signnoise_label is not None:  # general labels: sort is not needed, mark per run of equal labels
+                lab = torch.as_tensor(signnoise_label).bool().cpu().numpy()
+                out = bytearray()
+                i = 0
+                while i < n:
+                    j = i
+                    while j < n and lab[j] == lab[i]:
+                        j += 1
+                    out += bytes(pack_aedat2(ev[i:j], self.width, self.height, noise_from=-1 if lab[i] else 0).cpu().numpy())
+                    i = j
+                data = bytes(out)
+                self._write(data, ev)
+                return
+        data = pack_aedat2(ev, self.width, self.height, noise_from=noise_from).cpu().numpy().tobytes()
+        self._write(data, ev)
+
+    def _write(self, data, ev):
+        n = len(data) // 8
+        if self.numEventsWritten == 0:  # aedat2_output.py:173-179: a first byte '#' would read as a comment line
+            while data[0:1] == b'#':
+                data = data[8:]
+        self.file.write(data)
+        self.numEventsWritten += n
+        on = int((ev[:, 3] > 0).sum().item())
+        self.numOnEvents += on
+        self.numOffEvents += n - on
+        self.file.flush()
+
+
+class DeviceTextOutput:
+    """Text event sink (v2ecore/output/ae_text_output.py:51-101: `t x y p[ label]` per line, p in {0, 1}, t the Python
+    repr of the float64 value of the float32 time stamp).  The integer columns are converted on the GPU (same kernel as
+    the HDF5 rows); producing a shortest round-trip decimal of t is Python's float repr, on the host."""
+
+    def __init__(self, filepath, label_signal_noise=False):
+        import atexit
+        self.filepath = filepath
+        self.label_signal_noise = label_signal_noise
+        self.numEventsWritten = 0
+        self.file = open(filepath, 'w')
+        self._writeHeader()
+        atexit.register(self.cleanup)
+
+    def cleanup(self):
+        self.close()
+
+    def close(self):
+        if self.file:
+            self.file.close()
+            self.file = None
+
+    def _writeHeader(self):  # ae_text_output.py:51-66
+        import datetime
+        import getpass
+        import time
+        if not self.label_signal_noise:
+            fmt = '# Format is time (float s), x, y, polarity (0=off, 1=on) as specified at http://rpg.ifi.uzh.ch/davis_data.html\n'
+        else:
+            fmt = ('# Format is time (float s), x, y, polarity (0=off, 1=on), signal/noise (1/0)\n#  as specified at '
+                   'http://rpg.ifi.uzh.ch/davis_data.html\n')
+        date = datetime.datetime.now().strftime('# Creation time: %I:%M%p %B %d %Y\n')
+        tms = '# Creation time: System.currentTimeMillis() {}\n'.format(int(time.time() * 1000.))
+        user = '# User name: {}\n'.format(getpass.getuser())
+        for line in ('#!events.txt\n', '# This is a text DVS created by v2e (see https://github.com/SensorsINI/v2e)\n', fmt, date,
+                     tms, user):
+            self.file.write(line)
+
+    def appendEvents(self, events, signnoise_label=None, n_signal=None):
+        if self.file is None:
+            raise Exception('output file closed already')
+        if events is None or len(events) == 0:
+            return
+        ev = events if torch.is_tensor(events) else torch.from_numpy(events.astype('float32', copy=False))
+        if not ev.is_cuda:
+            ev = ev.cuda()
+        n = int(ev.shape[0])
+        cols = pack_h5(ev).cpu().numpy()             # x, y as int32, p: -1 -> 0, +1 -> 1 (same as ((p + 1) / 2).astype(int32))
+        t = ev[:, 0].double().cpu().numpy()          # events[:, 0].astype(float)
+        lab = None
+        if self.label_signal_noise:
+            if n_signal is not None:
+                lab = [1 if i < int(n_signal) else 0 for i in range(n)]
+            elif signnoise_label is not None:
+                lab = [int(v) for v in signnoise_label]
+        if lab is None:
+            self.file.writelines('{} {} {} {}\n'.format(t[i], cols[i, 1], cols[i, 2], cols[i, 3]) for i in range(n))
+        else:
+            self.file.writelines('{} {} {} {} {}\n'.format(t[i], cols[i, 1], cols[i, 2], cols[i, 3], lab[i]) for i in range(n))
+        self.numEventsWritten += n
+
+
 class EventFrameAccumulator:
     """Device version of EventRenderer.accumulate_event_frame (renderer.py:368-400): ON/OFF 2-D histogram of a
     slice of events added to a running, clipped frame.  The exposure-mode slicing (renderer.py:161-366) stays
