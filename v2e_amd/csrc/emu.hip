@@ -1489,6 +1489,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
     // frames 4.86 us/frame, of 64 frames 5.18; K = 16 with 64: 5.27)
     int m = 1;
     if (const char *ev = getenv("V2E_AMD_CHAIN_M")) { const int v = atoi(ev); if (v >= 1 && v <= 64) m = v; }
+    m = std::max(1, std::min(m, 64 / K)); // k_cemit sums a batch's per-frame event counts one frame per lane
     const int E = m * K;
     if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap) {
         hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_cf); hipFree(h->ch_cT);
@@ -1633,7 +1634,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
         if (mark(ev_side, h->side)) return V2E_EHIP;
         if (!no_emit) {
-            k_cframe<<<dim3(1, NC, ea.nE), BLOCK, 0, h->side>>>(a, ea);
+            k_cframe<<<dim3(1, NC, ea.nE), CFRAME_THREADS, 0, h->side>>>(a, ea);
             k_cemit<<<dim3(h->ngroups, NC, ea.nE), BLOCK, REC_LDS, h->side>>>(a, ea);
         }
         if (mark(ev_side, h->side)) return V2E_EHIP;

@@ -31,6 +31,7 @@
 #pragma once
 
 constexpr int CHAIN_K_MAX = 32;
+constexpr int CFRAME_THREADS = 1024;
 constexpr int CHAIN_SUB = 8; // frames whose records are in LDS at a time (4 KB per frame and workgroup)
 constexpr int CHAIN_MAX_ITERS = 1024; // k_cframe keeps one total per key in LDS
 
@@ -535,16 +536,23 @@ struct CEmitArgs {
 };
 
 // One workgroup per (frame, clip): M, per key the prefix over waves and the total, prefix over keys, shuffle parameters.
-__global__ __launch_bounds__(BLOCK) void k_cframe(KArgs a, CEmitArgs ea)
+__global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea)
 {
-    __shared__ int s_red[BLOCK / WAVE];
+    __shared__ int s_red[CFRAME_THREADS / WAVE];
     __shared__ uint32_t s_T[2 * CHAIN_MAX_ITERS + 2];
+    constexpr int NW = CFRAME_THREADS / WAVE; // one wave per key row: 16 rows at a time (a frame has 2 + 2 M of them)
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
     const uint16_t *wm = ea.wmax + ((size_t)slot * ea.n_clips + clip) * ea.nwp;
     int m = 0;
-    for (int k = tid; k < ea.nwaves; k += BLOCK) m = max(m, (int)wm[k]);
-    const int M = block_max_finish(m, s_red, lane, wave);
+    for (int k = tid; k < ea.nwaves; k += CFRAME_THREADS) m = max(m, (int)wm[k]);
+    m = wave_max_i32(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    int M = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) M = max(M, s_red[q]);
+    M = __builtin_amdgcn_readfirstlane(M);
     CFrame *cf = ea.cf + (size_t)z * ea.n_clips + clip;
     v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips + clip;
     if (M > a.max_iters) { // the frame is not emitted; the caller sees the flag
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(BLOCK) void k_cframe(KArgs a, CEmitArgs ea)
     const int nk = 2 + 2 * M;
     const uint8_t *tot = ea.wtot + ((size_t)slot * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
     uint32_t *pre = ea.cpre + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
-    for (int k = wave; k < nk; k += BLOCK / WAVE) { // one wave per key row, 16 waves' totals per lane and step
+    for (int k = wave; k < nk; k += NW) { // one wave per key row, 16 waves' totals per lane and step
         uint32_t carry = 0;
         for (int w0 = 0; w0 < ea.nwp; w0 += 16 * WAVE) {
             const int wi = w0 + lane * 16;
@@ -649,53 +657,80 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
     const int p = g * BLOCK + tid;
     const bool valid = p < a.npx;
     const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
-    unsigned long long ev0 = ea.off_in[clip];
-    for (int j = 0; j < z; ++j) ev0 += ea.cf[(size_t)j * ea.n_clips + clip].n_events;
     v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips;
-    const int M = __builtin_amdgcn_readfirstlane(cf->M);
-    const uint32_t n_signal = __builtin_amdgcn_readfirstlane((int)cf->n_signal);
-    const uint32_t n_events = __builtin_amdgcn_readfirstlane((int)cf->n_events);
+    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
+    const uint32_t *cT = ea.cT + zc * a.nkeys_cap, *ckb = ea.ckbase + zc * a.nkeys_cap;
+    const uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp + wave_g;
+    const uint32_t *perm = ea.cperm + zc * a.max_iters * 8;
+    const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
+    const int ICH = ea.ich; // iterations per pass: their 2 * ICH keys in the wave's lanes, at most 64 * ICH records
+    // ------------------------------------------------------------ every load of the common case, issued back to back (one
+    // memory round trip per wave instead of one per early-exit test): frame table, offsets, count word, wave max, timestamp
+    // tables, ts_mem as it was, and the first pass's per-key totals / prefixes / shuffle parameters (rows beyond the
+    // frame's keys hold older frames' values: masked once M is known)
+    const uint32_t off_lo = (uint32_t)ea.off_in[clip], off_hi = (uint32_t)(ea.off_in[clip] >> 32);
+    const uint32_t nj = lane < z ? ea.cf[(size_t)lane * ea.n_clips + clip].n_events : 0u; // lane j: frame j of the batch (E <= 64)
+    const int M_v = cf->M;
+    const uint32_t nsig_v = cf->n_signal, nev_v = cf->n_events, disc_v = cf->discarded;
+    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
+    const int wm_v = (int)ea.wmax[((size_t)slot * ea.n_clips + clip) * ea.nwp + wave_g];
+    const FrameTab ftb(c, lane);
+    float tsm = (valid && a.has_refr && ea.tsold) ? ea.tsold[sp] : 0.f; // meaningful on rule-on frames only
+    uint32_t T_0 = 0, kbase_0 = 0, P_0 = 0;
+    if (lane < 2 * ICH && 2 + lane < a.nkeys_cap) {
+        T_0 = cT[2 + lane];
+        kbase_0 = ckb[2 + lane];
+        P_0 = pre[(size_t)(2 + lane) * ea.nwp];
+    }
+    uint4 pa_0 = make_uint4(0u, 0u, 0u, 0u), pb_0 = make_uint4(0u, 1u, 0u, 0u);
+    if (shuf && lane < ICH && lane < a.max_iters) {
+        pa_0 = ((const uint4 *)(perm + (size_t)lane * 8))[0];
+        pb_0 = ((const uint4 *)(perm + (size_t)lane * 8))[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long ev0 = ((unsigned long long)off_hi << 32 | off_lo) + (unsigned long long)wave_sum_u32(nj & 0xFFFFFFu) +
+                             ((unsigned long long)wave_sum_u32(nj >> 24) << 24); // + the events of the batch's earlier frames
+    const int M = __builtin_amdgcn_readfirstlane(M_v);
+    const uint32_t n_signal = __builtin_amdgcn_readfirstlane((int)nsig_v);
+    const uint32_t n_events = __builtin_amdgcn_readfirstlane((int)nev_v);
     if (g == 0 && tid == 0) {
         rec[clip].ev_offset = ev0;
         if (z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events;
     }
-    if (cf->discarded) return;
-    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
-    const int wmw = __builtin_amdgcn_readfirstlane((int)ea.wmax[((size_t)slot * ea.n_clips + clip) * ea.nwp + wave_g]);
+    if (__builtin_amdgcn_readfirstlane((int)disc_v)) return;
+    const int wmw = __builtin_amdgcn_readfirstlane(wm_v);
     const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0), sf = __ballot((cw & CNT_SHOT_OFF) != 0);
     if (wmw == 0 && (so | sf) == 0ull) return; // nothing of this wave in the frame
-    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
-    const FrameTab ftb(c, lane);
     const int n = M > 0 ? M : 1;
     bool use_refr;
     const TsGen tg = frame_tsgen(a, c, ftb, n, use_refr);
-    float tsm = (valid && use_refr && ea.tsold) ? ea.tsold[sp] : 0.f;
     const int mag = (int)(cw & CNT_MASK);
     const bool neg = (cw & CNT_NEG) != 0;
     float4 *ev = ea.events + (size_t)clip * ea.cap;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float fx = (float)(p % a.W), fy = (float)(p / a.W);
-    const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
     uint32_t *rec_w = s_crec + (size_t)wave * ea.capw;
-    const uint32_t *cT = ea.cT + zc * a.nkeys_cap, *ckb = ea.ckbase + zc * a.nkeys_cap;
-    const uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp + wave_g;
-    const uint32_t *perm = ea.cperm + zc * a.max_iters * 8;
     bool dropped = false;
     const int iters = min(wmw, M);
-    const int ICH = ea.ich; // iterations per pass: their 2 * ICH keys in the wave's lanes, at most 64 * ICH records
     for (int i0 = 0; i0 < iters; i0 += ICH) {
         const int i1 = min(i0 + ICH, iters);
-        const int key = 2 + 2 * i0 + lane; // lanes 0..61: the ON / OFF keys of iterations i0 .. i0+30
+        const int key = 2 + 2 * i0 + lane; // lanes 0 .. 2 ICH - 1: the ON / OFF keys of iterations i0 .. i0 + ICH - 1
+        const bool key_on = lane < 2 * ICH && key < 2 + 2 * i1;
         uint32_t T_k = 0, kbase_k = 0, P_k = 0;
-        if (lane < 2 * ICH && key < 2 + 2 * i1) {
-            T_k = cT[key];
-            kbase_k = ckb[key];
-            P_k = pre[(size_t)key * ea.nwp];
-        }
         uint4 pa = make_uint4(0u, 0u, 0u, 0u), pb = make_uint4(0u, 1u, 0u, 0u);
-        if (shuf && lane < ICH && i0 + lane < i1) {
-            pa = ((const uint4 *)(perm + (size_t)(i0 + lane) * 8))[0];
-            pb = ((const uint4 *)(perm + (size_t)(i0 + lane) * 8))[1];
+        if (i0 == 0) { // prefetched
+            if (key_on) { T_k = T_0; kbase_k = kbase_0; P_k = P_0; }
+            if (shuf && lane < ICH && lane < i1) { pa = pa_0; pb = pb_0; }
+        } else {
+            if (key_on) {
+                T_k = cT[key];
+                kbase_k = ckb[key];
+                P_k = pre[(size_t)key * ea.nwp];
+            }
+            if (shuf && lane < ICH && i0 + lane < i1) {
+                pa = ((const uint4 *)(perm + (size_t)(i0 + lane) * 8))[0];
+                pb = ((const uint4 *)(perm + (size_t)(i0 + lane) * 8))[1];
+            }
         }
         // pass 1
         uint32_t nrec = 0;
@@ -737,7 +772,7 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
                 pm.k[0] = (uint32_t)__shfl((int)pa.x, il); pm.k[1] = (uint32_t)__shfl((int)pa.y, il);
                 pm.k[2] = (uint32_t)__shfl((int)pa.z, il); pm.k[3] = (uint32_t)__shfl((int)pa.w, il);
                 pm.sh = (uint32_t)__shfl((int)pb.x, il); pm.a = (uint32_t)__shfl((int)pb.y, il);
-                pm.amask = (uint32_t)__shfl((int)pb.z, il); pm.n = (uint32_t)__shfl((int)pb.w, il);
+                pm.amask = 0u; pm.n = (uint32_t)__shfl((int)pb.w, il);
                 pm.rmask = (1u << pm.sh) - 1u;
                 if (has) cidx = v2e_perm_apply(&pm, cidx);
             }
