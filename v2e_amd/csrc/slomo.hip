@@ -18,6 +18,7 @@
 // slice are staged in LDS; both operand reads are then `lane base + immediate` ds_read_b32
 // over 32 consecutive dwords per half-wave (conflict-free).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -691,23 +692,26 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     CONV(tU, 512, nullptr, 0, 0, 10, tA, h / 32, w / 32);
     CONV(tA, 512, nullptr, 0, 0, 11, tB, h / 32, w / 32);
     // up1..up5: skip concat fused into conv2 (x first, skip second)
-    UPS(tB, 512, h / 16, w / 16);
-    CONV(tU, 512, nullptr, 0, 0, 12, tA, h / 16, w / 16);
+    static const int fuse_up = getenv("V2E_AMD_FUSE_UP") ? atoi(getenv("V2E_AMD_FUSE_UP")) : 0; // dev: bit u-1 = fuse the bilinear x2 of up<u> into its conv loader
+    static const int fuse_pool = getenv("V2E_AMD_FUSE_POOL") ? atoi(getenv("V2E_AMD_FUSE_POOL")) : 0;
+#define UPCONV(U, X, C, IDX, Y, HH, WW)                                                    \
+    do {                                                                                    \
+        if (fuse_up & (1 << ((U) - 1))) CONV((X), (C), nullptr, 0, 2, (IDX), (Y), (HH), (WW)); \
+        else { UPS((X), (C), (HH), (WW)); CONV(tU, (C), nullptr, 0, 0, (IDX), (Y), (HH), (WW)); } \
+    } while (0)
+    UPCONV(1, tB, 512, 12, tA, h / 16, w / 16);
     CONV(tA, 512, s5, 512, 0, 13, tB, h / 16, w / 16);
-    UPS(tB, 512, h / 8, w / 8);
-    CONV(tU, 512, nullptr, 0, 0, 14, tA, h / 8, w / 8);
+    UPCONV(2, tB, 512, 14, tA, h / 8, w / 8);
     CONV(tA, 256, s4, 256, 0, 15, tB, h / 8, w / 8);
-    UPS(tB, 256, h / 4, w / 4);
-    CONV(tU, 256, nullptr, 0, 0, 16, tA, h / 4, w / 4);
+    UPCONV(3, tB, 256, 16, tA, h / 4, w / 4);
     CONV(tA, 128, s3, 128, 0, 17, tB, h / 4, w / 4);
-    UPS(tB, 128, h / 2, w / 2);
-    CONV(tU, 128, nullptr, 0, 0, 18, tA, h / 2, w / 2);
+    UPCONV(4, tB, 128, 18, tA, h / 2, w / 2);
     CONV(tA, 64, s2, 64, 0, 19, tB, h / 2, w / 2);
-    UPS(tB, 64, h, w);
-    CONV(tU, 64, nullptr, 0, 0, 20, tA, h, w);
+    UPCONV(5, tB, 64, 20, tA, h, w);
     CONV(tA, 32, s1, 32, 0, 21, tB, h, w);
     // conv3 (+ leaky relu, model.py:225)
     CONV(tB, 32, nullptr, 0, 0, 22, y, h, w);
+#undef UPCONV
 #undef POOL
 #undef UPS
 #undef CONV
