@@ -12,7 +12,7 @@ a = a[len(a) // 3:]  # skip warm-up
 dur = (a[:, 1] - a[:, 0]) / 1e3
 gap = (a[1:, 0] - a[:-1, 1]) / 1e3
 per = (a[1:, 0] - a[:-1, 0]) / 1e3
-ok = per < 50  # drop run boundaries
+ok = per < 400  # drop run boundaries
 print("%s: %d launches; duration mean %.2f us (p50 %.2f p90 %.2f); gap mean %.2f (p50 %.2f p90 %.2f); period mean %.2f p50 %.2f" % (
     pat, len(a), dur.mean(), np.median(dur), np.percentile(dur, 90), gap[ok].mean(), np.median(gap[ok]), np.percentile(gap[ok], 90),
     per[ok].mean(), np.median(per[ok])))

@@ -743,7 +743,8 @@ struct v2e_emu {
     unsigned *ch_bar = nullptr;     // [ch_launch_cap][ch_K][n_clips]
     void *ch_base2 = nullptr, *ch_lp2 = nullptr; // second set of state planes (ping-pong between launches)
     float *ch_ts2 = nullptr;
-    CFrame *ch_cf = nullptr;        // [ch_K][n_clips]
+    CFrame *ch_cf = nullptr;        // [2][ch_E][n_clips]
+    unsigned *ch_cdone = nullptr;   // [2][ch_E][n_clips] k_cframe's per-frame completion counters
     uint32_t *ch_cT = nullptr, *ch_ckbase = nullptr, *ch_cperm = nullptr, *ch_cpre = nullptr;
     int ch_nkeys_cap = 0;           // nkeys_cap the chain scratch was sized for
 };
@@ -942,7 +943,7 @@ int v2e_emu_destroy(v2e_emu *h)
     if (h->ahead) hipStreamDestroy(h->ahead);
     if (h->tables) hipStreamDestroy(h->tables);
     hipFree(h->ch_base2); hipFree(h->ch_lp2); hipFree(h->ch_ts2); hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase);
-    hipFree(h->ch_cperm); hipFree(h->ch_cpre);
+    hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_cdone);
     hipFree(h->cnt_b); hipFree(h->gtot[0]); hipFree(h->gtot[1]); hipFree(h->gmaxv[0]); hipFree(h->gmaxv[1]);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     hipFree(h->off_dev);
@@ -1455,8 +1456,8 @@ static int chain_frames_per_launch(const v2e_emu *h, bool has_refr)
     // the benchmark clip) repeats a whole launch.  Small grids (bounded by latency): 32 frames, records through LDS 8 frames
     // = 32 KB at a time, so that two chain workgroups (64 KB) always fit a CU beside the parallel kernels, which are capped
     // at 4 x 24 KB (the redo rendezvous needs every chain workgroup resident).  Large grids (bounded by throughput, records
-    // built in the chain): 16 frames, 8 where a redo is possible.
-    int K = chain_small_grid(h) ? 32 : (has_refr ? 8 : 16);
+    // built in the chain): 32 frames (1280x720 noisy: 16 frames 6.24, 32 frames 6.49 Gev/s), 8 where a redo is possible.
+    int K = chain_small_grid(h) ? 32 : (has_refr ? 8 : 32);
     if (const char *ev = getenv("V2E_AMD_CHAIN_K")) { const int v = atoi(ev); if (v >= 1 && v <= CHAIN_K_MAX) K = v; }
     return K;
 }
@@ -1512,6 +1513,9 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
         V2E_HIP(hipMemset(h->ch_wtot, 0, (size_t)h->ch_D * nc * h->nkeys_cap * h->ch_nwp));
         V2E_HIP(hipMalloc(&h->ch_cf, 2 * sizeof(CFrame) * E * nc)); // two sets: k_cframe(b + 1) beside k_cemit(b)
         V2E_HIP(hipMemset(h->ch_cf, 0, 2 * sizeof(CFrame) * E * nc));
+        hipFree(h->ch_cdone);
+        V2E_HIP(hipMalloc(&h->ch_cdone, 2 * sizeof(unsigned) * E * nc));
+        V2E_HIP(hipMemset(h->ch_cdone, 0, 2 * sizeof(unsigned) * E * nc));
         V2E_HIP(hipMalloc(&h->ch_cT, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap)); // two sets: k_cframe(b + 1) beside k_cemit(b)
         V2E_HIP(hipMalloc(&h->ch_ckbase, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap)); // two sets: k_cframe(b + 1) beside k_cemit(b)
         V2E_HIP(hipMalloc(&h->ch_cperm, 2 * sizeof(uint32_t) * E * nc * h->max_iters * 8)); // two sets: k_cframe(b + 1) beside k_cemit(b)
@@ -1619,6 +1623,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         const size_t set = (size_t)(b & 1) * E * NC; // table set of this batch
         ea.cf = h->ch_cf + set; ea.cT = h->ch_cT + set * h->nkeys_cap; ea.ckbase = h->ch_ckbase + set * h->nkeys_cap;
         ea.cperm = h->ch_cperm + set * h->max_iters * 8; ea.cpre = h->ch_cpre + set * h->nkeys_cap * h->ch_nwp;
+        ea.cdone = h->ch_cdone + set;
         ea.events = (float4 *)events; ea.cap = cap;
         ea.off_in = h->pipe_off + (size_t)(b & 1) * NC;
         ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * NC;
@@ -1634,7 +1639,10 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
         if (mark(ev_side, h->side)) return V2E_EHIP;
         if (!no_emit) {
-            k_cframe<<<dim3(1, NC, ea.nE), CFRAME_THREADS, 0, h->side>>>(a, ea);
+            // a key row of a small grid is a couple of steps of one wave: one workgroup per frame; of a large grid (1280x720:
+            // 14 400 waves) a segmented scan by a workgroup of its own
+            if (h->ch_nwp <= 4096) k_cframe1<<<dim3(1, NC, ea.nE), CFRAME_THREADS, 0, h->side>>>(a, ea);
+            else k_cframe<<<dim3(std::min(h->nkeys_cap, CFRAME_ROWS), NC, ea.nE), CFRAME_THREADS, 0, h->side>>>(a, ea);
             k_cemit<<<dim3(h->ngroups, NC, ea.nE), BLOCK, REC_LDS, h->side>>>(a, ea);
         }
         if (mark(ev_side, h->side)) return V2E_EHIP;

@@ -532,11 +532,12 @@ struct CEmitArgs {
     unsigned long long cap;
     const unsigned long long *off_in;
     unsigned long long *off_out;
+    unsigned *cdone;     // [E][n_clips] k_cframe: row workgroups done per frame (self-resetting)
     int capw, ich; // event records per wave in LDS; iterations per pass of k_cemit (64 * ich <= capw, 2 * ich <= 62)
 };
 
-// One workgroup per (frame, clip): M, per key the prefix over waves and the total, prefix over keys, shuffle parameters.
-__global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea)
+// Small grids (a key row is a couple of steps of one wave): one workgroup per (frame, clip), one wave per key row.
+__global__ __launch_bounds__(CFRAME_THREADS) void k_cframe1(KArgs a, CEmitArgs ea)
 {
     __shared__ int s_red[CFRAME_THREADS / WAVE];
     __shared__ uint32_t s_T[2 * CHAIN_MAX_ITERS + 2];
@@ -620,6 +621,166 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
     }
     const uint32_t n_signal = carry;
     uint32_t *perm = ea.cperm + ((size_t)z * ea.n_clips + clip) * a.max_iters * 8;
+    if (a.shuffle && a.rng_mode == V2E_RNG_PHILOX) {
+        const uint32_t fbase = ea.fidx_base ? *ea.fidx_base : 0u;
+        for (int i = lane; i < M; i += WAVE) {
+            uint32_t pk[4], sh, aa, amask;
+            const uint32_t n_i = s_T[2 + 2 * i] + s_T[3 + 2 * i];
+            v2e_perm_shape(n_i, &sh, &aa, &amask);
+            v2e_perm_keys(a.seed, (uint32_t)clip, fbase + (uint32_t)fe, (uint32_t)i, pk);
+            uint4 *pp = (uint4 *)(perm + (size_t)i * 8);
+            pp[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            pp[1] = make_uint4(sh, aa, amask, n_i);
+        }
+    }
+    if (lane == 0) {
+        const uint32_t son = a.do_shot ? s_T[0] : 0u, soff = a.do_shot ? s_T[1] : 0u;
+        cf->M = M; cf->n_signal = n_signal; cf->n_events = n_signal + son + soff; cf->discarded = 0u;
+        rec->max_events = M;
+        rec->n_signal = n_signal;
+        rec->n_events = n_signal + son + soff;
+        rec->n_on = sum_on + son;
+        rec->n_off = sum_off + soff;
+    }
+}
+
+// Per frame: M, per key the prefix over waves and the total, prefix over keys, shuffle parameters.  One workgroup per
+// (key row, frame, clip): a row's exclusive prefix over the frame's waves is a segmented scan by the workgroup's 16 waves
+// (each takes a contiguous sixteenth of the row).  The workgroup that finishes LAST for a frame (a counter per frame)
+// reads the rows' totals and builds what k_cemit needs per key and iteration.  CFRAME_ROWS rows have a workgroup each;
+// frames with more rows have the last-row workgroup walk the rest.  (Large grids; small ones: k_cframe1.)
+constexpr int CFRAME_ROWS = 24; // M <= 11 fully parallel
+
+__global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea)
+{
+    constexpr int NW = CFRAME_THREADS / WAVE;
+    __shared__ int s_red[NW];
+    __shared__ uint32_t s_seg[NW];
+    __shared__ uint32_t s_T[2 * CHAIN_MAX_ITERS + 2];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int r0 = blockIdx.x, clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const size_t zc = (size_t)z * ea.n_clips + clip;
+    const uint16_t *wm = ea.wmax + ((size_t)slot * ea.n_clips + clip) * ea.nwp;
+    int m = 0;
+    for (int k = tid; k < ea.nwaves; k += CFRAME_THREADS) m = max(m, (int)wm[k]);
+    m = wave_max_i32(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    int M = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) M = max(M, s_red[q]);
+    M = __builtin_amdgcn_readfirstlane(M);
+    CFrame *cf = ea.cf + zc;
+    v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips + clip;
+    const bool discard = M > a.max_iters; // the frame is not emitted; the caller sees the flag
+    const int nk = discard ? 0 : 2 + 2 * M;
+    const uint8_t *tot = ea.wtot + ((size_t)slot * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
+    uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp;
+    uint32_t *cT = ea.cT + zc * a.nkeys_cap;
+    // this workgroup's row(s): r0, and for the last row workgroup every row beyond the grid
+    const int seg = ((ea.nwp + NW - 1) / NW + 15) / 16 * 16; // entries per wave, a multiple of the 16 a lane takes
+    for (int k = r0; k < nk; k += (r0 == (int)gridDim.x - 1 ? 1 : nk)) {
+        const int lo = wave * seg, hi = min(lo + seg, ea.nwp);
+        uint32_t wsum = 0; // pass 1: this wave's segment total
+        for (int w0 = lo; w0 < hi; w0 += 16 * WAVE) {
+            const int wi = w0 + lane * 16;
+            uint32_t lane_tot = 0;
+            if (wi < hi) {
+                const uint4 t4 = *(const uint4 *)(tot + (size_t)k * ea.nwp + wi);
+                const uint4 m0 = *(const uint4 *)(wm + wi), m1 = *(const uint4 *)(wm + wi + 8);
+                const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
+                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                    // a wave writes only the rows of its own iterations; above them the slot holds an older frame's bytes
+                    lane_tot += (uint32_t)k < 2u + 2u * wmj ? ((tw[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 0u;
+                }
+            }
+            wsum += wave_sum_u32(lane_tot);
+        }
+        __syncthreads(); // s_seg of the previous row is no longer read
+        if (lane == 0) s_seg[wave] = wsum;
+        __syncthreads();
+        uint32_t carry = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            carry += q < wave ? s_seg[q] : 0u;
+            total += s_seg[q];
+        }
+        for (int w0 = lo; w0 < hi; w0 += 16 * WAVE) { // pass 2: prefixes (the row is L2-resident by now)
+            const int wi = w0 + lane * 16;
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = 0u;
+            if (wi < hi) {
+                const uint4 t4 = *(const uint4 *)(tot + (size_t)k * ea.nwp + wi);
+                const uint4 m0 = *(const uint4 *)(wm + wi), m1 = *(const uint4 *)(wm + wi + 8);
+                const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
+                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                    v[j] = (uint32_t)k < 2u + 2u * wmj ? ((tw[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 0u;
+                }
+            }
+            uint32_t lane_tot = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) lane_tot += v[j];
+            uint32_t run = carry + wave_excl_scan_u32(lane_tot, lane);
+            carry += wave_sum_u32(lane_tot);
+            if (wi < hi) {
+                uint32_t o[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { o[j] = run; run += v[j]; }
+                uint4 *dst = (uint4 *)(pre + (size_t)k * ea.nwp + wi);
+                dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+                dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
+            }
+        }
+        if (tid == 0) cT[k] = total;
+    }
+    // ---- last workgroup of the frame: everything per key / per iteration
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned old = __hip_atomic_fetch_add(ea.cdone + zc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == gridDim.x - 1;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ea.cdone + zc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next batch
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (discard) {
+        if (tid == 0) {
+            cf->M = M; cf->n_events = 0u; cf->n_signal = 0u; cf->discarded = 1u;
+            rec->max_events = M;
+            atomicOr(&rec->flags, V2E_FLAG_ITERS_CLAMPED);
+        }
+        return;
+    }
+    for (int k = tid; k < nk; k += CFRAME_THREADS) s_T[k] = __hip_atomic_load(cT + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t *ckb = ea.ckbase + zc * a.nkeys_cap;
+    uint32_t carry = 0, sum_on = 0, sum_off = 0;
+    for (int kb = 0; kb < nk; kb += WAVE) {
+        const int key = kb + lane;
+        const uint32_t T_k = key < nk ? s_T[key] : 0u;
+        const uint32_t sig = key >= 2 ? T_k : 0u;
+        const uint32_t kbase = carry + wave_excl_scan_u32(sig, lane);
+        if (key < nk) ckb[key] = kbase;
+        sum_on += wave_sum_u32((lane & 1) ? 0u : sig);
+        sum_off += wave_sum_u32((lane & 1) ? sig : 0u);
+        carry += wave_sum_u32(sig);
+    }
+    const uint32_t n_signal = carry;
+    uint32_t *perm = ea.cperm + zc * a.max_iters * 8;
     if (a.shuffle && a.rng_mode == V2E_RNG_PHILOX) {
         const uint32_t fbase = ea.fidx_base ? *ea.fidx_base : 0u;
         for (int i = lane; i < M; i += WAVE) {
