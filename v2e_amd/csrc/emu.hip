@@ -1461,6 +1461,11 @@ static int chain_frames_per_launch(const v2e_emu *h, bool has_refr)
     if (const char *ev = getenv("V2E_AMD_CHAIN_K")) { const int v = atoi(ev); if (v >= 1 && v <= CHAIN_K_MAX) K = v; }
     return K;
 }
+// records built inside the chain (large grids) or by k_ahead (small grids); V2E_AMD_CHAIN_FUSED=0/1 overrides (dev)
+static bool chain_fused_records(const v2e_emu *h) {
+    static const int fused_env = getenv("V2E_AMD_CHAIN_FUSED") ? atoi(getenv("V2E_AMD_CHAIN_FUSED")) : -1;
+    return fused_env >= 0 ? fused_env != 0 : !chain_small_grid(h);
+}
 
 // workgroups of k_chain a CU holds (the redo rendezvous needs a clip's workgroups co-resident); the occupancy API can
 // over-report by one per CU (MI355X guide), hence the margin
@@ -1521,7 +1526,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
         V2E_HIP(hipMalloc(&h->ch_cperm, 2 * sizeof(uint32_t) * E * nc * h->max_iters * 8)); // two sets: k_cframe(b + 1) beside k_cemit(b)
         V2E_HIP(hipMalloc(&h->ch_cpre, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp)); // two sets: k_cframe(b + 1) beside k_cemit(b)
         V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
-        h->ch_max_blocks = chain_blocks_per_cu(K, !chain_small_grid(h)) * h->n_cu;
+        h->ch_max_blocks = chain_blocks_per_cu(K, chain_fused_records(h)) * h->n_cu;
         h->drop_graphs();
     }
     const int n_launch = (n_frames + K - 1) / K + 1;
@@ -1567,7 +1572,7 @@ static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p, int dtype,
     if (p->refractory_period_s > 0) {
         // the redo rendezvous needs a clip's workgroups co-resident; and where only a few clips of a large multi-clip grid
         // are, the clip loop inside the workgroup serialises them: k_main per frame is faster there (64 clips: 10.3 vs 8.9 Gev/s)
-        if ((long long)h->ngroups > (long long)chain_blocks_per_cu(chain_frames_per_launch(h, true), !chain_small_grid(h)) * h->n_cu) return false;
+        if ((long long)h->ngroups > (long long)chain_blocks_per_cu(chain_frames_per_launch(h, true), chain_fused_records(h)) * h->n_cu) return false;
         if (!chain_small_grid(h) && !force) return false;
     }
     return true;
@@ -1608,8 +1613,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     if (has_refr) gy = std::max(1, std::min(NC, h->ch_max_blocks / std::max(h->ngroups, 1)));
     dim3 grid(h->ngroups, gy);
     // large grids build the records inside the chain (no k_ahead, no record traffic): see k_chain
-    static const int fused_env = getenv("V2E_AMD_CHAIN_FUSED") ? atoi(getenv("V2E_AMD_CHAIN_FUSED")) : -1;
-    const bool fused_rec = fused_env >= 0 ? fused_env != 0 : !chain_small_grid(h);
+    const bool fused_rec = chain_fused_records(h);
     static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
     static const int par_lds_env = getenv("V2E_AMD_PAR_LDS") ? atoi(getenv("V2E_AMD_PAR_LDS")) : -1;
     const int par_lds = par_lds_env >= 0 ? par_lds_env : 0; // dev: LDS reservation capping the parallel kernels' occupancy (measured: no gain)
@@ -1814,7 +1818,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
             h->ev_join.push_back(e1);
         }
     }
-    h->last_kind = legacy ? 0 : (fused ? 2 : (chain ? (chain_small_grid(h) && !getenv("V2E_AMD_CHAIN_FUSED") ? 3 : 4) : 1));
+    h->last_kind = legacy ? 0 : (fused ? 2 : (chain ? (chain_fused_records(h) ? 4 : 3) : 1));
     h->last_fpl = chain ? h->ch_K : (pipe ? K : 1);
     h->last_fpb = chain ? h->ch_E : (pipe ? h->pipe_E : 1);
     auto enqueue = [&](hipStream_t st, hipEvent_t *evs, int *nm) -> int {
