@@ -229,10 +229,19 @@ typedef struct v2e_conv_desc {
     const float *weight; /* device, pre-packed [Cin][k][k][Cout] (v2e_pack_conv_weight) */
     const float *bias;   /* device [Cout] */
     int32_t cin, cout, ksize;
+    int32_t pad_;
+    const void *weight_s3; /* device, split-bf16 weights (v2e_pack_conv_weight_s3) or NULL: f32-MFMA kernel only */
 } v2e_conv_desc;
 
 /* repack torch [Cout][Cin][k][k] -> [Cin][k][k][Cout] on device */
 int v2e_pack_conv_weight(const float *w_oihw, float *w_packed, int cout, int cin, int k, void *stream);
+
+/*
+ * The same weights split exactly into three bf16 pieces (w = p0 + p1 + p2) for the bf16-matrix-core convolution that
+ * keeps f32 accuracy (six piece products per multiply, f32 accumulation; v2e_amd/csrc/slomo_s3.h):
+ * [Cin/16][k*k][3][2][Cout][8 bf16] = 6 bytes per weight.  cin must be a multiple of 16.
+ */
+int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, int k, void *stream);
 
 /*
  * y = leaky_relu(conv2d(cat(x0, x1), W) + b, 0.1), stride 1, zero pad (k-1)/2, NCHW f32.

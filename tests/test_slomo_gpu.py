@@ -25,7 +25,8 @@ def _rand(rng, shape, scale=1.0):
     return ((rng.integers(0, 1 << 16, size=shape).astype(np.float32) / 32768.0) - 1.0) * np.float32(scale)
 
 
-def _conv_hip(x0, x1, pre, w, b, out_hw):
+def _conv_hip(x0, x1, pre, w, b, out_hw, split=False):
+    """split: also hand the layer its split-bf16 weights, which makes v2e_conv2d_lrelu take the bf16-matrix-core kernel."""
     from v2e_amd import _capi
     from v2e_amd._capi import ConvDesc, check
     lib = _capi.lib()
@@ -37,6 +38,10 @@ def _conv_hip(x0, x1, pre, w, b, out_hw):
     check(lib.v2e_pack_conv_weight(C.c_void_p(tw.data_ptr()), C.c_void_p(wp.data_ptr()), co, ci, k, s), "pack")
     tb = torch.from_numpy(b).to(dev)
     d = ConvDesc(wp.data_ptr(), tb.data_ptr(), ci, co, k)
+    if split:
+        w3 = torch.empty(ci * k * k * co * 6, dtype=torch.uint8, device=dev)
+        check(lib.v2e_pack_conv_weight_s3(C.c_void_p(tw.data_ptr()), C.c_void_p(w3.data_ptr()), co, ci, k, s), "pack_s3")
+        d.weight_s3 = w3.data_ptr()
     t0 = torch.from_numpy(x0).to(dev)
     t1 = torch.from_numpy(x1).to(dev) if x1 is not None else None
     n = x0.shape[0]
@@ -83,6 +88,46 @@ CONV_CASES = [
 ]
 
 
+# the split-bf16 kernel (slomo_s3.h: plain loads, cin % 16 == 0, cout % 32 == 0): every tile shape conv_dispatch_s3
+# selects, ragged edges, the fused concat, several weight groups per chunk (5x5, 7x7), several chunks
+S3_CASES = [
+    (3, 16, 0, 32, 3, 40, 72, 0),     # TW=8 (32x8 tiles), masked rows
+    (3, 32, 0, 64, 2, 24, 32, 0),     # TW=32, masked rows
+    (3, 64, 0, 32, 2, 64, 96, 0),     # up5.conv1 shape class
+    (3, 32, 32, 32, 1, 32, 64, 0),    # up5.conv2: concat, one chunk per source... two chunks each
+    (3, 16, 16, 64, 2, 16, 48, 0),    # TW=16, concat at a chunk boundary
+    (3, 256, 256, 256, 1, 8, 40, 0),  # up.conv2 at a 40-wide level
+    (3, 512, 0, 512, 3, 16, 20, 0),   # 16x20 level: 8x20 five-wave tiles
+    (3, 64, 0, 64, 2, 8, 20, 0),
+    (3, 128, 0, 128, 24, 32, 32, 0),  # many images
+    (5, 32, 0, 64, 2, 24, 64, 0),     # down1.conv1
+    (5, 64, 0, 64, 1, 40, 96, 0),     # down1.conv2, ragged rows
+    (7, 32, 0, 32, 2, 24, 64, 0),     # conv2
+    (7, 32, 0, 32, 1, 256, 320, 0),   # conv2 at the benchmark resolution
+    (3, 64, 0, 64, 3, 8, 10, 0),      # 8x10 level: no split-bf16 tile -> must fall back to the f32 kernel and still be right
+]
+
+
+@pytest.mark.parametrize("case", S3_CASES)
+def test_split_bf16_conv_layer_matches_oracle(case, oracle_lib):
+    k, c0, c1, cout, n, h, w, pre = case
+    rng = np.random.Generator(np.random.PCG64(77 + k * 1000 + c0 + cout + h))
+    x0 = _rand(rng, (n, c0, h, w))
+    x1 = _rand(rng, (n, c1, h, w)) if c1 else None
+    cin = c0 + c1
+    wt = _rand(rng, (cout, cin, k, k), 1.5 / np.sqrt(cin * k * k))
+    b = _rand(rng, (cout,), 0.1)
+    y = _conv_hip(x0, x1, 0, wt, b, (h, w), split=True)
+    y32 = _conv_hip(x0, x1, 0, wt, b, (h, w), split=False)
+    xin = x0 if x1 is None else np.concatenate((x0, x1), axis=1)
+    ref = oracle_lib.conv2d_lrelu(xin, wt, b)
+    assert not np.isnan(y).any(), "output not fully written"
+    assert relerr(y, ref) < TOL
+    assert relerr(y, y32) < TOL  # and it is not the same kernel twice (except where it falls back by design)
+    if not (h == 8 and w == 10):
+        assert not np.array_equal(y, y32)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_layer_matches_oracle(case, oracle_lib):
     k, c0, c1, cout, n, h, w, pre = case
@@ -106,12 +151,15 @@ def test_conv_layer_matches_oracle(case, oracle_lib):
     assert relerr(y, ref) < TOL
 
 
-def _engine(seed_f=101, seed_i=102):
+CONV_MATHS = ("bf16x3", "f32")  # the default (split-bf16 on the bf16 matrix cores) and the f32 matrix-core kernels
+
+
+def _engine(seed_f=101, seed_i=102, conv_math=None):
     from v2e_amd.slomo import SloMoEngine
     from v2e_amd.synth import portable_unet_state_dict
     sd_f, sd_i = portable_unet_state_dict(2, 4, seed_f), portable_unet_state_dict(12, 5, seed_i)
     eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
-                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, "cuda")
+                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, "cuda", conv_math=conv_math)
     return eng, sd_f, sd_i
 
 
@@ -123,11 +171,13 @@ def _pairs(z):
     return I0, I1
 
 
-def test_interpolation_matches_reference_golden():
+@pytest.mark.parametrize("conv_math", CONV_MATHS)
+def test_interpolation_matches_reference_golden(conv_math):
     z = np.load(os.path.join(GOLDEN, "slomo_unet_64x96.npz"))
     I0, I1 = _pairs(z)
     ts = list(z["ts"])
-    eng, _, _ = _engine()
+    eng, _, _ = _engine(conv_math=conv_math)
+    assert eng.conv_math == conv_math and eng.interp_net.conv_math == conv_math
     Ft = eng.interpolate(torch.from_numpy(I0).cuda(), torch.from_numpy(I1).cuda(), ts)
     nt, b = len(ts), I0.shape[0]
     assert relerr(eng.last["flow"].cpu().numpy(), z["flow"]) < TOL
@@ -135,7 +185,8 @@ def test_interpolation_matches_reference_golden():
     assert relerr(Ft.cpu().numpy(), z["Ft"]) < TOL
 
 
-def test_interpolation_matches_reference_at_benchmark_shape():
+@pytest.mark.parametrize("conv_math", CONV_MATHS)
+def test_interpolation_matches_reference_at_benchmark_shape(conv_math):
     """BASELINE configs[2] SloMo stage as bench.py runs it: 320x256 (346x260 source), U=10, batch of 8 pairs ->
     80 samples through the interpolation UNet (the wide k_conv<5,4,2,...> / <3,8,2,...,32> tiles are dispatched at
     the 160x128 level).  The fixture holds the reference's result for 2 pairs; they are tiled 4x, and every copy
@@ -145,7 +196,7 @@ def test_interpolation_matches_reference_at_benchmark_shape():
     I0, I1 = bench_shape_inputs(z)
     ts = list(z["ts"])
     sf, si = (int(v) for v in z["seeds"])
-    eng, _, _ = _engine(sf, si)
+    eng, _, _ = _engine(sf, si, conv_math)
     rep = 4
     tI0 = torch.from_numpy(np.tile(I0, (rep, 1, 1, 1))).cuda()
     tI1 = torch.from_numpy(np.tile(I1, (rep, 1, 1, 1))).cuda()
@@ -163,7 +214,8 @@ def test_interpolation_matches_reference_at_benchmark_shape():
     assert np.array_equal(Ft[:, :b], Ft[:, b:2 * b]) and np.array_equal(intrp[:, :b], intrp[:, 3 * b:])
 
 
-def test_interpolation_matches_reference_at_trained_scale():
+@pytest.mark.parametrize("conv_math", CONV_MATHS)
+def test_interpolation_matches_reference_at_trained_scale(conv_math):
     """conv3 heads scaled so |flow| reaches 30 px and the visibility logit 100 (fixture generated by the reference);
     tolerance as in tests/test_slomo_oracle_golden.py: 1e-5 of each tensor's scale (the scaled heads magnify the
     reference's own f32 summation-order noise), 1e-4 absolute on Ft."""
@@ -178,7 +230,7 @@ def test_interpolation_matches_reference_at_trained_scale():
         sd["conv3.weight"] = sd["conv3.weight"] * np.float32(s)
         sd["conv3.bias"] = sd["conv3.bias"] * np.float32(s)
     eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
-                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, "cuda")
+                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, "cuda", conv_math=conv_math)
     Ft = eng.interpolate(torch.from_numpy(I0).cuda(), torch.from_numpy(I1).cuda(), ts).cpu().numpy()
     assert close_scaled(eng.last["flow"].cpu().numpy(), z["flow"]) < TOL
     assert close_scaled(eng.last["intrp"].cpu().numpy().reshape(len(ts), I0.shape[0], 5, 64, 96), z["intrp"]) < TOL

@@ -32,6 +32,8 @@ struct ConvArgs {
     float *y;
     int n, h, w_, cin, cout;
     int tiles_x, tiles_y;
+    const void *ws3; // split-bf16 weights (slomo_s3.h) or nullptr
+    int dbg;         // dev (V2E_AMD_S3_DBG): 1 no multiplies, 2 no global loads after the first chunk, 4 no staging after the first chunk
 };
 
 // element fetch with the producer op fused: PRE 0 plain, 1 avg_pool2d(2) of a [2H][2W] source,
@@ -255,6 +257,8 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
         }
     }
 }
+
+#include "slomo_s3.h"
 
 // ... one output per thread, for widths that are not a multiple of 4
 __global__ __launch_bounds__(256) void k_avgpool2_scalar(const float *__restrict__ x, float *__restrict__ y, long long nc, int h, int w)
@@ -586,9 +590,44 @@ static int conv_dispatch(const ConvArgs &a, int ks, int pre, hipStream_t s)
     return 0;
 }
 
+// split-bf16 path (slomo_s3.h): returns 1 when no tile fits (the caller falls back to the f32-MFMA kernel)
+static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
+{
+    // 32-channel tiles (60 KB of LDS: two workgroups per CU, so one stages while the other multiplies) measured faster
+    // than 64-channel ones at every level (16 samples: 3x3 143-174 vs 121-153 TF/s, 5x5 172-183 vs 146-160)
+    static const int variant = getenv("V2E_AMD_S3_VARIANT") ? atoi(getenv("V2E_AMD_S3_VARIANT")) : 0; // dev: tile choice
+    const bool c64 = a.cout % 64 == 0 && variant == 6;
+    if (ks == 3) {
+        if (a.w_ % 32 == 0) {
+            if (variant == 2 && a.cout % 64 == 0) return launch_conv_s3<3, 2, 2, 8, 32>(a, s);
+            if (variant == 3) return launch_conv_s3<3, 1, 4, 4, 32>(a, s);
+            if (variant == 4 && a.cout % 64 == 0) return launch_conv_s3<3, 2, 4, 4, 32>(a, s);
+            if (variant == 7) return launch_conv_s3<3, 1, 2, 4, 32, 2>(a, s);
+            return c64 ? launch_conv_s3<3, 2, 2, 4, 32>(a, s) : launch_conv_s3<3, 1, 2, 4, 32>(a, s);
+        }
+        if (a.w_ % 16 == 0) return c64 ? launch_conv_s3<3, 2, 2, 4, 16>(a, s) : (variant == 7 ? launch_conv_s3<3, 1, 2, 4, 16, 2>(a, s) : launch_conv_s3<3, 1, 2, 4, 16>(a, s));
+        if (a.w_ % 8 == 0) return c64 ? launch_conv_s3<3, 2, 2, 4, 8>(a, s) : (variant == 7 ? launch_conv_s3<3, 1, 2, 4, 8, 2>(a, s) : launch_conv_s3<3, 1, 2, 4, 8>(a, s));
+        if (a.w_ % 20 == 0 && a.h % 8 == 0) return c64 ? launch_conv_s3<3, 2, 1, 5, 20>(a, s) : launch_conv_s3<3, 1, 1, 5, 20>(a, s);
+        return 1;
+    }
+    if (ks == 5 && a.w_ % 32 == 0) return c64 ? launch_conv_s3<5, 2, 2, 4, 32>(a, s) : launch_conv_s3<5, 1, 2, 4, 32>(a, s);
+    if (ks == 7 && a.w_ % 32 == 0) return launch_conv_s3<7, 1, 2, 4, 32>(a, s);
+    return 1;
+}
+
 } // namespace
 
 extern "C" {
+
+int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, int k, void *stream)
+{
+    V2E_REQUIRE(w_oihw && w_s3 && cout > 0 && cin > 0 && k > 0, "bad pack args");
+    V2E_REQUIRE(cin % 16 == 0, "split-bf16 weights: cin must be a multiple of 16");
+    const size_t total = (size_t)(cin / 8) * k * k * cout;
+    k_pack_weight_s3<<<v2e_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, (uint4 *)w_s3, cout, cin, k * k);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
 
 int v2e_pack_conv_weight(const float *w_oihw, float *w_packed, int cout, int cin, int k, void *stream)
 {
@@ -619,6 +658,9 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     a.w = conv->weight; a.bias = conv->bias; a.y = y;
     a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout;
     a.tiles_x = a.tiles_y = 0;
+    a.ws3 = conv->weight_s3;
+    static const int s3_dbg = getenv("V2E_AMD_S3_DBG") ? atoi(getenv("V2E_AMD_S3_DBG")) : 0;
+    a.dbg = s3_dbg;
     if (conv->ksize == 3 && pre == 0 && c1 == 0 && (conv->cout == 4 || conv->cout == 5)) {
         const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;
         dim3 grid((unsigned)(n * tiles_x * tiles_y));
@@ -626,6 +668,12 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
         else k_conv3x3_small<5><<<grid, 256, 0, (hipStream_t)stream>>>(x0, conv->weight, conv->bias, y, n, conv->cin, h, w, tiles_x, tiles_y);
         V2E_HIP(hipGetLastError());
         return 0;
+    }
+    static const bool s3_off = getenv("V2E_AMD_CONV_F32") != nullptr; // dev: force the f32-MFMA kernel
+    if (a.ws3 && !s3_off && pre == 0 && conv->cin % 16 == 0 && conv->cout % 32 == 0 && (c1 == 0 || c0 % 16 == 0)) {
+        const int r3 = conv_dispatch_s3(a, conv->ksize, (hipStream_t)stream);
+        if (r3 == 0) { V2E_HIP(hipGetLastError()); return 0; }
+        if (r3 != 1) return r3;
     }
     int rc = conv_dispatch(a, conv->ksize, pre, (hipStream_t)stream);
     if (rc) { v2e_set_error("unsupported conv: k=%d pre=%d", conv->ksize, pre); return rc; }

@@ -1,0 +1,261 @@
+// slomo_s3.h -- the UNet convolutions on the bf16 matrix cores at f32 accuracy (included by slomo.hip).
+//
+// v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate (157 TF/s peak, 1/16 of the bf16 MFMA rate).  Here every f32
+// operand is split EXACTLY into three bf16 pieces, x = p0 + p1 + p2 (round-to-nearest at each step: p0 = bf16(x),
+// p1 = bf16(x - p0), p2 = x - p0 - p1, which has at most 8 significant bits left and is therefore a bf16), and of
+// the nine piece products of w*x the six with i + j <= 2 are accumulated in f32 by v_mfma_f32_32x32x16_bf16 (bf16 x
+// bf16 products are exact in f32).  The dropped terms p1*q2 + p2*q1 + p2*q2 are <= 2^-24 |w x| (|p1| <= 2^-9 |x|,
+// |p2| <= 2^-17 |x|): below one f32 rounding of the product itself, so the result differs from the f32-MFMA kernel (an
+// fmaf chain) by summation order only -- both are checked against the same reference-generated goldens at
+// 1e-5 * max(1,|y|).  Six bf16 MFMAs of K=16 (6 x 32 cycles) replace eight f32 MFMAs of K=2 (8 x 64 cycles): the
+// matrix-core time of a layer drops 2.67x; the price is operand bytes (6 B per element in LDS instead of 4).
+//
+// Same implicit GEMM as k_conv: D[co][pixel] += W[co][k] X[k][pixel]; a K=16 slab is 16 consecutive input channels
+// at one (ky,kx) tap, a lane holding 8 of them (one 16-byte LDS read per operand piece):
+//   patch  in LDS  [piece][ci/8][py][px][8 bf16]     (split while staging, one thread = 8 channels of one patch pixel)
+//   weights in LDS [tap][piece][ci/8][co][8 bf16]    (split ONCE at pack time: v2e_pack_conv_weight_s3)
+// A and B use the same (lane>>5, element) -> channel assignment, so the contraction pairs the right channels whatever
+// order the hardware walks a lane's eight elements in.
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // plain vector type: stays in registers (uint4 arrays went to scratch)
+
+// two f32 -> their three bf16 pieces, packed (first element in the low half)
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t &q0, uint32_t &q1, uint32_t &q2)
+{
+    const f32x2 v0 = {a, b};
+    q0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2)); // v_cvt_pk_bf16_f32 (RNE)
+    const float ra = a - __uint_as_float(q0 << 16), rb = b - __uint_as_float(q0 & 0xFFFF0000u); // exact
+    const f32x2 v1 = {ra, rb};
+    q1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2));
+    const float sa = ra - __uint_as_float(q1 << 16), sb = rb - __uint_as_float(q1 & 0xFFFF0000u); // exact, <= 8 bits
+    const f32x2 v2 = {sa, sb};
+    q2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2));
+}
+
+// weights: torch [Cout][Cin][k][k] f32 -> [Cin/16][k*k][piece][ci/8 (2)][Cout][8 bf16]; one thread per 16-byte unit triple
+__global__ void k_pack_weight_s3(const float *__restrict__ w, uint4 *__restrict__ ws, int cout, int cin, int kk)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(cin / 8) * kk * cout;
+    if (i >= total) return;
+    const int co = (int)(i % cout);
+    size_t r = i / cout;
+    const int cig = (int)(r % 2); r /= 2;
+    const int tap = (int)(r % kk);
+    const int chunk = (int)(r / kk);
+    const float *src = w + ((size_t)co * cin + chunk * 16 + cig * 8) * kk + tap;
+    uint32_t q[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3_pair(src[(size_t)(2 * e) * kk], src[(size_t)(2 * e + 1) * kk], q[0][e], q[1][e], q[2][e]);
+    const size_t base = ((size_t)chunk * kk + tap) * 6;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) ws[(base + p * 2 + cig) * cout + co] = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
+}
+
+// registers: two 4-wave workgroups per CU (60 KB of LDS each) means two waves per SIMD, i.e. up to 256 VGPRs; left alone the
+// compiler aims for more waves than the LDS allows and spills the prefetch registers to scratch.  Five-wave 20-wide tiles
+// (49 KB) fit three workgroups per CU.
+template <int KS, int CT, int PT, int WP, int TW, int NB>
+__global__ __launch_bounds__(WP * 64)
+__attribute__((amdgpu_waves_per_eu(CT * PT * WP <= 5 ? 3 : (CT * PT * WP <= 8 ? 2 : 1), CT * PT * WP <= 5 ? 4 : (CT * PT * WP <= 10 ? 2 : 1))))
+void k_conv_s3(ConvArgs a)
+{
+    constexpr int NT = WP * 64;
+    constexpr int PAD = KS / 2;
+    constexpr int NPX = WP * PT * 32;
+    constexpr int TH = NPX / TW;
+    constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PP = PH * PW;
+    constexpr int COT = CT * 32;
+    constexpr int KK = KS * KS;
+    constexpr int G = KS == 3 ? 9 : KS; // taps whose weights are resident in LDS at a time (3x3: all; else one kernel row)
+    constexpr int NG = KK / G;
+    constexpr int NPI = (2 * PP + NT - 1) / NT; // patch items per thread; item = 8 channels of one patch pixel
+    constexpr int WU = G * 6 * COT;             // 16-byte weight units per group
+    constexpr int NWU = (WU + NT - 1) / NT;
+    static_assert(NPX % TW == 0, "tile");
+    extern __shared__ u32x4 s3_smem[];
+    u32x4 *sp = s3_smem;          // [3][2][PP]
+    u32x4 *sw = s3_smem + 6 * PP; // [G][3][2][COT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hsel = lane >> 5, l31 = lane & 31;
+    int bx = blockIdx.x;
+    const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
+    const int ty_i = bx % a.tiles_y;
+    const int n = bx / a.tiles_y;
+    const int oy0 = ty_i * TH, ox0 = tx_i * TW;
+    const int cobase = blockIdx.y * COT;
+    const int hw = a.h * a.w_;
+    const u32x4 *wsrc = (const u32x4 *)a.ws3;
+
+    int bofs[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int m = (wave * PT + pt) * 32 + l31;
+        bofs[pt] = hsel * PP + (m / TW) * PW + (m % TW);
+    }
+    const int aofs = hsel * COT + l31;
+
+    int pinfo[NPI]; // first channel of the item: offset inside one sample's chunk, or -1 (zero padding / unused)
+#pragma unroll
+    for (int j = 0; j < NPI; ++j) {
+        const int i = tid + j * NT;
+        int v = -1;
+        if (i < 2 * PP) {
+            const int cig = i / PP, r = i - cig * PP;
+            const int py = r / PW, px = r - py * PW;
+            const int gy = oy0 + py - PAD, gx = ox0 + px - PAD;
+            if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_) v = cig * 8 * hw + gy * a.w_ + gx;
+        }
+        pinfo[j] = v;
+    }
+    int woff[NWU]; // unit -> offset inside one group's weight block (units)
+#pragma unroll
+    for (int j = 0; j < NWU; ++j) {
+        const int u = tid + j * NT;
+        const int uu = u < WU ? u : WU - 1; // surplus threads load a valid unit and do not store it
+        const int r = uu / COT, c = uu - r * COT;
+        woff[j] = r * a.cout + cobase + c;
+    }
+
+    f32x16 acc[CT][PT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+
+    float pv[NPI][8];
+    u32x4 wv[NWU];
+    // loads are unconditional (padding reads a valid address and is zeroed by a select): no branches between them
+    auto prefetch_patch = [&](int cb) {
+        const float *src;
+        int cs, C;
+        if (cb < a.c0) { src = a.x0; cs = cb; C = a.c0; }
+        else { src = a.x1; cs = cb - a.c0; C = a.c1; }
+        const float *base = src + ((size_t)n * C + cs) * hw;
+#pragma unroll
+        for (int j = 0; j < NPI; ++j) {
+            const int pi = pinfo[j];
+            const float *q = base + (pi < 0 ? 0 : pi);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[j][e] = q[(size_t)e * hw];
+        }
+    };
+    auto prefetch_w = [&](int cb, int g) {
+        const u32x4 *wb = wsrc + ((size_t)(cb >> 4) * KK + g * G) * 6 * a.cout;
+#pragma unroll
+        for (int j = 0; j < NWU; ++j) wv[j] = wb[woff[j]];
+    };
+
+    // NB operand register sets: with 2, tap t+1 is read from LDS before the multiplies of tap t are issued
+    bf16x8 av[NB][3][CT], bv[NB][3][PT];
+    auto load_ops = [&](int t, int buf, int ky0) {
+        const int ky = KS == 3 ? t / 3 : 0, kx = KS == 3 ? t % 3 : t;
+        const int koff_p = (ky0 + ky) * PW + kx;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) av[buf][p][ct] = __builtin_bit_cast(bf16x8, sw[aofs + (t * 6 + p * 2) * COT + ct * 32]);
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) bv[buf][p][pt] = __builtin_bit_cast(bf16x8, sp[bofs[pt] + p * 2 * PP + koff_p]);
+        }
+    };
+
+    prefetch_w(0, 0);
+    prefetch_patch(0);
+    for (int cb = 0; cb < a.cin; cb += 16) {
+        for (int g = 0; g < NG; ++g) {
+            const bool stage = !(a.dbg & 4) || (cb == 0 && g == 0);
+            if (stage) __syncthreads(); // everyone is done reading what is about to be overwritten
+            if (g == 0 && stage) {
+#pragma unroll
+                for (int j = 0; j < NPI; ++j) {
+                    const int i = tid + j * NT;
+                    if (i < 2 * PP) {
+                        const bool ok = pinfo[j] >= 0;
+                        uint32_t q[3][4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) split3_pair(ok ? pv[j][2 * e] : 0.f, ok ? pv[j][2 * e + 1] : 0.f, q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) sp[p * 2 * PP + i] = u32x4{q[p][0], q[p][1], q[p][2], q[p][3]};
+                    }
+                }
+            }
+            if (stage) {
+#pragma unroll
+                for (int j = 0; j < NWU; ++j) {
+                    const int u = tid + j * NT;
+                    if (u < WU) sw[u] = wv[j];
+                }
+                __syncthreads();
+            }
+            const bool last_g = g + 1 == NG;
+            const bool more = cb + 16 < a.cin && !(a.dbg & 2);
+            if (!last_g) { if (!(a.dbg & 2)) prefetch_w(cb, g + 1); }
+            else if (more) { prefetch_w(cb + 16, 0); prefetch_patch(cb + 16); }
+            if (a.dbg & 1) continue;
+            const int ky0 = KS == 3 ? 0 : g; // G == KS: group g is kernel row g
+            // operands of tap t+1 are read from LDS before the multiplies of tap t are issued (two register sets)
+            if (NB == 2) load_ops(0, 0, ky0);
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                const int cur = NB == 2 ? (t & 1) : 0;
+                if (NB == 1) load_ops(t, 0, ky0);
+                else if (t + 1 < G) load_ops(t + 1, cur ^ 1, ky0);
+                if (NB == 2) __builtin_amdgcn_sched_barrier(0);
+                // six piece products, small ones first; consecutive multiplies go to different accumulators
+#define S3_MFMA(PA, PB)                                                                                              \
+    _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)               \
+        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][PA][ct], bv[cur][PB][pt], acc[ct][pt], 0, 0, 0);
+                S3_MFMA(2, 0) S3_MFMA(0, 2) S3_MFMA(1, 1) S3_MFMA(1, 0) S3_MFMA(0, 1) S3_MFMA(0, 0)
+#undef S3_MFMA
+                if (NB == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // epilogue as k_conv: register r of a lane is channel (r&3)+8(r>>2)+4*hsel of pixel l31
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int m = (wave * PT + pt) * 32 + l31;
+        const int oy = oy0 + m / TW, ox = ox0 + (m % TW);
+        const bool pok = oy < a.h && ox < a.w_;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = cobase + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (pok) {
+                    float v = acc[ct][pt][r] + a.bias[ch];
+                    v = v > 0.f ? v : v * 0.1f;
+                    a.y[(((size_t)n * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int CT, int PT, int WP, int TW, int NB = 1>
+static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
+{
+    ConvArgs a = a0;
+    constexpr int TH = WP * PT * 32 / TW;
+    constexpr int PP = (TH + KS - 1) * (TW + KS - 1);
+    constexpr int G = KS == 3 ? 9 : KS;
+    constexpr size_t lds = (size_t)(6 * PP + G * 6 * CT * 32) * 16;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_set = false; // one per instantiation
+    if (!attr_set) {
+        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    a.tiles_x = (a.w_ + TW - 1) / TW;
+    a.tiles_y = (a.h + TH - 1) / TH;
+    dim3 grid((unsigned)(a.n * a.tiles_x * a.tiles_y), (unsigned)(a.cout / (CT * 32)));
+    k_conv_s3<KS, CT, PT, WP, TW, NB><<<grid, WP * 64, lds, s>>>(a);
+    return 0;
+}

@@ -39,8 +39,12 @@ def _ptr(t):
 class HipUNet:
     """One UNet's weights, repacked [Cin][k][k][Cout] in HBM, and its forward pass."""
 
-    def __init__(self, state_dict, cin, cout, device):
+    def __init__(self, state_dict, cin, cout, device, conv_math="bf16x3"):
         import ctypes as C
+        if conv_math not in ("bf16x3", "f32"):
+            raise ValueError("conv_math must be 'bf16x3' (f32 operands split exactly into three bf16 pieces, six piece "
+                             "products on the bf16 matrix cores, f32 accumulation) or 'f32' (f32 matrix-core instructions)")
+        self.conv_math = conv_math
         self.lib = _capi.lib()
         self.device = torch.device(device)
         self.cin, self.cout = cin, cout
@@ -57,6 +61,12 @@ class HipUNet:
             self._keep += [wp, b]
             descs[i].weight = wp.data_ptr()
             descs[i].bias = b.data_ptr()
+            descs[i].weight_s3 = None
+            if conv_math == "bf16x3" and ci % 16 == 0 and co % 32 == 0:
+                w3 = torch.empty(ci * kh * kw * co * 6, dtype=torch.uint8, device=self.device)
+                check(self.lib.v2e_pack_conv_weight_s3(_ptr(w), _ptr(w3), co, ci, kh, stream), "v2e_pack_conv_weight_s3")
+                self._keep.append(w3)
+                descs[i].weight_s3 = w3.data_ptr()
             descs[i].cin, descs[i].cout, descs[i].ksize = ci, co, kh
         torch.cuda.synchronize(self.device)
         assert descs[0].cin == cin and descs[22].cout == cout
@@ -91,15 +101,21 @@ def time_coefficients(ts):
 class SloMoEngine:
     """Flow UNet + interpolation UNet + warps/fusion for batches of frame pairs, on device."""
 
-    def __init__(self, flow_state_dict, interp_state_dict, device="cuda"):
+    def __init__(self, flow_state_dict, interp_state_dict, device="cuda", conv_math=None):
+        """conv_math: 'bf16x3' (default; every f32 operand split exactly into three bf16 pieces, six piece products on the
+        bf16 matrix cores, f32 accumulation -- f32 accuracy, v2e_amd/csrc/slomo_s3.h) or 'f32' (f32 matrix-core
+        instructions); the environment variable V2E_AMD_CONV_MATH sets the default."""
+        if conv_math is None:
+            conv_math = os.environ.get("V2E_AMD_CONV_MATH", "bf16x3")
+        self.conv_math = conv_math
         if not torch.cuda.is_available():
             raise _capi.V2EAmdError("v2e_amd.SloMoEngine needs a ROCm GPU; there is no CPU fallback")
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = _capi.lib()
-        self.flow_net = HipUNet(flow_state_dict, 2, 4, self.device)
-        self.interp_net = HipUNet(interp_state_dict, 12, 5, self.device)
+        self.flow_net = HipUNet(flow_state_dict, 2, 4, self.device, conv_math)
+        self.interp_net = HipUNet(interp_state_dict, 12, 5, self.device, conv_math)
         self._x2 = None
 
     def _stream(self):
