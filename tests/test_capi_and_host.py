@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     from v2e_amd._capi import ConvDesc, EmuParams, FrameRec
     assert C.sizeof(FrameRec) == 32
     assert C.sizeof(EmuParams) == 16 + 12 * 8 + 8 + 8 + 8 + 8  # ... + log_input, photoreceptor_noise, vrms
-    assert C.sizeof(ConvDesc) == 32 or C.sizeof(ConvDesc) == 28
+    assert C.sizeof(ConvDesc) == 40 and ConvDesc.weight_s3.offset == 32  # two pointers, 3 ints + pad, split-bf16 weights
 
 
 def test_emulator_constructor_surface():

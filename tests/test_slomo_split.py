@@ -1,0 +1,83 @@
+"""The exact three-way bf16 split behind the default SuperSloMo convolution math (v2e_amd/csrc/slomo_s3.h).
+
+CPU: the split restated in numpy -- x == p0 + p1 + p2 exactly, every piece a bf16, the dropped piece products bounded by
+2^-24 |w x|, and the six kept products summed in double equal the f32 product to that bound.
+GPU: v2e_pack_conv_weight_s3 writes exactly those pieces in the layout the kernel reads.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+
+def bf16_rne(x):
+    """float32 -> nearest bf16 (ties to even), returned as float32."""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def split3(x):
+    x = np.asarray(x, np.float32)
+    p0 = bf16_rne(x)
+    r1 = (x - p0).astype(np.float32)
+    p1 = bf16_rne(r1)
+    r2 = (r1 - p1).astype(np.float32)
+    p2 = bf16_rne(r2)
+    return p0, p1, p2
+
+
+def _samples(seed, n):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mant = rng.integers(0, 1 << 23, size=n, dtype=np.uint32)
+    exp = rng.integers(127 - 20, 127 + 8, size=n, dtype=np.uint32)  # 1e-6 .. 256
+    sign = rng.integers(0, 2, size=n, dtype=np.uint32)
+    x = ((sign << 31) | (exp << 23) | mant).view(np.float32)
+    edge = np.array([0.0, 1.0, -1.0, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -9, 1.0 + 2.0 ** -23, 255.0 / 256, 0.428, 3.0e-5], np.float32)
+    return np.concatenate((x, edge))
+
+
+def test_split_is_exact_and_pieces_are_bf16():
+    x = _samples(1, 200_000)
+    p0, p1, p2 = split3(x)
+    for p in (p0, p1, p2):
+        assert np.all((p.view(np.uint32) & 0xFFFF) == 0), "piece is not a bf16"
+    # exact reconstruction (evaluated in double: the three pieces do not overlap)
+    assert np.array_equal(p0.astype(np.float64) + p1.astype(np.float64) + p2.astype(np.float64), x.astype(np.float64))
+    ax = np.abs(x.astype(np.float64))
+    assert np.all(np.abs(p1) <= ax * 2.0 ** -8) and np.all(np.abs(p2) <= ax * 2.0 ** -16)
+
+
+def test_six_products_reproduce_the_f32_product_to_2_pow_minus_24():
+    w = _samples(2, 100_000)
+    x = _samples(3, 100_000)
+    pw, px = [p.astype(np.float64) for p in split3(w)], [p.astype(np.float64) for p in split3(x)]
+    kept = sum(pw[i] * px[j] for i in range(3) for j in range(3) if i + j <= 2)
+    exact = w.astype(np.float64) * x.astype(np.float64)
+    err = np.abs(kept - exact)
+    assert np.all(err <= np.abs(exact) * 2.0 ** -23)          # worst case
+    nz = exact != 0
+    assert np.mean(err[nz] / np.abs(exact[nz])) < 2.0 ** -26  # typical: far below one f32 rounding (2^-24)
+
+
+@pytest.mark.gpu
+def test_pack_kernel_writes_the_numpy_pieces():
+    from v2e_amd import _capi
+    from v2e_amd._capi import check
+    lib = _capi.lib()
+    rng = np.random.Generator(np.random.PCG64(5))
+    cout, cin, k = 64, 48, 3
+    w = (rng.standard_normal((cout, cin, k, k)) * 0.05).astype(np.float32)
+    dev = torch.device("cuda")
+    tw = torch.from_numpy(w).to(dev)
+    w3 = torch.empty(cin * k * k * cout * 6, dtype=torch.uint8, device=dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib.v2e_pack_conv_weight_s3(C.c_void_p(tw.data_ptr()), C.c_void_p(w3.data_ptr()), cout, cin, k, s), "pack_s3")
+    torch.cuda.synchronize()
+    got = w3.cpu().numpy().view(np.uint16).reshape(cin // 16, k * k, 3, 2, cout, 8)  # [chunk][tap][piece][ci/8][co][8]
+    pieces = split3(w)
+    for p in range(3):
+        hi = (pieces[p].view(np.uint32) >> 16).astype(np.uint16)          # [co][ci][ky][kx]
+        want = hi.reshape(cout, cin // 16, 2, 8, k * k).transpose(1, 4, 2, 0, 3)  # [chunk][tap][ci/8][co][8]
+        assert np.array_equal(got[:, :, p], want), "piece %d" % p

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 F32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: f32-input MFMA, dense
+BF16_MFMA_PEAK = 2.5e15  # MI355X_MICROARCH.md: bf16 MFMA, dense (32x32x16)
 HBM_PEAK = 8.0e12
 
 
@@ -111,18 +112,45 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5):
     torch.cuda.synchronize(device)
     sec_u = e0.elapsed_time(e1) * 1e-3 / iters
     fl_u = U * B * unet_flops(12, 5, H, W)
+    s3 = eng.conv_math == "bf16x3"
+    # executed matrix-core work: with split-bf16 operands every f32 multiply-add is six bf16 ones (the 12-channel conv1,
+    # the 8x10 level and the 5-channel head stay on f32 instructions: ~6 % of the FLOPs)
+    ach = fl_u / sec_u
+    roof = {"bound": "mfma", "kernel": ("k_conv_s3" if s3 else "k_conv") + " (23 launches of the interpolation UNet)",
+            "achieved": round(ach * (6 if s3 else 1) / 1e12, 2), "peak": (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK) / 1e12,
+            "unit": "TFLOP/s", "frac": round(ach * (6 if s3 else 1) / (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK), 4),
+            "traffic": slomo_pmc_traffic(), "f32_equivalent_TFLOPs": round(ach / 1e12, 2),
+            "f32_equivalent_vs_f32_mfma_peak": round(ach / F32_MFMA_PEAK, 4),
+            "whole_step_TFLOPs": round(flops / sec / 1e12, 2),
+            "note": ("achieved = algorithmic f32 FLOPs of the UNet x 6 (bf16 piece products executed per f32 multiply: x = p0+p1+p2 "
+                     "exactly, products with i+j<=2) / time, against the dense bf16 MFMA peak; f32_equivalent is the same time "
+                     "priced in the algorithm's own f32 FLOPs (the f32 matrix-core peak is 157.3 TF/s)") if s3 else
+                    "f32 matrix-core instructions (v_mfma_f32_32x32x2_f32)"}
     return {
         "metric": "interpolated frames/s (SuperSloMo flow UNet + per-t warps + interpolation UNet + fusion)",
         "value": round(U * B / sec, 2), "unit": "frames/s",
         "config": {"workload": "BASELINE configs[2] SloMo stage: 320x256 (346x260 source), U=%d, batch of %d pairs, "
                                "seeded random-init weights (checkpoint not available offline)" % (U, B)},
-        "dtype": "f32", "ms_per_batch": round(sec * 1e3, 3),
+        "dtype": "f32" + (" (operands split exactly into 3 bf16 pieces, 6 products on the bf16 matrix cores, f32 accumulation)" if s3 else ""),
+        "conv_math": eng.conv_math, "ms_per_batch": round(sec * 1e3, 3),
         "gflop_per_frame": round(flops / (U * B) / 1e9, 2),
-        "roofline": {"bound": "mfma", "kernel": "k_conv (23 launches of the interpolation UNet)",
-                     "achieved": round(fl_u / sec_u / 1e12, 2), "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": round(fl_u / sec_u / F32_MFMA_PEAK, 4), "traffic": None,
-                     "whole_step_TFLOPs": round(flops / sec / 1e12, 2)},
+        "roofline": roof,
     }
+
+
+def slomo_pmc_traffic():
+    """HBM bytes per interpolation-UNet forward (80 samples) from the committed rocprofv3 PMC passes
+    (profiles/r02_slomo_counters.txt, line '# unet_forward_bytes <fetch> <write>'), or None."""
+    import os
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for line in open(os.path.join(root, "profiles", "r02_slomo_counters.txt")):
+            if line.startswith("# unet_forward_bytes"):
+                parts = line.split()
+                return int(float(parts[2]) + float(parts[3]))
+    except Exception:
+        pass
+    return None
 
 
 def batched_emulator_bench(device, n_clips=64, frames=60, H=260, W=346):

@@ -33,7 +33,6 @@ struct ConvArgs {
     int n, h, w_, cin, cout;
     int tiles_x, tiles_y;
     const void *ws3; // split-bf16 weights (slomo_s3.h) or nullptr
-    int dbg;         // dev (V2E_AMD_S3_DBG): 1 no multiplies, 2 no global loads after the first chunk, 4 no staging after the first chunk
 };
 
 // element fetch with the producer op fused: PRE 0 plain, 1 avg_pool2d(2) of a [2H][2W] source,
@@ -659,8 +658,6 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout;
     a.tiles_x = a.tiles_y = 0;
     a.ws3 = conv->weight_s3;
-    static const int s3_dbg = getenv("V2E_AMD_S3_DBG") ? atoi(getenv("V2E_AMD_S3_DBG")) : 0;
-    a.dbg = s3_dbg;
     if (conv->ksize == 3 && pre == 0 && c1 == 0 && (conv->cout == 4 || conv->cout == 5)) {
         const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;
         dim3 grid((unsigned)(n * tiles_x * tiles_y));

@@ -4,9 +4,11 @@
 // operand is split EXACTLY into three bf16 pieces, x = p0 + p1 + p2 (round-to-nearest at each step: p0 = bf16(x),
 // p1 = bf16(x - p0), p2 = x - p0 - p1, which has at most 8 significant bits left and is therefore a bf16), and of
 // the nine piece products of w*x the six with i + j <= 2 are accumulated in f32 by v_mfma_f32_32x32x16_bf16 (bf16 x
-// bf16 products are exact in f32).  The dropped terms p1*q2 + p2*q1 + p2*q2 are <= 2^-24 |w x| (|p1| <= 2^-9 |x|,
-// |p2| <= 2^-17 |x|): below one f32 rounding of the product itself, so the result differs from the f32-MFMA kernel (an
-// fmaf chain) by summation order only -- both are checked against the same reference-generated goldens at
+// bf16 products are exact in f32).  The dropped terms p1*q2 + p2*q1 + p2*q2 are <= 2^-23 |w x| in the worst case
+// (|p1| <= 2^-8 |x|, |p2| <= 2^-16 |x|) and 2^-26 |w x| on average (tests/test_slomo_split.py): at or below one f32
+// rounding of the product itself, so the result differs from the f32-MFMA kernel (an fmaf chain) by no more than
+// summation order does -- measured against double-precision sums it is the closer of the two
+// (scripts/conv_s3_check.hip) -- and both are checked against the same reference-generated goldens at
 // 1e-5 * max(1,|y|).  Six bf16 MFMAs of K=16 (6 x 32 cycles) replace eight f32 MFMAs of K=2 (8 x 64 cycles): the
 // matrix-core time of a layer drops 2.67x; the price is operand bytes (6 B per element in LDS instead of 4).
 //
@@ -129,10 +131,14 @@ void k_conv_s3(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
 
-    float pv[NPI][8];
-    u32x4 wv[NWU];
+    // global -> register prefetch, DEEP chunks ahead.  A fetch round trip is ~4 us under load and one chunk of a
+    // 3x3 layer is ~2.4 us of multiplies, so the 3x3 kernels (one weight group per chunk) keep TWO chunks in flight
+    // in two register sets; 5x5 / 7x7 chunks are 3-5x longer and have no registers to spare.
+    constexpr int DEEP = (NG == 1 && CT * PT == 2) ? 2 : 1;
+    float pv[DEEP][NPI][8];
+    u32x4 wv[DEEP][NWU];
     // loads are unconditional (padding reads a valid address and is zeroed by a select): no branches between them
-    auto prefetch_patch = [&](int cb) {
+    auto prefetch_patch = [&](int set, int cb) {
         const float *src;
         int cs, C;
         if (cb < a.c0) { src = a.x0; cs = cb; C = a.c0; }
@@ -143,13 +149,35 @@ void k_conv_s3(ConvArgs a)
             const int pi = pinfo[j];
             const float *q = base + (pi < 0 ? 0 : pi);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pv[j][e] = q[(size_t)e * hw];
+            for (int e = 0; e < 8; ++e) pv[set][j][e] = q[(size_t)e * hw];
         }
     };
-    auto prefetch_w = [&](int cb, int g) {
+    auto prefetch_w = [&](int set, int cb, int g) {
         const u32x4 *wb = wsrc + ((size_t)(cb >> 4) * KK + g * G) * 6 * a.cout;
 #pragma unroll
-        for (int j = 0; j < NWU; ++j) wv[j] = wb[woff[j]];
+        for (int j = 0; j < NWU; ++j) wv[set][j] = wb[woff[j]];
+    };
+    auto stage_patch = [&](int set) { // split and store this thread's patch items
+#pragma unroll
+        for (int j = 0; j < NPI; ++j) {
+            const int i = tid + j * NT;
+            if (i < 2 * PP) {
+                const bool ok = pinfo[j] >= 0;
+                uint32_t q[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    split3_pair(ok ? pv[set][j][2 * e] : 0.f, ok ? pv[set][j][2 * e + 1] : 0.f, q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) sp[p * 2 * PP + i] = u32x4{q[p][0], q[p][1], q[p][2], q[p][3]};
+            }
+        }
+    };
+    auto stage_w = [&](int set) {
+#pragma unroll
+        for (int j = 0; j < NWU; ++j) {
+            const int u = tid + j * NT;
+            if (u < WU) sw[u] = wv[set][j];
+        }
     };
 
     // NB operand register sets: with 2, tap t+1 is read from LDS before the multiplies of tap t are issued
@@ -165,56 +193,77 @@ void k_conv_s3(ConvArgs a)
             for (int pt = 0; pt < PT; ++pt) bv[buf][p][pt] = __builtin_bit_cast(bf16x8, sp[bofs[pt] + p * 2 * PP + koff_p]);
         }
     };
-
-    prefetch_w(0, 0);
-    prefetch_patch(0);
-    for (int cb = 0; cb < a.cin; cb += 16) {
-        for (int g = 0; g < NG; ++g) {
-            const bool stage = !(a.dbg & 4) || (cb == 0 && g == 0);
-            if (stage) __syncthreads(); // everyone is done reading what is about to be overwritten
-            if (g == 0 && stage) {
+    auto compute_group = [&](int ky0) { // the G taps whose weights are in LDS
+        if (NB == 2) load_ops(0, 0, ky0);
 #pragma unroll
-                for (int j = 0; j < NPI; ++j) {
-                    const int i = tid + j * NT;
-                    if (i < 2 * PP) {
-                        const bool ok = pinfo[j] >= 0;
-                        uint32_t q[3][4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) split3_pair(ok ? pv[j][2 * e] : 0.f, ok ? pv[j][2 * e + 1] : 0.f, q[0][e], q[1][e], q[2][e]);
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) sp[p * 2 * PP + i] = u32x4{q[p][0], q[p][1], q[p][2], q[p][3]};
-                    }
-                }
-            }
-            if (stage) {
-#pragma unroll
-                for (int j = 0; j < NWU; ++j) {
-                    const int u = tid + j * NT;
-                    if (u < WU) sw[u] = wv[j];
-                }
-                __syncthreads();
-            }
-            const bool last_g = g + 1 == NG;
-            const bool more = cb + 16 < a.cin && !(a.dbg & 2);
-            if (!last_g) { if (!(a.dbg & 2)) prefetch_w(cb, g + 1); }
-            else if (more) { prefetch_w(cb + 16, 0); prefetch_patch(cb + 16); }
-            if (a.dbg & 1) continue;
-            const int ky0 = KS == 3 ? 0 : g; // G == KS: group g is kernel row g
-            // operands of tap t+1 are read from LDS before the multiplies of tap t are issued (two register sets)
-            if (NB == 2) load_ops(0, 0, ky0);
-#pragma unroll
-            for (int t = 0; t < G; ++t) {
-                const int cur = NB == 2 ? (t & 1) : 0;
-                if (NB == 1) load_ops(t, 0, ky0);
-                else if (t + 1 < G) load_ops(t + 1, cur ^ 1, ky0);
-                if (NB == 2) __builtin_amdgcn_sched_barrier(0);
-                // six piece products, small ones first; consecutive multiplies go to different accumulators
+        for (int t = 0; t < G; ++t) {
+            const int cur = NB == 2 ? (t & 1) : 0;
+            if (NB == 1) load_ops(t, 0, ky0);
+            else if (t + 1 < G) load_ops(t + 1, cur ^ 1, ky0);
+            if (NB == 2) __builtin_amdgcn_sched_barrier(0);
+            // six piece products, small ones first; consecutive multiplies go to different accumulators
 #define S3_MFMA(PA, PB)                                                                                              \
     _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)               \
         acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][PA][ct], bv[cur][PB][pt], acc[ct][pt], 0, 0, 0);
-                S3_MFMA(2, 0) S3_MFMA(0, 2) S3_MFMA(1, 1) S3_MFMA(1, 0) S3_MFMA(0, 1) S3_MFMA(0, 0)
+            S3_MFMA(2, 0) S3_MFMA(0, 2) S3_MFMA(1, 1) S3_MFMA(1, 0) S3_MFMA(0, 1) S3_MFMA(0, 0)
 #undef S3_MFMA
-                if (NB == 2) __builtin_amdgcn_sched_barrier(0);
+            if (NB == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (DEEP == 2) {
+        prefetch_w(0, 0, 0);
+        prefetch_patch(0, 0);
+        int cb = 0;
+        if (a.cin >= 64) {
+            prefetch_w(DEEP - 1, 16, 0);
+            prefetch_patch(DEEP - 1, 16);
+            // steady state: both chunks of the pair have a successor two chunks on, so the prefetch is unconditional (no
+            // branch between the loads of a set and its use) and the wait before staging a set covers that set only:
+            // the newer set's loads stay in flight across the barrier
+            for (; cb + 64 <= a.cin; cb += 32) {
+#pragma unroll
+                for (int set = 0; set < DEEP; ++set) {
+                    const int c = cb + 16 * set;
+                    __syncthreads(); // everyone is done reading what is about to be overwritten
+                    stage_patch(set);
+                    stage_w(set);
+                    __syncthreads();
+                    prefetch_w(set, c + 32, 0);
+                    prefetch_patch(set, c + 32);
+                    compute_group(0);
+                }
+            }
+        } else if (a.cin > 16) {
+            prefetch_w(DEEP - 1, 16, 0);
+            prefetch_patch(DEEP - 1, 16);
+        }
+        for (; cb < a.cin; cb += 32) { // the last one to three chunks
+#pragma unroll
+            for (int set = 0; set < DEEP; ++set) {
+                const int c = cb + 16 * set;
+                if (c < a.cin) {
+                    __syncthreads();
+                    stage_patch(set);
+                    stage_w(set);
+                    __syncthreads();
+                    if (c + 32 < a.cin) { prefetch_w(set, c + 32, 0); prefetch_patch(set, c + 32); }
+                    compute_group(0);
+                }
+            }
+        }
+    } else {
+        prefetch_w(0, 0, 0);
+        prefetch_patch(0, 0);
+        for (int cb = 0; cb < a.cin; cb += 16) {
+            for (int g = 0; g < NG; ++g) {
+                __syncthreads(); // everyone is done reading what is about to be overwritten
+                if (g == 0) stage_patch(0);
+                stage_w(0);
+                __syncthreads();
+                if (g + 1 < NG) prefetch_w(0, cb, g + 1);
+                else if (cb + 16 < a.cin) { prefetch_w(0, cb + 16, 0); prefetch_patch(0, cb + 16); }
+                compute_group(KS == 3 ? 0 : g); // G == KS: group g is kernel row g
             }
         }
     }
