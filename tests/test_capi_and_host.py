@@ -68,8 +68,8 @@ def test_emulator_errors_like_reference():
             EventEmulator(**kw)
     with pytest.raises(SystemExit):  # emulator.py:196-204: v2e_quit when the rate or the cutoff is zero
         EventEmulator(photoreceptor_noise=True, shot_noise_rate_hz=0.0, cutoff_hz=10)
-    e = EventEmulator(photoreceptor_noise=True, shot_noise_rate_hz=1.0, cutoff_hz=10, rng_mode="philox")
-    with pytest.raises(NotImplementedError):  # device-resident clips: frame API only
+    e = EventEmulator(photoreceptor_noise=True, shot_noise_rate_hz=1.0, cutoff_hz=10, rng_mode="tape")
+    with pytest.raises(ValueError):  # device-resident clips need the Philox streams (tape mode needs the host per frame)
         e.generate_events_batch(np.zeros((2, 4, 4), np.uint8), [0.0, 0.1])
     with pytest.raises(ValueError):
         EventEmulator(rng_mode="bogus")

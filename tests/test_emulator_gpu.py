@@ -105,7 +105,7 @@ PIPELINES = [0, 1, 256, 257, 64, 65, 192, 193, 32, 33, 16, 17, 513]
 
 
 @pytest.mark.parametrize("use_graph", PIPELINES)
-@pytest.mark.parametrize("name", [n for n in PHILOX_FIXTURES if "pnoise" not in n])  # photoreceptor noise: frame API only
+@pytest.mark.parametrize("name", [n for n in PHILOX_FIXTURES if "pnoise" not in n])  # photoreceptor noise: its own test below
 def test_hip_philox_device_resident_clip_matches_reference(name, use_graph):
     """Whole clip on device (no host sync between frames; optionally one hipGraph), all three pipelines."""
     fx = PhiloxFixture(name)
@@ -123,6 +123,33 @@ def test_hip_philox_device_resident_clip_matches_reference(name, use_graph):
     if fx.ts_mem_sha:
         assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
+@pytest.mark.parametrize("use_graph", [True, 0, 1, 16, 17])
+def test_hip_philox_device_resident_photoreceptor_noise(use_graph):
+    """photoreceptor_noise=True (emulator.py:694-703) in the device-resident API: the noise plane lives in HBM across the
+    run (and across runs: the clip is fed in two pieces), events and state equal the reference-generated fixture."""
+    from v2e_amd._capi import V2EAmdError
+    name = "philox_pnoise_97x131"
+    fx = PhiloxFixture(name)
+    emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+    cut = len(fx.frames) // 2 + 1
+    ev0, c0 = emu.generate_events_batch(fx.frames[:cut], fx.times[:cut], use_graph=use_graph)
+    ev1, c1 = emu.generate_events_batch(fx.frames[cut:], fx.times[cut:], use_graph=use_graph)
+    counts = list(c0) + list(c1)
+    assert counts == list(fx.n_events)
+    ev = np.concatenate([e for e in (ev0, ev1) if e is not None and len(e)])
+    row = 0
+    for k, n in enumerate(counts):
+        if n:
+            assert sha(ev[row:row + n]) == fx.ev_sha[k], "frame %d event digest differs" % k
+        row += n
+    st = _state(emu)
+    assert sha(st["base_log_frame"]) == fx.base_sha
+    assert sha(st["lp_log_frame"]) == fx.lp_sha
+    assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+    with pytest.raises(V2EAmdError):  # the chain pipelines do not carry the noise plane: refused, not silently noiseless
+        emu.generate_events_batch(fx.frames[-2:], [fx.times[-1] + 0.01, fx.times[-1] + 0.02], use_graph=257)
 
 
 @pytest.mark.parametrize("pipe_e", [1, 2, 3, 4, 6])

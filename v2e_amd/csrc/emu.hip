@@ -1748,7 +1748,8 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(p->rng_mode == V2E_RNG_PHILOX, "v2e_emu_run is the device-resident Philox path");
-    V2E_REQUIRE(!p->photoreceptor_noise, "photoreceptor noise is implemented by the frame-at-a-time API only");
+    V2E_REQUIRE(!p->photoreceptor_noise || !(use_graph & (32 | 64 | 256)),
+                "photoreceptor noise runs on the count/rank/scan/emit pipeline (the other pipelines do not carry the noise plane)");
     V2E_REQUIRE(frames && t_prev && t_frame && events && recs_dev && n_frames > 0, "bad run args");
     V2E_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1778,7 +1779,9 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     V2E_HIP(hipEventRecord(h->ev_stage[sq], s));
     KArgs a = make_kargs(h, p);
     const int mode = use_graph & 3;          // 0 plain launches, 1 hipGraph, 2 instrumented
-    const bool legacy = (use_graph & 16) != 0; // 4-kernel count/rank/scan/emit pipeline (kept for A/B)
+    // 4-kernel count/rank/scan/emit pipeline: kept for A/B, and the one that carries the photoreceptor-noise plane
+    // (emulator.py:694-703: one more f64 state plane and one more Philox normal per pixel and frame)
+    const bool legacy = (use_graph & 16) != 0 || p->photoreceptor_noise != 0;
     // Default: the k_step chain + deferred emission batches while a frame is a few workgroups per CU (the run is
     // bounded by the per-frame launch latency, so only the dependency chain may be on it); one k_main launch per
     // frame with emission on the chain once the grid is large enough to be throughput-bound (each pixel touched
@@ -1788,7 +1791,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     // of the explicit pipeline bits (|16 |32 |64 |128) selects the earlier pipelines (kept for A/B and as the fallback)
     const bool chain_ok = chain_eligible(h, p, dtype, (use_graph & 256) != 0);
     V2E_REQUIRE(!(use_graph & 256) || chain_ok, "k_chain cannot run this configuration (max_iters or a grid too large for the redo rendezvous)");
-    const bool chain = chain_ok && ((use_graph & 256) != 0 || (!(use_graph & (16 | 32 | 64 | 128 | 512)) && !getenv("V2E_AMD_NO_CHAIN")));
+    const bool chain = chain_ok && !legacy && ((use_graph & 256) != 0 || (!(use_graph & (16 | 32 | 64 | 128 | 512)) && !getenv("V2E_AMD_NO_CHAIN")));
     const bool fused = !legacy && !chain && ((use_graph & 32) != 0 || (!(use_graph & 64) && !small_grid));
     const bool pipe = !legacy && !fused && !chain;
     // Two frames per launch (k_step2, second frame finalised speculatively) needs the grid co-resident for the

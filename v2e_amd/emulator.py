@@ -598,8 +598,6 @@ class EventEmulator(object):
         """
         if self.rng_mode != "philox":
             raise ValueError("generate_events_batch needs rng_mode='philox' (tape mode needs the host per frame)")
-        if self.photoreceptor_noise:
-            raise NotImplementedError("photoreceptor_noise is implemented by the frame-at-a-time API (generate_events) only")
         if isinstance(frames, np.ndarray):
             if frames.dtype not in (np.uint8, np.float32, np.float64):
                 frames = frames.astype(np.float64)
@@ -630,6 +628,26 @@ class EventEmulator(object):
                     t_frames[f], tp))
             t_prev.append(tp)
             tp = t_frames[f]
+        if self.photoreceptor_noise:  # emulator.py:694-703, the noise plane stays on the device for the whole run
+            if self.photoreceptor_noise_arr is None:
+                self._pn_plane = torch.zeros((1, eng.npx_pad), dtype=torch.float64, device=eng.device)
+                self.photoreceptor_noise_arr = eng.plane(self._pn_plane)
+            rates = [1.0 / (t_frames[f] - t_prev[f - start]) for f in range(start, F)]
+            if self.photoreceptor_noise_vrms is not None:
+                self._pn_vrms = float(self.photoreceptor_noise_vrms)
+            else:
+                # the reference recomputes the amplitude when the sample rate moves by 10 % (emulator_utils.py:217-220);
+                # inside one device-resident run the amplitude is one number
+                if any(abs(r / rates[0] - 1) >= 0.1 for r in rates):
+                    raise ValueError("photoreceptor_noise: the frame interval changes by more than 10 % inside this run; "
+                                     "split the run there (or use generate_events per frame)")
+                if self._pn_last_rate is None or abs(rates[0] / self._pn_last_rate - 1) >= 0.1:
+                    self._pn_vrms = photoreceptor_noise_vrms(self.shot_noise_rate_hz, self.cutoff_hz, rates[0],
+                                                             self.pos_thres_nominal, self.neg_thres_nominal, self.sigma_thres)
+                    self._pn_last_rate = rates[0]
+            eng.set_pnoise(self._pn_plane, None)
+            if isinstance(use_graph, bool) or use_graph in (0, 1):
+                use_graph = int(use_graph) | 16  # the pipeline that carries the noise plane
         P = self._params()
         if cap is None:
             cap = max(4 * H * W, 1 << 16) * min(nrun, 64)
