@@ -7,7 +7,8 @@ from v2e_amd.slomo import HipUNet
 from v2e_amd.synth import portable_unet_state_dict
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda")
-net = HipUNet({k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}, 12, 5, dev)
+net = HipUNet({k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}, 12, 5, dev,
+              os.environ.get("V2E_AMD_CONV_MATH", "bf16x3"))
 x = torch.rand((n, 12, 256, 320), device=dev) - 0.4
 for _ in range(3):
     net.forward(x)

@@ -389,6 +389,15 @@ def test_event_buffer_overflow_is_reported():
     emu = _mk(fx, seed=fx.seed, rng_mode="philox")
     with pytest.raises(V2EAmdError, match="capacity"):
         emu.generate_events_batch(fx.frames, fx.times, cap=1000)
+    # the pixel state is past the failed run: further frames are refused until reset(), after which the clip runs again
+    with pytest.raises(V2EAmdError, match="reset"):
+        emu.generate_events_batch(fx.frames[-2:], [fx.times[-1] + 0.01, fx.times[-1] + 0.02])
+    with pytest.raises(V2EAmdError, match="reset"):
+        emu.generate_events(fx.frames[-1], float(fx.times[-1]) + 0.03)
+    emu.reset()
+    emu.t_previous = 0
+    ev, counts = emu.generate_events_batch(fx.frames, fx.times)
+    assert list(counts) == list(fx.n_events)
 
 
 def test_many_iterations_grow_scratch(oracle_lib):

@@ -33,6 +33,7 @@ struct ConvArgs {
     int n, h, w_, cin, cout;
     int tiles_x, tiles_y;
     const void *ws3; // split-bf16 weights (slomo_s3.h) or nullptr
+    int ncb;         // slomo_s3.h: channel blocks when the grid is 1-D in XCD order, else 0
 };
 
 // element fetch with the producer op fused: PRE 0 plain, 1 avg_pool2d(2) of a [2H][2W] source,

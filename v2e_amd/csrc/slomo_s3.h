@@ -84,12 +84,25 @@ void k_conv_s3(ConvArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hsel = lane >> 5, l31 = lane & 31;
-    int bx = blockIdx.x;
+    // workgroup -> (pixel tile, channel block).  Workgroups go to the 8 XCDs round-robin by linear id and each XCD has its
+    // own L2, so the channel blocks of ONE pixel tile are consecutive on ONE XCD (ids L, L+8, L+16, ...): the tile's input
+    // patch crosses the fabric once instead of once per channel block, and since the workgroups of an XCD walk the
+    // input-channel chunks roughly in step, the weight slices they share stay L2-resident too (measured: DESIGN.md 4).
+    int bx, cblk;
+    if (a.ncb > 0) {
+        const int L = blockIdx.x, j = L >> 3;
+        cblk = j % a.ncb;
+        bx = (j / a.ncb) * 8 + (L & 7);
+        if (bx >= a.n * a.tiles_x * a.tiles_y) return; // padding of the last group of 8 pixel tiles
+    } else {
+        bx = blockIdx.x;
+        cblk = blockIdx.y;
+    }
     const int tx_i = bx % a.tiles_x; bx /= a.tiles_x;
     const int ty_i = bx % a.tiles_y;
     const int n = bx / a.tiles_y;
     const int oy0 = ty_i * TH, ox0 = tx_i * TW;
-    const int cobase = blockIdx.y * COT;
+    const int cobase = cblk * COT;
     const int hw = a.h * a.w_;
     const u32x4 *wsrc = (const u32x4 *)a.ws3;
 
@@ -304,7 +317,12 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     }
     a.tiles_x = (a.w_ + TW - 1) / TW;
     a.tiles_y = (a.h + TH - 1) / TH;
-    dim3 grid((unsigned)(a.n * a.tiles_x * a.tiles_y), (unsigned)(a.cout / (CT * 32)));
+    static const int order = getenv("V2E_AMD_S3_ORDER") ? atoi(getenv("V2E_AMD_S3_ORDER")) : 1; // dev: 0 = pixel tiles fastest (2-D grid)
+    const int ntiles = a.n * a.tiles_x * a.tiles_y, ncb = a.cout / (CT * 32);
+    // measured at 40 samples: +6 % where a pixel tile has >= 4 channel blocks (256->128 at 64x80, 512->256 at 32x40), within
+    // noise at 2 blocks, -3 % on the five-wave 20-wide tiles (16 blocks: more workgroups than an XCD holds at once)
+    a.ncb = ((order == 1 && KS == 3 && WP == 4 && ncb >= 4) || (order == 2 && ncb > 1)) ? ncb : 0;
+    dim3 grid = a.ncb ? dim3((unsigned)((ntiles + 7) / 8 * 8 * ncb)) : dim3((unsigned)ntiles, (unsigned)ncb);
     k_conv_s3<KS, CT, PT, WP, TW, NB><<<grid, WP * 64, lds, s>>>(a);
     return 0;
 }

@@ -326,6 +326,7 @@ class EventEmulator(object):
             logger.warning("dvs_params {} not known: Using commandline assigned options".format(model))
 
     def reset(self):  # emulator.py:558-578
+        self._failed = None
         self.num_events_total = 0
         self.num_events_on = 0
         self.num_events_off = 0
@@ -427,6 +428,8 @@ class EventEmulator(object):
         return self._generate_events(new_frame, t_frame)
 
     def _generate_events(self, new_frame, t_frame):
+        if getattr(self, "_failed", None):
+            raise _capi.V2EAmdError("a previous device-resident run failed (%s); call reset()" % self._failed)
         if self.frame_h5_dataset is not None:
             fr = new_frame.detach().cpu().numpy() if torch.is_tensor(new_frame) else np.asarray(new_frame)
             self.frame_h5_dataset[self.frame_counter] = fr.astype(np.uint8)
@@ -596,6 +599,8 @@ class EventEmulator(object):
         result stays valid until the second-next call.  Pixel state, frame counter and t_previous advance at enqueue
         time; the event counters (num_events_*) when result() is called; errors (capacity, max_iters) are raised there.
         """
+        if getattr(self, "_failed", None):
+            raise _capi.V2EAmdError("a previous device-resident run failed (%s); call reset()" % self._failed)
         if self.rng_mode != "philox":
             raise ValueError("generate_events_batch needs rng_mode='philox' (tape mode needs the host per frame)")
         if isinstance(frames, np.ndarray):
@@ -650,7 +655,10 @@ class EventEmulator(object):
                 use_graph = int(use_graph) | 16  # the pipeline that carries the noise plane
         P = self._params()
         if cap is None:
-            cap = max(4 * H * W, 1 << 16) * min(nrun, 64)
+            # 4 events per pixel and frame (the reference never drops events; a clip that exceeds this raises below and
+            # leaves the instance unusable until reset()), bounded to 4 GiB of rows for very long runs
+            per_frame = max(4 * H * W, 1 << 16)
+            cap = per_frame * min(nrun, max(64, (4 << 30) // (16 * per_frame)))
         which = 0 if _single_buffer else self.__dict__.setdefault("_async_flip", 0)
         if not _single_buffer:
             self._async_flip = which ^ 1
@@ -673,15 +681,20 @@ class EventEmulator(object):
         if self.refractory_period_s > 0:  # emulator.py:830 on the frames just run: how often was the rule active?
             m = np.maximum(r["max_events"], 1)
             self._refr_mostly_on = bool(np.mean(self.refractory_period_s > pend.dts / m) > 0.05)
+        # the device state has already advanced past the failed run: the instance refuses further frames until reset()
+        err = None
         if (r["flags"] & _capi.FLAG_ITERS_CLAMPED).any():
-            raise _capi.V2EAmdError("a pixel produced more than max_iters=%d events in one frame; "
-                                    "construct with a larger max_iters" % eng.max_iters)
-        if (r["flags"] & _capi.FLAG_SYNC_TIMEOUT).any():
-            raise _capi.V2EAmdError("in-kernel workgroup rendezvous timed out (GPU oversubscribed?); "
-                                    "set V2E_AMD_NO_INKERNEL_SYNC=1 to use the two-launch pipeline")
-        if (r["flags"] & _capi.FLAG_EVENTS_DROPPED).any():
-            raise _capi.V2EAmdError("event buffer capacity %d exceeded (needed %d); pass a larger cap" % (
-                pend.ev.shape[1], int(r["n_events"].sum())))
+            err = ("a pixel produced more than max_iters=%d events in one frame; construct with a larger max_iters"
+                   % eng.max_iters)
+        elif (r["flags"] & _capi.FLAG_SYNC_TIMEOUT).any():
+            err = ("in-kernel workgroup rendezvous timed out (GPU oversubscribed?); "
+                   "set V2E_AMD_NO_INKERNEL_SYNC=1 to use the two-launch pipeline")
+        elif (r["flags"] & _capi.FLAG_EVENTS_DROPPED).any():
+            err = "event buffer capacity %d exceeded (needed %d); pass a larger cap" % (
+                pend.ev.shape[1], int(r["n_events"].sum()))
+        if err is not None:
+            self._failed = err
+            raise _capi.V2EAmdError(err + " -- the pixel state is past this run: call reset() before feeding more frames")
         pend.counts[pend.start:] = r["n_events"]
         total = int(r["n_events"].sum())
         self.num_events_total += total
