@@ -696,6 +696,7 @@ class EventEmulator(object):
             self._failed = err
             raise _capi.V2EAmdError(err + " -- the pixel state is past this run: call reset() before feeding more frames")
         pend.counts[pend.start:] = r["n_events"]
+        pend.rec_host = r
         total = int(r["n_events"].sum())
         self.num_events_total += total
         self.num_events_on += int(r["n_on"].sum())

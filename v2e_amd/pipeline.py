@@ -83,10 +83,17 @@ class VideoToEvents:
         U = self.U
         ts = [(k + 0.5) / U for k in range(U)]
         out = torch.empty(((N - 1) * U, H, W), dtype=torch.uint8, device=dev)
+        # the flow UNet sees up to 64 pairs at a time (its small levels fill the GPU only with many samples; a pair's
+        # flow does not depend on what else is in the batch), the interpolation UNet U x batch_size samples
+        fc = self.batch_size * max(1, 64 // self.batch_size)  # pairs per flow-UNet call: whole interpolation batches
+        flow, f0, f1 = None, 0, 0
         for b0 in range(0, N - 1, self.batch_size):
             b1 = min(b0 + self.batch_size, N - 1)
             B = b1 - b0
-            Ft = self.eng.interpolate(x[b0:b1], x[b0 + 1:b1 + 1], ts)  # [U,B,1,h,w]
+            if b0 >= f1:
+                f0, f1 = b0, min(b0 + fc, N - 1)
+                flow = self.eng.flow(x[f0:f1], x[f0 + 1:f1 + 1])
+            Ft = self.eng.interpolate(x[b0:b1], x[b0 + 1:b1 + 1], ts, flow=flow[b0 - f0:b1 - f0].contiguous())  # [U,B,1,h,w]
             q = torch.empty((B * U, h, w), dtype=torch.uint8, device=dev)
             check(self.lib.v2e_f32_to_u8_trunc(_ptr(Ft), _ptr(q), U, B, h * w, self.mean, 1, s()), "v2e_f32_to_u8_trunc")
             out[b0 * U:b1 * U] = self._rs_out(q)
