@@ -239,7 +239,8 @@ int v2e_pack_conv_weight(const float *w_oihw, float *w_packed, int cout, int cin
 /*
  * The same weights split exactly into three bf16 pieces (w = p0 + p1 + p2) for the bf16-matrix-core convolution that
  * keeps f32 accuracy (six piece products per multiply, f32 accumulation; v2e_amd/csrc/slomo_s3.h):
- * [Cin/16][k*k][3][2][Cout][8 bf16] = 6 bytes per weight.  cin must be a multiple of 16.
+ * [ceil(Cin/16)][k*k][3][2][Cout][8 bf16] = 6 bytes per weight of the padded tensor (a last partial 16-channel chunk
+ * is padded with zero weights): w_s3 must hold ceil(cin/16)*16 * k*k * cout * 6 bytes.
  */
 int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, int k, void *stream);
 

@@ -29,7 +29,7 @@ static int run_case(const Case &c, int reps)
     for (auto &v : hb) v = frand();
     float *dx, *dw, *dwp, *db, *dy;
     void *dw3;
-    CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&dwp, nw * 4)); CK(hipMalloc(&dw3, nw * 6));
+    CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&dwp, nw * 4)); CK(hipMalloc(&dw3, (size_t)c.cout * ((c.cin + 15) / 16 * 16) * kk * 6));
     CK(hipMalloc(&db, c.cout * 4)); CK(hipMalloc(&dy, ny * 4));
     CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw, hw_.data(), nw * 4, hipMemcpyHostToDevice));
@@ -102,7 +102,7 @@ int main(int argc, char **argv)
     const Case cases[] = {
         {3, 16, 32, 3, 40, 72},  {3, 32, 64, 2, 24, 32}, // ragged / masked tiles
         {3, 64, 32, N, 256, 320}, {3, 128, 64, N, 128, 160}, {3, 256, 128, N, 64, 80}, {3, 512, 256, N, 32, 40},
-        {3, 512, 512, N, 16, 20}, {5, 32, 64, N, 128, 160},  {5, 64, 64, N, 128, 160}, {7, 32, 32, N, 256, 320},
+        {3, 512, 512, N, 16, 20}, {5, 32, 64, N, 128, 160},  {5, 64, 64, N, 128, 160}, {7, 32, 32, N, 256, 320}, {7, 12, 32, N, 256, 320},
     };
     for (const Case &c : cases) bad += run_case(c, full ? 3 : 5);
     printf(bad ? "MISMATCH in %d cases\n" : "all cases within 1e-5 (%d)\n", bad);

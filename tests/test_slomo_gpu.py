@@ -39,7 +39,7 @@ def _conv_hip(x0, x1, pre, w, b, out_hw, split=False):
     tb = torch.from_numpy(b).to(dev)
     d = ConvDesc(wp.data_ptr(), tb.data_ptr(), ci, co, k)
     if split:
-        w3 = torch.empty(ci * k * k * co * 6, dtype=torch.uint8, device=dev)
+        w3 = torch.empty((ci + 15) // 16 * 16 * k * k * co * 6, dtype=torch.uint8, device=dev)
         check(lib.v2e_pack_conv_weight_s3(C.c_void_p(tw.data_ptr()), C.c_void_p(w3.data_ptr()), co, ci, k, s), "pack_s3")
         d.weight_s3 = w3.data_ptr()
     t0 = torch.from_numpy(x0).to(dev)
@@ -104,6 +104,9 @@ S3_CASES = [
     (5, 64, 0, 64, 1, 40, 96, 0),     # down1.conv2, ragged rows
     (7, 32, 0, 32, 2, 24, 64, 0),     # conv2
     (7, 32, 0, 32, 1, 256, 320, 0),   # conv2 at the benchmark resolution
+    (7, 12, 0, 32, 2, 24, 64, 0),     # interp UNet conv1: 12 channels, the 16-channel chunk padded with zeros
+    (7, 8, 0, 32, 1, 40, 96, 0),      # ... a whole empty channel group, ragged rows
+    (7, 24, 0, 64, 1, 32, 32, 0),     # ... second chunk partial, two channel blocks
     (3, 64, 0, 64, 3, 8, 10, 0),      # 8x10 level: no split-bf16 tile -> must fall back to the f32 kernel and still be right
 ]
 

@@ -296,27 +296,24 @@ __global__ __launch_bounds__(256) void k_avgpool2(const float *__restrict__ x, f
 }
 
 // F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) as its own pass:
-// [nc][h/2][w/2] -> [nc][h][w].  One thread = 4 consecutive outputs (one float4 store); the source
-// coordinates of outputs 4j..4j+3 are 2j-0.25, 2j+0.25, 2j+0.75, 2j+1.25, so the fractional weights
-// are the exact constants 0.75/0.25 that fetch<2> computes (0 at the clamped left/top edge), and
+// [nc][h/2][w/2] -> [nc][h][w].  One thread = 2 rows x 4 consecutive outputs (two float4 stores) from 2 source rows x 4
+// columns: output rows 2t-1 and 2t both lie between source rows t-1 and t (weights 0.75/0.25 and 0.25/0.75; at the
+// top edge the clamped coordinate gives weight 0 to the second row), and the source coordinates of outputs 4j..4j+3 are
+// 2j-0.25, 2j+0.25, 2j+0.75, 2j+1.25, so the fractional weights are the exact constants that fetch<2> computes, and
 // the products/sums are evaluated in the same order.
 __global__ __launch_bounds__(256) void k_upsample2(const float *__restrict__ x, float *__restrict__ y, long long nc, int h, int w)
 {
     const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
     const int wq = w >> 2;
-    const long long total = nc * h * wq;
+    const int sh = h >> 1, sw = w >> 1;
+    const long long total = nc * (sh + 1) * wq;
     if (q >= total) return;
     const int j = (int)(q % wq);
     const long long r = q / wq;
-    const int gy = (int)(r % h);
-    const long long c = r / h;
-    const int sh = h >> 1, sw = w >> 1;
-    float ry = ((float)gy + 0.5f) * 0.5f - 0.5f;
-    ry = ry < 0.f ? 0.f : ry;
-    const int y0 = (int)ry;
-    const int y1 = y0 + (y0 < sh - 1 ? 1 : 0);
-    const float ly = ry - (float)y0, hy = 1.f - ly;
-    const float *p0 = x + (c * sh + y0) * (long long)sw, *p1 = x + (c * sh + y1) * (long long)sw;
+    const int t = (int)(r % (sh + 1)); // output rows 2t-1 (t >= 1) and 2t (t < sh)
+    const long long c = r / (sh + 1);
+    const int ya = t - 1 < 0 ? 0 : t - 1, yb = t == 0 ? (sh > 1 ? 1 : 0) : (t < sh ? t : sh - 1); // t == 0: the reference's y1 (weight 0)
+    const float *p0 = x + (c * sh + ya) * (long long)sw, *p1 = x + (c * sh + yb) * (long long)sw;
     // source columns 2j-1 .. 2j+2, clamped
     const int cm = 2 * j - 1 < 0 ? 0 : 2 * j - 1, c0 = 2 * j, c1 = 2 * j + 1 < sw ? 2 * j + 1 : sw - 1,
               c2 = 2 * j + 2 < sw ? 2 * j + 2 : sw - 1;
@@ -325,12 +322,23 @@ __global__ __launch_bounds__(256) void k_upsample2(const float *__restrict__ x, 
     const float lx0 = j == 0 ? 0.f : 0.75f, hx0 = 1.f - lx0; // output 4j: x0 = 2j-1 (0 when clamped), x1 = x0+1
     // when j == 0 the reference has x0 = 0, x1 = min(1, sw-1); a_m == a_0 there and lx = 0
     const float t00 = j == 0 ? a_0 : a_m, t01 = j == 0 ? a_1 : a_0, u00 = j == 0 ? b_0 : b_m, u01 = j == 0 ? b_1 : b_0;
-    float4 o;
-    o.x = hy * (hx0 * t00 + lx0 * t01) + ly * (hx0 * u00 + lx0 * u01);
-    o.y = hy * (0.75f * a_0 + 0.25f * a_1) + ly * (0.75f * b_0 + 0.25f * b_1);
-    o.z = hy * (0.25f * a_0 + 0.75f * a_1) + ly * (0.25f * b_0 + 0.75f * b_1);
-    o.w = hy * (0.75f * a_1 + 0.25f * a_2) + ly * (0.75f * b_1 + 0.25f * b_2);
-    *(float4 *)(y + (c * h + gy) * (long long)w + 4 * j) = o;
+    // the four horizontal blends of each source row (same for both output rows)
+    const float ax = hx0 * t00 + lx0 * t01, ay = 0.75f * a_0 + 0.25f * a_1, az = 0.25f * a_0 + 0.75f * a_1, aw = 0.75f * a_1 + 0.25f * a_2;
+    const float bx = hx0 * u00 + lx0 * u01, by = 0.75f * b_0 + 0.25f * b_1, bz = 0.25f * b_0 + 0.75f * b_1, bw = 0.75f * b_1 + 0.25f * b_2;
+    if (t >= 1) { // row 2t-1: ry = t - 0.75 -> y0 = t-1, ly = 0.25
+        const float ly = ((float)(2 * t - 1) + 0.5f) * 0.5f - 0.5f - (float)(t - 1), hy = 1.f - ly;
+        float4 o;
+        o.x = hy * ax + ly * bx; o.y = hy * ay + ly * by; o.z = hy * az + ly * bz; o.w = hy * aw + ly * bw;
+        *(float4 *)(y + (c * h + 2 * t - 1) * (long long)w + 4 * j) = o;
+    }
+    if (t < sh) { // row 2t: ry = t - 0.25 (clamped to 0 at the top) -> y0 = max(t-1, 0), ly = 0.75 (0 at the top)
+        float ry = ((float)(2 * t) + 0.5f) * 0.5f - 0.5f;
+        ry = ry < 0.f ? 0.f : ry;
+        const float ly = ry - (float)ya, hy = 1.f - ly;
+        float4 o;
+        o.x = hy * ax + ly * bx; o.y = hy * ay + ly * by; o.z = hy * az + ly * bz; o.w = hy * aw + ly * bw;
+        *(float4 *)(y + (c * h + 2 * t) * (long long)w + 4 * j) = o;
+    }
 }
 
 // same, one output per thread, for widths that are not a multiple of 4
@@ -611,7 +619,7 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
         return 1;
     }
     if (ks == 5 && a.w_ % 32 == 0) return c64 ? launch_conv_s3<5, 2, 2, 4, 32>(a, s) : launch_conv_s3<5, 1, 2, 4, 32>(a, s);
-    if (ks == 7 && a.w_ % 32 == 0) return launch_conv_s3<7, 1, 2, 4, 32>(a, s);
+    if (ks == 7 && a.w_ % 32 == 0) return a.cin % 16 == 0 ? launch_conv_s3<7, 1, 2, 4, 32>(a, s) : launch_conv_s3<7, 1, 2, 4, 32, 1, true>(a, s);
     return 1;
 }
 
@@ -622,8 +630,8 @@ extern "C" {
 int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, int k, void *stream)
 {
     V2E_REQUIRE(w_oihw && w_s3 && cout > 0 && cin > 0 && k > 0, "bad pack args");
-    V2E_REQUIRE(cin % 16 == 0, "split-bf16 weights: cin must be a multiple of 16");
-    const size_t total = (size_t)(cin / 8) * k * k * cout;
+    const size_t total = (size_t)((cin + 15) / 16) * 2 * k * k * cout; // [ceil(cin/16)][k*k][3][2][cout] 16-byte units / 3
+
     k_pack_weight_s3<<<v2e_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, (uint4 *)w_s3, cout, cin, k * k);
     V2E_HIP(hipGetLastError());
     return 0;
@@ -668,7 +676,10 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
         return 0;
     }
     static const bool s3_off = getenv("V2E_AMD_CONV_F32") != nullptr; // dev: force the f32-MFMA kernel
-    if (a.ws3 && !s3_off && pre == 0 && conv->cin % 16 == 0 && conv->cout % 32 == 0 && (c1 == 0 || c0 % 16 == 0)) {
+    // split-bf16 kernel: whole 16-channel chunks -- or the 12-channel 7x7 conv1, whose last chunk is padded with zeros
+    // (a third of its multiplies wasted and still 1.4x the f32 kernel; the 2-channel conv1 of the flow UNet is not worth it)
+    const bool s3_cin = conv->cin % 16 == 0 || (conv->ksize == 7 && c1 == 0 && conv->cin >= 8);
+    if (a.ws3 && !s3_off && pre == 0 && s3_cin && conv->cout % 32 == 0 && (c1 == 0 || c0 % 16 == 0)) {
         const int r3 = conv_dispatch_s3(a, conv->ksize, (hipStream_t)stream);
         if (r3 == 0) { V2E_HIP(hipGetLastError()); return 0; }
         if (r3 != 1) return r3;
@@ -715,7 +726,7 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     } while (0)
 #define UPS(X, C, HH, WW)                                                                        \
     do {                                                                                         \
-        if ((WW) % 4 == 0) k_upsample2<<<v2e_cdiv((int64_t)n * (C) * (HH) * ((WW) / 4), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW)); \
+        if ((WW) % 4 == 0) k_upsample2<<<v2e_cdiv((int64_t)n * (C) * ((HH) / 2 + 1) * ((WW) / 4), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW)); \
         else k_upsample2_scalar<<<v2e_cdiv((int64_t)n * (C) * (HH) * (WW), 256), 256, 0, st>>>((X), tU, (long long)n * (C), (HH), (WW)); \
     } while (0)
     // conv1, conv2

@@ -41,17 +41,23 @@ __device__ __forceinline__ void split3_pair(float a, float b, uint32_t &q0, uint
 __global__ void k_pack_weight_s3(const float *__restrict__ w, uint4 *__restrict__ ws, int cout, int cin, int kk)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)(cin / 8) * kk * cout;
+    const int nchunk = (cin + 15) / 16; // a last partial chunk is padded with zero weights
+    const size_t total = (size_t)nchunk * 2 * kk * cout;
     if (i >= total) return;
     const int co = (int)(i % cout);
     size_t r = i / cout;
     const int cig = (int)(r % 2); r /= 2;
     const int tap = (int)(r % kk);
     const int chunk = (int)(r / kk);
-    const float *src = w + ((size_t)co * cin + chunk * 16 + cig * 8) * kk + tap;
+    const int c0 = chunk * 16 + cig * 8;
+    const float *src = w + ((size_t)co * cin + c0) * kk + tap;
     uint32_t q[3][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) split3_pair(src[(size_t)(2 * e) * kk], src[(size_t)(2 * e + 1) * kk], q[0][e], q[1][e], q[2][e]);
+    for (int e = 0; e < 4; ++e) {
+        const float w0 = c0 + 2 * e < cin ? src[(size_t)(2 * e) * kk] : 0.f;
+        const float w1 = c0 + 2 * e + 1 < cin ? src[(size_t)(2 * e + 1) * kk] : 0.f;
+        split3_pair(w0, w1, q[0][e], q[1][e], q[2][e]);
+    }
     const size_t base = ((size_t)chunk * kk + tap) * 6;
 #pragma unroll
     for (int p = 0; p < 3; ++p) ws[(base + p * 2 + cig) * cout + co] = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
@@ -60,7 +66,8 @@ __global__ void k_pack_weight_s3(const float *__restrict__ w, uint4 *__restrict_
 // registers: two 4-wave workgroups per CU (60 KB of LDS each) means two waves per SIMD, i.e. up to 256 VGPRs; left alone the
 // compiler aims for more waves than the LDS allows and spills the prefetch registers to scratch.  Five-wave 20-wide tiles
 // (49 KB) fit three workgroups per CU.
-template <int KS, int CT, int PT, int WP, int TW, int NB>
+// PADC: cin is not a multiple of 16 (the 12-channel conv1): channels beyond cin are staged as zeros (their weights are zero too)
+template <int KS, int CT, int PT, int WP, int TW, int NB, bool PADC = false>
 __global__ __launch_bounds__(WP * 64)
 __attribute__((amdgpu_waves_per_eu(CT * PT * WP <= 5 ? 3 : (CT * PT * WP <= 8 ? 2 : 1), CT * PT * WP <= 5 ? 4 : (CT * PT * WP <= 10 ? 2 : 1))))
 void k_conv_s3(ConvArgs a)
@@ -115,10 +122,12 @@ void k_conv_s3(ConvArgs a)
     const int aofs = hsel * COT + l31;
 
     int pinfo[NPI]; // first channel of the item: offset inside one sample's chunk, or -1 (zero padding / unused)
+    int pcig[NPI];  // PADC: the item's channel group (0 / 1)
 #pragma unroll
     for (int j = 0; j < NPI; ++j) {
         const int i = tid + j * NT;
         int v = -1;
+        pcig[j] = i < PP ? 0 : 1;
         if (i < 2 * PP) {
             const int cig = i / PP, r = i - cig * PP;
             const int py = r / PW, px = r - py * PW;
@@ -161,8 +170,15 @@ void k_conv_s3(ConvArgs a)
         for (int j = 0; j < NPI; ++j) {
             const int pi = pinfo[j];
             const float *q = base + (pi < 0 ? 0 : pi);
+            if (PADC) { // channels beyond cin: read the last valid one (zeroed when staged)
+                const int nv = a.cin - cb - pcig[j] * 8; // valid channels of this item (may be <= 0: all padding)
+                if (nv <= 0) q = base;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pv[set][j][e] = q[(size_t)e * hw];
+                for (int e = 0; e < 8; ++e) pv[set][j][e] = q[(size_t)(nv <= 0 ? 0 : (e < nv ? e : nv - 1)) * hw];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[set][j][e] = q[(size_t)e * hw];
+            }
         }
     };
     auto prefetch_w = [&](int set, int cb, int g) {
@@ -170,16 +186,18 @@ void k_conv_s3(ConvArgs a)
 #pragma unroll
         for (int j = 0; j < NWU; ++j) wv[set][j] = wb[woff[j]];
     };
-    auto stage_patch = [&](int set) { // split and store this thread's patch items
+    auto stage_patch = [&](int set, int cbs = 0) { // split and store this thread's patch items (cbs: the chunk, PADC only)
 #pragma unroll
         for (int j = 0; j < NPI; ++j) {
             const int i = tid + j * NT;
             if (i < 2 * PP) {
                 const bool ok = pinfo[j] >= 0;
+                const int nv = PADC ? a.cin - cbs - pcig[j] * 8 : 8;
                 uint32_t q[3][4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    split3_pair(ok ? pv[set][j][2 * e] : 0.f, ok ? pv[set][j][2 * e + 1] : 0.f, q[0][e], q[1][e], q[2][e]);
+                    split3_pair(ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f,
+                                q[0][e], q[1][e], q[2][e]);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) sp[p * 2 * PP + i] = u32x4{q[p][0], q[p][1], q[p][2], q[p][3]};
             }
@@ -271,7 +289,7 @@ void k_conv_s3(ConvArgs a)
         for (int cb = 0; cb < a.cin; cb += 16) {
             for (int g = 0; g < NG; ++g) {
                 __syncthreads(); // everyone is done reading what is about to be overwritten
-                if (g == 0) stage_patch(0);
+                if (g == 0) stage_patch(0, cb);
                 stage_w(0);
                 __syncthreads();
                 if (g + 1 < NG) prefetch_w(0, cb, g + 1);
@@ -301,7 +319,7 @@ void k_conv_s3(ConvArgs a)
     }
 }
 
-template <int KS, int CT, int PT, int WP, int TW, int NB = 1>
+template <int KS, int CT, int PT, int WP, int TW, int NB = 1, bool PADC = false>
 static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
 {
     ConvArgs a = a0;
@@ -312,7 +330,7 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false; // one per instantiation
     if (!attr_set) {
-        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB, PADC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     a.tiles_x = (a.w_ + TW - 1) / TW;
@@ -323,6 +341,6 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     // noise at 2 blocks, -3 % on the five-wave 20-wide tiles (16 blocks: more workgroups than an XCD holds at once)
     a.ncb = ((order == 1 && KS == 3 && WP == 4 && ncb >= 4) || (order == 2 && ncb > 1)) ? ncb : 0;
     dim3 grid = a.ncb ? dim3((unsigned)((ntiles + 7) / 8 * 8 * ncb)) : dim3((unsigned)ntiles, (unsigned)ncb);
-    k_conv_s3<KS, CT, PT, WP, TW, NB><<<grid, WP * 64, lds, s>>>(a);
+    k_conv_s3<KS, CT, PT, WP, TW, NB, PADC><<<grid, WP * 64, lds, s>>>(a);
     return 0;
 }

@@ -62,8 +62,8 @@ class HipUNet:
             descs[i].weight = wp.data_ptr()
             descs[i].bias = b.data_ptr()
             descs[i].weight_s3 = None
-            if conv_math == "bf16x3" and ci % 16 == 0 and co % 32 == 0:
-                w3 = torch.empty(ci * kh * kw * co * 6, dtype=torch.uint8, device=self.device)
+            if conv_math == "bf16x3" and co % 32 == 0 and (ci % 16 == 0 or (kh == 7 and ci >= 8)):
+                w3 = torch.empty((ci + 15) // 16 * 16 * kh * kw * co * 6, dtype=torch.uint8, device=self.device)
                 check(self.lib.v2e_pack_conv_weight_s3(_ptr(w), _ptr(w3), co, ci, kh, stream), "v2e_pack_conv_weight_s3")
                 self._keep.append(w3)
                 descs[i].weight_s3 = w3.data_ptr()
