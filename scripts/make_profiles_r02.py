@@ -122,10 +122,10 @@ def slomo():
 #   12.1 GB read + 10.3 GB written + 0.12 GB of split weights.  Writes match; what is fetched beyond 12.1 GB is the input
 #   patch of a pixel tile re-read once per 32-channel block of the output (cout/32 times, plus the halo) where those
 #   blocks do not meet in one L2, and the weight slices re-read per pixel tile -- the channel blocks of a tile are
-#   consecutive on one XCD for the layers with >= 4 blocks (slomo_s3.h).  At 28 ms per forward the fetch rate is
-#   ~1.5 TB/s: the convolutions are not HBM-bound (bound: the matrix pipe, DESIGN.md section 4).
+#   consecutive on one XCD for the layers with >= 4 blocks (slomo_s3.h).  At 26 ms per forward the fetch rate is
+#   ~1 TB/s: the convolutions are not HBM-bound (bound: the matrix pipe, DESIGN.md section 4).
 # matrix-core utilisation: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) per kernel from the table below, e.g.
-#   k_conv_s3<3,1,2,4,32> 1415.6M / (4 x 688.7M) = 0.51, k_conv_s3<7,...> 0.62, k_conv<7,4,...> (f32) 0.81.
+#   k_conv_s3<3,1,2,4,32> 0.51, k_conv_s3<7,...> 0.62, and with V2E_AMD_CONV_MATH=f32 k_conv<7,4,...> 0.81 (first pass of the round).
 #
 # ---- matrix-core counters (default conv math)
 """ % (fb, wb, fb / 1e9, wb / 1e9, fb32 / 1e9, wb32 / 1e9) + mf + "\n# ---- HBM traffic, default conv math\n" + ft + wt +
