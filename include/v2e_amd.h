@@ -244,11 +244,15 @@ int v2e_pack_conv_weight(const float *w_oihw, float *w_packed, int cout, int cin
  */
 int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, int k, void *stream);
 
+/* activations in the same split form: x [n][c][h][w] f32 -> xs [3 pieces][n][c/8][h][w][8 bf16] (6 bytes per element;
+ * c a multiple of 8).  A convolution takes such an input with pre = 3 (3x3 layers with split weights). */
+int v2e_split3_nchw(const float *x, void *xs, int n, int c, int h, int w, void *stream);
+
 /*
  * y = leaky_relu(conv2d(cat(x0, x1), W) + b, 0.1), stride 1, zero pad (k-1)/2, NCHW f32.
  * x1 may be NULL (c1 = 0).  pre: 0 none, 1 avg_pool2d(x0,2) fused on load (x0 is
  * [N][c0][2H][2W]), 2 bilinear x2 upsample (align_corners=False) fused on load
- * (x0 is [N][c0][H/2][W/2]).
+ * (x0 is [N][c0][H/2][W/2]), 3 x0 is a pre-split tensor (v2e_split3_nchw; 3x3 layers with split weights only).
  */
 int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre,
                      const v2e_conv_desc *conv, float *y, int n, int h, int w, void *stream);

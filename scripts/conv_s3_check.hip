@@ -41,9 +41,29 @@ static int run_case(const Case &c, int reps)
     d.weight = dwp; d.bias = db; d.cin = c.cin; d.cout = c.cout; d.ksize = c.ks; d.pad_ = 0;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    float ms[2] = {0, 0};
-    for (int mode = 0; mode < 2; ++mode) {
+    float ms[3] = {0, 0, 0};
+    std::vector<float> y3p;
+    void *dxs = nullptr;
+    const bool presplit = getenv("S3_PRESPLIT") && c.ks == 3 && c.cin % 16 == 0 && c.w % 8 == 0;
+    if (presplit) {
+        CK(hipMalloc(&dxs, nx * 6));
+        CV(v2e_split3_nchw(dx, dxs, c.n, c.cin, c.h, c.w, nullptr));
+        y3p.resize(ny);
+    }
+    for (int mode = 0; mode < (presplit ? 3 : 2); ++mode) {
         d.weight_s3 = mode ? dw3 : nullptr;
+        if (mode == 2) {
+            CK(hipMemset(dy, 0xFF, ny * 4));
+            for (int i = 0; i < 2; ++i) CV(v2e_conv2d_lrelu((const float *)dxs, c.cin, nullptr, 0, 3, &d, dy, c.n, c.h, c.w, nullptr));
+            CK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < reps; ++i) CV(v2e_conv2d_lrelu((const float *)dxs, c.cin, nullptr, 0, 3, &d, dy, c.n, c.h, c.w, nullptr));
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms[2], e0, e1));
+            ms[2] /= reps;
+            CK(hipMemcpy(y3p.data(), dy, ny * 4, hipMemcpyDeviceToHost));
+            continue;
+        }
         CK(hipMemset(dy, 0xFF, ny * 4));
         for (int i = 0; i < 2; ++i) CV(v2e_conv2d_lrelu(dx, c.cin, nullptr, 0, 0, &d, dy, c.n, c.h, c.w, nullptr));
         CK(hipEventRecord(e0, nullptr));
@@ -85,6 +105,12 @@ static int run_case(const Case &c, int reps)
     printf("k%d %4d->%4d n%-3d %3dx%-3d  f32 %8.1f us %6.1f TF | s3 %8.1f us %6.1f TF (x%.2f) | s3-f32 max %.2e scaled %.2e nan %zu | vs f64: f32 %.2e  s3 %.2e  (|y|max %.1f)\n",
            c.ks, c.cin, c.cout, c.n, c.h, c.w, ms[0] * 1e3, flop / ms[0] / 1e9, ms[1] * 1e3, flop / ms[1] / 1e9, ms[0] / ms[1], dmax, dscaled, nbad,
            e32, e3, ymax);
+    if (presplit) {
+        size_t diff = 0;
+        for (size_t i = 0; i < ny; ++i) diff += y3p[i] != y3[i];
+        printf("      pre-split input: %8.1f us %6.1f TF (x%.2f vs in-kernel split), %zu outputs differ\n", ms[2] * 1e3, flop / ms[2] / 1e9, ms[1] / ms[2], diff);
+        CK(hipFree(dxs));
+    }
     fflush(stdout);
     CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dwp)); CK(hipFree(dw3)); CK(hipFree(db)); CK(hipFree(dy));
     return (nbad == 0 && e3 < 1e-5 && dscaled < 5e-5) ? 0 : 1; // both kernels against the double-precision sums

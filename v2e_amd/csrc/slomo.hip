@@ -34,6 +34,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     const void *ws3; // split-bf16 weights (slomo_s3.h) or nullptr
     int ncb;         // slomo_s3.h: channel blocks when the grid is 1-D in XCD order, else 0
+    long long xs_plane; // slomo_s3.h, pre-split input: 16-byte units per piece plane (n * C/8 * h * w)
 };
 
 // element fetch with the producer op fused: PRE 0 plain, 1 avg_pool2d(2) of a [2H][2W] source,
@@ -599,6 +600,16 @@ static int conv_dispatch(const ConvArgs &a, int ks, int pre, hipStream_t s)
 }
 
 // split-bf16 path (slomo_s3.h): returns 1 when no tile fits (the caller falls back to the f32-MFMA kernel)
+// pre-split input (pre == 3): 3x3 layers only (dev: measured against in-kernel splitting by scripts/conv_s3_check)
+static int conv_dispatch_s3_presplit(const ConvArgs &a, int ks, hipStream_t s)
+{
+    if (ks != 3) return 1;
+    if (a.w_ % 32 == 0) return launch_conv_s3<3, 1, 2, 4, 32, 1, 2>(a, s);
+    if (a.w_ % 16 == 0) return launch_conv_s3<3, 1, 2, 4, 16, 1, 2>(a, s);
+    if (a.w_ % 8 == 0) return launch_conv_s3<3, 1, 2, 4, 8, 1, 2>(a, s);
+    return 1;
+}
+
 static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
 {
     // 32-channel tiles (60 KB of LDS: two workgroups per CU, so one stages while the other multiplies) measured faster
@@ -619,7 +630,7 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
         return 1;
     }
     if (ks == 5 && a.w_ % 32 == 0) return c64 ? launch_conv_s3<5, 2, 2, 4, 32>(a, s) : launch_conv_s3<5, 1, 2, 4, 32>(a, s);
-    if (ks == 7 && a.w_ % 32 == 0) return a.cin % 16 == 0 ? launch_conv_s3<7, 1, 2, 4, 32>(a, s) : launch_conv_s3<7, 1, 2, 4, 32, 1, true>(a, s);
+    if (ks == 7 && a.w_ % 32 == 0) return a.cin % 16 == 0 ? launch_conv_s3<7, 1, 2, 4, 32>(a, s) : launch_conv_s3<7, 1, 2, 4, 32, 1, 1>(a, s);
     return 1;
 }
 
@@ -633,6 +644,15 @@ int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, 
     const size_t total = (size_t)((cin + 15) / 16) * 2 * k * k * cout; // [ceil(cin/16)][k*k][3][2][cout] 16-byte units / 3
 
     k_pack_weight_s3<<<v2e_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, (uint4 *)w_s3, cout, cin, k * k);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_split3_nchw(const float *x, void *xs, int n, int c, int h, int w, void *stream)
+{
+    V2E_REQUIRE(x && xs && n > 0 && c > 0 && c % 8 == 0 && h > 0 && w > 0, "bad split args (channels must be a multiple of 8)");
+    const long long nc8 = (long long)n * (c / 8);
+    k_split3_nchw<<<v2e_cdiv(nc8 * h * w, 256), 256, 0, (hipStream_t)stream>>>(x, (uint4 *)xs, nc8, h * w);
     V2E_HIP(hipGetLastError());
     return 0;
 }
@@ -652,6 +672,17 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     V2E_REQUIRE(x0 && conv && conv->weight && conv->bias && y, "null conv arg");
     V2E_REQUIRE(c0 + c1 == conv->cin && (c1 == 0 || x1), "channel split does not match the layer");
     V2E_REQUIRE(pre == 0 || c1 == 0, "fused pool/upsample takes a single source");
+    if (pre == 3) { // x0 is a pre-split tensor (v2e_split3_nchw)
+        V2E_REQUIRE(conv->weight_s3 && conv->cin % 16 == 0 && conv->cout % 32 == 0, "pre-split input needs split weights, cin % 16 == 0, cout % 32 == 0");
+        ConvArgs a;
+        a.x0 = x0; a.x1 = nullptr; a.c0 = c0; a.c1 = 0; a.w = conv->weight; a.bias = conv->bias; a.y = y;
+        a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout; a.tiles_x = a.tiles_y = 0;
+        a.ws3 = conv->weight_s3; a.xs_plane = (long long)n * (c0 / 8) * h * w;
+        const int r3 = conv_dispatch_s3_presplit(a, conv->ksize, (hipStream_t)stream);
+        V2E_REQUIRE(r3 == 0, "no pre-split tile for this layer shape");
+        V2E_HIP(hipGetLastError());
+        return 0;
+    }
     V2E_REQUIRE(pre != 2 || (h % 2 == 0 && w % 2 == 0), "upsample target must be even");
     V2E_REQUIRE(conv->cin % 2 == 0, "cin must be even");
     V2E_REQUIRE(c1 == 0 || c0 % 8 == 0, "first concat source must be a multiple of 8 channels");

@@ -63,15 +63,33 @@ __global__ void k_pack_weight_s3(const float *__restrict__ w, uint4 *__restrict_
     for (int p = 0; p < 3; ++p) ws[(base + p * 2 + cig) * cout + co] = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
 }
 
+// activations: [n][C][h][w] f32 -> [piece][n][C/8][h][w][8 bf16] (C a multiple of 8); one thread per (n, c/8, pixel)
+__global__ __launch_bounds__(256) void k_split3_nchw(const float *__restrict__ x, uint4 *__restrict__ xs, long long nc8, int hw)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc8 * hw) return;
+    const long long g = i / hw;
+    const int p = (int)(i - g * hw);
+    const float *src = x + (g * 8) * hw + p;
+    uint32_t q[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3_pair(src[(size_t)(2 * e) * hw], src[(size_t)(2 * e + 1) * hw], q[0][e], q[1][e], q[2][e]);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) xs[(size_t)pc * nc8 * hw + i] = make_uint4(q[pc][0], q[pc][1], q[pc][2], q[pc][3]);
+}
+
 // registers: two 4-wave workgroups per CU (60 KB of LDS each) means two waves per SIMD, i.e. up to 256 VGPRs; left alone the
 // compiler aims for more waves than the LDS allows and spills the prefetch registers to scratch.  Five-wave 20-wide tiles
 // (49 KB) fit three workgroups per CU.
-// PADC: cin is not a multiple of 16 (the 12-channel conv1): channels beyond cin are staged as zeros (their weights are zero too)
-template <int KS, int CT, int PT, int WP, int TW, int NB, bool PADC = false>
+// MODE 1 (PADC): cin is not a multiple of 16 (the 12-channel conv1): channels beyond cin are staged as zeros (their weights
+// are zero too).  MODE 2 (PRES): the input arrives already split, [piece][n][C/8][h][w][8 bf16] (k_split3_nchw or a
+// producer that writes this layout): staging is three 16-byte loads and three 16-byte LDS stores per item, no conversion.
+template <int KS, int CT, int PT, int WP, int TW, int NB, int MODE = 0>
 __global__ __launch_bounds__(WP * 64)
 __attribute__((amdgpu_waves_per_eu(CT * PT * WP <= 5 ? 3 : (CT * PT * WP <= 8 ? 2 : 1), CT * PT * WP <= 5 ? 4 : (CT * PT * WP <= 10 ? 2 : 1))))
 void k_conv_s3(ConvArgs a)
 {
+    constexpr bool PADC = MODE == 1, PRES = MODE == 2;
     constexpr int NT = WP * 64;
     constexpr int PAD = KS / 2;
     constexpr int NPX = WP * PT * 32;
@@ -132,7 +150,7 @@ void k_conv_s3(ConvArgs a)
             const int cig = i / PP, r = i - cig * PP;
             const int py = r / PW, px = r - py * PW;
             const int gy = oy0 + py - PAD, gx = ox0 + px - PAD;
-            if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_) v = cig * 8 * hw + gy * a.w_ + gx;
+            if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w_) v = cig * (PRES ? 1 : 8) * hw + gy * a.w_ + gx; // PRES: 16-byte units
         }
         pinfo[j] = v;
     }
@@ -157,10 +175,21 @@ void k_conv_s3(ConvArgs a)
     // 3x3 layer is ~2.4 us of multiplies, so the 3x3 kernels (one weight group per chunk) keep TWO chunks in flight
     // in two register sets; 5x5 / 7x7 chunks are 3-5x longer and have no registers to spare.
     constexpr int DEEP = (NG == 1 && CT * PT == 2) ? 2 : 1;
-    float pv[DEEP][NPI][8];
+    float pv[PRES ? 1 : DEEP][PRES ? 1 : NPI][8];
+    u32x4 pvs[PRES ? DEEP : 1][PRES ? NPI : 1][3]; // PRES: the item's three pieces as they are in memory
     u32x4 wv[DEEP][NWU];
     // loads are unconditional (padding reads a valid address and is zeroed by a select): no branches between them
     auto prefetch_patch = [&](int set, int cb) {
+        if (PRES) {
+            const u32x4 *base = (const u32x4 *)a.x0 + ((size_t)n * (a.c0 >> 3) + (cb >> 3)) * hw;
+#pragma unroll
+            for (int j = 0; j < NPI; ++j) {
+                const int pi = pinfo[j] < 0 ? 0 : pinfo[j];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pvs[PRES ? set : 0][PRES ? j : 0][p] = base[(size_t)p * a.xs_plane + pi];
+            }
+            return;
+        }
         const float *src;
         int cs, C;
         if (cb < a.c0) { src = a.x0; cs = cb; C = a.c0; }
@@ -190,7 +219,13 @@ void k_conv_s3(ConvArgs a)
 #pragma unroll
         for (int j = 0; j < NPI; ++j) {
             const int i = tid + j * NT;
-            if (i < 2 * PP) {
+            if (PRES) {
+                if (i < 2 * PP) {
+                    const bool ok = pinfo[j] >= 0;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) sp[p * 2 * PP + i] = ok ? pvs[PRES ? set : 0][PRES ? j : 0][p] : u32x4{0u, 0u, 0u, 0u};
+                }
+            } else if (i < 2 * PP) {
                 const bool ok = pinfo[j] >= 0;
                 const int nv = PADC ? a.cin - cbs - pcig[j] * 8 : 8;
                 uint32_t q[3][4];
@@ -319,7 +354,7 @@ void k_conv_s3(ConvArgs a)
     }
 }
 
-template <int KS, int CT, int PT, int WP, int TW, int NB = 1, bool PADC = false>
+template <int KS, int CT, int PT, int WP, int TW, int NB = 1, int MODE = 0>
 static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
 {
     ConvArgs a = a0;
@@ -330,7 +365,7 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false; // one per instantiation
     if (!attr_set) {
-        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB, PADC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     a.tiles_x = (a.w_ + TW - 1) / TW;
@@ -341,6 +376,6 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     // noise at 2 blocks, -3 % on the five-wave 20-wide tiles (16 blocks: more workgroups than an XCD holds at once)
     a.ncb = ((order == 1 && KS == 3 && WP == 4 && ncb >= 4) || (order == 2 && ncb > 1)) ? ncb : 0;
     dim3 grid = a.ncb ? dim3((unsigned)((ntiles + 7) / 8 * 8 * ncb)) : dim3((unsigned)ntiles, (unsigned)ncb);
-    k_conv_s3<KS, CT, PT, WP, TW, NB, PADC><<<grid, WP * 64, lds, s>>>(a);
+    k_conv_s3<KS, CT, PT, WP, TW, NB, MODE><<<grid, WP * 64, lds, s>>>(a);
     return 0;
 }
