@@ -1,6 +1,7 @@
 """Side measurements reported by bench.py next to the headline number: the SuperSloMo
 path (interpolated frames/s, f32-MFMA roofline) and the emulator with many clips per launch
 (how far the same kernels go once the launch is large enough to leave the latency floor)."""
+import os
 import time
 
 import numpy as np
@@ -185,7 +186,7 @@ def batched_emulator_bench(device, n_clips=64, frames=60, H=260, W=346):
     def run(k):
         t_prev = np.array([[(k * frames + j) * dt] * n_clips for j in range(frames)])
         t_frame = t_prev + dt
-        eng.run(P, frames_run, t_prev, t_frame, 1 + k * frames, ev, recs, use_graph=1)
+        eng.run(P, frames_run, t_prev, t_frame, 1 + k * frames, ev, recs, use_graph=int(os.environ.get("V2E_AMD_BATCHED_UG", "1")))
 
     run(0)
     torch.cuda.synchronize(device)
