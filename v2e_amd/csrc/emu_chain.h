@@ -304,6 +304,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
         // ---- passes: [redo of the previous launch]* then this launch's own frames
         bool redone = false;
         int round = 0, last_exact = -1;
+        uint32_t pred_v = 0u; // lane k: the M frame k was run under in the pass whose row is being checked
         for (;;) {
             int fs, fn;
             uint32_t *gM_dst;
@@ -313,15 +314,20 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     gM_v = 0u;
                     if (lane < ca.pnf) gM_v = ca.gM_prev[((size_t)round * ca.n_clips + clip) * ca.K + lane];
                 }
-                const unsigned long long hit = __ballot(gM_v != 0u && lane > last_exact);
+                // The pass that wrote this row ran frame k > last_exact under the PREDICTION pred_v[k] (0 = rule off; the own
+                // pass predicts 0 everywhere).  Where row and prediction agree the frame was computed exactly; the first
+                // disagreement j has everything before it exact, hence M(j) = row[j] exact (0: the rule is off there after
+                // all).  The next pass takes j exactly and the row's values after j as its predictions -- a launch with
+                // several rule-on frames usually settles in ONE redo pass instead of one pass per such frame.
+                const unsigned long long hit = __ballot(gM_v != pred_v && lane > last_exact);
                 const int j = hit ? (int)__builtin_ctzll(hit) : -1;
-                const uint32_t Mj = hit ? lane_value(gM_v, j) : 0u;
                 if (j < 0) {
                     own = true;
                 } else {
                     __syncthreads();
-                    if (tid == 0) s_exact[j] = Mj;
+                    if (tid < CHAIN_K_MAX && tid > last_exact) s_exact[tid] = gM_v; // < j: verified, j: exact, > j: predictions
                     __syncthreads();
+                    pred_v = lane > j ? gM_v : 0u;
                     last_exact = j;
                     ++round;
                     redone = true;
