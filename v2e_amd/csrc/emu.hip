@@ -729,7 +729,7 @@ struct v2e_emu {
     double prof_emit_ms = 0.0;
     int prof_emit_batches = 0, prof_step_launches = 0;
     // K-frames-per-launch chain (emu_chain.h); allocated on first use by v2e_emu_run
-    int ch_K = 0, ch_D = 0, ch_nwp = 0, ch_launch_cap = 0, ch_resident_clips = 0, ch_max_blocks = 0;
+    int ch_K = 0, ch_D = 0, ch_nD = 3, ch_nwp = 0, ch_launch_cap = 0, ch_resident_clips = 0, ch_max_blocks = 0;
     uint32_t *ch_cnt = nullptr;     // [ch_D][n_clips][npx_pad]
     uint16_t *ch_wmax = nullptr;    // [ch_D][n_clips][ch_nwp]
     uint8_t *ch_wtot = nullptr;     // [ch_D][n_clips][nkeys_cap][ch_nwp]
@@ -1507,7 +1507,14 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
         h->ch_launch_cap = 0;
         h->ch_K = K;
         h->ch_E = E;
-        h->ch_D = 3 * E; // batch b is read by its emission while the chain is in batch b + 1 and k_ahead fills batch b + 2
+        // Ring of frame slots, nD batches deep.  Three is the minimum (batch b is read by its emission while the chain is in
+        // batch b + 1 and k_ahead fills batch b + 2); the chain then waits for k_cemit(b - 3) at batch boundaries.  Deeper
+        // rings (V2E_AMD_CHAIN_RING) let it run further ahead and measured SLOWER: 8.5 Gev/s with 3 batches, 7.3 with 5 or 7
+        // -- three batches of slots and records (174 MB at 346x260) stay in the 256 MB MALL, five do not.
+        int nD = 3;
+        if (const char *ev = getenv("V2E_AMD_CHAIN_RING")) { const int v = atoi(ev); if (v >= 3 && v <= 16) nD = v; }
+        h->ch_nD = nD;
+        h->ch_D = nD * E;
         h->ch_nwp = (h->ngroups * (BLOCK / WAVE) + 15) / 16 * 16;
         h->ch_nkeys_cap = h->nkeys_cap;
         const size_t nc = (size_t)h->n_clips;
@@ -1584,13 +1591,13 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
 {
     // Four streams: `s` the chain (k_chain, K frames per launch); h->ahead k_ahead, h->tables k_cframe, h->side k_cemit, the
     // last three in batches of E = m K frames (batch b = frames [b E, (b + 1) E) = chain launches [b m, (b + 1) m)).
-    //   k_ahead(b)  before chain launch b m; overwrites the records of batch b - 3, last read by launch (b - 2) m (its redo)
+    //   k_ahead(b)  before chain launch b m; overwrites the records of batch b - nD, last read by launch (b - nD + 1) m (its redo)
     //   k_cframe(b) once batch b is final: after the launch that validated its last K frames (or, without a refractory
     //               period, after its last launch); k_cemit(b) after k_cframe(b)
-    //   chain launch b m overwrites the ring slots of batch b - 3: after k_cemit(b - 3)
+    //   chain launch b m overwrites the ring slots of batch b - nD: after k_cemit(b - nD)   (nD = ch_D / E batches in the ring)
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
     const bool has_refr = p->refractory_period_s > 0;
-    const int K = h->ch_K, E = h->ch_E, m = E / K, D = h->ch_D, NC = h->n_clips;
+    const int K = h->ch_K, E = h->ch_E, m = E / K, D = h->ch_D, NC = h->n_clips, nD = h->ch_nD;
     const int nB = (n_frames + K - 1) / K;           // chain launches with frames
     const int nL = has_refr ? nB + 1 : nB;           // + the tail launch that validates the last K frames
     const int nEB = (n_frames + E - 1) / E;          // batches of the parallel kernels
@@ -1660,7 +1667,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         aa.ctl = h->run_ctl; aa.fidx_base = h->run_fidx;
         aa.f0 = b * E; aa.nf = std::min((b + 1) * E, n_frames) - b * E; aa.D = D; aa.n_clips = NC;
         aa.rec = h->ch_rec;
-        if (b >= 3) V2E_HIP(hipStreamWaitEvent(h->ahead, h->ev_chain[(b - 2) * m], 0));
+        if (b >= nD) V2E_HIP(hipStreamWaitEvent(h->ahead, h->ev_chain[(b - nD + 1) * m], 0)); // records of batch b - nD: last read by that launch's redo
         // frame pairs touched by the batch: at most nf / 2 + 1 (the device knows the run's first frame index, the host's
         // capture does not: one extra pair covers either alignment; threads of a pair outside the batch return)
         dim3 ga(h->ngroups, NC, aa.nf / 2 + 1);
@@ -1704,7 +1711,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
         if (!tail && L % m == 0) {
             const int b = L / m;
-            if (b >= 3) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[b - 3], 0)); // ring slots of batch b: read by k_cemit(b - 3)
+            if (b >= nD) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[b - nD], 0)); // ring slots of batch b: read by k_cemit(b - nD)
             if (!fused_rec) V2E_HIP(hipStreamWaitEvent(s, h->ev_ahead[b], 0));
         }
         if (L == 0 && mark(ev_main, s)) return V2E_EHIP;
