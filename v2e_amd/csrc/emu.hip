@@ -734,6 +734,7 @@ struct v2e_emu {
     uint16_t *ch_wmax = nullptr;    // [ch_D][n_clips][ch_nwp]
     uint8_t *ch_wtot = nullptr;     // [ch_D][n_clips][nkeys_cap][ch_nwp]
     float *ch_tsold = nullptr;      // [ch_D][n_clips][npx_pad] (refractory runs)
+    void *ch_ck = nullptr;          // refractory runs: 2 launch parities x 3 checkpoints x (base 8 B, lp 8 B, ts 4 B) planes
     uint4 *ch_rec = nullptr;        // [ch_D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
     hipStream_t ahead = nullptr, tables = nullptr; // k_ahead / k_cframe run beside the chain and the event writer
     std::vector<hipEvent_t> ev_ahead, ev_chain, ev_tables;
@@ -935,7 +936,7 @@ int v2e_emu_destroy(v2e_emu *h)
     for (hipEvent_t e : h->ev_fork) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_join) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
-    hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_gM); hipFree(h->ch_bar);
+    hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck); hipFree(h->ch_gM); hipFree(h->ch_bar);
     hipFree(h->ch_rec);
     for (hipEvent_t e : h->ev_ahead) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_chain) hipEventDestroy(e);
@@ -1498,11 +1499,11 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
     m = std::max(1, std::min(m, 64 / K)); // k_cemit sums a batch's per-frame event counts one frame per lane
     const int E = m * K;
     if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap) {
-        hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_cf); hipFree(h->ch_cT);
+        hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck); hipFree(h->ch_cf); hipFree(h->ch_cT);
         hipFree(h->ch_ckbase); hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_gM); hipFree(h->ch_bar);
         hipFree(h->ch_rec);
         h->ch_rec = nullptr;
-        h->ch_cnt = nullptr; h->ch_wmax = nullptr; h->ch_wtot = nullptr; h->ch_tsold = nullptr; h->ch_cf = nullptr; h->ch_cT = nullptr;
+        h->ch_cnt = nullptr; h->ch_wmax = nullptr; h->ch_wtot = nullptr; h->ch_tsold = nullptr; h->ch_ck = nullptr; h->ch_cf = nullptr; h->ch_cT = nullptr;
         h->ch_ckbase = nullptr; h->ch_cperm = nullptr; h->ch_cpre = nullptr; h->ch_gM = nullptr; h->ch_bar = nullptr;
         h->ch_launch_cap = 0;
         h->ch_K = K;
@@ -1551,6 +1552,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
         grow(h->ev_join, n_launch + 1) || grow(h->ev_tables, n_launch + 1)) return V2E_EHIP;
     if (has_refr) {
         if (!h->ch_tsold) V2E_HIP(hipMalloc(&h->ch_tsold, sizeof(float) * (size_t)h->ch_D * h->n_clips * h->npx_pad));
+        if (!h->ch_ck) V2E_HIP(hipMalloc(&h->ch_ck, (size_t)2 * 3 * 20 * h->n_clips * h->npx_pad)); // see ChainArgs::ckc_base
         if (!h->ch_base2) {
             const size_t n = (size_t)h->n_clips * h->npx_pad;
             V2E_HIP(hipMalloc(&h->ch_base2, sizeof(double) * n));
@@ -1706,6 +1708,19 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.base_fix = xb[in]; ca.lp_fix = xl[in]; ca.ts_fix = xt[in];
         ca.base_out = xb[out]; ca.lp_out = xl[out]; ca.ts_out = xt[out];
         ca.base_pin = xb[pin]; ca.lp_pin = xl[pin]; ca.ts_pin = xt[pin];
+        static const bool no_ckpt = getenv("V2E_AMD_CHAIN_NO_CKPT") != nullptr; // dev: every redo restarts at the launch's first frame
+        if (has_refr && K > CHAIN_SUB && h->ch_ck && !no_ckpt) {
+            const size_t plane = (size_t)3 * NC * h->npx_pad; // elements per (parity, quantity)
+            auto ck = [&](int par, char *&bp, char *&lpp, float *&tp) {
+                char *q = (char *)h->ch_ck + (size_t)par * plane * 20;
+                bp = q; lpp = q + plane * 8; tp = (float *)(q + plane * 16);
+            };
+            char *b0, *l0, *b1, *l1; float *t0, *t1;
+            ck(L % 2, b0, l0, t0);
+            ck((L + 1) % 2, b1, l1, t1);
+            ca.ckc_base = b0; ca.ckc_lp = l0; ca.ckc_ts = t0;
+            ca.ckp_base = b1; ca.ckp_lp = l1; ca.ckp_ts = t1;
+        }
         ca.recs = recs;
         ca.store_out = tail && in != 0;
         ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
@@ -1914,7 +1929,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
     int lg = legacy ? 1 : (fused ? 2 : (chain ? 3 : 0)); push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
-    push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_E, sizeof(h->ch_E)); push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold));
+    push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_E, sizeof(h->ch_E)); push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold)); push(&h->ch_ck, sizeof(h->ch_ck));
     push(&h->pipe_tsold, sizeof(h->pipe_tsold)); push(&h->pipe_bck, sizeof(h->pipe_bck)); push(&K, sizeof(K));
     int nis = getenv("V2E_AMD_NO_INKERNEL_SYNC") ? 1 : 0; push(&nis, sizeof(nis));
     hipGraphExec_t exec = nullptr;

@@ -58,6 +58,12 @@ struct ChainArgs {
     const float *ts_pin;
     void *base_fix, *lp_fix;          // == *_in, written after a redo so that the next launch can redo this one
     float *ts_fix;
+    // refractory runs, K > CHAIN_SUB: the state before frames 8, 16, 24 of a pass ([3][n_clips][npx_pad] each), so that a
+    // redo restarts at the checkpoint below the first frame to fix instead of at the launch's first frame
+    void *ckc_base, *ckc_lp;          // written by this launch's own pass
+    float *ckc_ts;
+    void *ckp_base, *ckp_lp;          // the previous launch's: read to restart its redo, rewritten by the redo passes
+    float *ckp_ts;
     v2e_frame_rec *recs;              // [n_frames][n_clips]
     int store_out;                    // tail launch: state must be copied to *_out even without a redo
     unsigned long long *dbg;          // dev tool: [ngroups][16] wall-clock stamps of one launch, or nullptr
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
         bool redone = false;
         int round = 0, last_exact = -1;
         uint32_t pred_v = 0u; // lane k: the M frame k was run under in the pass whose row is being checked
+        int c0 = 0;           // first frame of the pass (a redo pass may restart at a checkpoint)
         for (;;) {
             int fs, fn;
             uint32_t *gM_dst;
@@ -331,20 +338,34 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     last_exact = j;
                     ++round;
                     redone = true;
-                    if (valid) { // the previous launch's input state
-                        b = ((const R *)ca.base_pin)[sp];
-                        if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.lp_pin)[sp];
-                        tsm = ca.ts_pin[sp];
+                    // restart point: every frame before j is exact, so is the checkpoint at or below j (written by the
+                    // own pass, or by the redo pass before this one, in which the frames up to j were exact already)
+                    c0 = ca.ckp_base ? (j / CHAIN_SUB) * CHAIN_SUB : 0;
+                    if (valid) {
+                        if (c0 == 0) { // the previous launch's input state
+                            b = ((const R *)ca.base_pin)[sp];
+                            if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.lp_pin)[sp];
+                            tsm = ca.ts_pin[sp];
+                        } else {
+                            const size_t cs = ((size_t)(c0 / CHAIN_SUB - 1) * ca.n_clips + clip) * a.npx_pad + p;
+                            b = ((const R *)ca.ckp_base)[cs];
+                            if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.ckp_lp)[cs];
+                            tsm = ca.ckp_ts[cs];
+                        }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(b), "+v"(lp), "+v"(tsm) : : "memory");
                 }
             }
-            if (own) { fs = ca.f0; fn = ca.nf; gM_dst = ca.gM_cur + (size_t)clip * ca.K; }
+            if (own) { fs = ca.f0; fn = ca.nf; gM_dst = ca.gM_cur + (size_t)clip * ca.K; c0 = 0; }
             else { fs = ca.pf0; fn = ca.pnf; gM_dst = ca.gM_prev + ((size_t)round * ca.n_clips + clip) * ca.K; }
             if (redone) { // a redo pass, or the own pass after one: its inputs replace what the prologue staged
                 fill_scalars(fs, fn);
-                stage(fs, fn);
+                stage(fs + c0, fn - c0);
             }
+            // checkpoints of this pass go to the set of the launch whose frames it runs
+            void *const ck_base = own ? ca.ckc_base : ca.ckp_base;
+            void *const ck_lp = own ? ca.ckc_lp : ca.ckp_lp;
+            float *const ck_ts = own ? ca.ckc_ts : ca.ckp_ts;
             if (own) V2E_STAMP_C(2);
             float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f; // FUSED: the draws of the current frame pair
             bool have_pair = false;
@@ -472,7 +493,13 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 lp = lpn;
                 if (own && k < 12) V2E_STAMP_C(3 + k);
             };
-            for (int k0 = 0; k0 < fn; k0 += CHAIN_SUB) {
+            for (int k0 = c0; k0 < fn; k0 += CHAIN_SUB) {
+                if (ck_base && k0 > c0 && valid) { // state before frame k0
+                    const size_t cs = ((size_t)(k0 / CHAIN_SUB - 1) * ca.n_clips + clip) * a.npx_pad + p;
+                    ((R *)ck_base)[cs] = b;
+                    if (a.has_cutoff || a.do_shot) ((R *)ck_lp)[cs] = lp;
+                    ck_ts[cs] = tsm;
+                }
                 uint4 nx[CHAIN_SUB];
                 const int nnext = min(CHAIN_SUB, fn - k0 - CHAIN_SUB); // frames of the next sub-pass (<= 0: none)
 #pragma unroll
