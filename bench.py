@@ -88,6 +88,20 @@ def pmc_traffic_per_launch(kernel):
     return None
 
 
+def rocprof_kernel_us(kernel):
+    """Average duration (us) of the chain kernel in the committed rocprofv3 kernel trace of this same command
+    (profiles/r02_emulator_chain_kernel_trace.txt), or None: the HIP-event figure measured live is the launch-to-launch
+    PERIOD of the dependency chain (gaps and waits included); the profiler's is the kernel alone."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r02_emulator_chain_kernel_trace.txt")):
+            parts = line.split()
+            if len(parts) > 4 and parts[0].isdigit() and (kernel + "<") in line:
+                return float(parts[2])
+    except Exception:
+        pass
+    return None
+
+
 def recorded_reference():
     """The unmodified reference timed on the build container's CPU (scripts/cpu_reference_baseline.py): recorded,
     because /root/reference does not exist on the GPU box."""
@@ -315,6 +329,12 @@ def main():
             "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK, 5), "traffic": pmc_traffic_per_launch(kname.split("(")[0]),
             "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
+            "rocprof_recorded": (lambda us: None if us is None else {
+                "avg_kernel_us": us, "achieved_GBps": round(step_bytes / (us * 1e-6) / 1e9, 2),
+                "frac": round(step_bytes / (us * 1e-6) / HBM_PEAK, 5),
+                "note": "kernel duration alone from profiles/r02_emulator_chain_kernel_trace.txt; avg_launch_us below is the "
+                        "launch-to-launch period of the chain (gaps, ring waits and redo passes included) and is what "
+                        "`achieved` / `frac` use"})(rocprof_kernel_us(kname.split("(")[0])),
             "avg_launch_us": {kname: round(step_us, 3),
                               "event_batch(k_cframe+k_cemit)": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3)},
             "emission": {"frames_per_batch": fpb, "algorithmic_bytes_per_frame": int(emit_bytes)},
