@@ -14,6 +14,9 @@ TAPE_FIXTURES = ["tape_defaults_40x48", "tape_noisy_40x48", "tape_clean_40x48", 
 PHILOX_FIXTURES = ["philox_moving_dot_64x64", "philox_defaults_346x260", "philox_noisy_346x260",
                    "philox_refractory_346x260", "philox_noisy_1280x720", "philox_hdr_97x131",
                    "philox_pnoise_97x131"]
+# 1280x720 runs long enough for full 32-frame chain launches, a validating successor and a wrap of the ring of frame
+# slots (104 frames, noisy preset), and with a refractory period of 2 ms (26 frames): tests/golden/make_golden_hd_long.py
+PHILOX_HD_FIXTURES = ["philox_noisy_1280x720_long", "philox_refractory_1280x720"]
 PNOISE_VRMS = 0.03125  # the noise amplitude the photoreceptor-noise fixtures were generated with
 
 

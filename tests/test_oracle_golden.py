@@ -4,7 +4,7 @@ rows, final float64/float32 state planes."""
 import numpy as np
 import pytest
 
-from fixtures import (PHILOX_FIXTURES, TAPE_FIXTURES, TAPE_LIVE_FIXTURES, LiveTapeFixture, PhiloxFixture, TapeFixture,
+from fixtures import (PHILOX_FIXTURES, PHILOX_HD_FIXTURES, TAPE_FIXTURES, TAPE_LIVE_FIXTURES, LiveTapeFixture, PhiloxFixture, TapeFixture,
                       events_equal, sha)
 
 
@@ -26,7 +26,7 @@ def test_oracle_replays_reference_tape(name, oracle_lib):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
 
 
-@pytest.mark.parametrize("name", PHILOX_FIXTURES)
+@pytest.mark.parametrize("name", PHILOX_FIXTURES + PHILOX_HD_FIXTURES)
 def test_oracle_philox_matches_reference_with_philox_source(name, oracle_lib):
     fx = PhiloxFixture(name)
     emu = oracle_lib.OracleEmulator(seed=fx.seed, rng_mode="philox", **fx.kw)

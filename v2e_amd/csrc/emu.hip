@@ -1464,7 +1464,8 @@ static int chain_frames_per_launch(const v2e_emu *h, bool has_refr)
 }
 // records built inside the chain (large grids) or by k_ahead (small grids); V2E_AMD_CHAIN_FUSED=0/1 overrides (dev)
 static bool chain_fused_records(const v2e_emu *h) {
-    static const int fused_env = getenv("V2E_AMD_CHAIN_FUSED") ? atoi(getenv("V2E_AMD_CHAIN_FUSED")) : -1;
+    const char *fe = getenv("V2E_AMD_CHAIN_FUSED"); // read per call: tests switch it per emulator instance
+    const int fused_env = fe ? atoi(fe) : -1;
     return fused_env >= 0 ? fused_env != 0 : !chain_small_grid(h);
 }
 
