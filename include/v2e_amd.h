@@ -182,44 +182,45 @@ int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const
  * recs_dev[f][clip] (device, caller-owned).  No host synchronisation inside.
  * use_graph, low two bits: 0 plain launches, 1 capture the launch sequence into a hipGraph
  * (cached while every baked-in pointer/size is unchanged), 2 instrumented (see
- * v2e_emu_last_profile).  Default pipeline: the k_step dependency chain (one launch per frame:
- * base/ts_mem update of frame f-1 + counts of frame f) with the event list built behind it, several
- * frames per launch, on a second stream that joins `stream` before the call's work ends.
- * That is the choice while a frame is a few workgroups per CU (latency-bound); larger grids use one
- * k_main launch per frame with emission on the chain (each pixel touched once).  |32 forces the
- * latter, |64 the former, |16 selects the unfused count/rank/scan/emit pipeline (kept for A/B
- * measurements); all three give identical results.  On grids of at most two workgroups per CU the
- * chain takes two frames per launch (k_step2: the second frame's base update is speculative on the
- * refractory rule being off, validated -- and on the rare miss repaired in-kernel -- by the next
- * launch); |128 forces one frame per launch.
+ * v2e_emu_last_profile).  Pipeline: k_chain -- K frames per launch with the per-pixel state in
+ * registers (32 on small grids and without a refractory period, 8 on large grids where the
+ * refractory rule may force a redo, 1 where a clip's workgroups cannot be co-resident), the rule-off
+ * speculation of a launch validated (and redone from a checkpoint on a miss) by the next launch --
+ * with the event list built behind it in batches (k_ctot, k_cframe, k_cemit) on a second stream that
+ * joins `stream` before the call's work ends; on small grids the state-independent part of every
+ * frame (lin-log, low-pass coefficient, Philox draws, leak step, shot decisions) is precomputed by
+ * k_ahead on a third.  |128: one frame per launch (clips on which the refractory rule is active on
+ * most frames).  |16 selects the unfused count/rank/scan/emit kernels, one frame at a time (kept for
+ * A/B measurements; also what runs photoreceptor noise, float64 log-encoded frames and more than
+ * 1024 events per pixel and frame); |256 insists on k_chain (error where it cannot run).  All give
+ * identical results.
  */
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames,
                 const double *t_prev, const double *t_frame, uint32_t frame_idx0, float *events,
                 uint64_t cap, v2e_frame_rec *recs_dev, int use_graph, void *stream);
 
-/* After an instrumented v2e_emu_run (blocking: a hipEvent before every launch): summed
- * milliseconds per kernel class and frames.  k_step pipeline: ms_count = the chain of
- * launches + 1 k_step launches (first to last, gaps included), ms_emit = the emission batches
- * (v2e_emu_last_profile_pipe), others 0; k_main pipeline: ms_count = k_main, ms_rank = k_refr;
- * |16: k_count, k_rank, k_scan, k_emit. */
+/* After an instrumented v2e_emu_run (blocking): summed milliseconds per kernel class and frames.
+ * k_chain pipeline: ms_count = the chain launches (HIP events before the first and after the last,
+ * gaps included), ms_emit = the emission batches (v2e_emu_last_profile_pipe), others 0;
+ * |16: k_count, k_rank, k_scan, k_emit (a hipEvent before every launch). */
 int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *ms_scan,
                          double *ms_emit, int *launches);
 
-/* The launch schedule v2e_emu_run uses for n_frames frames (no GPU needed; for tests and tooling): returns the number
- * of chain launches and, if out != NULL, writes per launch 8 int32: the frames it counts (c0, c1), the frame it
- * finalises exactly (e1), the speculated frame it validates (e2), the emission batch it must wait for before reusing
- * ring slots, the first and the number of emission batches that become launchable after it, 0; -1 = none.
- * frames_per_launch: 1 (k_step) or 2 (k_step2, frames_per_batch even). */
-int v2e_emu_pipe_plan(int n_frames, int frames_per_batch, int frames_per_launch, int32_t *out, int cap);
+/* The launch schedule v2e_emu_run uses for a run of n_frames frames (no GPU needed; for tests and tooling): returns the
+ * number of chain launches and, if out != NULL, writes per launch 8 int32: the frames it advances (f0, nf; nf = 0: the
+ * tail launch that only validates), the frames of its predecessor it validates (pf0, pnf), the emission batch it must wait
+ * for before reusing ring slots, the k_ahead batch it needs, the k_ahead batch enqueued behind it, the emission batch
+ * that is final once it is enqueued; -1 = none.  Batch b = frames [b * frames_per_batch, (b + 1) * frames_per_batch). */
+int v2e_emu_chain_plan(int n_frames, int frames_per_launch, int frames_per_batch, int ring_batches, int has_refractory,
+                       int fused_records, int32_t *out, int cap);
 
-/* Default pipeline only: emission batches timed by the last instrumented run and the frames
- * per emission batch this handle uses (chosen at create time; env V2E_AMD_PIPE_E overrides), and
- * the number of chain launches ms_count covers (step_launches may be NULL). */
+/* Emission batches timed by the last instrumented run, the frames per emission batch, and the
+ * number of chain launches ms_count covers (step_launches may be NULL). */
 int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch, int *step_launches);
 
-/* Which pipeline the last v2e_emu_run on this handle used: kind 0 = unfused count/rank/scan/emit, 1 = k_step / k_step2
- * chain + deferred emission, 2 = k_main per frame, 3 = k_chain (K frames per launch, state in registers; 4 = the same with
- * the per-frame records built inside the chain); frames_per_launch of the dependency chain and frames per emission batch. */
+/* Which pipeline the last v2e_emu_run on this handle used: kind 0 = unfused count/rank/scan/emit, 3 = k_chain (K frames
+ * per launch, state in registers; records from k_ahead), 4 = k_chain with the per-frame records built inside the chain;
+ * frames_per_launch of the dependency chain and frames per emission batch. */
 int v2e_emu_last_pipeline(v2e_emu *h, int *kind, int *frames_per_launch, int *frames_per_batch);
 
 /* ------------------------------------------------------------- SuperSloMo */

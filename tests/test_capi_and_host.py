@@ -132,46 +132,57 @@ def test_photoreceptor_noise_amplitude_port():
     assert photoreceptor_noise_vrms(1.0, 300.0, 3000.0, 0.4, 0.4, 0.03) > np.mean(v)
 
 
-@pytest.mark.parametrize("K", [1, 2])
-def test_pipeline_launch_schedule_invariants(K):
-    """v2e_emu_pipe_plan, the schedule v2e_emu_run enqueues: every frame is counted exactly once and in order,
-    finalised exactly once by a later launch, speculated frames (and only those) are validated by the launch after,
-    an emission batch is launched once and only after all its frames are final, and no ring slot is overwritten before
-    the emission batch that reads it was waited for."""
+@pytest.mark.parametrize("has_refr", [0, 1])
+@pytest.mark.parametrize("fused", [0, 1])
+def test_chain_launch_schedule_invariants(has_refr, fused):
+    """v2e_emu_chain_plan, the schedule v2e_emu_run enqueues (no GPU needed): every frame is advanced exactly once and in
+    order; with a refractory period every launch validates exactly its predecessor's frames and a tail launch validates the
+    last ones; an emission batch is launched once, in order, and only when all its frames are final (validated, or -- without
+    a refractory period -- advanced); a ring slot is not overwritten before the emission batch that reads it was waited for;
+    k_ahead batches are produced before the launch that needs them and never more than the ring holds."""
     import ctypes as C
     from v2e_amd import _capi
     lib = _capi.lib()
-    for E in (2, 4, 16, 32) if K == 2 else (1, 2, 3, 5, 16, 32):
-        D = 2 * E
-        for F in list(range(1, 3 * D + 4)) + [300]:
-            n = lib.v2e_emu_pipe_plan(F, E, K, None, 0)
-            buf = (C.c_int32 * (8 * n))()
-            assert lib.v2e_emu_pipe_plan(F, E, K, buf, n) == n
-            plan = np.frombuffer(buf, dtype=np.int32).reshape(n, 8)
-            counted_at, final_at, spec_at, emitted_at, waited = {}, {}, {}, {}, set()
-            nb = (F + E - 1) // E
-            for L, (c0, c1, e1, e2, wb, ef, ec, _) in enumerate(plan):
-                if wb >= 0:
-                    assert wb in emitted_at and emitted_at[wb] < L, "waits for a batch that was never launched"
-                    waited.add(wb)
-                for c in (c0, c1):
-                    if c >= 0:
-                        assert c not in counted_at and c == len(counted_at), "frames must be counted once, in order"
-                        # the slot of frame c was last used by frame c - D: its batch must have been waited for
-                        assert c < D or (c - D) // E in waited, "ring slot reused before its emission batch was waited for"
-                        counted_at[c] = L
-                if e1 >= 0:
-                    assert e1 in counted_at and counted_at[e1] < L and e1 not in final_at
-                    final_at[e1] = L
-                if e2 >= 0:
-                    assert spec_at.get(e2) == L - 1, "validates a frame the previous launch did not speculate on"
-                    final_at[e2] = L
-                if K == 2 and c0 >= 0 and c1 >= 0:
-                    spec_at[c0] = L  # c0 is finalised speculatively when it has a partner
-                for b in range(ef, ef + ec):
-                    assert b not in emitted_at
-                    assert all(f in final_at for f in range(b * E, min((b + 1) * E, F))), "batch launched before its frames are final"
-                    emitted_at[b] = L
-            assert sorted(counted_at) == list(range(F)) and sorted(final_at) == list(range(F))
-            assert all(f in final_at and final_at[f] == L + 1 for f, L in spec_at.items()), "every speculation is validated"
-            assert sorted(emitted_at) == list(range(nb))
+    for K, m in ((1, 1), (1, 8), (1, 32), (2, 1), (3, 2), (5, 6), (8, 1), (8, 4), (11, 2), (16, 2), (32, 1), (32, 2)):
+        E = K * m
+        for nD in (3, 5):
+            D = nD * E
+            for F in list(range(1, 2 * D + 5, max(1, D // 7))) + [300]:
+                n = lib.v2e_emu_chain_plan(F, K, E, nD, has_refr, fused, None, 0)
+                buf = (C.c_int32 * (8 * n))()
+                assert lib.v2e_emu_chain_plan(F, K, E, nD, has_refr, fused, buf, n) == n
+                plan = np.frombuffer(buf, dtype=np.int32).reshape(n, 8)
+                nb = (F + E - 1) // E
+                advanced, final, emitted, waited, ahead = 0, 0, [], set(), {0, 1} if not fused else set()
+                for L, (f0, nf, pf0, pnf, wj, wa, an, eb) in enumerate(plan):
+                    if wj >= 0:
+                        assert wj in emitted, "waits for an emission batch that was never launched"
+                        waited.add(wj)
+                    if wa >= 0:
+                        assert not fused and wa in ahead, "needs records no k_ahead launch produced"
+                    assert f0 == advanced and 0 <= nf <= K, "frames must be advanced once, in order"
+                    for f in range(f0, f0 + nf):  # the slot of frame f was last used by frame f - D
+                        assert f < D or (f - D) // E in waited, "ring slot reused before its emission batch was waited for"
+                    if has_refr:
+                        assert (pnf == 0) == (L == 0)
+                        if L > 0:
+                            assert (pf0, pnf) == (plan[L - 1][0], plan[L - 1][1]), "validates something else than its predecessor"
+                            final = pf0 + pnf
+                    else:
+                        assert pnf == 0
+                    advanced += nf
+                    if not has_refr:
+                        final = advanced
+                    if an >= 0:
+                        assert not fused and an not in ahead and an < nb
+                        # its records overwrite those of batch an - nD, whose frames (and their redo) must be behind the chain
+                        assert an < nD or (an - nD + 1) * E <= f0 + nf
+                        ahead.add(an)
+                    if eb >= 0:
+                        assert eb == len(emitted), "emission batches in order, once"
+                        assert min((eb + 1) * E, F) <= final, "batch launched before its frames are final"
+                        emitted.append(eb)
+                assert advanced == F and final == F and emitted == list(range(nb))
+                assert (plan[-1][1] == 0) == bool(has_refr), "a tail launch iff there is something left to validate"
+                if not fused:
+                    assert ahead >= set(range(nb))

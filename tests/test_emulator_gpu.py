@@ -98,16 +98,14 @@ def test_hip_philox_frame_api_matches_reference(name):
 
 
 # use_graph: low bits 0 plain launches / 1 hipGraph; no pipeline bit: k_chain (K frames per launch, state in registers)
-# wherever it can run, |256 insists on it; the earlier pipelines: |64 k_step chain + deferred emission batches (two
-# frames per launch on small grids, |128: one), |32 one k_main per frame (emission on the chain), |16 unfused
-# count/rank/scan/emit, |512 their size heuristic
-PIPELINES = [0, 1, 256, 257, 64, 65, 192, 193, 32, 33, 16, 17, 513]
+# wherever it can run, |256 insists on it, |128 one frame per launch; |16 the unfused count/rank/scan/emit kernels
+PIPELINES = [0, 1, 256, 257, 128, 129, 16, 17]
 
 
 @pytest.mark.parametrize("use_graph", PIPELINES)
 @pytest.mark.parametrize("name", [n for n in PHILOX_FIXTURES if "pnoise" not in n])  # photoreceptor noise: its own test below
 def test_hip_philox_device_resident_clip_matches_reference(name, use_graph):
-    """Whole clip on device (no host sync between frames; optionally one hipGraph), all three pipelines."""
+    """Whole clip on device (no host sync between frames; optionally one hipGraph), every pipeline."""
     fx = PhiloxFixture(name)
     emu = _mk(fx, seed=fx.seed, rng_mode="philox")
     ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph)
@@ -152,28 +150,6 @@ def test_hip_philox_device_resident_photoreceptor_noise(use_graph):
         emu.generate_events_batch(fx.frames[-2:], [fx.times[-1] + 0.01, fx.times[-1] + 0.02], use_graph=257)
 
 
-@pytest.mark.parametrize("pipe_e", [1, 2, 3, 4, 6])
-@pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260"])
-def test_step_chain_pipeline_ring_wraps(name, pipe_e, monkeypatch):
-    """Few frames per emission batch: the ring of frame slots wraps several times within the fixture clip, the
-    step chain waits on emission batches, partial last batch."""
-    monkeypatch.setenv("V2E_AMD_PIPE_E", str(pipe_e))
-    fx = PhiloxFixture(name)
-    for use_graph in (64, 65, 192, 193):
-        emu = _mk(fx, seed=fx.seed, rng_mode="philox")
-        ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph)
-        assert list(counts) == list(fx.n_events)
-        row = 0
-        for k, n in enumerate(counts):
-            if n:
-                assert sha(ev[row:row + n]) == fx.ev_sha[k], "frame %d event digest differs" % k
-            row += n
-        st = _state(emu)
-        assert sha(st["base_log_frame"]) == fx.base_sha
-        if fx.ts_mem_sha:
-            assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
-
-
 @pytest.mark.parametrize("chain_k", [1, 2, 3, 5, 8, 11, 16, 32])
 @pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260", "philox_defaults_346x260"])
 def test_chain_launch_lengths_and_ring_wrap(name, chain_k, monkeypatch):
@@ -181,6 +157,7 @@ def test_chain_launch_lengths_and_ring_wrap(name, chain_k, monkeypatch):
     launches wait on emission batches, partial last launch; with the refractory fixture every launch redoes its
     predecessor (rule on in most frames), several passes per launch once K > 1."""
     monkeypatch.setenv("V2E_AMD_CHAIN_K", str(chain_k))
+    monkeypatch.setenv("V2E_AMD_CHAIN_M", "1")  # emission batches of K frames: a ring of 3 K slots
     fx = PhiloxFixture(name)
     for use_graph in (256, 257):
         emu = _mk(fx, seed=fx.seed, rng_mode="philox")
@@ -201,8 +178,8 @@ def test_chain_launch_lengths_and_ring_wrap(name, chain_k, monkeypatch):
 @pytest.mark.parametrize("refr", [0.0005, 0.002])
 def test_pipelines_agree_on_benchmark_clip(refr, oracle_lib):
     """BASELINE configs[1] at full size (346x260, 300 frames, dt = 1/300 s): every device-resident pipeline gives the
-    same event stream, records and final state.  refr = 0.5 ms: the two-frame chain mis-speculates on ~1 % of the
-    frames; 2 ms: on most of them (in-kernel repair path on every launch)."""
+    same event stream, records and final state.  refr = 0.5 ms: the chain mis-speculates on ~1 % of the frames; 2 ms: on
+    most of them (redo passes on every launch)."""
     from v2e_amd import EventEmulator
     from v2e_amd.synth import sincos_gradient_frames
     F = 300
@@ -211,7 +188,7 @@ def test_pipelines_agree_on_benchmark_clip(refr, oracle_lib):
     kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak_rate_hz=.01, shot_noise_rate_hz=.001,
               refractory_period_s=refr)
     ref = None
-    for use_graph in (257, 65, 129, 33, 17):  # k_chain, two-frame chain, one-frame chain, k_main per frame, 4-kernel
+    for use_graph in (257, 129, 17):  # k_chain 32 frames per launch, one frame per launch, count/rank/scan/emit
         emu = EventEmulator(device="cuda", seed=1, rng_mode="philox", **kw)
         ev, counts = emu.generate_events_batch(frames, times, use_graph=use_graph)
         st = (sha(ev), list(counts), sha(emu.base_log_frame.cpu().numpy()), sha(emu.timestamp_mem.cpu().numpy()),
@@ -231,8 +208,8 @@ def test_pipelines_agree_on_benchmark_clip(refr, oracle_lib):
 
 @pytest.mark.parametrize("chunk", [1, 2, 3, 5])
 def test_clip_in_small_runs_equals_whole_clip(chunk):
-    """Runs of 1, 2, 3, 5 frames (odd and even: the two-frame chain's last launch differs) chained through the
-    carried state == one run."""
+    """Runs of 1, 2, 3, 5 frames chained through the carried state == one run (every run ends in a tail launch that
+    copies the state back when the number of launches is odd)."""
     fx = PhiloxFixture("philox_refractory_346x260")
     emu = _mk(fx, seed=fx.seed, rng_mode="philox")
     evs, cnts = [], []
@@ -337,16 +314,19 @@ def test_philox_init_planes_match_oracle(oracle_lib):
     assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
 
 
-def test_multi_clip_engine_equals_single_clips(oracle_lib):
-    """n_clips pixel arrays advanced by one launch == independent single-clip runs (Philox clip streams)."""
+@pytest.mark.parametrize("shape", [(60, 100, 8, 3, 0.002), (260, 346, 12, 64, 0.002), (260, 346, 12, 64, 0.0005), (480, 640, 6, 2, 0.0)])
+def test_multi_clip_engine_equals_single_clips(shape, oracle_lib):
+    """n_clips pixel arrays advanced by one launch == independent single-clip runs (Philox clip streams): 3 small clips;
+    64 clips of 346x260 with a refractory period (bench.py's `batched` workload: more workgroups than are co-resident,
+    clips walked a few at a time, redo passes with rendezvous per clip); 2 clips of 640x480 without one."""
     from v2e_amd.emulator import EventEmulator
     from v2e_amd.engine import EmuEngine
     from v2e_amd.synth import int_gradient_frames
-    H, W, F, NC = 60, 100, 8, 3
+    H, W, F, NC, refr = shape
     clips = [int_gradient_frames(F, H, W, seed=20 + c, noise=8, as_array=True) for c in range(NC)]
     times = [i / 300 for i in range(F)]
-    proto = EventEmulator(device="cuda", seed=5, rng_mode="philox", cutoff_hz=300, leak_rate_hz=0.2,
-                          shot_noise_rate_hz=4.0, refractory_period_s=0.002)
+    kw = dict(cutoff_hz=300, leak_rate_hz=0.2, shot_noise_rate_hz=4.0, refractory_period_s=refr)
+    proto = EventEmulator(device="cuda", seed=5, rng_mode="philox", **kw)
     proto._thres_scalar = (0.2, 0.2)
     proto._thres_is_scalar = False
     P = proto._params()
@@ -360,17 +340,19 @@ def test_multi_clip_engine_equals_single_clips(oracle_lib):
     t_prev = np.array([[0.0] * NC] + [[times[f]] * NC for f in range(1, F - 1)])
     t_frame = np.array([[times[f]] * NC for f in range(1, F)])
     eng.run(P, frames[1:].contiguous(), t_prev, t_frame, 1, ev, recs, use_graph=True)
+    assert eng.last_pipeline()[0].startswith("k_chain")
     r = eng.recs_to_numpy(recs)
-    evh = ev.cpu().numpy()
-    for c in range(NC):
-        ora = oracle_lib.OracleEmulator(seed=5, rng_mode="philox", clip=c, cutoff_hz=300, leak_rate_hz=0.2,
-                                        shot_noise_rate_hz=4.0, refractory_period_s=0.002)
+    assert not r["flags"].any()
+    for c in (range(NC) if NC <= 3 else (0, 1, 7, 31, 62, 63)):
+        ora = oracle_lib.OracleEmulator(seed=5, rng_mode="philox", clip=c, **kw)
         oev = [ora.generate_events(clips[c][f], times[f]) for f in range(F)]
         ref = np.concatenate([e for e in oev if e is not None])
         n = int(r["n_events"][:, c].sum())
-        assert n == len(ref)
-        assert np.array_equal(evh[c, :n], ref)
+        assert n == len(ref), "clip %d" % c
+        assert np.array_equal(ev[c, :n].cpu().numpy(), ref), "clip %d" % c
         assert np.array_equal(eng.plane(eng.base, c).cpu().numpy(), ora.base_log_frame)
+        if refr > 0:
+            assert np.array_equal(eng.plane(eng.ts_mem, c).cpu().numpy(), ora.timestamp_mem)
 
 
 def test_run_to_run_determinism():
@@ -416,10 +398,10 @@ def test_many_iterations_grow_scratch(oracle_lib):
     assert ora.last["M"] > 64
 
 
-@pytest.mark.parametrize("use_graph", [257, 65, 193, 33, 17])
+@pytest.mark.parametrize("use_graph", [257, 129, 17])
 @pytest.mark.parametrize("refr", [0.0, 0.0004])
 def test_device_resident_clip_many_iterations(use_graph, refr, oracle_lib):
-    """> 31 events per pixel per frame: several 64-key chunks in the fused kernels, refractory on/off."""
+    """> 31 events per pixel per frame: several 64-key chunks in k_ctot / k_cemit, refractory on/off."""
     from v2e_amd import EventEmulator
     kw = dict(pos_thres=0.03, neg_thres=0.04, sigma_thres=0.01, cutoff_hz=200, leak_rate_hz=0.2, shot_noise_rate_hz=30.0,
               refractory_period_s=refr)

@@ -643,8 +643,6 @@ __global__ __launch_bounds__(BLOCK) void k_permute(const float4 *__restrict__ in
     if (j < n) out[row0 + j] = in[row0 + (unsigned long long)idx[j]];
 }
 
-#include "emu_fused.h"
-#include "emu_pipe.h"
 #include "emu_chain.h"
 
 } // namespace
@@ -677,18 +675,14 @@ struct v2e_emu {
     uint32_t *cnt = nullptr, *hist = nullptr, *tot = nullptr;
     void *pn_arr = nullptr;           // photoreceptor_noise_arr plane (v2e_emu_set_pnoise)
     const float *pn_tape = nullptr;
-    // fused pipeline scratch (double-buffered by frame parity)
     int ngroups = 0;
     float *lut_L = nullptr;
     double *lut_I = nullptr;
-    uint32_t *cnt_b = nullptr;
-    uint16_t *gtot[2] = {nullptr, nullptr}; // [n_clips][nkeys_cap][ngp], key-major u16
-    int ngp = 0;
-    int *gmaxv[2] = {nullptr, nullptr};
     v2e_frame_rec *rec_ring = nullptr; // [RING][n_clips]
     FrameCtl *ctl_ring = nullptr;      // [RING][n_clips]
     FrameCtl *ctl_host = nullptr;      // pinned staging [RING][n_clips]
     unsigned long long *off_dev = nullptr, *off_host = nullptr; // [n_clips] explicit event offsets
+    uint32_t *frame_out = nullptr, *frame_out_host = nullptr;   // v2e_emu_frame: {n_events, n_on, n_off, M, flags} per clip
     // multi-frame run
     FrameCtl *run_ctl = nullptr;       // device [run_cap][n_clips]
     FrameCtl *run_ctl_host2[2] = {nullptr, nullptr}; // pinned staging, two sets
@@ -704,40 +698,24 @@ struct v2e_emu {
     unsigned long long graph_clock = 0;
     void drop_graphs() { for (auto &g : graphs) hipGraphExecDestroy(g.exec); graphs.clear(); }
     unsigned long long *dbg = nullptr; // dev tool (v2e_emu_debug_timeline)
-    unsigned *run_bar = nullptr;       // [run_cap + 1][n_clips] rendezvous counters of the fused pipeline
-    uint32_t *pre32 = nullptr, *tot32 = nullptr; // k_scan2 outputs (large grids only)
     int n_cu = 256;
-    int max_resident_blocks = 0;       // k_main workgroups the device can hold at once (occupancy query)
     double prof_ms[4] = {0, 0, 0, 0}; // count, rank, scan, emit (use_graph == 2)
     int prof_launches = 0;
-    // decoupled pipeline (emu_pipe.h): ring of pipe_D = 2 * pipe_E frame slots + the emission stream
-    int pipe_E = 8, pipe_D = 16;
-    uint32_t *pipe_cnt = nullptr;  // [pipe_D][n_clips][npx_pad]
-    int *pipe_gmax = nullptr;      // [pipe_D][n_clips][ngroups]
-    float *pipe_tsold = nullptr;   // [pipe_D][n_clips][npx_pad], allocated on first use with a refractory period
-    uint16_t *pipe_gtT = nullptr;  // [pipe_D][n_clips][nkeys_cap][ngp]
-    int *pipe_rowext = nullptr;    // [pipe_D][n_clips][ngroups]
-    uint32_t *pipe_nw = nullptr;   // [pipe_D][n_clips][ngroups]
-    uint32_t *pipe_pre32 = nullptr, *pipe_tot32 = nullptr; // large grids: [pipe_E][n_clips][nkeys_cap][ngp] / [..][nkeys_cap]
-    FrameTable *pipe_ftab = nullptr;  // [pipe_E][n_clips] per-frame tables of the emission side (ngp == 512 only)
-    uint32_t *pipe_pre512 = nullptr;  // [pipe_E][n_clips][FT_KEYS][512]
-    void *pipe_bck = nullptr, *pipe_lpn = nullptr; // [pipe_D][n_clips][npx_pad] float64 slots: k_step2 checkpoints (base before the
-                                                   // speculative finalise, lp after the frame); allocated on first use
-    unsigned long long *pipe_off = nullptr; // [2][n_clips] event offset at the start of the current / next emission batch
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> ev_fork, ev_join;
-    double prof_emit_ms = 0.0;
     int prof_emit_batches = 0, prof_step_launches = 0;
+    unsigned long long *run_off = nullptr; // [2][n_clips] event offset at the start of the current / next emission batch
+    hipStream_t side = nullptr;        // the emission side of the chain: k_ctot, k_cframe, k_cemit
+    std::vector<hipEvent_t> ev_fork, ev_join;
     // K-frames-per-launch chain (emu_chain.h); allocated on first use by v2e_emu_run
-    int ch_K = 0, ch_D = 0, ch_nD = 3, ch_nwp = 0, ch_launch_cap = 0, ch_resident_clips = 0, ch_max_blocks = 0;
+    int ch_K = 0, ch_D = 0, ch_nD = 3, ch_nwp = 0, ch_launch_cap = 0, ch_max_blocks = 0, ch_fused = -1, ch_inst = -1;
     uint32_t *ch_cnt = nullptr;     // [ch_D][n_clips][npx_pad]
-    uint16_t *ch_wmax = nullptr;    // [ch_D][n_clips][ch_nwp]
-    uint8_t *ch_wtot = nullptr;     // [ch_D][n_clips][nkeys_cap][ch_nwp]
+    uint32_t *ch_ruleM = nullptr;   // [ch_D][n_clips]
+    uint16_t *ch_wmax = nullptr;    // [2][ch_E][n_clips][ch_nwp]
+    uint8_t *ch_wtot = nullptr;     // [2][ch_E][n_clips][nkeys_cap][ch_nwp]
     float *ch_tsold = nullptr;      // [ch_D][n_clips][npx_pad] (refractory runs)
     void *ch_ck = nullptr;          // refractory runs: 2 launch parities x 3 checkpoints x (base 8 B, lp 8 B, ts 4 B) planes
     uint4 *ch_rec = nullptr;        // [ch_D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
-    hipStream_t ahead = nullptr, tables = nullptr; // k_ahead / k_cframe run beside the chain and the event writer
-    std::vector<hipEvent_t> ev_ahead, ev_chain, ev_tables;
+    hipStream_t ahead = nullptr;    // k_ahead runs beside the chain and the event writer
+    std::vector<hipEvent_t> ev_ahead, ev_chain;
     int ch_E = 0;                   // frames per k_ahead launch / emission batch (a multiple of ch_K)
     int last_kind = -1, last_fpl = 0, last_fpb = 0; // v2e_emu_last_pipeline
     uint32_t *ch_gM = nullptr;      // [ch_launch_cap][ch_K + 1][n_clips][ch_K]
@@ -748,6 +726,7 @@ struct v2e_emu {
     unsigned *ch_cdone = nullptr;   // [2][ch_E][n_clips] k_cframe's per-frame completion counters
     uint32_t *ch_cT = nullptr, *ch_ckbase = nullptr, *ch_cperm = nullptr, *ch_cpre = nullptr;
     int ch_nkeys_cap = 0;           // nkeys_cap the chain scratch was sized for
+    int occ_cache[24];              // workgroups of a k_chain instantiation a CU holds (-1: not queried yet)
 };
 
 static thread_local char g_err[512] = "";
@@ -820,38 +799,6 @@ static int alloc_iter_scratch(v2e_emu *h, int max_iters)
     h->nkeys_cap = 2 * max_iters + 2;
     V2E_HIP(hipMalloc(&h->hist, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap * h->nwaves));
     V2E_HIP(hipMalloc(&h->tot, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap));
-    for (int q = 0; q < 2; ++q) {
-        if (h->gtot[q]) { V2E_HIP(hipFree(h->gtot[q])); h->gtot[q] = nullptr; }
-        V2E_HIP(hipMalloc(&h->gtot[q], sizeof(uint16_t) * (size_t)h->n_clips * h->ngp * h->nkeys_cap));
-        V2E_HIP(hipMemset(h->gtot[q], 0, sizeof(uint16_t) * (size_t)h->n_clips * h->ngp * h->nkeys_cap));
-        V2E_HIP(hipMemset(h->gmaxv[q], 0, sizeof(int) * (size_t)h->n_clips * h->ngroups));
-    }
-    {
-        const size_t nrow = (size_t)h->pipe_D * h->n_clips * h->nkeys_cap * h->ngp, ng = (size_t)h->pipe_D * h->n_clips * h->ngroups;
-        if (h->pipe_gtT) { V2E_HIP(hipFree(h->pipe_gtT)); h->pipe_gtT = nullptr; }
-        V2E_HIP(hipMalloc(&h->pipe_gtT, sizeof(uint16_t) * nrow));
-        V2E_HIP(hipMemset(h->pipe_gtT, 0, sizeof(uint16_t) * nrow));
-        V2E_HIP(hipMemset(h->pipe_rowext, 0, sizeof(int) * ng));
-        V2E_HIP(hipMemset(h->pipe_gmax, 0, sizeof(int) * ng));
-        V2E_HIP(hipMemset(h->pipe_nw, 0, sizeof(uint32_t) * ng));
-        if (h->pipe_pre32) { V2E_HIP(hipFree(h->pipe_pre32)); h->pipe_pre32 = nullptr; }
-        if (h->pipe_tot32) { V2E_HIP(hipFree(h->pipe_tot32)); h->pipe_tot32 = nullptr; }
-        if (h->ngroups > 1024) {
-            const size_t npre = (size_t)h->pipe_E * h->n_clips * h->nkeys_cap * h->ngp;
-            V2E_HIP(hipMalloc(&h->pipe_pre32, sizeof(uint32_t) * npre));
-            V2E_HIP(hipMalloc(&h->pipe_tot32, sizeof(uint32_t) * (size_t)h->pipe_E * h->n_clips * h->nkeys_cap));
-            V2E_HIP(hipMemset(h->pipe_pre32, 0, sizeof(uint32_t) * npre));
-            V2E_HIP(hipMemset(h->pipe_tot32, 0, sizeof(uint32_t) * (size_t)h->pipe_E * h->n_clips * h->nkeys_cap));
-        }
-    }
-    if (h->pre32) { V2E_HIP(hipFree(h->pre32)); h->pre32 = nullptr; }
-    if (h->tot32) { V2E_HIP(hipFree(h->tot32)); h->tot32 = nullptr; }
-    if (h->ngroups > 1024) { // large grids: prefix-scan launch instead of per-workgroup re-reduction
-        V2E_HIP(hipMalloc(&h->pre32, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap * h->ngp));
-        V2E_HIP(hipMalloc(&h->tot32, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap));
-        V2E_HIP(hipMemset(h->pre32, 0, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap * h->ngp));
-        V2E_HIP(hipMemset(h->tot32, 0, sizeof(uint32_t) * (size_t)h->n_clips * h->nkeys_cap));
-    }
     h->drop_graphs();
     return 0;
 }
@@ -873,44 +820,20 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
     h->npx_pad = v2e_emu_npx_pad(H, W);
     h->nwaves = (h->npx + WAVE - 1) / WAVE;
     h->ngroups = (h->npx + BLOCK - 1) / BLOCK;
-    h->ngp = (h->ngroups + 511) / 512 * 512;
+    for (int &v : h->occ_cache) v = -1;
     V2E_HIP(hipMalloc(&h->cnt, sizeof(uint32_t) * (size_t)n_clips * h->npx_pad));
-    V2E_HIP(hipMalloc(&h->cnt_b, sizeof(uint32_t) * (size_t)n_clips * h->npx_pad));
     V2E_HIP(hipMalloc(&h->lut_L, sizeof(float) * 256));
     V2E_HIP(hipMalloc(&h->lut_I, sizeof(double) * 256));
     k_lut<<<1, 256>>>(h->lut_L, h->lut_I);
     V2E_HIP(hipDeviceSynchronize());
     {
-        int per_cu = 0, ncu = 0;
-        V2E_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_main<double, uint8_t>, BLOCK, 0));
+        int ncu = 0;
         V2E_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
-        // the occupancy API can over-report by one workgroup per CU (MI355X guide): keep a margin
-        per_cu = per_cu > 4 ? 4 : (per_cu > 1 ? per_cu - 1 : 0);
-        h->max_resident_blocks = per_cu * ncu;
         h->n_cu = ncu;
     }
-    for (int q = 0; q < 2; ++q) V2E_HIP(hipMalloc(&h->gmaxv[q], sizeof(int) * (size_t)n_clips * h->ngroups));
-    {
-        // frames per emission launch: as many as keep the ring (count words + ts_mem copies) under ~1 GiB
-        size_t per_frame = (size_t)n_clips * h->npx_pad * 24, e = PIPE_E_MAX;
-        while (e > 4 && 2 * e * per_frame > ((size_t)1 << 30)) e >>= 1;
-        if (const char *ev = getenv("V2E_AMD_PIPE_E")) { int v = atoi(ev); if (v >= 1 && v <= PIPE_E_MAX) e = (size_t)v; }
-        h->pipe_E = (int)e;
-        h->pipe_D = 2 * h->pipe_E;
-        const size_t ng = (size_t)h->pipe_D * n_clips * h->ngroups;
-        V2E_HIP(hipMalloc(&h->pipe_cnt, sizeof(uint32_t) * (size_t)h->pipe_D * n_clips * h->npx_pad));
-        V2E_HIP(hipMalloc(&h->pipe_gmax, sizeof(int) * ng));
-        V2E_HIP(hipMalloc(&h->pipe_rowext, sizeof(int) * ng));
-        V2E_HIP(hipMalloc(&h->pipe_nw, sizeof(uint32_t) * ng));
-        V2E_HIP(hipMalloc(&h->pipe_off, sizeof(unsigned long long) * 2 * n_clips));
-        V2E_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        if (h->ngp == 512) {
-            V2E_HIP(hipMalloc(&h->pipe_ftab, sizeof(FrameTable) * (size_t)h->pipe_E * n_clips));
-            V2E_HIP(hipMalloc(&h->pipe_pre512, sizeof(uint32_t) * (size_t)h->pipe_E * n_clips * FT_KEYS * 512));
-            V2E_HIP(hipMemset(h->pipe_ftab, 0, sizeof(FrameTable) * (size_t)h->pipe_E * n_clips));
-        }
-    }
-    int rc = alloc_iter_scratch(h, max_iters); // also zeroes gtot/gmaxv (clean-row invariant)
+    V2E_HIP(hipMalloc(&h->run_off, sizeof(unsigned long long) * 2 * n_clips));
+    V2E_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    int rc = alloc_iter_scratch(h, max_iters);
     if (rc) return rc;
     V2E_HIP(hipMalloc(&h->rec_ring, sizeof(v2e_frame_rec) * RING * n_clips));
     V2E_HIP(hipMemset(h->rec_ring, 0, sizeof(v2e_frame_rec) * RING * n_clips));
@@ -930,30 +853,26 @@ int v2e_emu_destroy(v2e_emu *h)
     hipSetDevice(h->device);
     h->drop_graphs();
     hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
-    hipFree(h->lut_L); hipFree(h->lut_I); hipFree(h->pre32); hipFree(h->tot32);
-    hipFree(h->pipe_cnt); hipFree(h->pipe_gmax); hipFree(h->pipe_tsold); hipFree(h->pipe_gtT); hipFree(h->pipe_rowext);
-    hipFree(h->pipe_nw); hipFree(h->pipe_ftab); hipFree(h->pipe_pre512); hipFree(h->pipe_bck); hipFree(h->pipe_lpn); hipFree(h->pipe_pre32); hipFree(h->pipe_tot32); hipFree(h->pipe_off);
+    hipFree(h->lut_L); hipFree(h->lut_I); hipFree(h->run_off);
     for (hipEvent_t e : h->ev_fork) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_join) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
-    hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck); hipFree(h->ch_gM); hipFree(h->ch_bar);
-    hipFree(h->ch_rec);
+    hipFree(h->ch_cnt); hipFree(h->ch_ruleM); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck);
+    hipFree(h->ch_gM); hipFree(h->ch_bar); hipFree(h->ch_rec);
     for (hipEvent_t e : h->ev_ahead) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_chain) hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_tables) hipEventDestroy(e);
     if (h->ahead) hipStreamDestroy(h->ahead);
-    if (h->tables) hipStreamDestroy(h->tables);
     hipFree(h->ch_base2); hipFree(h->ch_lp2); hipFree(h->ch_ts2); hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase);
     hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_cdone);
-    hipFree(h->cnt_b); hipFree(h->gtot[0]); hipFree(h->gtot[1]); hipFree(h->gmaxv[0]); hipFree(h->gmaxv[1]);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     hipFree(h->off_dev);
     if (h->off_host) hipHostFree(h->off_host);
     if (h->run_ctl) hipFree(h->run_ctl);
-    if (h->run_bar) hipFree(h->run_bar);
     for (int q = 0; q < 2; ++q) { if (h->run_ctl_host2[q]) hipHostFree(h->run_ctl_host2[q]); if (h->ev_stage[q]) hipEventDestroy(h->ev_stage[q]); }
     hipFree(h->run_fidx);
     if (h->run_fidx_host) hipHostFree(h->run_fidx_host);
+    hipFree(h->frame_out);
+    if (h->frame_out_host) hipHostFree(h->frame_out_host);
     delete h;
     return 0;
 }
@@ -1195,320 +1114,114 @@ static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, cons
     return 0;
 }
 
-// Fused pipeline: F+1 launches of k_main (+F of k_refr when the refractory period is non-zero).
-static int enqueue_run_fused(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
-                             float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, hipEvent_t *evs = nullptr,
-                             int *n_marks = nullptr)
-{
-    const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
-    V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
-    dim3 grid(h->ngroups, h->n_clips);
-    int mark = 0;
-    const bool has_refr = p->refractory_period_s > 0;
-    const bool inkernel = has_refr && !getenv("V2E_AMD_NO_INKERNEL_SYNC") &&
-                          (long long)h->ngroups * h->n_clips <= (long long)h->max_resident_blocks;
-    if (inkernel) V2E_HIP(zero_async(h->run_bar, sizeof(unsigned) * (size_t)(n_frames + 1) * h->n_clips, s));
-    for (int f = 0; f <= n_frames; ++f) {
-        FusedArgs fa;
-        memset(&fa, 0, sizeof(fa));
-        fa.do_count = f < n_frames;
-        fa.do_emit = f > 0;
-        fa.frame = fa.do_count ? (const char *)frames + (size_t)f * h->n_clips * h->npx * esz : nullptr;
-        fa.ctl_c = h->run_ctl + (size_t)(fa.do_count ? f : 0) * h->n_clips;
-        fa.ctl_e = h->run_ctl + (size_t)(f > 0 ? f - 1 : 0) * h->n_clips;
-        fa.rec_e = recs + (size_t)(f > 0 ? f - 1 : 0) * h->n_clips;
-        fa.rec_ee = f >= 2 ? recs + (size_t)(f - 2) * h->n_clips : nullptr;
-        fa.fidx_base = h->run_fidx;
-        fa.fidx_c = (uint32_t)f;
-        fa.fidx_e = (uint32_t)(f > 0 ? f - 1 : 0);
-        fa.par_c = f & 1;
-        fa.par_e = (f + 1) & 1;
-        fa.ngroups = h->ngroups;
-        fa.cnt2[0] = h->cnt; fa.cnt2[1] = h->cnt_b;
-        fa.gtT2[0] = h->gtot[0]; fa.gtT2[1] = h->gtot[1];
-        fa.ngp = h->ngp;
-        fa.gmax2[0] = h->gmaxv[0]; fa.gmax2[1] = h->gmaxv[1];
-        fa.events = (float4 *)events;
-        fa.cap = cap;
-        fa.dbg = (h->dbg && f == n_frames / 2) ? h->dbg : nullptr; // dev timeline of one mid-run launch
-        fa.bar = inkernel ? h->run_bar : nullptr;
-        fa.pre32 = h->pre32; fa.tot32 = h->tot32;
-        static const bool no_rec = getenv("V2E_AMD_NO_EVENT_RECORDS") != nullptr;
-        fa.capw = no_rec ? 0 : 512; // 8 KB of records per workgroup; a wave with more events in a frame takes the iteration loop
-        const size_t rec_lds = sizeof(uint32_t) * (size_t)fa.capw * (BLOCK / WAVE);
-        if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
-        DISPATCH_FT(dtype, {
-            if (p->f64_state) k_main<double, FT><<<grid, BLOCK, rec_lds, s>>>(a, fa);
-            else k_main<float, FT><<<grid, BLOCK, rec_lds, s>>>(a, fa);
-        });
-        const bool scan2 = h->pre32 != nullptr;
-        if (fa.do_count && has_refr && !inkernel) {
-            if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
-            k_refr<<<grid, BLOCK, 0, s>>>(a, fa.ctl_c, fa.cnt2[fa.par_c], fa.gtT2[fa.par_c], h->ngp, fa.gmax2[fa.par_c], h->ngroups);
-        }
-        if (fa.do_count && scan2)
-            k_scan2<<<dim3(SCAN_BLOCKS, h->n_clips), BLOCK, 0, s>>>(a, fa.gtT2[fa.par_c], h->ngp, fa.gmax2[fa.par_c], h->ngroups, h->pre32, h->tot32);
-    }
-    if (evs) V2E_HIP(hipEventRecord(evs[mark++], s));
-    if (n_marks) *n_marks = mark;
-    V2E_HIP(hipGetLastError());
-    return 0;
-}
-
-// The launch schedule of the decoupled pipeline, as plain data (also exported for the CPU tests).  One entry per
-// chain launch: the frames it counts (c0, c1), the frame it finalises exactly (e1) and the speculated frame it
-// validates (e2) -- -1 where absent --, the emission batch whose completion it must wait for before overwriting
-// ring slots (wait_batch), and the emission batches [emit_first, emit_first + emit_count) that become launchable
-// once it is enqueued, batch b covering frames [b * E, min((b + 1) * E, n_frames)).
-struct PipeLaunch { int c0, c1, e1, e2, wait_batch, emit_first, emit_count; };
-
-static std::vector<PipeLaunch> pipe_plan(int n_frames, int E, int K)
-{
-    const int D = 2 * E;
-    std::vector<PipeLaunch> plan;
-    int emitted = 0;
-    auto take_final_batches = [&](PipeLaunch &pl, int last_final) { // batches all of whose frames are <= last_final
-        pl.emit_first = emitted;
-        while (emitted * E < n_frames && std::min((emitted + 1) * E, n_frames) - 1 <= last_final) ++emitted;
-        pl.emit_count = emitted - pl.emit_first;
-    };
-    if (K == 1) {
-        for (int f = 0; f <= n_frames; ++f) { // k_step(f) = finalise(f - 1) + count(f)
-            PipeLaunch pl;
-            pl.c0 = f < n_frames ? f : -1; pl.c1 = -1; pl.e1 = f - 1; pl.e2 = -1;
-            pl.wait_batch = (f % E == 0 && f >= D && f < n_frames) ? (f - D) / E : -1;
-            take_final_batches(pl, f - 1);
-            plan.push_back(pl);
-        }
-    } else {
-        const int n_launch = (n_frames + 1) / 2 + 1;
-        for (int L = 0; L < n_launch; ++L) { // k_step2: counts 2L and 2L+1, finalises the last frame counted before, validates the one before that
-            PipeLaunch pl;
-            const int c0 = 2 * L, c1 = 2 * L + 1;
-            pl.c0 = c0 < n_frames ? c0 : -1;
-            pl.c1 = c1 < n_frames ? c1 : -1;
-            pl.e1 = std::min(c0, n_frames) - 1;
-            // e1 - 1 was finalised speculatively iff it is an even frame (a c0) that had a partner -- which e1 is
-            pl.e2 = (pl.e1 >= 1 && (pl.e1 - 1) % 2 == 0) ? pl.e1 - 1 : -1;
-            pl.wait_batch = (pl.c0 >= 0 && c0 % E == 0 && c0 >= D) ? (c0 - D) / E : -1;
-            take_final_batches(pl, pl.e1);
-            plan.push_back(pl);
-        }
-    }
-    return plan;
-}
-
-// Decoupled pipeline (emu_pipe.h): the k_step chain on `s`, emission batches on h->side.  With
-// ev_main / ev_side (instrumented run) an event is recorded before the first and after the last
-// k_step (events between dependent launches would lengthen the very gaps being measured) and
-// around every emission batch.
-static int enqueue_run_pipe(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
-                            float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, int K, std::vector<hipEvent_t> *ev_main = nullptr,
-                            std::vector<hipEvent_t> *ev_side = nullptr)
-{
-    const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
-    const bool has_refr = p->refractory_period_s > 0;
-    V2E_REQUIRE(!has_refr || h->pipe_tsold, "pipe_tsold not allocated");
-    V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips, s));
-    V2E_HIP(zero_async(h->pipe_off, sizeof(unsigned long long) * 2 * h->n_clips, s));
-    if (K == 2) V2E_HIP(zero_async(h->run_bar, sizeof(unsigned) * (size_t)((n_frames + 1) / 2 + 1) * h->n_clips, s));
-    const int PIPE_E = h->pipe_E, PIPE_D = h->pipe_D;
-    const size_t st_px = (size_t)h->n_clips * h->npx_pad, st_g = (size_t)h->n_clips * h->ngroups;
-    auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t st) -> int {
-        if (!v) return 0;
-        hipEvent_t e;
-        V2E_HIP(hipEventCreate(&e));
-        v->push_back(e);
-        V2E_HIP(hipEventRecord(e, st));
-        return 0;
-    };
-    dim3 grid(h->ngroups, h->n_clips);
-    // emission batch b = frames [b * E, f_end): launched once they are all final, behind the chain on h->side
-    auto launch_emission = [&](int b, int f_end) -> int {
-        EmitArgs ea;
-        memset(&ea, 0, sizeof(ea));
-        ea.ctl = h->run_ctl;
-        ea.recs = recs;
-        ea.fidx_base = h->run_fidx;
-        ea.f0 = b * PIPE_E;
-        ea.nE = f_end - ea.f0;
-        ea.D = PIPE_D;
-        ea.ngroups = h->ngroups; ea.ngp = h->ngp; ea.n_clips = h->n_clips;
-        ea.cnt = h->pipe_cnt; ea.gmax = h->pipe_gmax; ea.tsold = has_refr ? h->pipe_tsold : nullptr;
-        ea.gtT = h->pipe_gtT; ea.rowext = h->pipe_rowext; ea.nw = h->pipe_nw;
-        ea.pre32 = h->pipe_pre32; ea.tot32 = h->pipe_tot32;
-        ea.events = (float4 *)events; ea.cap = cap;
-        ea.off_in = h->pipe_off + (size_t)(b & 1) * h->n_clips;
-        ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * h->n_clips;
-        V2E_HIP(hipEventRecord(h->ev_fork[b], s));
-        V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
-        dim3 ge(h->ngroups, h->n_clips, ea.nE);
-        if (mark(ev_side, h->side)) return V2E_EHIP;
-        // While the step chain is latency-bound (a grid of a few workgroups per CU) the emission kernels must
-        // not fill the CUs, or the next k_step's workgroups queue behind them: a dynamic-LDS reservation caps
-        // them at 4 workgroups per CU (160 KB LDS; k_emit2_multi uses its reservation for the event records).
-        // Large grids are throughput-bound: no cap.
-        const int lds_pad = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu ? 32000 : 0;
-        static const bool no_tables = getenv("V2E_AMD_NO_FRAME_TABLES") != nullptr;
-        ea.ftab = no_tables ? nullptr : h->pipe_ftab;
-        ea.pre512 = h->pipe_pre512;
-        constexpr int REC_LDS = 32000; // k_emit2_multi: 4 waves x 2000 event records (a wave has at most 64 x 31)
-        ea.capw = REC_LDS / 4 / (BLOCK / WAVE);
-        k_tot_multi<<<ge, BLOCK, lds_pad / 2, h->side>>>(a, ea); // the light kernel of the two: 8 per CU measured best
-        if (h->pipe_pre32) k_scan2_multi<<<dim3(SCAN_BLOCKS, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
-        if (ea.ftab) {
-            k_frame_multi<<<dim3(1, h->n_clips, ea.nE), BLOCK, 0, h->side>>>(a, ea);
-            k_emit2_multi<<<ge, BLOCK, REC_LDS, h->side>>>(a, ea);
-            k_emit_big<<<dim3(64, h->n_clips), BLOCK, 0, h->side>>>(a, ea); // frames without a table (M > 31), if any
-        } else {
-            k_emit_multi<<<ge, BLOCK, lds_pad, h->side>>>(a, ea);
-        }
-        if (mark(ev_side, h->side)) return V2E_EHIP;
-        V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
-        return 0;
-    };
-    const std::vector<PipeLaunch> plan = pipe_plan(n_frames, PIPE_E, K);
-    auto emit_ready = [&](const PipeLaunch &pl) -> int {
-        for (int b = pl.emit_first; b < pl.emit_first + pl.emit_count; ++b)
-            if (launch_emission(b, std::min((b + 1) * PIPE_E, n_frames))) return V2E_EHIP;
-        return 0;
-    };
-    for (size_t li = 0; K == 1 && li < plan.size(); ++li) {
-        const PipeLaunch &pl = plan[li];
-        const int f = (int)li;
-        if (pl.wait_batch >= 0) // the slot this step writes was read by that emission batch
-            V2E_HIP(hipStreamWaitEvent(s, h->ev_join[pl.wait_batch], 0));
-        StepArgs sa;
-        memset(&sa, 0, sizeof(sa));
-        sa.do_count = f < n_frames;
-        sa.do_final = f > 0;
-        const int sc = f % PIPE_D, se = (f + PIPE_D - 1) % PIPE_D;
-        sa.frame = sa.do_count ? (const char *)frames + (size_t)f * h->n_clips * h->npx * esz : nullptr;
-        sa.ctl_c = h->run_ctl + (size_t)(sa.do_count ? f : 0) * h->n_clips;
-        sa.ctl_e = h->run_ctl + (size_t)(f > 0 ? f - 1 : 0) * h->n_clips;
-        sa.fidx_base = h->run_fidx;
-        sa.fidx_c = (uint32_t)f;
-        sa.ngroups = h->ngroups;
-        sa.cnt_c = h->pipe_cnt + sc * st_px;
-        sa.cnt_e = h->pipe_cnt + se * st_px;
-        sa.gmax_c = h->pipe_gmax + sc * st_g;
-        sa.gmax_e = h->pipe_gmax + se * st_g;
-        sa.tsold_e = h->pipe_tsold ? h->pipe_tsold + se * st_px : nullptr;
-        sa.dbg = (h->dbg && f == n_frames / 2) ? h->dbg : nullptr;
-        if (f == 0 && mark(ev_main, s)) return V2E_EHIP;
-        DISPATCH_FT(dtype, {
-            if (p->f64_state) k_step<double, FT><<<grid, BLOCK, 0, s>>>(a, sa);
-            else k_step<float, FT><<<grid, BLOCK, 0, s>>>(a, sa);
-        });
-        if (emit_ready(pl)) return V2E_EHIP; // batches whose frames are all final: emit them behind the chain
-    }
-    // two frames per launch (k_step2): launch L counts frames 2L and 2L+1, finalises 2L-1 exactly and validates 2L-2
-    const size_t sz_r = p->f64_state ? 8 : 4;
-    const int n_launch2 = (n_frames + 1) / 2 + 1;
-    for (int L = 0; K == 2 && L < (int)plan.size(); ++L) {
-        const PipeLaunch &pl = plan[L];
-        const int c0 = 2 * L, c1 = 2 * L + 1, e1 = pl.e1, e2 = pl.e1 - 1;
-        const bool has_c0 = pl.c0 >= 0, has_c1 = pl.c1 >= 0, has_e1 = pl.e1 >= 0, has_e2 = pl.e2 >= 0;
-        if (pl.wait_batch >= 0) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[pl.wait_batch], 0));
-        auto slot = [&](int f) { return (size_t)(((f % PIPE_D) + PIPE_D) % PIPE_D); };
-        auto clampf = [&](int f) { return (size_t)std::min(std::max(f, 0), n_frames - 1); };
-        Step2Args sa;
-        memset(&sa, 0, sizeof(sa));
-        sa.frame0 = has_c0 ? (const char *)frames + (size_t)c0 * h->n_clips * h->npx * esz : nullptr;
-        sa.frame1 = has_c1 ? (const char *)frames + (size_t)c1 * h->n_clips * h->npx * esz : nullptr;
-        sa.ctl_c0 = h->run_ctl + clampf(c0) * h->n_clips;
-        sa.ctl_c1 = h->run_ctl + clampf(c1) * h->n_clips;
-        sa.ctl_e1 = h->run_ctl + clampf(e1) * h->n_clips;
-        sa.ctl_e2 = h->run_ctl + clampf(e2) * h->n_clips;
-        sa.fidx_base = h->run_fidx;
-        sa.fidx_c0 = (uint32_t)c0; sa.fidx_c1 = (uint32_t)c1; sa.fidx_e1 = (uint32_t)std::max(e1, 0);
-        sa.has_e1 = has_e1; sa.has_e2 = has_e2; sa.ngroups = h->ngroups;
-        sa.cnt_e2 = h->pipe_cnt + slot(e2) * st_px; sa.cnt_e1 = h->pipe_cnt + slot(e1) * st_px;
-        sa.cnt_c0 = h->pipe_cnt + slot(c0) * st_px; sa.cnt_c1 = h->pipe_cnt + slot(c1) * st_px;
-        sa.gmax_e2 = h->pipe_gmax + slot(e2) * st_g; sa.gmax_e1 = h->pipe_gmax + slot(e1) * st_g;
-        sa.gmax_c0 = h->pipe_gmax + slot(c0) * st_g; sa.gmax_c1 = h->pipe_gmax + slot(c1) * st_g;
-        if (has_refr) {
-            sa.tsold_e2 = h->pipe_tsold + slot(e2) * st_px; sa.tsold_e1 = h->pipe_tsold + slot(e1) * st_px;
-            sa.bck_e2 = (const char *)h->pipe_bck + slot(e2) * st_px * sz_r; sa.lpn_e2 = (const char *)h->pipe_lpn + slot(e2) * st_px * sz_r;
-            sa.bck_c0 = (char *)h->pipe_bck + slot(c0) * st_px * sz_r; sa.lpn_c0 = (char *)h->pipe_lpn + slot(c0) * st_px * sz_r;
-        }
-        sa.bar = h->run_bar + (size_t)L * h->n_clips;
-        sa.rec_e1 = recs + clampf(e1) * h->n_clips;
-        sa.dbg = (h->dbg && L == n_launch2 / 2) ? h->dbg : nullptr;
-        if (L == 0 && mark(ev_main, s)) return V2E_EHIP;
-        DISPATCH_FT(dtype, {
-            if (p->f64_state) k_step2<double, FT><<<grid, BLOCK, 0, s>>>(a, sa);
-            else k_step2<float, FT><<<grid, BLOCK, 0, s>>>(a, sa);
-        });
-        if (emit_ready(pl)) return V2E_EHIP; // after this launch every frame <= e1 is final
-    }
-    if (mark(ev_main, s)) return V2E_EHIP;
-    V2E_HIP(hipStreamWaitEvent(s, h->ev_join[(n_frames - 1) / PIPE_E], 0)); // join: the run is complete on `s`
-    V2E_HIP(hipGetLastError());
-    return 0;
-}
 
 // ------------------------------------------------------------------ K frames per launch (emu_chain.h)
 static bool chain_small_grid(const v2e_emu *h) { return (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu; }
 
-static int chain_frames_per_launch(const v2e_emu *h, bool has_refr)
+// records built inside the chain (large grids) or by k_ahead (small grids); V2E_AMD_CHAIN_FUSED=0/1 overrides (dev / tests)
+static bool chain_fused_records(const v2e_emu *h, int dtype)
 {
-    // The launch boundary (~4 us) and the prologue are paid once per K frames; a redo (rule-on frame: ~1 % of the frames of
-    // the benchmark clip) repeats a whole launch.  Small grids (bounded by latency): 32 frames, records through LDS 8 frames
-    // = 32 KB at a time, so that two chain workgroups (64 KB) always fit a CU beside the parallel kernels, which are capped
-    // at 4 x 24 KB (the redo rendezvous needs every chain workgroup resident).  Large grids (bounded by throughput, records
-    // built in the chain): 32 frames (1280x720 noisy: 16 frames 6.24, 32 frames 6.49 Gev/s), 8 where a redo is possible.
-    int K = chain_small_grid(h) ? 32 : (has_refr ? 8 : 32);
-    if (const char *ev = getenv("V2E_AMD_CHAIN_K")) { const int v = atoi(ev); if (v >= 1 && v <= CHAIN_K_MAX) K = v; }
-    return K;
-}
-// records built inside the chain (large grids) or by k_ahead (small grids); V2E_AMD_CHAIN_FUSED=0/1 overrides (dev)
-static bool chain_fused_records(const v2e_emu *h) {
+    if (dtype != V2E_DT_U8) return true; // k_ahead's record path is instantiated for uint8 frames only
     const char *fe = getenv("V2E_AMD_CHAIN_FUSED"); // read per call: tests switch it per emulator instance
     const int fused_env = fe ? atoi(fe) : -1;
     return fused_env >= 0 ? fused_env != 0 : !chain_small_grid(h);
 }
 
-// workgroups of k_chain a CU holds (the redo rendezvous needs a clip's workgroups co-resident); the occupancy API can
-// over-report by one per CU (MI355X guide), hence the margin
-static int chain_blocks_per_cu(int K, bool fused)
+static size_t chain_dyn_lds(bool fused) { return fused ? 0 : (size_t)CHAIN_SUB * BLOCK * (sizeof(uint4) + sizeof(uint32_t)); }
+
+static const void *chain_fn(bool f64, int dtype, bool fused)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void *)k_chain<double, uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        hipFuncSetAttribute((const void *)k_chain<float, uint8_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        attr_set = true;
+    if (!fused) return f64 ? (const void *)k_chain<double, uint8_t, false> : (const void *)k_chain<float, uint8_t, false>;
+    switch (dtype) {
+    case V2E_DT_U8: return f64 ? (const void *)k_chain<double, uint8_t, true> : (const void *)k_chain<float, uint8_t, true>;
+    case V2E_DT_F32: return f64 ? (const void *)k_chain<double, float, true> : (const void *)k_chain<float, float, true>;
+    default: return f64 ? (const void *)k_chain<double, double, true> : (const void *)k_chain<float, double, true>;
     }
+}
+
+// workgroups of the k_chain instantiation that will run which a CU holds (the redo rendezvous needs a clip's workgroups
+// co-resident); the occupancy API can over-report by one per CU (MI355X guide), hence the margin.  Queried once per
+// (handle = device, instantiation).
+static int chain_blocks_per_cu(v2e_emu *h, bool f64, int dtype, bool fused)
+{
+    const int key = (f64 ? 1 : 0) | ((dtype & 3) << 1) | (fused ? 8 : 0);
+    if (h->occ_cache[key] >= 0) return h->occ_cache[key];
     int per_cu = 0;
-    hipError_t e;
-    if (fused) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<double, double, true>, BLOCK, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain<double, uint8_t, false>, BLOCK, (size_t)std::min(K, CHAIN_SUB) * BLOCK * sizeof(uint4));
-    if (e != hipSuccess) return 0;
-    if (per_cu <= 2) return per_cu; // LDS-bound counts are exact
-    return std::min(per_cu - 1, 6);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_fn(f64, dtype, fused), BLOCK, chain_dyn_lds(fused)) != hipSuccess) per_cu = 0;
+    if (per_cu > 2) per_cu = std::min(per_cu - 1, 6); // LDS-bound counts (<= 2) are exact
+    h->occ_cache[key] = per_cu;
+    return per_cu;
+}
+
+// Frames per chain launch.  The launch boundary (~4 us) and the prologue are paid once per K frames; a redo (rule-on frame:
+// ~1 % of the frames of the benchmark clip) repeats a launch from a checkpoint.  Small grids (bounded by latency) and large
+// grids without a refractory period: 32 (1280x720 noisy: 16 frames 6.24, 32 frames 6.49 Gev/s); large grids where a redo is
+// possible: 8.  A clip whose workgroups cannot all be resident cannot hold the redo rendezvous: one frame per launch, where
+// the one frame a redo fixes is the launch's last and nothing is left to verify (|128 asks for that too: clips on which the
+// rule is active on most frames would redo most launches).
+static int chain_frames_per_launch(const v2e_emu *h, bool has_refr, int use_graph, int max_blocks)
+{
+    int K = chain_small_grid(h) ? 32 : (has_refr ? 8 : 32);
+    if (const char *ev = getenv("V2E_AMD_CHAIN_K")) { const int v = atoi(ev); if (v >= 1 && v <= CHAIN_K_MAX) K = v; }
+    if (has_refr && ((use_graph & 128) || h->ngroups > max_blocks)) K = 1;
+    return K;
+}
+
+// The launch schedule of a run, as plain data (exported for the CPU tests): per chain launch the frames it advances
+// [f0, f0 + nf) and validates [pf0, pf0 + pnf), the emission batch whose completion frees the ring slots it overwrites,
+// the k_ahead batch it needs, the k_ahead batch enqueued behind it, the emission batch that is final once it is enqueued.
+struct ChainLaunch { int f0, nf, pf0, pnf, wait_join, wait_ahead, ahead_next, emit_batch; };
+
+static std::vector<ChainLaunch> chain_plan(int n_frames, int K, int E, int nD, bool has_refr, bool fused)
+{
+    const int m = E / K;
+    const int nB = (n_frames + K - 1) / K;           // chain launches with frames
+    const int nL = has_refr ? nB + 1 : nB;           // + the tail launch that validates the last K frames
+    const int nEB = (n_frames + E - 1) / E;          // batches of the parallel kernels
+    std::vector<ChainLaunch> plan;
+    for (int L = 0; L < nL; ++L) {
+        ChainLaunch c;
+        const bool tail = L >= nB;
+        c.f0 = tail ? n_frames : L * K;
+        c.nf = tail ? 0 : std::min((L + 1) * K, n_frames) - L * K;
+        c.pf0 = (L - 1) * K;
+        c.pnf = (has_refr && L > 0) ? std::min(L * K, n_frames) - (L - 1) * K : 0;
+        const bool first = !tail && L % m == 0; // first launch of batch L / m
+        c.wait_join = (first && L / m >= nD) ? L / m - nD : -1;
+        c.wait_ahead = (first && !fused) ? L / m : -1;
+        c.ahead_next = (first && !fused && L / m + 2 < nEB) ? L / m + 2 : -1;
+        const int fin = has_refr ? L - 1 : L; // what is final now: with a refractory period the launch just validated
+        c.emit_batch = (fin >= 0 && ((fin + 1) % m == 0 || fin == nB - 1)) ? fin / m : -1;
+        plan.push_back(c);
+    }
+    return plan;
 }
 
 // scratch of the chain pipeline: everything a captured run must not allocate
-static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
+static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_frames, int use_graph)
 {
     const bool has_refr = p->refractory_period_s > 0;
-    const int K = chain_frames_per_launch(h, has_refr);
+    const bool fused = chain_fused_records(h, dtype);
+    const int inst = (p->f64_state ? 1 : 0) | ((dtype & 3) << 1) | (fused ? 8 : 0);
+    const int max_blocks = chain_blocks_per_cu(h, p->f64_state != 0, dtype, fused) * h->n_cu;
+    const int K = chain_frames_per_launch(h, has_refr, use_graph, max_blocks);
     // frames per k_ahead launch and per emission batch: a multiple of K (measured at 346x260: K = 32 with batches of 32
-    // frames 4.86 us/frame, of 64 frames 5.18; K = 16 with 64: 5.27)
-    int m = 1;
+    // frames 4.86 us/frame, of 64 frames 5.18); small grids 32 frames, large ones max(K, 8) (their ring is what costs memory)
+    int m = std::max(1, (chain_small_grid(h) ? 32 : std::max(K, 8)) / K);
     if (const char *ev = getenv("V2E_AMD_CHAIN_M")) { const int v = atoi(ev); if (v >= 1 && v <= 64) m = v; }
     m = std::max(1, std::min(m, 64 / K)); // k_cemit sums a batch's per-frame event counts one frame per lane
     const int E = m * K;
-    if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap) {
-        hipFree(h->ch_cnt); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck); hipFree(h->ch_cf); hipFree(h->ch_cT);
-        hipFree(h->ch_ckbase); hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_gM); hipFree(h->ch_bar);
-        hipFree(h->ch_rec);
-        h->ch_rec = nullptr;
+    if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap || h->ch_fused != (int)fused) {
+        hipFree(h->ch_cnt); hipFree(h->ch_ruleM); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck);
+        hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase); hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_gM);
+        hipFree(h->ch_bar); hipFree(h->ch_rec); hipFree(h->ch_cdone);
+        h->ch_rec = nullptr; h->ch_cdone = nullptr; h->ch_ruleM = nullptr;
         h->ch_cnt = nullptr; h->ch_wmax = nullptr; h->ch_wtot = nullptr; h->ch_tsold = nullptr; h->ch_ck = nullptr; h->ch_cf = nullptr; h->ch_cT = nullptr;
         h->ch_ckbase = nullptr; h->ch_cperm = nullptr; h->ch_cpre = nullptr; h->ch_gM = nullptr; h->ch_bar = nullptr;
         h->ch_launch_cap = 0;
         h->ch_K = K;
         h->ch_E = E;
+        h->ch_fused = fused;
         // Ring of frame slots, nD batches deep.  Three is the minimum (batch b is read by its emission while the chain is in
         // batch b + 1 and k_ahead fills batch b + 2); the chain then waits for k_cemit(b - 3) at batch boundaries.  Deeper
         // rings (V2E_AMD_CHAIN_RING) let it run further ahead and measured SLOWER: 8.5 Gev/s with 3 batches, 7.3 with 5 or 7
@@ -1521,26 +1234,29 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
         h->ch_nkeys_cap = h->nkeys_cap;
         const size_t nc = (size_t)h->n_clips;
         V2E_HIP(hipMalloc(&h->ch_cnt, sizeof(uint32_t) * h->ch_D * nc * h->npx_pad));
-        V2E_HIP(hipMalloc(&h->ch_wmax, sizeof(uint16_t) * h->ch_D * nc * h->ch_nwp));
-        V2E_HIP(hipMemset(h->ch_wmax, 0, sizeof(uint16_t) * h->ch_D * nc * h->ch_nwp));
-        V2E_HIP(hipMalloc(&h->ch_wtot, (size_t)h->ch_D * nc * h->nkeys_cap * h->ch_nwp));
-        V2E_HIP(hipMemset(h->ch_wtot, 0, (size_t)h->ch_D * nc * h->nkeys_cap * h->ch_nwp));
-        V2E_HIP(hipMalloc(&h->ch_cf, 2 * sizeof(CFrame) * E * nc)); // two sets: k_cframe(b + 1) beside k_cemit(b)
+        V2E_HIP(hipMalloc(&h->ch_ruleM, sizeof(uint32_t) * h->ch_D * nc));
+        V2E_HIP(hipMemset(h->ch_ruleM, 0, sizeof(uint32_t) * h->ch_D * nc));
+        // two sets of emission tables: a batch's tables are rebuilt while nothing else reads them, alternating keeps the
+        // option of overlapping k_cframe(b + 1) with k_cemit(b)
+        V2E_HIP(hipMalloc(&h->ch_wmax, 2 * sizeof(uint16_t) * E * nc * h->ch_nwp));
+        V2E_HIP(hipMemset(h->ch_wmax, 0, 2 * sizeof(uint16_t) * E * nc * h->ch_nwp));
+        V2E_HIP(hipMalloc(&h->ch_wtot, (size_t)2 * E * nc * h->nkeys_cap * h->ch_nwp));
+        V2E_HIP(hipMemset(h->ch_wtot, 0, (size_t)2 * E * nc * h->nkeys_cap * h->ch_nwp));
+        V2E_HIP(hipMalloc(&h->ch_cf, 2 * sizeof(CFrame) * E * nc));
         V2E_HIP(hipMemset(h->ch_cf, 0, 2 * sizeof(CFrame) * E * nc));
-        hipFree(h->ch_cdone);
         V2E_HIP(hipMalloc(&h->ch_cdone, 2 * sizeof(unsigned) * E * nc));
         V2E_HIP(hipMemset(h->ch_cdone, 0, 2 * sizeof(unsigned) * E * nc));
-        V2E_HIP(hipMalloc(&h->ch_cT, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap)); // two sets: k_cframe(b + 1) beside k_cemit(b)
-        V2E_HIP(hipMalloc(&h->ch_ckbase, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap)); // two sets: k_cframe(b + 1) beside k_cemit(b)
-        V2E_HIP(hipMalloc(&h->ch_cperm, 2 * sizeof(uint32_t) * E * nc * h->max_iters * 8)); // two sets: k_cframe(b + 1) beside k_cemit(b)
-        V2E_HIP(hipMalloc(&h->ch_cpre, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp)); // two sets: k_cframe(b + 1) beside k_cemit(b)
-        V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
-        h->ch_max_blocks = chain_blocks_per_cu(K, chain_fused_records(h)) * h->n_cu;
+        V2E_HIP(hipMalloc(&h->ch_cT, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap));
+        V2E_HIP(hipMalloc(&h->ch_ckbase, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap));
+        V2E_HIP(hipMalloc(&h->ch_cperm, 2 * sizeof(uint32_t) * E * nc * h->max_iters * 8));
+        V2E_HIP(hipMalloc(&h->ch_cpre, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp));
+        if (!fused) V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
         h->drop_graphs();
     }
+    h->ch_max_blocks = max_blocks;
+    h->ch_inst = inst;
     const int n_launch = (n_frames + K - 1) / K + 1;
     if (!h->ahead) V2E_HIP(hipStreamCreateWithFlags(&h->ahead, hipStreamNonBlocking));
-    if (!h->tables) V2E_HIP(hipStreamCreateWithFlags(&h->tables, hipStreamNonBlocking));
     auto grow = [&](std::vector<hipEvent_t> &v, size_t n) -> int {
         while (v.size() < n) {
             hipEvent_t e;
@@ -1550,7 +1266,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
         return 0;
     };
     if (grow(h->ev_ahead, n_launch + 1) || grow(h->ev_chain, n_launch + 1) || grow(h->ev_fork, n_launch + 1) ||
-        grow(h->ev_join, n_launch + 1) || grow(h->ev_tables, n_launch + 1)) return V2E_EHIP;
+        grow(h->ev_join, n_launch + 1)) return V2E_EHIP;
     if (has_refr) {
         if (!h->ch_tsold) V2E_HIP(hipMalloc(&h->ch_tsold, sizeof(float) * (size_t)h->ch_D * h->n_clips * h->npx_pad));
         if (!h->ch_ck) V2E_HIP(hipMalloc(&h->ch_ck, (size_t)2 * 3 * 20 * h->n_clips * h->npx_pad)); // see ChainArgs::ckc_base
@@ -1574,17 +1290,12 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int n_frames)
     return 0;
 }
 
-// can this run go through k_chain?  (the redo path needs the grid co-resident for its rendezvous)
-static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p, int dtype, bool force)
+// can this run go through k_chain?  (otherwise: the count / rank / scan / emit kernels, one frame at a time)
+static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p, int dtype)
 {
     if (h->max_iters > CHAIN_MAX_ITERS) return false;
-    if (dtype == V2E_DT_F64 && p->log_input) return false; // k_ahead's records carry the lin-log value as float32
-    if (p->refractory_period_s > 0) {
-        // the redo rendezvous needs a clip's workgroups co-resident; and where only a few clips of a large multi-clip grid
-        // are, the clip loop inside the workgroup serialises them: k_main per frame is faster there (64 clips: 10.3 vs 8.9 Gev/s)
-        if ((long long)h->ngroups > (long long)chain_blocks_per_cu(chain_frames_per_launch(h, true), chain_fused_records(h)) * h->n_cu) return false;
-        if (!chain_small_grid(h) && !force) return false;
-    }
+    if (dtype == V2E_DT_F64 && p->log_input) return false; // the frame record carries the lin-log value as float32
+    if (p->photoreceptor_noise) return false;              // one more state plane and normal per pixel
     return true;
 }
 
@@ -1592,20 +1303,22 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
                              float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, std::vector<hipEvent_t> *ev_main = nullptr,
                              std::vector<hipEvent_t> *ev_side = nullptr)
 {
-    // Four streams: `s` the chain (k_chain, K frames per launch); h->ahead k_ahead, h->tables k_cframe, h->side k_cemit, the
-    // last three in batches of E = m K frames (batch b = frames [b E, (b + 1) E) = chain launches [b m, (b + 1) m)).
+    // Three streams: `s` the chain (k_chain, K frames per launch); h->ahead k_ahead; h->side k_ctot, k_cframe, k_cemit; the
+    // last two in batches of E = m K frames (batch b = frames [b E, (b + 1) E) = chain launches [b m, (b + 1) m)).
     //   k_ahead(b)  before chain launch b m; overwrites the records of batch b - nD, last read by launch (b - nD + 1) m (its redo)
-    //   k_cframe(b) once batch b is final: after the launch that validated its last K frames (or, without a refractory
-    //               period, after its last launch); k_cemit(b) after k_cframe(b)
+    //   emission(b) once batch b is final: after the launch that validated its last K frames (or, without a refractory
+    //               period, after its last launch)
     //   chain launch b m overwrites the ring slots of batch b - nD: after k_cemit(b - nD)   (nD = ch_D / E batches in the ring)
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
     const bool has_refr = p->refractory_period_s > 0;
     const int K = h->ch_K, E = h->ch_E, m = E / K, D = h->ch_D, NC = h->n_clips, nD = h->ch_nD;
-    const int nB = (n_frames + K - 1) / K;           // chain launches with frames
-    const int nL = has_refr ? nB + 1 : nB;           // + the tail launch that validates the last K frames
-    const int nEB = (n_frames + E - 1) / E;          // batches of the parallel kernels
+    const bool fused_rec = h->ch_fused != 0;
+    const std::vector<ChainLaunch> plan = chain_plan(n_frames, K, E, nD, has_refr, fused_rec);
+    const int nL = (int)plan.size();
+    const int nB = (n_frames + K - 1) / K;
+    const int nEB = (n_frames + E - 1) / E;
     V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * NC, s));
-    V2E_HIP(zero_async(h->pipe_off, sizeof(unsigned long long) * 2 * NC, s));
+    V2E_HIP(zero_async(h->run_off, sizeof(unsigned long long) * 2 * NC, s));
     if (has_refr) {
         V2E_HIP(zero_async(h->ch_gM, sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K, s));
         V2E_HIP(zero_async(h->ch_bar, sizeof(unsigned) * (size_t)nL * K * NC, s));
@@ -1619,40 +1332,36 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         return 0;
     };
     // clips resident at once: with a refractory period every workgroup of a clip must be resident for the redo rendezvous
+    // (K = 1 has no rendezvous: all clips at once)
     int gy = NC;
-    if (has_refr) gy = std::max(1, std::min(NC, h->ch_max_blocks / std::max(h->ngroups, 1)));
+    if (has_refr && K > 1) gy = std::max(1, std::min(NC, h->ch_max_blocks / std::max(h->ngroups, 1)));
     dim3 grid(h->ngroups, gy);
-    // large grids build the records inside the chain (no k_ahead, no record traffic): see k_chain
-    const bool fused_rec = chain_fused_records(h);
     static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
-    static const int par_lds_env = getenv("V2E_AMD_PAR_LDS") ? atoi(getenv("V2E_AMD_PAR_LDS")) : -1;
-    const int par_lds = par_lds_env >= 0 ? par_lds_env : 0; // dev: LDS reservation capping the parallel kernels' occupancy (measured: no gain)
     auto launch_emission = [&](int b) -> int { // fork event ev_fork[b] has been recorded on `s`
         CEmitArgs ea;
         memset(&ea, 0, sizeof(ea));
         ea.ctl = h->run_ctl; ea.recs = recs; ea.fidx_base = h->run_fidx;
         ea.f0 = b * E; ea.nE = std::min((b + 1) * E, n_frames) - ea.f0; ea.D = D; ea.n_clips = NC;
         ea.nwp = h->ch_nwp; ea.nwaves = h->ngroups * (BLOCK / WAVE); ea.E = E;
-        ea.cnt = h->ch_cnt; ea.wmax = h->ch_wmax; ea.wtot = h->ch_wtot; ea.tsold = has_refr ? h->ch_tsold : nullptr;
+        ea.cnt = h->ch_cnt; ea.tsold = has_refr ? h->ch_tsold : nullptr; ea.ruleM = has_refr ? h->ch_ruleM : nullptr;
         const size_t set = (size_t)(b & 1) * E * NC; // table set of this batch
+        ea.wmax = h->ch_wmax + set * h->ch_nwp; ea.wtot = h->ch_wtot + set * h->nkeys_cap * h->ch_nwp;
         ea.cf = h->ch_cf + set; ea.cT = h->ch_cT + set * h->nkeys_cap; ea.ckbase = h->ch_ckbase + set * h->nkeys_cap;
         ea.cperm = h->ch_cperm + set * h->max_iters * 8; ea.cpre = h->ch_cpre + set * h->nkeys_cap * h->ch_nwp;
         ea.cdone = h->ch_cdone + set;
         ea.events = (float4 *)events; ea.cap = cap;
-        ea.off_in = h->pipe_off + (size_t)(b & 1) * NC;
-        ea.off_out = h->pipe_off + (size_t)((b + 1) & 1) * NC;
-        // event records of k_cemit: 64 x ich per wave and pass.  The chain's workgroups need their LDS (4 KB per frame) on
+        ea.off_in = h->run_off + (size_t)(b & 1) * NC;
+        ea.off_out = h->run_off + (size_t)((b + 1) & 1) * NC;
+        // event records of k_cemit: 64 x ich per wave and pass.  The chain's workgroups need their LDS (5 KB per frame) on
         // every CU: 15 iterations per pass (most frames have fewer) keep an emission workgroup at 15 KB
         static const int ich_env = getenv("V2E_AMD_CEMIT_ICH") ? atoi(getenv("V2E_AMD_CEMIT_ICH")) : 0;
         ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 15;
         ea.capw = 64 * ea.ich;
-        // small grids: k_cemit and k_ahead reserve 24 KB of LDS per workgroup, i.e. at most four of them per CU beside the chain
-        const int REC_LDS = std::max(ea.capw * 4 * (BLOCK / WAVE), par_lds);
-        // (k_cframe on a stream of its own, beside k_cemit of the previous batch, crashed hipStreamEndCapture on ROCm 7.0:
-        // both stay on h->side, in order)
+        const int REC_LDS = ea.capw * 4 * (BLOCK / WAVE);
         V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
         if (mark(ev_side, h->side)) return V2E_EHIP;
         if (!no_emit) {
+            k_ctot<<<dim3(h->ngroups, NC, ea.nE), BLOCK, 0, h->side>>>(a, ea);
             // a key row of a small grid is a couple of steps of one wave: one workgroup per frame; of a large grid (1280x720:
             // 14 400 waves) a segmented scan by a workgroup of its own
             if (h->ch_nwp <= 4096) k_cframe1<<<dim3(1, NC, ea.nE), CFRAME_THREADS, 0, h->side>>>(a, ea);
@@ -1674,7 +1383,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         // frame pairs touched by the batch: at most nf / 2 + 1 (the device knows the run's first frame index, the host's
         // capture does not: one extra pair covers either alignment; threads of a pair outside the batch return)
         dim3 ga(h->ngroups, NC, aa.nf / 2 + 1);
-        DISPATCH_FT(dtype, { k_ahead<FT><<<ga, BLOCK, par_lds, h->ahead>>>(a, aa); });
+        k_ahead<uint8_t><<<ga, BLOCK, 0, h->ahead>>>(a, aa);
         V2E_HIP(hipEventRecord(h->ev_ahead[b], h->ahead));
         return 0;
     };
@@ -1688,16 +1397,15 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b)
         if (launch_ahead(b)) return V2E_EHIP;
     for (int L = 0; L < nL; ++L) {
-        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] chain launch %d / %d (nEB %d m %d)\n", L, nL, nEB, m);
-        const bool tail = L >= nB;
+        const ChainLaunch &pl = plan[L];
+        const bool tail = pl.nf == 0;
         ChainArgs ca;
         memset(&ca, 0, sizeof(ca));
         ca.frames = frames; ca.frame_stride = (unsigned long long)NC * h->npx * esz; ca.fidx_base = h->run_fidx;
         ca.ctl = h->run_ctl;
-        ca.f0 = tail ? n_frames : L * K; ca.nf = tail ? 0 : std::min((L + 1) * K, n_frames) - L * K;
-        ca.pf0 = (L - 1) * K; ca.pnf = (has_refr && L > 0) ? std::min(L * K, n_frames) - (L - 1) * K : 0;
-        ca.D = D; ca.n_clips = NC; ca.nwp = h->ch_nwp; ca.K = K; ca.ngroups = h->ngroups;
-        ca.cnt = h->ch_cnt; ca.wmax = h->ch_wmax; ca.wtot = h->ch_wtot; ca.tsold = has_refr ? h->ch_tsold : nullptr;
+        ca.f0 = pl.f0; ca.nf = pl.nf; ca.pf0 = pl.pf0; ca.pnf = pl.pnf;
+        ca.D = D; ca.n_clips = NC; ca.K = K; ca.ngroups = h->ngroups;
+        ca.cnt = h->ch_cnt; ca.ruleM = h->ch_ruleM; ca.tsold = has_refr ? h->ch_tsold : nullptr;
         ca.rec = h->ch_rec;
         if (has_refr) {
             ca.gM_cur = h->ch_gM + (size_t)L * (K + 1) * NC * K;
@@ -1725,11 +1433,8 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.recs = recs;
         ca.store_out = tail && in != 0;
         ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
-        if (!tail && L % m == 0) {
-            const int b = L / m;
-            if (b >= nD) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[b - nD], 0)); // ring slots of batch b: read by k_cemit(b - nD)
-            if (!fused_rec) V2E_HIP(hipStreamWaitEvent(s, h->ev_ahead[b], 0));
-        }
+        if (pl.wait_join >= 0) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[pl.wait_join], 0)); // ring slots: read by k_cemit of that batch
+        if (pl.wait_ahead >= 0) V2E_HIP(hipStreamWaitEvent(s, h->ev_ahead[pl.wait_ahead], 0));
         if (L == 0 && mark(ev_main, s)) return V2E_EHIP;
         if (fused_rec) {
             DISPATCH_FT(dtype, {
@@ -1737,24 +1442,15 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
                 else k_chain<float, FT, true><<<grid, BLOCK, 0, s>>>(a, ca);
             });
         } else {
-            const size_t rec_lds = (size_t)std::min(K, CHAIN_SUB) * BLOCK * sizeof(uint4);
-            if (p->f64_state) k_chain<double, uint8_t, false><<<grid, BLOCK, rec_lds, s>>>(a, ca);
-            else k_chain<float, uint8_t, false><<<grid, BLOCK, rec_lds, s>>>(a, ca);
+            const size_t lds = chain_dyn_lds(false);
+            if (p->f64_state) k_chain<double, uint8_t, false><<<grid, BLOCK, lds, s>>>(a, ca);
+            else k_chain<float, uint8_t, false><<<grid, BLOCK, lds, s>>>(a, ca);
         }
-        if (L % m == 0) {
-            V2E_HIP(hipEventRecord(h->ev_chain[L], s));
-            const int b = L / m;
-            if (!fused_rec && b + 2 < nEB && launch_ahead(b + 2)) return V2E_EHIP;
-        }
-        // what is final now: with a refractory period the frames up to launch L - 1's (just validated), without one up to L's
-        const int fin_launch = has_refr ? L - 1 : L;
-        if (fin_launch >= 0) {
-            const bool last = fin_launch == nB - 1;
-            if ((fin_launch + 1) % m == 0 || last) {
-                const int b = fin_launch / m;
-                V2E_HIP(hipEventRecord(h->ev_fork[b], s));
-                if (launch_emission(b)) return V2E_EHIP;
-            }
+        if (L % m == 0) V2E_HIP(hipEventRecord(h->ev_chain[L], s));
+        if (pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
+        if (pl.emit_batch >= 0) {
+            V2E_HIP(hipEventRecord(h->ev_fork[pl.emit_batch], s));
+            if (launch_emission(pl.emit_batch)) return V2E_EHIP;
         }
     }
     if (mark(ev_main, s)) return V2E_EHIP;
@@ -1771,9 +1467,8 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(p->rng_mode == V2E_RNG_PHILOX, "v2e_emu_run is the device-resident Philox path");
-    V2E_REQUIRE(!p->photoreceptor_noise || !(use_graph & (32 | 64 | 256)),
-                "photoreceptor noise runs on the count/rank/scan/emit pipeline (the other pipelines do not carry the noise plane)");
     V2E_REQUIRE(frames && t_prev && t_frame && events && recs_dev && n_frames > 0, "bad run args");
+    V2E_REQUIRE(dtype == V2E_DT_U8 || dtype == V2E_DT_F32 || dtype == V2E_DT_F64, "bad frame dtype");
     V2E_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (n_frames > h->run_cap) {
@@ -1783,8 +1478,6 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         h->run_cap = n_frames;
         V2E_HIP(hipMalloc(&h->run_ctl, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
         for (int q = 0; q < 2; ++q) V2E_HIP(hipHostMalloc(&h->run_ctl_host2[q], sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
-        if (h->run_bar) V2E_HIP(hipFree(h->run_bar));
-        V2E_HIP(hipMalloc(&h->run_bar, sizeof(unsigned) * (size_t)(h->run_cap + 1) * h->n_clips));
         h->drop_graphs();
     }
     // two pinned staging sets, each guarded by the event of the upload that last read it: the host prepares run n + 1
@@ -1802,61 +1495,24 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     V2E_HIP(hipEventRecord(h->ev_stage[sq], s));
     KArgs a = make_kargs(h, p);
     const int mode = use_graph & 3;          // 0 plain launches, 1 hipGraph, 2 instrumented
-    // 4-kernel count/rank/scan/emit pipeline: kept for A/B, and the one that carries the photoreceptor-noise plane
-    // (emulator.py:694-703: one more f64 state plane and one more Philox normal per pixel and frame)
-    const bool legacy = (use_graph & 16) != 0 || p->photoreceptor_noise != 0;
-    // Default: the k_step chain + deferred emission batches while a frame is a few workgroups per CU (the run is
-    // bounded by the per-frame launch latency, so only the dependency chain may be on it); one k_main launch per
-    // frame with emission on the chain once the grid is large enough to be throughput-bound (each pixel touched
-    // once).  |32 / |64 force the one or the other.
-    const bool small_grid = (long long)h->ngroups * h->n_clips <= 4ll * h->n_cu;
-    // K frames per launch with the state in registers (emu_chain.h) wherever it can run: |256 insists on it, |512 or any
-    // of the explicit pipeline bits (|16 |32 |64 |128) selects the earlier pipelines (kept for A/B and as the fallback)
-    const bool chain_ok = chain_eligible(h, p, dtype, (use_graph & 256) != 0);
-    V2E_REQUIRE(!(use_graph & 256) || chain_ok, "k_chain cannot run this configuration (max_iters or a grid too large for the redo rendezvous)");
-    const bool chain = chain_ok && !legacy && ((use_graph & 256) != 0 || (!(use_graph & (16 | 32 | 64 | 128 | 512)) && !getenv("V2E_AMD_NO_CHAIN")));
-    const bool fused = !legacy && !chain && ((use_graph & 32) != 0 || (!(use_graph & 64) && !small_grid));
-    const bool pipe = !legacy && !fused && !chain;
-    // Two frames per launch (k_step2, second frame finalised speculatively) needs the grid co-resident for the
-    // rare in-kernel rendezvous of its recovery path: grids of at most two workgroups per CU.  |128 forces one
-    // frame per launch (also what a caller should pick for clips on which the refractory rule is mostly active).
-    const int K = (pipe && h->pipe_E % 2 == 0 && (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu && !(use_graph & 128) &&
-                   !getenv("V2E_AMD_NO_SPECULATION")) ? 2 : 1;
+    // K frames per launch with the state in registers (emu_chain.h) wherever it can run: |256 insists on it; |16 selects the
+    // count / rank / scan / emit kernels one frame at a time (kept for A/B; also what carries the photoreceptor-noise plane,
+    // emulator.py:694-703, float64 log-encoded frames and more than CHAIN_MAX_ITERS events per pixel and frame)
+    const bool chain_ok = chain_eligible(h, p, dtype);
+    V2E_REQUIRE(!(use_graph & 256) || chain_ok, "k_chain cannot run this configuration (max_iters, photoreceptor noise or float64 log frames)");
+    const bool chain = chain_ok && ((use_graph & 256) != 0 || !(use_graph & 16));
+    const bool legacy = !chain;
     if (chain) {
-        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] chain_alloc n_frames=%d\n", n_frames);
-        rc = chain_alloc(h, p, n_frames);
-        if (getenv("V2E_AMD_TRACE")) fprintf(stderr, "[v2e] chain_alloc rc=%d K=%d E=%d D=%d\n", rc, h->ch_K, h->ch_E, h->ch_D);
+        rc = chain_alloc(h, p, dtype, n_frames, use_graph);
         if (rc) return rc;
     }
-    if (pipe) { // everything the capture must not allocate
-        if (p->refractory_period_s > 0 && !h->pipe_tsold)
-            V2E_HIP(hipMalloc(&h->pipe_tsold, sizeof(float) * (size_t)h->pipe_D * h->n_clips * h->npx_pad));
-        if (K == 2 && p->refractory_period_s > 0 && !h->pipe_bck) {
-            V2E_HIP(hipMalloc(&h->pipe_bck, sizeof(double) * (size_t)h->pipe_D * h->n_clips * h->npx_pad));
-            V2E_HIP(hipMalloc(&h->pipe_lpn, sizeof(double) * (size_t)h->pipe_D * h->n_clips * h->npx_pad));
-        }
-        const size_t nb = (size_t)(n_frames + h->pipe_E - 1) / h->pipe_E;
-        while (h->ev_fork.size() < nb) {
-            hipEvent_t e0, e1;
-            V2E_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-            V2E_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-            h->ev_fork.push_back(e0);
-            h->ev_join.push_back(e1);
-        }
+    h->last_kind = legacy ? 0 : (h->ch_fused ? 4 : 3);
+    h->last_fpl = chain ? h->ch_K : 1;
+    h->last_fpb = chain ? h->ch_E : 1;
+    if (mode == 0) {
+        if (legacy) return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, nullptr);
+        return enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s);
     }
-    h->last_kind = legacy ? 0 : (fused ? 2 : (chain ? (chain_fused_records(h) ? 4 : 3) : 1));
-    h->last_fpl = chain ? h->ch_K : (pipe ? K : 1);
-    h->last_fpb = chain ? h->ch_E : (pipe ? h->pipe_E : 1);
-    auto enqueue = [&](hipStream_t st, hipEvent_t *evs, int *nm) -> int {
-        if (legacy) {
-            if (nm) *nm = 4 * n_frames + 1;
-            return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs);
-        }
-        if (fused) return enqueue_run_fused(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, evs, nm);
-        if (chain) return enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st);
-        return enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, st, K);
-    };
-    if (mode == 0) return enqueue(s, nullptr, nullptr);
     if (mode == 2 && chain) { // instrumented: chain time from events on `s`, emission batches from events on the side stream
         std::vector<hipEvent_t> em, es;
         rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, &em, &es);
@@ -1878,46 +1534,22 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         for (hipEvent_t e : es) hipEventDestroy(e);
         return rc;
     }
-    if (mode == 2 && pipe) { // instrumented: step-chain time from events on `s`, emission batches from events on the side stream
-        std::vector<hipEvent_t> em, es;
-        rc = enqueue_run_pipe(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, K, &em, &es);
-        if (rc == 0) {
-            V2E_HIP(hipStreamSynchronize(s));
-            for (int k = 0; k < 4; ++k) h->prof_ms[k] = 0.0;
-            float ms = 0.f;
-            V2E_HIP(hipEventElapsedTime(&ms, em.front(), em.back()));
-            h->prof_ms[0] = ms; // n_frames + 1 k_step launches, or (n_frames + 1) / 2 + 1 k_step2 launches
-            h->prof_step_launches = K == 2 ? (n_frames + 1) / 2 + 1 : n_frames + 1;
-            for (size_t i = 0; i + 1 < es.size(); i += 2) {
-                V2E_HIP(hipEventElapsedTime(&ms, es[i], es[i + 1]));
-                h->prof_ms[3] += ms;
-            }
-            h->prof_launches = n_frames;
-            h->prof_emit_batches = (int)(es.size() / 2);
-        }
-        for (hipEvent_t e : em) hipEventDestroy(e);
-        for (hipEvent_t e : es) hipEventDestroy(e);
-        return rc;
-    }
-    if (mode == 2) { // instrumented: a hipEvent before every launch (bench.py roofline leg); blocking
+    if (mode == 2) { // instrumented: a hipEvent before every launch; blocking
         const int ne = 4 * n_frames + 4;
         std::vector<hipEvent_t> evs(ne);
         for (int i = 0; i < ne; ++i) V2E_HIP(hipEventCreate(&evs[i]));
-        int marks = 0;
-        rc = enqueue(s, evs.data(), &marks);
+        rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, evs.data());
         if (rc == 0) {
             V2E_HIP(hipStreamSynchronize(s));
             for (int k = 0; k < 4; ++k) h->prof_ms[k] = 0.0;
-            const bool refr = p->refractory_period_s > 0;
-            for (int i = 0; i < marks - 1; ++i) {
+            for (int i = 0; i < 4 * n_frames; ++i) {
                 float ms = 0.f;
                 V2E_HIP(hipEventElapsedTime(&ms, evs[i], evs[i + 1]));
-                int cls;
-                if (legacy) cls = i & 3;
-                else cls = (refr && marks > n_frames + 2) ? (i < 2 * n_frames ? (i & 1) : 0) : 0; // k_main / k_refr alternate
-                h->prof_ms[cls] += ms;
+                h->prof_ms[i & 3] += ms;
             }
             h->prof_launches = n_frames;
+            h->prof_emit_batches = 0;
+            h->prof_step_launches = n_frames;
         }
         for (int i = 0; i < ne; ++i) hipEventDestroy(evs[i]);
         return rc;
@@ -1929,10 +1561,12 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&a, sizeof(a)); push(&frames, sizeof(frames)); push(&dtype, sizeof(dtype)); push(&n_frames, sizeof(n_frames));
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
-    int lg = legacy ? 1 : (fused ? 2 : (chain ? 3 : 0)); push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
-    push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_E, sizeof(h->ch_E)); push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold)); push(&h->ch_ck, sizeof(h->ch_ck));
-    push(&h->pipe_tsold, sizeof(h->pipe_tsold)); push(&h->pipe_bck, sizeof(h->pipe_bck)); push(&K, sizeof(K));
-    int nis = getenv("V2E_AMD_NO_INKERNEL_SYNC") ? 1 : 0; push(&nis, sizeof(nis));
+    int lg = legacy ? 1 : 3; push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
+    if (chain) {
+        push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_E, sizeof(h->ch_E)); push(&h->ch_fused, sizeof(h->ch_fused)); push(&h->ch_nD, sizeof(h->ch_nD));
+        push(&h->ch_max_blocks, sizeof(h->ch_max_blocks));
+        push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold)); push(&h->ch_ck, sizeof(h->ch_ck)); push(&h->ch_cnt, sizeof(h->ch_cnt));
+    }
     hipGraphExec_t exec = nullptr;
     for (auto &cg : h->graphs)
         if (cg.key == key) { exec = cg.exec; cg.used = ++h->graph_clock; break; }
@@ -1946,7 +1580,8 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         hipStream_t cs;
         V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        rc = enqueue(cs, nullptr, nullptr);
+        if (legacy) rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs, nullptr);
+        else rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
         hipStreamDestroy(cs);
@@ -1960,7 +1595,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     return 0;
 }
 
-// dev tool (not part of the public header): enable / read back the in-kernel timeline of k_main
+// dev tool (not part of the public header): enable / read back the in-kernel timeline of one mid-run k_chain launch
 int v2e_emu_debug_timeline(v2e_emu *h, unsigned long long *out_host /* [ngroups][16] or NULL to enable */, int *ngroups)
 {
     V2E_REQUIRE(h, "null");
@@ -1986,16 +1621,18 @@ int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *
     return 0;
 }
 
-int v2e_emu_pipe_plan(int n_frames, int frames_per_batch, int frames_per_launch, int32_t *out, int cap)
+int v2e_emu_chain_plan(int n_frames, int frames_per_launch, int frames_per_batch, int ring_batches, int has_refractory,
+                       int fused_records, int32_t *out, int cap)
 {
-    V2E_REQUIRE(n_frames > 0 && frames_per_batch > 0 && (frames_per_launch == 1 || (frames_per_launch == 2 && frames_per_batch % 2 == 0)),
-                "bad plan arguments");
-    const std::vector<PipeLaunch> plan = pipe_plan(n_frames, frames_per_batch, frames_per_launch);
+    V2E_REQUIRE(n_frames > 0 && frames_per_launch >= 1 && frames_per_launch <= CHAIN_K_MAX && frames_per_batch >= frames_per_launch &&
+                frames_per_batch % frames_per_launch == 0 && ring_batches >= 3, "bad plan arguments");
+    const std::vector<ChainLaunch> plan = chain_plan(n_frames, frames_per_launch, frames_per_batch, ring_batches, has_refractory != 0,
+                                                     fused_records != 0);
     if (out) {
         V2E_REQUIRE(cap >= (int)plan.size(), "plan buffer too small");
         for (size_t i = 0; i < plan.size(); ++i) {
-            const PipeLaunch &p = plan[i];
-            const int32_t row[8] = {p.c0, p.c1, p.e1, p.e2, p.wait_batch, p.emit_first, p.emit_count, 0};
+            const ChainLaunch &c = plan[i];
+            const int32_t row[8] = {c.f0, c.nf, c.pf0, c.pnf, c.wait_join, c.wait_ahead, c.ahead_next, c.emit_batch};
             memcpy(out + 8 * i, row, sizeof(row));
         }
     }
@@ -2013,7 +1650,7 @@ int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_bat
 {
     V2E_REQUIRE(h && emit_batches && frames_per_batch, "null");
     *emit_batches = h->prof_emit_batches;
-    *frames_per_batch = h->last_kind >= 3 ? h->ch_E : h->pipe_E;
+    *frames_per_batch = h->last_fpb;
     if (step_launches) *step_launches = h->prof_step_launches;
     return 0;
 }

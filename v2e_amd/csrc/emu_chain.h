@@ -1,4 +1,4 @@
-// emu_chain.h -- K frames per chain launch, per-pixel state in registers (included by emu.hip after emu_pipe.h).
+// emu_chain.h -- the device-resident run: K frames per chain launch, per-pixel state in registers (included by emu.hip).
 //
 // The frame-to-frame dependency of the DVS pixel model is per pixel, except for ONE global number per frame: the
 // frame's max event count M, and only through the refractory rule (emulator.py:830: the rule is applied iff
@@ -10,21 +10,23 @@
 //   exact floor-division -> shot-noise decision -> count word to the frame's ring slot -> finalise (emulator.py:
 //   936-942) ASSUMING the rule is off -> next frame.  State goes back to HBM once per launch: the per-pixel state
 //   crosses HBM once per K frames, and a launch boundary (~4 us between dependent launches, longer than two
-//   frames of arithmetic) is paid once per K frames instead of once per frame (k_step) or two (k_step2).
+//   frames of arithmetic) is paid once per K frames.
 //
-//   What the event list needs beyond the count words is produced on the way, per WAVE (no workgroup barrier in the
-//   frame loop): the wave's max count and its (iteration, polarity) event totals (ballot/popcount), key-major u8
-//   rows [key][wave].  A prefix over waves (k_cframe) turns them into row offsets; k_cemit writes the rows, every
-//   wave on its own.  No per-workgroup totals pass (k_tot_multi), no second read of the count plane for it.
+//   The chain is a dependency chain of ~1.4 waves per SIMD at 346x260: every instruction in its frame loop is exposed
+//   latency.  So the loop holds ONLY what the pixel state needs; everything the event list needs beyond the count word --
+//   the per-wave max and (iteration, polarity) totals -- is recomputed from the count words by k_ctot on the emission
+//   stream, at full occupancy (round 2 had it in the chain: half of its instruction stream).
 //
-//   Speculation check: a wave whose max count reaches the frame's rule threshold (FrameCtl::refr_on_n, host-
-//   computed with the reference's own float64 predicate) publishes it with an atomicMax into the launch's gM row.
+//   Speculation check: a wave with a lane whose count reaches the frame's rule threshold (FrameCtl::refr_on_n, host-
+//   computed with the reference's own float64 predicate) publishes its max with an atomicMax into the launch's gM row.
 //   The NEXT launch reads that row first.  All zero (almost always): the previous launch was right.  Otherwise the
 //   first flagged frame j was a rule-on frame and M(j) = gM[j] is exact (everything before j was right), and the
 //   previous launch is REDONE from its own input state (state planes ping-pong between launches, so it is still
-//   there) with j finalised by the rule -- ts_mem as it was goes to the frame's tsold slot for the emission side,
-//   the wave totals are the filtered ones -- frames after j speculated again, published into the next gM row,
-//   one grid rendezvous (clip_barrier, co-resident grids only), and the check repeats on the frames after j.
+//   there) with j finalised by the rule -- ts_mem as it was goes to the frame's tsold slot for the emission side, M to
+//   its ruleM slot -- frames after j run under the previous pass's flagged maxima as predictions, published into the
+//   next gM row, one grid rendezvous (clip_barrier, co-resident grids only), and the check repeats on the frames after j.
+//   When j is the launch's last frame nothing is left to verify and there is no rendezvous: grids too large to be
+//   co-resident run with K = 1 and need none at all.
 //   lp_log_frame never depends on the speculation; everything is deterministic.
 //
 //   Clips (independent pixel arrays) beyond what is co-resident are walked by a loop inside the workgroup.
@@ -35,6 +37,84 @@ constexpr int CFRAME_THREADS = 1024;
 constexpr int CHAIN_SUB = 8; // frames whose records are in LDS at a time (4 KB per frame and workgroup)
 constexpr int CHAIN_MAX_ITERS = 1024; // k_cframe keeps one total per key in LDS
 
+// exact floor(a/b) for a >= 0, b > 0: equals c10::div_floor_floating (whose fmod / re-divide /
+// "+1 if frac > 0.5" steps exist to return exactly this) without the fmod loop.
+template <typename R> __device__ __forceinline__ R floor_div_pos(R a, R b)
+{
+    if (!(b > (R)0) || !(a >= (R)0)) return div_floor<R>(a, b); // generic path keeps every corner case
+    if (a < b) return (R)0;
+    R q = floor(a / b);
+    R r = fma(-q, b, a); // exactly rounded a - q*b: its sign is the true sign
+    if (r < (R)0) q -= (R)1;
+    else if (r >= b) q += (R)1;
+    return q;
+}
+
+// Grid-wide rendezvous of the `target` workgroups of one clip (MI355X guide, Guideline 16 hand-off
+// in its counter form): every wave drains its stores, one lane does the agent-scope release, the
+// relaxed arrive, a relaxed bounded poll, and the agent-scope acquire; __syncthreads() extends it
+// to the workgroup.  Requires every workgroup of the grid to be resident (checked by the host).
+__device__ __forceinline__ bool clip_barrier(unsigned *ctr, unsigned target)
+{
+    __shared__ int s_ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > 2000000u) { ok = 0; break; } // bounded: never hang the GPU
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// Timestamps and refractory switch of one frame once its max count n is known (block-uniform).
+// The per-n tables of the frame's FrameCtl are fetched one entry per lane BEFORE n is known
+// (FrameTab), then broadcast: no memory round trip and no float64 division after the reduction.
+struct FrameTab {
+    float start, step, end;
+    uint32_t refr_mask;
+    __device__ __forceinline__ FrameTab(const FrameCtl *c, int lane)
+        : start(c->ts_start[lane & 31]), step(c->ts_stepf[lane & 31]), end(c->ts_end), refr_mask(c->refr_mask) {}
+};
+
+__device__ __forceinline__ TsGen frame_tsgen(const KArgs &a, const FrameCtl *c, const FrameTab &ft, int n, bool &use_refr)
+{
+    if (n <= 32) {
+        use_refr = a.has_refr && ((ft.refr_mask >> (n - 1)) & 1u);
+        return TsGen(__uint_as_float(lane_value(__float_as_uint(ft.start), n - 1)), ft.end,
+                     __uint_as_float(lane_value(__float_as_uint(ft.step), n - 1)), n);
+    }
+    const double t_prev = c->t_prev, t_frame = c->t_frame;
+    use_refr = a.has_refr && a.refr > (t_frame - t_prev) / (double)n;
+    FrameCtl cc;
+    cc.t_prev = t_prev; cc.t_frame = t_frame;
+    return TsGen(cc, n, nullptr);
+}
+
+// Event rows written through to memory (system-scope buffer store): they are final output that nothing on the
+// device reads back, and as dirty L2 lines they would be written back by the release at the end of every chain
+// launch that happens to run meanwhile.
+typedef float v2e_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_event_wt(float4 *ev_clip, unsigned long long row, float t, float x, float y, float pol)
+{
+    if (row < 0x7000000ull) { // byte offset below 2^31
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)ev_clip, 0, 0x7fffffff, 0x00020000);
+        const v2e_f4 v = {t, x, y, pol};
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(row * 16ull), 0, 17); // sc0 sc1
+    } else {
+        ev_clip[row] = make_float4(t, x, y, pol);
+    }
+}
+
 struct ChainArgs {
     const void *frames;               // FUSED: frames of the run, frame f at frames + f * frame_stride (bytes)
     unsigned long long frame_stride;
@@ -42,10 +122,9 @@ struct ChainArgs {
     const FrameCtl *ctl;              // [n_frames][n_clips]
     int f0, nf;                       // this launch advances frames [f0, f0 + nf) of the run (nf = 0: tail launch)
     int pf0, pnf;                     // the previous launch's frames, to be validated (pnf = 0: nothing to validate)
-    int D, n_clips, nwp, K, ngroups;
+    int D, n_clips, K, ngroups;
     uint32_t *cnt;                    // [D][n_clips][npx_pad] count words, slot = frame % D
-    uint16_t *wmax;                   // [D][n_clips][nwp] per-wave max count
-    uint8_t *wtot;                    // [D][n_clips][nkeys_cap][nwp] per-wave key totals (<= 64 each)
+    uint32_t *ruleM;                  // [D][n_clips] M of a frame finalised by the refractory rule, 0 otherwise
     float *tsold;                     // [D][n_clips][npx_pad] ts_mem before a rule-on frame's update, or nullptr
     const uint4 *rec;                 // [D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
     uint32_t *gM_prev, *gM_cur;       // [K + 1][n_clips][K] rule-on maxima: row r = after r redo passes
@@ -71,14 +150,7 @@ struct ChainArgs {
 
 // Per-frame outputs of the chain are written through to memory: as dirty L2 lines they would all be written back by the
 // release at the end of the launch, on the critical path between two dependent launches.
-#ifndef V2E_CHAIN_WT
-#define V2E_CHAIN_WT 1
-#endif
-#if V2E_CHAIN_WT
 #define WT_STORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-#else
-#define WT_STORE(ptr, val) (*(ptr) = (val))
-#endif
 
 #define V2E_STAMP_C(i) do { if (ca.dbg && tid == 0) ca.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
 
@@ -198,22 +270,24 @@ template <typename R> __device__ __forceinline__ R floor_div_rcp(R a, R b, R rb)
 // FUSED = false: the frames' records come from k_ahead through LDS (small grids: the chain is one wave per SIMD and every
 // instruction in it is latency).  FUSED = true: the chain builds each record itself (large grids: the occupancy hides
 // latencies, and the records' 32 B per pixel and frame of extra HBM traffic would be what bounds the run).
+// Dynamic LDS (FUSED = false): [CHAIN_SUB][BLOCK] uint4 records + [CHAIN_SUB][BLOCK] count words.
 template <typename R, typename FT, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
 {
-    extern __shared__ uint4 s_arec[];         // [CHAIN_SUB][BLOCK] k_ahead's records of the frames in flight
-    __shared__ uint32_t s_exact[CHAIN_K_MAX]; // M of the previous launch's frames known to be rule-on (0: speculate)
-    __shared__ uint32_t s_mon[CHAIN_K_MAX];   // per frame of the pass: FrameCtl::refr_on_n
+    extern __shared__ uint4 s_arec[];         // [CHAIN_SUB][BLOCK] k_ahead's records of the frames in flight, then s_cw
     __shared__ float s_lutL[FUSED ? 256 : 1]; // FUSED: lin-log tables and the pass's frame scalars
     __shared__ double s_lutI[FUSED ? 256 : 1];
     __shared__ double s_dtau[FUSED ? CHAIN_K_MAX : 1], s_shot[FUSED ? CHAIN_K_MAX : 1];
     __shared__ float s_dtime[FUSED ? CHAIN_K_MAX : 1];
     constexpr bool U8 = sizeof(FT) == 1;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int g = blockIdx.x;
     const int p = g * BLOCK + tid;
     const bool valid = p < a.npx;
-    const int wave_g = g * (BLOCK / WAVE) + wave;
+    // the count words of a sub-pass wait in LDS and go out together behind it: vector memory operations retire in order
+    // and the counter covers stores too, so a store inside the frame loop would stand between the loop and the arrival
+    // of the next sub-pass's records
+    uint32_t *const s_cw = (uint32_t *)(s_arec + (size_t)CHAIN_SUB * BLOCK);
     __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
     V2E_STAMP_C(0);
     uint32_t fbase = 0u;
@@ -229,11 +303,9 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
     for (int clip = blockIdx.y; clip < ca.n_clips; clip += (int)gridDim.y) {
         if (clip != (int)blockIdx.y) __syncthreads(); // the LDS tables of the previous clip are no longer read
         const size_t sp = (size_t)clip * a.npx_pad + p;
-        // A pass's records go through LDS, CHAIN_SUB frames at a time, their loads in flight at once: vector memory
-        // operations retire in order, so a load issued inside the frame loop would wait for the write acknowledgements of
-        // the stores before it.  The next CHAIN_SUB frames' records are fetched into registers BEFORE the current ones are
-        // processed (older than those frames' stores) and moved to LDS after them.  Every thread reads back only what it
-        // wrote: no barrier.
+        // A pass's records go through LDS, CHAIN_SUB frames at a time, their loads in flight at once.  The next CHAIN_SUB
+        // frames' records are fetched into registers BEFORE the current ones are processed and moved to LDS after them.
+        // Every thread reads back only what it wrote: no barrier.
         auto stage = [&](const int fs, const int fn) __attribute__((always_inline)) { // the first CHAIN_SUB frames of a pass
             if (FUSED || !valid) return;
             uint4 t[CHAIN_SUB];
@@ -246,16 +318,14 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             for (int j = 0; j < CHAIN_SUB; ++j)
                 if (j < fn) s_arec[(size_t)j * BLOCK + tid] = t[j];
         };
-        auto fill_scalars = [&](const int fs, const int fn) __attribute__((always_inline)) {
+        auto fill_scalars = [&](const int fs, const int fn) __attribute__((always_inline)) { // FUSED: the pass's frame scalars
+            if (!FUSED) return;
             __syncthreads();
             if (tid < fn) {
                 const FrameCtl *c = ca.ctl + (size_t)(fs + tid) * ca.n_clips + clip;
-                s_mon[tid] = c->refr_on_n;
-                if (FUSED) {
-                    s_dtau[tid] = c->dt_over_tau;
-                    s_shot[tid] = c->shot_base;
-                    s_dtime[tid] = (float)(c->t_frame - c->t_prev);
-                }
+                s_dtau[tid] = c->dt_over_tau;
+                s_shot[tid] = c->shot_base;
+                s_dtime[tid] = (float)(c->t_frame - c->t_prev);
             }
             __syncthreads();
         };
@@ -265,53 +335,57 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
         float thp = 1.f, thn = 1.f;
         R b = (R)0, lp = (R)0;
         float tsm = 0.f;
+        const bool lp_state = a.has_cutoff || a.do_shot || ca.store_out; // lp_log_frame carried through the launch
         if (valid) {
             thp = a.pos_thres[sp];
             thn = a.neg_thres[sp];
             b = ((const R *)ca.base_in)[sp];
-            if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.lp_in)[sp];
+            if (lp_state) lp = ((const R *)ca.lp_in)[sp];
             if (a.has_refr) tsm = ca.ts_in[sp];
         }
         bool own = !(a.has_refr && ca.pnf > 0);
         uint32_t gM_v = 0u; // lane k: rule-on max of the previous launch's frame k as its own pass left it
         if (!own && lane < ca.pnf) gM_v = ca.gM_prev[(size_t)clip * ca.K + lane];
-        uint32_t mon_r = 0xFFFFFFFFu;
+        // lane k of every wave: the rule threshold (FrameCtl::refr_on_n) of frame k of this launch / of the previous one
+        uint32_t mon_own = 0xFFFFFFFFu, mon_prev = 0xFFFFFFFFu;
+        if (a.has_refr) {
+            if (lane < ca.nf) mon_own = ca.ctl[(size_t)(ca.f0 + lane) * ca.n_clips + clip].refr_on_n;
+            if (!own && lane < ca.pnf) mon_prev = ca.ctl[(size_t)(ca.pf0 + lane) * ca.n_clips + clip].refr_on_n;
+        }
         double dtau_r = 0.0, shot_r = 0.0;
         float dtime_r = 0.f, nr = 0.f;
-        if (tid < ca.nf) {
+        if (FUSED && tid < ca.nf) {
             const FrameCtl *c = ca.ctl + (size_t)(ca.f0 + tid) * ca.n_clips + clip;
-            mon_r = c->refr_on_n;
-            if (FUSED) {
-                dtau_r = c->dt_over_tau;
-                shot_r = c->shot_base;
-                dtime_r = (float)(c->t_frame - c->t_prev);
-            }
+            dtau_r = c->dt_over_tau;
+            shot_r = c->shot_base;
+            dtime_r = (float)(c->t_frame - c->t_prev);
         }
         if (FUSED && valid && a.do_leak) nr = a.noise_rate[sp];
         stage(ca.f0, ca.nf); // this launch's own frames (almost always the only pass)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(b), "+v"(lp), "+v"(tsm), "+v"(thp), "+v"(thn), "+v"(gM_v), "+v"(mon_r) : : "memory");
-        if (tid < CHAIN_K_MAX) {
-            s_exact[tid] = 0u;
-            s_mon[tid] = mon_r;
-            if (FUSED) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(b), "+v"(lp), "+v"(tsm), "+v"(thp), "+v"(thn), "+v"(gM_v), "+v"(mon_own), "+v"(mon_prev) : : "memory");
+        if (FUSED) {
+            if (tid < CHAIN_K_MAX) {
                 s_dtau[tid] = dtau_r;
                 s_shot[tid] = shot_r;
                 s_dtime[tid] = dtime_r;
             }
+            __syncthreads();
         }
-        __syncthreads();
         const float lk = a.leak_hz_f * nr;                                          // FUSED: emulator_utils.py:126
         const float ppre = a.scalar_thres ? a.pos_pre_scalar : a.pos_nom_f / thp;   // FUSED: emulator.py:475-478
         const float npre = a.scalar_thres ? a.neg_pre_scalar : a.neg_nom_f / thn;
         const R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;       // emulator_utils.py:154-157 divisors
         const R tnd = a.scalar_thres ? (R)a.neg_div : (R)thn;
-        const R rtp = (R)1 / tpd, rtn = (R)1 / tnd;
+        R rtp = (R)1 / tpd, rtn = (R)1 / tnd;
+        // (opaque to the optimiser: it would otherwise sink the two divisions into the frame loop, behind the select)
+        asm volatile("" : "+v"(rtp), "+v"(rtn));
         V2E_STAMP_C(1);
         // ---- passes: [redo of the previous launch]* then this launch's own frames
         bool redone = false;
         int round = 0, last_exact = -1;
-        uint32_t pred_v = 0u; // lane k: the M frame k was run under in the pass whose row is being checked
-        int c0 = 0;           // first frame of the pass (a redo pass may restart at a checkpoint)
+        uint32_t pred_v = 0u;  // lane k: the M frame k was run under in the pass whose row is being checked
+        uint32_t exact_v = 0u; // lane k: M of the previous launch's frame k in the coming redo pass (0: speculate)
+        int c0 = 0;            // first frame of the pass (a redo pass may restart at a checkpoint)
         for (;;) {
             int fs, fn;
             uint32_t *gM_dst;
@@ -331,9 +405,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 if (j < 0) {
                     own = true;
                 } else {
-                    __syncthreads();
-                    if (tid < CHAIN_K_MAX && tid > last_exact) s_exact[tid] = gM_v; // < j: verified, j: exact, > j: predictions
-                    __syncthreads();
+                    if (lane > last_exact) exact_v = gM_v; // < j: verified, j: exact, > j: predictions
                     pred_v = lane > j ? gM_v : 0u;
                     last_exact = j;
                     ++round;
@@ -344,12 +416,12 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     if (valid) {
                         if (c0 == 0) { // the previous launch's input state
                             b = ((const R *)ca.base_pin)[sp];
-                            if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.lp_pin)[sp];
+                            if (lp_state) lp = ((const R *)ca.lp_pin)[sp];
                             tsm = ca.ts_pin[sp];
                         } else {
                             const size_t cs = ((size_t)(c0 / CHAIN_SUB - 1) * ca.n_clips + clip) * a.npx_pad + p;
                             b = ((const R *)ca.ckp_base)[cs];
-                            if (a.has_cutoff || a.do_shot) lp = ((const R *)ca.ckp_lp)[cs];
+                            if (lp_state) lp = ((const R *)ca.ckp_lp)[cs];
                             tsm = ca.ckp_ts[cs];
                         }
                     }
@@ -362,6 +434,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 fill_scalars(fs, fn);
                 stage(fs + c0, fn - c0);
             }
+            const uint32_t mon_v = own ? mon_own : mon_prev;
             // checkpoints of this pass go to the set of the launch whose frames it runs
             void *const ck_base = own ? ca.ckc_base : ca.ckp_base;
             void *const ck_lp = own ? ca.ckc_lp : ca.ckp_lp;
@@ -369,14 +442,13 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             if (own) V2E_STAMP_C(2);
             float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f; // FUSED: the draws of the current frame pair
             bool have_pair = false;
-            auto frame_body = [&](const int k) __attribute__((always_inline)) {
+            int slot = 0; // ring slot of the frame in hand: (fs + k) % D, advanced without a division per frame
+            auto frame_body = [&](const int k, const uint4 rc_in) __attribute__((always_inline)) {
                 const int f = fs + k;
-                const int slot = f % ca.D;
-                const FrameCtl *c = ca.ctl + (size_t)f * ca.n_clips + clip; // rule-on frames only (timestamp tables)
-                const uint32_t Mon = s_mon[k];
-                const uint32_t exM = own ? 0u : s_exact[k];
-                // k_ahead's record: eps (+ shot decisions in its two free bits), lin-log value, leak step
-                uint4 rc;
+                const uint32_t Mon = (uint32_t)__builtin_amdgcn_readlane((int)mon_v, k);
+                const uint32_t exM = own ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)exact_v, k);
+                // the frame's record: eps (+ shot decisions in its two free bits), lin-log value, leak step
+                uint4 rc = rc_in;
                 if (FUSED) {
                     FT px = (FT)0;
                     if (valid) px = ((const FT *)((const char *)ca.frames + (size_t)f * ca.frame_stride))[(size_t)clip * a.npx + p];
@@ -389,8 +461,6 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     const bool even = v2e_frame_half(gf) != 0u;
                     rc = make_frame_record<FT>(a, px, s_lutL, s_lutI, s_dtau[k], s_shot[k], s_dtime[k], lk, thp, ppre, npre,
                                                even ? r_even : r_odd, even ? u_even : u_odd);
-                } else {
-                    rc = s_arec[(size_t)(k % CHAIN_SUB) * BLOCK + tid];
                 }
                 const double eps = __longlong_as_double((long long)(((unsigned long long)(rc.y & 0x3FFFFFFFu) << 32) | rc.x));
                 const double L = (double)__uint_as_float(rc.z);
@@ -408,78 +478,39 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 uint32_t cw = mag > 0 ? (((uint32_t)mag & CNT_MASK) | (neg ? CNT_NEG : 0u)) : 0u;
                 if (a.do_shot) cw |= (rc.y >> 30) << 25; // CNT_SHOT_ON / CNT_SHOT_OFF
                 if (!valid) cw = 0u;
-                if (valid) WT_STORE(&ca.cnt[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p], cw);
-                const int magv = valid ? mag : 0;
-                const int wm = wave_max_i32(magv);
-                if (lane == 0) {
-                    WT_STORE(&ca.wmax[((size_t)slot * ca.n_clips + clip) * ca.nwp + wave_g], (uint16_t)min(wm, 65535));
-                    // speculation check: only a wave that reaches the rule threshold says so
-                    if (a.has_refr && k > (own ? -1 : last_exact) && (uint32_t)wm >= Mon) atomicMax(gM_dst + k, (uint32_t)wm);
+                if (FUSED) {
+                    if (valid) WT_STORE(&ca.cnt[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p], cw);
+                } else {
+                    s_cw[(size_t)(k % CHAIN_SUB) * BLOCK + tid] = cw;
                 }
-                // ---- finalise (emulator.py:830-842, 936-942) -- by the refractory rule where M is known to switch it on --
-                // and, in the same walk over the wave's iterations, this wave's (iteration, polarity) totals:
-                // key 0/1 shot ON/OFF, key 2+2i / 3+2i iteration i ON/OFF (after the rule).  The rule-on walk is its own
-                // copy of the loop: nothing it loads (timestamp tables) may be live in the common path, or the common
-                // path inherits a wait for every outstanding store.
+                const int magv = valid ? mag : 0;
+                // speculation check: only a wave with a lane that reaches the rule threshold says so
+                if (a.has_refr && k > (own ? -1 : last_exact) && __ballot((uint32_t)magv >= Mon) != 0ull) {
+                    const int wm = wave_max_i32(magv);
+                    if (lane == 0) atomicMax(gM_dst + k, (uint32_t)wm);
+                }
+                // ---- finalise (emulator.py:830-842, 936-942) -- by the refractory rule where M is known to switch it on.
+                // The rule-on walk is its own branch: nothing it loads (timestamp tables) may be live in the common path,
+                // or the common path inherits a wait for every outstanding store.
                 int fcount = magv;
-                uint8_t *trow = ca.wtot + (((size_t)slot * ca.n_clips + clip) * a.nkeys_cap) * ca.nwp + wave_g;
-                const int wmc = min(wm, a.max_iters); // beyond max_iters the frame is flagged and not emitted
-                const int nkw = 2 + 2 * wmc;
-                const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
-                const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
-                bool ruled = false;
+                uint32_t rule_m = 0u;
                 if (exM != 0u) {
+                    const FrameCtl *c = ca.ctl + (size_t)f * ca.n_clips + clip;
                     const FrameTab ftb(c, lane);
+                    bool ruled = false;
                     const TsGen tg = frame_tsgen(a, c, ftb, (int)exM, ruled);
                     if (ruled) {
+                        rule_m = exM;
                         if (valid) ca.tsold[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p] = tsm; // ts_mem as it was
                         fcount = 0;
-                        for (int kb = 0; kb < nkw; kb += WAVE) {
-                            uint32_t mine = 0;
-                            const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
-                            const int i_hi = min((kb + WAVE - 2) / 2, wmc);
-                            for (int i = i_lo; i < i_hi; ++i) {
-                                bool pass = magv > i;
-                                if (pass) {
-                                    const float t = tg(i);
-                                    const float pt = 1.0f * t - tsm;
-                                    pass = pt > a.refr_f;
-                                    if (pass) { tsm = t; ++fcount; }
-                                }
-                                const unsigned long long bo = __ballot(pass && !neg);
-                                const unsigned long long bf = __ballot(pass && neg);
-                                const int kl = 2 + 2 * i - kb;
-                                if (lane == kl) mine = (uint32_t)__popcll(bo);
-                                if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
-                            }
-                            if (kb == 0) {
-                                if (lane == 0) mine = (uint32_t)__popcll(so);
-                                if (lane == 1) mine = (uint32_t)__popcll(sf);
-                            }
-                            if (kb + lane < nkw) WT_STORE(&trow[(size_t)(kb + lane) * ca.nwp], (uint8_t)mine);
+                        for (int i = 0; i < magv; ++i) { // emulator.py:836-842, this pixel's iterations
+                            const float t = tg(i);
+                            const float pt = 1.0f * t - tsm;
+                            if (pt > a.refr_f) { tsm = t; ++fcount; }
                         }
                     }
                 }
-                if (!ruled) {
-                    for (int kb = 0; kb < nkw; kb += WAVE) {
-                        uint32_t mine = 0;
-                        const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
-                        const int i_hi = min((kb + WAVE - 2) / 2, wmc);
-                        for (int i = i_lo; i < i_hi; ++i) {
-                            const bool pass = magv > i;
-                            const unsigned long long bo = __ballot(pass && !neg);
-                            const unsigned long long bf = __ballot(pass && neg);
-                            const int kl = 2 + 2 * i - kb;
-                            if (lane == kl) mine = (uint32_t)__popcll(bo);
-                            if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
-                        }
-                        if (kb == 0) {
-                            if (lane == 0) mine = (uint32_t)__popcll(so);
-                            if (lane == 1) mine = (uint32_t)__popcll(sf);
-                        }
-                        if (kb + lane < nkw) WT_STORE(&trow[(size_t)(kb + lane) * ca.nwp], (uint8_t)mine);
-                    }
-                }
+                if (a.has_refr && g == 0 && tid == 0) WT_STORE(&ca.ruleM[(size_t)slot * ca.n_clips + clip], rule_m);
                 if (valid) {
                     const bool shot = (cw & (CNT_SHOT_ON | CNT_SHOT_OFF)) != 0u;
                     if (fcount > 0 || shot) {
@@ -491,13 +522,14 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     }
                 }
                 lp = lpn;
+                if (++slot == ca.D) slot = 0;
                 if (own && k < 12) V2E_STAMP_C(3 + k);
             };
             for (int k0 = c0; k0 < fn; k0 += CHAIN_SUB) {
                 if (ck_base && k0 > c0 && valid) { // state before frame k0
                     const size_t cs = ((size_t)(k0 / CHAIN_SUB - 1) * ca.n_clips + clip) * a.npx_pad + p;
                     ((R *)ck_base)[cs] = b;
-                    if (a.has_cutoff || a.do_shot) ((R *)ck_lp)[cs] = lp;
+                    if (lp_state) ((R *)ck_lp)[cs] = lp;
                     ck_ts[cs] = tsm;
                 }
                 uint4 nx[CHAIN_SUB];
@@ -510,11 +542,26 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int kend = min(k0 + CHAIN_SUB, fn);
-                for (int k = k0; k < kend; ++k) frame_body(k);
+                const int slot0 = (fs + k0) % ca.D;
+                slot = slot0;
+                // the record of frame k + 1 is read from LDS while frame k computes
+                uint4 rc_cur = make_uint4(0u, 0u, 0u, 0u);
+                if (!FUSED) rc_cur = s_arec[(size_t)(k0 % CHAIN_SUB) * BLOCK + tid];
+                for (int k = k0; k < kend; ++k) {
+                    uint4 rc_nxt = make_uint4(0u, 0u, 0u, 0u);
+                    if (!FUSED && k + 1 < kend) rc_nxt = s_arec[(size_t)((k + 1) % CHAIN_SUB) * BLOCK + tid];
+                    frame_body(k, rc_cur);
+                    rc_cur = rc_nxt;
+                }
                 if (!FUSED && valid) {
 #pragma unroll
                     for (int j = 0; j < CHAIN_SUB; ++j)
                         if (j < nnext) s_arec[(size_t)j * BLOCK + tid] = nx[j];
+                    int sl = slot0;
+                    for (int k = k0; k < kend; ++k) { // the sub-pass's count words, behind the arrival of the next records
+                        WT_STORE(&ca.cnt[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p], s_cw[(size_t)(k % CHAIN_SUB) * BLOCK + tid]);
+                        if (++sl == ca.D) sl = 0;
+                    }
                 }
             }
             if (own) break;
@@ -522,9 +569,10 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             // workgroup of the clip publish before the check is repeated
             if (valid) {
                 ((R *)ca.base_fix)[sp] = b;
-                if (a.has_cutoff || a.do_shot) ((R *)ca.lp_fix)[sp] = lp;
+                if (lp_state) ((R *)ca.lp_fix)[sp] = lp;
                 ca.ts_fix[sp] = tsm;
             }
+            if (last_exact >= ca.pnf - 1) continue; // the fixed frame was the launch's last: nothing left to verify, no rendezvous
             // (not at raised priority: a spinning wave that outranks the other kernels' waves on its SIMD keeps them from
             // finishing, and the workgroups this one waits for may need their slots)
             __builtin_amdgcn_s_setprio(0);
@@ -534,7 +582,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
         }
         if (valid && (ca.nf > 0 || ca.store_out || redone)) {
             ((R *)ca.base_out)[sp] = b;
-            if (ca.nf > 0 || a.has_cutoff || a.do_shot) ((R *)ca.lp_out)[sp] = lp;
+            if (ca.nf > 0 || lp_state) ((R *)ca.lp_out)[sp] = lp;
             if (a.has_refr) ca.ts_out[sp] = tsm;
         }
         V2E_STAMP_C(15);
@@ -553,8 +601,9 @@ struct CEmitArgs {
     const uint32_t *fidx_base;
     int f0, nE, D, n_clips, nwp, nwaves, E;
     const uint32_t *cnt;
-    const uint16_t *wmax;
-    const uint8_t *wtot;
+    const uint32_t *ruleM; // [D][n_clips] (refractory runs) or nullptr
+    uint16_t *wmax;      // [E][n_clips][nwp] per-wave max count (k_ctot)
+    uint8_t *wtot;       // [E][n_clips][nkeys_cap][nwp] per-wave key totals, <= 64 each (k_ctot)
     const float *tsold;
     CFrame *cf;          // [E][n_clips]
     uint32_t *cT;        // [E][n_clips][nkeys_cap] events per key over all waves
@@ -569,6 +618,64 @@ struct CEmitArgs {
     int capw, ich; // event records per wave in LDS; iterations per pass of k_cemit (64 * ich <= capw, 2 * ich <= 62)
 };
 
+// What the event list needs from a frame's count words beyond the words themselves, per WAVE (every wave on its own, no
+// workgroup barrier): the wave's max count and its (iteration, polarity) event totals (ballot / popcount) as key-major u8
+// rows [key][wave]: key 0/1 shot ON/OFF, key 2+2i / 3+2i iteration i ON/OFF -- after the refractory filter on the frames
+// the chain finalised by the rule (ruleM != 0: the recurrence against ts_mem as it was, emulator.py:836-842).  A prefix
+// over waves (k_cframe) turns them into row offsets; k_cemit writes the rows.
+__global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
+{
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int wave_g = g * (BLOCK / WAVE) + wave;
+    const int p = g * BLOCK + tid;
+    const bool valid = p < a.npx;
+    const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
+    const size_t zc = (size_t)z * ea.n_clips + clip;
+    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
+    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
+    const uint32_t rM_v = ea.ruleM ? ea.ruleM[(size_t)slot * ea.n_clips + clip] : 0u;
+    const FrameTab ftb(c, lane);
+    float tsm = (valid && ea.tsold) ? ea.tsold[sp] : 0.f; // meaningful on rule-on frames only
+    const uint32_t rM = (uint32_t)__builtin_amdgcn_readfirstlane((int)rM_v);
+    const int magv = (int)(cw & CNT_MASK);
+    const bool neg = (cw & CNT_NEG) != 0;
+    const int wm = wave_max_i32(magv);
+    if (lane == 0) ea.wmax[zc * ea.nwp + wave_g] = (uint16_t)min(wm, 65535);
+    uint8_t *trow = ea.wtot + (zc * a.nkeys_cap) * ea.nwp + wave_g;
+    const int wmc = min(wm, a.max_iters); // beyond max_iters the frame is flagged and not emitted
+    const int nkw = 2 + 2 * wmc;
+    const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
+    const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+    bool ruled = false;
+    TsGen tg(0.f, 0.f, 0.f, 1);
+    if (rM != 0u) tg = frame_tsgen(a, c, ftb, (int)rM, ruled);
+    for (int kb = 0; kb < nkw; kb += WAVE) {
+        uint32_t mine = 0;
+        const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
+        const int i_hi = min((kb + WAVE - 2) / 2, wmc);
+        for (int i = i_lo; i < i_hi; ++i) {
+            bool pass = magv > i;
+            if (ruled && pass) {
+                const float t = tg(i);
+                const float pt = 1.0f * t - tsm;
+                pass = pt > a.refr_f;
+                if (pass) tsm = t;
+            }
+            const unsigned long long bo = __ballot(pass && !neg);
+            const unsigned long long bf = __ballot(pass && neg);
+            const int kl = 2 + 2 * i - kb;
+            if (lane == kl) mine = (uint32_t)__popcll(bo);
+            if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+        }
+        if (kb == 0) {
+            if (lane == 0) mine = (uint32_t)__popcll(so);
+            if (lane == 1) mine = (uint32_t)__popcll(sf);
+        }
+        if (kb + lane < nkw) trow[(size_t)(kb + lane) * ea.nwp] = (uint8_t)mine;
+    }
+}
+
 // Small grids (a key row is a couple of steps of one wave): one workgroup per (frame, clip), one wave per key row.
 __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe1(KArgs a, CEmitArgs ea)
 {
@@ -576,8 +683,8 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe1(KArgs a, CEmitArgs e
     __shared__ uint32_t s_T[2 * CHAIN_MAX_ITERS + 2];
     constexpr int NW = CFRAME_THREADS / WAVE; // one wave per key row: 16 rows at a time (a frame has 2 + 2 M of them)
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
-    const uint16_t *wm = ea.wmax + ((size_t)slot * ea.n_clips + clip) * ea.nwp;
+    const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z;
+    const uint16_t *wm = ea.wmax + ((size_t)z * ea.n_clips + clip) * ea.nwp;
     int m = 0;
     for (int k = tid; k < ea.nwaves; k += CFRAME_THREADS) m = max(m, (int)wm[k]);
     m = wave_max_i32(m);
@@ -598,7 +705,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe1(KArgs a, CEmitArgs e
         return;
     }
     const int nk = 2 + 2 * M;
-    const uint8_t *tot = ea.wtot + ((size_t)slot * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
+    const uint8_t *tot = ea.wtot + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
     uint32_t *pre = ea.cpre + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
     for (int k = wave; k < nk; k += NW) { // one wave per key row, 16 waves' totals per lane and step
         uint32_t carry = 0;
@@ -615,7 +722,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe1(KArgs a, CEmitArgs e
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                    // a wave writes only the rows of its own iterations; above them the slot holds an older frame's bytes
+                    // a wave writes only the rows of its own iterations; above them the table holds an older frame's bytes
                     v[j] = (uint32_t)k < 2u + 2u * wmj ? ((tw[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 0u;
                 }
             }
@@ -692,9 +799,9 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
     __shared__ uint32_t s_T[2 * CHAIN_MAX_ITERS + 2];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int r0 = blockIdx.x, clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int r0 = blockIdx.x, clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z;
     const size_t zc = (size_t)z * ea.n_clips + clip;
-    const uint16_t *wm = ea.wmax + ((size_t)slot * ea.n_clips + clip) * ea.nwp;
+    const uint16_t *wm = ea.wmax + ((size_t)z * ea.n_clips + clip) * ea.nwp;
     int m = 0;
     for (int k = tid; k < ea.nwaves; k += CFRAME_THREADS) m = max(m, (int)wm[k]);
     m = wave_max_i32(m);
@@ -708,7 +815,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
     v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips + clip;
     const bool discard = M > a.max_iters; // the frame is not emitted; the caller sees the flag
     const int nk = discard ? 0 : 2 + 2 * M;
-    const uint8_t *tot = ea.wtot + ((size_t)slot * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
+    const uint8_t *tot = ea.wtot + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
     uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp;
     uint32_t *cT = ea.cT + zc * a.nkeys_cap;
     // this workgroup's row(s): r0, and for the last row workgroup every row beyond the grid
@@ -727,7 +834,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                    // a wave writes only the rows of its own iterations; above them the slot holds an older frame's bytes
+                    // a wave writes only the rows of its own iterations; above them the table holds an older frame's bytes
                     lane_tot += (uint32_t)k < 2u + 2u * wmj ? ((tw[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 0u;
                 }
             }
@@ -867,7 +974,7 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
     const int M_v = cf->M;
     const uint32_t nsig_v = cf->n_signal, nev_v = cf->n_events, disc_v = cf->discarded;
     const uint32_t cw = valid ? ea.cnt[sp] : 0u;
-    const int wm_v = (int)ea.wmax[((size_t)slot * ea.n_clips + clip) * ea.nwp + wave_g];
+    const int wm_v = (int)ea.wmax[zc * ea.nwp + wave_g];
     const FrameTab ftb(c, lane);
     float tsm = (valid && a.has_refr && ea.tsold) ? ea.tsold[sp] : 0.f; // meaningful on rule-on frames only
     uint32_t T_0 = 0, kbase_0 = 0, P_0 = 0;

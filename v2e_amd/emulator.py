@@ -666,7 +666,7 @@ class EventEmulator(object):
         recs = eng.alloc_recs(nrun, which)
         ug = int(use_graph)
         if getattr(self, "_refr_mostly_on", False):
-            ug |= 128  # one frame per launch: the speculating chains would repair their speculation on most launches
+            ug |= 128  # one frame per launch: the speculating chain would redo most of its launches
         eng.run(P, frames_dev[start:], t_prev, t_frames[start:], self.frame_counter, ev, recs, use_graph=ug)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(eng.device))
@@ -687,8 +687,8 @@ class EventEmulator(object):
             err = ("a pixel produced more than max_iters=%d events in one frame; construct with a larger max_iters"
                    % eng.max_iters)
         elif (r["flags"] & _capi.FLAG_SYNC_TIMEOUT).any():
-            err = ("in-kernel workgroup rendezvous timed out (GPU oversubscribed?); "
-                   "set V2E_AMD_NO_INKERNEL_SYNC=1 to use the two-launch pipeline")
+            err = ("in-kernel workgroup rendezvous of a redo pass timed out (GPU shared with another process?); "
+                   "use_graph | 128 runs one frame per launch, which needs none")
         elif (r["flags"] & _capi.FLAG_EVENTS_DROPPED).any():
             err = "event buffer capacity %d exceeded (needed %d); pass a larger cap" % (
                 pend.ev.shape[1], int(r["n_events"].sum()))

@@ -207,7 +207,7 @@ class EmuEngine:
         """(kind, frames per chain launch, frames per emission batch) of the last run(); see v2e_emu_last_pipeline."""
         k, a, b = C.c_int(), C.c_int(), C.c_int()
         check(self.lib.v2e_emu_last_pipeline(self._h, C.byref(k), C.byref(a), C.byref(b)), "v2e_emu_last_pipeline")
-        names = {0: "k_count/k_rank/k_scan/k_emit", 1: "k_step", 2: "k_main", 3: "k_chain", 4: "k_chain(fused records)"}
+        names = {0: "k_count/k_rank/k_scan/k_emit", 3: "k_chain", 4: "k_chain(fused records)"}
         return names.get(k.value, "?"), a.value, b.value
 
     def alloc_recs(self, n_frames, which=0):
