@@ -8,7 +8,10 @@ default DVS parameters (v2e_args.py:150-204), Philox RNG, frames resident in HBM
 One *step* = one second of source video = 300 emulator frames advanced on device with no
 host synchronisation in between; the host prepares and enqueues step s+1 while step s
 executes (EventEmulator.generate_events_batch_async) and then reads step s's records.
-value = events emitted / wall time (Mevents/s), whole job.
+value = events emitted / wall time (Mevents/s), whole job.  The timed region of `--steps K` steps (bracketed by barrier +
+device synchronisation on both sides, max over ranks) is repeated `--blocks` times (default 9) and the MEDIAN block is the
+one reported (`ms_per_step`, `value`), with the spread of the blocks beside it: a 20-step region is 25 ms, and the first
+region after start-up runs a few percent slow.
 
 N > 1 (driver: python -m torch.distributed.run ...): one independent clip per GPU
 (BASELINE.json configs[4]); every step ends with an RCCL all-gather of the ranks' event
@@ -77,7 +80,7 @@ def pmc_traffic_per_launch(kernel):
     """HBM bytes per chain-kernel launch from the committed rocprofv3 PMC passes of this same command
     (profiles/r02_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs).  Counters cannot
     be read from inside this process, so the value is the recorded one or null."""
-    for name in ("r02_emulator_pmc_hbm.txt", "r01_emulator_pmc_hbm.txt"):
+    for name in ("r03_emulator_pmc_hbm.txt", "r02_emulator_pmc_hbm.txt"):
         try:
             for line in open(os.path.join(ROOT, "profiles", name)):
                 if line.startswith("# " + kernel + "<") or line.startswith("# " + kernel + " "):
@@ -93,7 +96,7 @@ def rocprof_kernel_us(kernel):
     (profiles/r02_emulator_chain_kernel_trace.txt), or None: the HIP-event figure measured live is the launch-to-launch
     PERIOD of the dependency chain (gaps and waits included); the profiler's is the kernel alone."""
     try:
-        for line in open(os.path.join(ROOT, "profiles", "r02_emulator_chain_kernel_trace.txt")):
+        for line in open(os.path.join(ROOT, "profiles", "r03_emulator_chain_kernel_trace.txt")):
             parts = line.split()
             if len(parts) > 4 and parts[0].isdigit() and (kernel + "<") in line:
                 return float(parts[2])
@@ -131,7 +134,7 @@ def cpu_baseline(frames_host, budget_s=15.0):
     ref = recorded_reference()
     if ref:
         runs = ref["emulator"]["runs"]
-        out["reference"] = {"kind": "reference, recorded (the reference tree exists only in the build container)",
+        out["reference"] = {"kind": "reference, recorded on a DIFFERENT host (the build container: the reference tree does not exist on the GPU box)",
                             "host": ref["host"], "script": "scripts/cpu_reference_baseline.py -> profiles/r02_cpu_reference.json",
                             "runs": [{"cores": r["threads"], "value": r["Mevents_per_s"], "unit": "Mevents/s",
                                       "frames_per_s": r["frames_per_s"]} for r in runs]}
@@ -212,6 +215,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=9, help="timed regions of --steps steps each; the median one is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the slomo / batched / frame-API side measurements")
     ap.add_argument("--no-allgather", action="store_true")
@@ -250,25 +254,36 @@ def main():
         return emu
 
     use_gather = (world > 1 or args.force_allgather) and not args.no_allgather
+    nblocks = max(1, args.blocks)
+
+    def timed_blocks(emu, gather):
+        """`nblocks` timed regions of K steps each on one emulator (the clip keeps running); every region is bracketed by
+        barrier + synchronize inside run_steps; (seconds, events) per region, seconds = max over ranks."""
+        res = []
+        for b in range(nblocks):
+            el, ne = run_steps(emu, frames_all, F, DT, K, Wm if b == 0 else 0, gather, dist, device, first_step=b * K + (Wm if b else 0))
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t[0].item())
+                n = torch.tensor([ne], dtype=torch.float64, device=device)
+                dist.all_reduce(n, op=dist.ReduceOp.SUM)
+                ne = int(n[0].item())
+            res.append((el, ne))
+        return res
+
+    def median_block(res):
+        order = sorted(range(len(res)), key=lambda i: res[i][0] / max(res[i][1], 1))
+        return res[order[len(order) // 2]]
+
     emu = make_emu()
     gather = EventStreamGatherer(device, world) if use_gather else None
-    elapsed, n_events = run_steps(emu, frames_all, F, DT, K, Wm, gather, dist, device)
+    blocks = timed_blocks(emu, gather)
+    elapsed, tot_events = median_block(blocks)
     compute_only = None
     if use_gather:  # the same loop without the exchange: how much of the N-GPU number the interconnect decides
         emu_c = make_emu()
-        el_c, n_c = run_steps(emu_c, frames_all, F, DT, K, Wm, None, dist, device)
-        compute_only = (el_c, n_c)
-
-    tot_events = n_events
-    if dist is not None:
-        t = torch.tensor([elapsed, compute_only[0] if compute_only else 0.0], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0].item())
-        ne = torch.tensor([n_events, compute_only[1] if compute_only else 0], dtype=torch.float64, device=device)
-        dist.all_reduce(ne, op=dist.ReduceOp.SUM)
-        tot_events = int(ne[0].item())
-        if compute_only:
-            compute_only = (float(t[1].item()), int(ne[1].item()))
+        compute_only = median_block(timed_blocks(emu_c, None))
 
     out = None
     if rank == 0:
@@ -279,6 +294,10 @@ def main():
             "unit": "Mevents/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 4),
+            "timed_blocks": {"blocks": nblocks, "steps_each": K, "reported": "median block",
+                             "Mevents_per_s": [round(ne / el / 1e6, 1) for el, ne in blocks],
+                             "spread_rel": round((max(ne / el for el, ne in blocks) - min(ne / el for el, ne in blocks)) /
+                                                 (tot_events / elapsed), 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 346x260 random-gradient video (SURVEY 8(d) config 2), "
@@ -294,7 +313,7 @@ def main():
                                    "ms_per_step": round(compute_only[0] / K * 1e3, 4),
                                    "note": "same loop, no event-stream exchange"}
             out["with_allgather"] = {"value": out["value"], "unit": "Mevents/s",
-                                     "bytes_gathered_per_rank_per_step": int(gather.bytes_gathered / max(K + Wm, 1)),
+                                     "bytes_gathered_per_rank_per_step": int(gather.bytes_gathered / max(nblocks * K + Wm, 1)),
                                      "wire_format": "8 B per event (v2e_events_pack64)"}
 
     # ---------------- roofline of the dominant emulator kernel (rank 0, HIP events, same workload)
@@ -319,33 +338,39 @@ def main():
         # base 16 + thresholds 8 + noise rate 4 + ts_mem 8) + 16 B/event; the chain kernel also writes the 4-byte count word the
         # event writer reads.  A launch covers `fpl` frames.
         n_step = max(prof.get("step_launches", 0), 1)
-        step_us = prof["count"] / n_step * 1e3
-        step_bytes = (bpp + 4) * npx * fpl
+        period_us = prof["count"] / n_step * 1e3   # first launch's start to last launch's end / launches
+        kernel_us = prof["rank"] / n_step * 1e3    # HIP events before and after every chain launch, on its stream: the kernels alone
+        step_bytes = bpp * npx * fpl               # 53 B per pixel and frame x the frames one launch advances
         emit_bytes = 16 * ev_per_frame + 4 * npx
-        ach = step_bytes / (step_us * 1e-6)
+        ach = step_bytes / (kernel_us * 1e-6)
         whole = (bpp * npx + 16 * ev_per_frame)
+        prof_file = "profiles/r03_emulator_pmc_hbm.txt"
         out["roofline"] = {
             "bound": "hbm", "kernel": kname.split("(")[0],
             "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK, 5), "traffic": pmc_traffic_per_launch(kname.split("(")[0]),
+            "frac": round(ach / HBM_PEAK, 5),
+            "traffic": pmc_traffic_per_launch(kname.split("(")[0]),
+            "traffic_source": prof_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; counters cannot be read "
+                                          "from inside the process)",
             "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
+            "avg_kernel_us": round(kernel_us, 3), "launches_timed": n_step,
+            "launch_period_us": round(period_us, 3),
+            "as_delivered": {"achieved_GBps": round(step_bytes / (period_us * 1e-6) / 1e9, 2),
+                             "frac": round(step_bytes / (period_us * 1e-6) / HBM_PEAK, 5),
+                             "note": "the same bytes against the chain's launch-to-launch period (gaps, ring waits and redo passes included)"},
             "rocprof_recorded": (lambda us: None if us is None else {
-                "avg_kernel_us": us, "achieved_GBps": round(step_bytes / (us * 1e-6) / 1e9, 2),
-                "frac": round(step_bytes / (us * 1e-6) / HBM_PEAK, 5),
-                "note": "kernel duration alone from profiles/r02_emulator_chain_kernel_trace.txt; avg_launch_us below is the "
-                        "launch-to-launch period of the chain (gaps, ring waits and redo passes included) and is what "
-                        "`achieved` / `frac` use"})(rocprof_kernel_us(kname.split("(")[0])),
-            "avg_launch_us": {kname: round(step_us, 3),
-                              "event_batch(k_cframe+k_cemit)": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3)},
+                "avg_kernel_us": us, "source": "profiles/r03_emulator_chain_kernel_trace.txt",
+                "frac": round(step_bytes / (us * 1e-6) / HBM_PEAK, 5)})(rocprof_kernel_us(kname.split("(")[0])),
+            "event_writer_us_per_batch": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3),
             "emission": {"frames_per_batch": fpb, "algorithmic_bytes_per_frame": int(emit_bytes)},
             "whole_step": {"algorithmic_bytes_per_frame": int(whole),
                            "achieved_GBps": round(whole * K * F / elapsed / 1e9, 2),
                            "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
-            "note": "avg_launch_us: HIP events before the first and after the last chain launch on its stream (includes the "
-                    "inter-launch gaps and the rare redo passes) and around every event batch on its stream; the per-pixel state "
-                    "(2.9 MB at 346x260) stays in registers for the launch's frames and is L2/MALL resident between launches, "
-                    "and one frame is only 1408 waves, so the chain is bounded by launch and instruction latency, not HBM "
-                    "(DESIGN.md section 3); whole_step prices the complete frame against the driver-timed region",
+            "note": "achieved = algorithmic bytes of the frames a chain launch advances / the launch's own duration, HIP events "
+                    "before and after every launch of an instrumented re-run of the last step's frames on the chain's stream; "
+                    "the per-pixel state (2.9 MB at 346x260) stays in registers for the launch's frames and one frame is only "
+                    "1408 waves, so the chain is bounded by instruction latency, not HBM (DESIGN.md section 3); whole_step prices "
+                    "the complete frame (state traffic + event rows) against the driver-timed region",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())
@@ -357,10 +382,11 @@ def main():
                 out["batched"] = batched_emulator_bench(device)
                 out["hd_noisy"] = hd_noisy_emulator_bench(device)
                 out["slomo"] = slomo_bench(device)
+                out["slomo_f32"] = slomo_bench(device, conv_math="f32")
                 ref = recorded_reference()
                 if ref:
                     out["slomo"]["cpu_baseline"] = {
-                        "kind": "reference, recorded (scripts/cpu_reference_baseline.py)", "host": ref["host"]["cpu"],
+                        "kind": "reference, recorded on a DIFFERENT host (scripts/cpu_reference_baseline.py, build container)", "host": ref["host"]["cpu"],
                         "runs": [{"cores": q["threads"], "batch_pairs": q["batch_pairs"], "value": q["interpolated_frames_per_s"],
                                   "unit": "frames/s"} for q in ref["slomo"]["runs"]]}
                 out["end_to_end"] = e2e_bench(device)

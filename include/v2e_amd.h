@@ -200,8 +200,9 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
                 uint64_t cap, v2e_frame_rec *recs_dev, int use_graph, void *stream);
 
 /* After an instrumented v2e_emu_run (blocking): summed milliseconds per kernel class and frames.
- * k_chain pipeline: ms_count = the chain launches (HIP events before the first and after the last,
- * gaps included), ms_emit = the emission batches (v2e_emu_last_profile_pipe), others 0;
+ * k_chain pipeline (a HIP event before and after every chain launch, on its stream): ms_count = first
+ * launch's start to last launch's end (gaps included), ms_rank = the sum of the chain kernels' own
+ * durations, ms_emit = the k_cemit launches (v2e_emu_last_profile_pipe), ms_scan 0;
  * |16: k_count, k_rank, k_scan, k_emit (a hipEvent before every launch). */
 int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *ms_scan,
                          double *ms_emit, int *launches);
@@ -324,6 +325,25 @@ int v2e_events_accumulate_frame(const float *events, int64_t n, double *current_
 
 /* Finished DVS frame in 0..1: (current_frame + full_scale) / (2 full_scale) in float64 (renderer.py:245-247, normalize_frame). */
 int v2e_frame_normalize(const double *current_frame, double *out, int n, double full_scale, void *stream);
+
+/* EventRenderer.render_events_to_frames on a device-resident packet (renderer.py:161-366; v2e_amd/csrc/render.hip).
+ * v2e_render_area_segments: the AREA_COUNT windows of a packet of n events (renderer.py:253-266, 292-298): area_counts
+ * (device int32 [nw][nh], carried from packet to packet, updated), seg_end[k] = end index (exclusive) of complete window k
+ * (the event that filled a cell; it opens the next window and is counted again there), out2[0] = number of complete windows,
+ * out2[1] = 1 if the walk ended on a trigger at the packet's last event. */
+int v2e_render_area_segments(const float *events, int64_t n, int32_t *area_counts, int nw, int nh, double area_dimension,
+                             int area_count, int32_t *seg_end, int64_t cap, int32_t *out2, void *stream);
+/* v2e_render_packet: every event i < n_used (= n - 1: the packet's last event is never accumulated, renderer.py:303-306)
+ * goes into the frame(s) of its exposure window -- mode 1 DURATION: bounds[0..n_bounds) the frame start times T_k, frame k =
+ * [T_k, T_k+1] (both ends inclusive, as searchsorted left / right), the open frame from T_{n_bounds-1}; 2 COUNT: frame
+ * i / count_per_frame; 3 AREA_COUNT: seg_end[0..n_seg); 4 SOURCE: frame 0 -- as hist(ON) - hist(OFF) over bins_y x bins_x bins
+ * (hist2d_numba_seq, v2e_utils.py:474-486).  frames_out [n_complete][bins_y][bins_x] float64 = (clip(+-full_scale) +
+ * full_scale) / (2 full_scale) (renderer.py:245-247, 396-400); cur_out (if has_open) = the clipped, un-normalised frame the
+ * packet ends in.  diff: device int32 scratch [(n_complete + has_open)][bins_y * bins_x]. */
+int v2e_render_packet(const float *events, int64_t n_used, int mode, const double *bounds, int n_bounds,
+                      int64_t count_per_frame, const int32_t *seg_end, int n_seg, int n_complete, int has_open, int32_t *diff,
+                      double *frames_out, double *cur_out, int bins_y, int bins_x, double y_lo, double y_hi, double x_lo,
+                      double x_hi, double full_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,8 @@ SIGNATURES = {
     "v2e_events_unpack64": (_i, [_vp, _vp, _i64, _vp]),
     "v2e_events_accumulate_frame": (_i, [_vp, _i64, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _vp]),
     "v2e_frame_normalize": (_i, [_vp, _vp, _i, _d, _vp]),
+    "v2e_render_area_segments": (_i, [_vp, _i64, _vp, _i, _i, _d, _i, _vp, _i64, _vp, _vp]),
+    "v2e_render_packet": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _vp]),
     "v2e_slomo_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 

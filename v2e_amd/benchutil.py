@@ -12,9 +12,10 @@ BF16_MFMA_PEAK = 2.5e15  # MI355X_MICROARCH.md: bf16 MFMA, dense (32x32x16)
 HBM_PEAK = 8.0e12
 
 
-def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device):
+def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device, first_step=0):
     """The timed loop of bench.py: `warmup` untimed steps, then `steps` steps of F frames bracketed by a barrier and a
-    device synchronisation on both sides; returns (seconds, events of this rank).  Step s + 1 is prepared and enqueued
+    device synchronisation on both sides; returns (seconds, events of this rank).  `first_step`: index of the first step
+    (time keeps running across consecutive calls on the same emulator).  Step s + 1 is prepared and enqueued
     while step s executes; the event stream of step s goes to `gather` (all-gather over the ranks) when there is one.
     Works on any object with EventEmulator's generate_events_batch_async (the CPU tests pass a stub)."""
     device = torch.device(device)
@@ -25,7 +26,8 @@ def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device):
     def enqueue(s):
         lo = 1 + (s % nclip) * F  # the synthetic clip is cycled through; time keeps running
         buf.copy_(frames_all[lo:lo + F])  # fixed buffer: the run's hipGraph bakes the pointer in
-        return emu.generate_events_batch_async(buf, [(1 + s * F + i) * dt for i in range(F)], return_device=True, use_graph=True)
+        return emu.generate_events_batch_async(buf, [(1 + s * F + i) * dt for i in range(F)], return_device=True,
+                                               use_graph=int(os.environ.get("V2E_AMD_BENCH_UG", "1")))
 
     def finish(pend):
         ev, counts = pend.result()
@@ -55,10 +57,10 @@ def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device):
             n += finish(pend)
         return n
 
-    loop(0, warmup)
+    loop(first_step, warmup)
     sync()
     t0 = time.perf_counter()
-    n_events = loop(warmup, steps)
+    n_events = loop(first_step + warmup, steps)
     sync()
     return time.perf_counter() - t0, n_events
 
@@ -78,7 +80,7 @@ def unet_flops(cin, cout, h, w):
     return 2 * macs
 
 
-def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5):
+def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     """Interpolated frames/s of slomo.py:338-433 at 320x256 (346x260 source), 10x slowdown.
 
     One iteration = one batch of B source pairs (B = 8, the v2e CLI default --batch_size) -> U*B interpolated frames: flow UNet on B
@@ -88,7 +90,7 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5):
     from .synth import portable_unet_state_dict
     sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
     eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
-                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, device)
+                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, device, conv_math=conv_math)
     g = torch.Generator(device=device)
     g.manual_seed(2)
     I0 = torch.rand((B, 1, H, W), device=device, generator=g) - 0.428

@@ -702,8 +702,9 @@ struct v2e_emu {
     double prof_ms[4] = {0, 0, 0, 0}; // count, rank, scan, emit (use_graph == 2)
     int prof_launches = 0;
     int prof_emit_batches = 0, prof_step_launches = 0;
-    unsigned long long *run_off = nullptr; // [2][n_clips] event offset at the start of the current / next emission batch
-    hipStream_t side = nullptr;        // the emission side of the chain: k_ctot, k_cframe, k_cemit
+    unsigned long long *run_off = nullptr; // [run_off_cap][n_clips] event offset at the start of every emission batch of the run
+    int run_off_cap = 0;
+    hipStream_t side = nullptr;        // the event writer of the chain: k_cemit
     std::vector<hipEvent_t> ev_fork, ev_join;
     // K-frames-per-launch chain (emu_chain.h); allocated on first use by v2e_emu_run
     int ch_K = 0, ch_D = 0, ch_nD = 3, ch_nwp = 0, ch_launch_cap = 0, ch_max_blocks = 0, ch_fused = -1, ch_inst = -1;
@@ -714,8 +715,10 @@ struct v2e_emu {
     float *ch_tsold = nullptr;      // [ch_D][n_clips][npx_pad] (refractory runs)
     void *ch_ck = nullptr;          // refractory runs: 2 launch parities x 3 checkpoints x (base 8 B, lp 8 B, ts 4 B) planes
     uint4 *ch_rec = nullptr;        // [ch_D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
-    hipStream_t ahead = nullptr;    // k_ahead runs beside the chain and the event writer
-    std::vector<hipEvent_t> ev_ahead, ev_chain;
+    hipStream_t ahead = nullptr;    // k_ahead runs beside the chain and the emission
+    hipStream_t tabs = nullptr;     // the emission tables (k_ctot, k_cframe, k_coff) of batch b + 1 beside the event writer on batch b
+    hipStream_t side2 = nullptr;    // the event writer of the odd batches (two batches' rows are written side by side)
+    std::vector<hipEvent_t> ev_ahead, ev_chain, ev_tab;
     int ch_E = 0;                   // frames per k_ahead launch / emission batch (a multiple of ch_K)
     int last_kind = -1, last_fpl = 0, last_fpb = 0; // v2e_emu_last_pipeline
     uint32_t *ch_gM = nullptr;      // [ch_launch_cap][ch_K + 1][n_clips][ch_K]
@@ -831,7 +834,6 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
         V2E_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
         h->n_cu = ncu;
     }
-    V2E_HIP(hipMalloc(&h->run_off, sizeof(unsigned long long) * 2 * n_clips));
     V2E_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
     int rc = alloc_iter_scratch(h, max_iters);
     if (rc) return rc;
@@ -861,7 +863,10 @@ int v2e_emu_destroy(v2e_emu *h)
     hipFree(h->ch_gM); hipFree(h->ch_bar); hipFree(h->ch_rec);
     for (hipEvent_t e : h->ev_ahead) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_chain) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_tab) hipEventDestroy(e);
     if (h->ahead) hipStreamDestroy(h->ahead);
+    if (h->tabs) hipStreamDestroy(h->tabs);
+    if (h->side2) hipStreamDestroy(h->side2);
     hipFree(h->ch_base2); hipFree(h->ch_lp2); hipFree(h->ch_ts2); hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase);
     hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_cdone);
     if (h->ctl_host) hipHostFree(h->ctl_host);
@@ -1115,6 +1120,78 @@ static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, cons
 }
 
 
+// ------------------------------------------------------------------ launch scheduling of the chain pipeline
+// The run is a DAG over three logical streams (chain, k_ahead + emission tables, event writer) with cross edges between
+// all of them.  It is either enqueued on three HIP streams with events, or built as an explicit hipGraph (kernel nodes
+// with their dependency lists).  Stream capture is NOT used for it: hipStreamEndCapture of a capture with edges between
+// two forked streams segfaults on this runtime (ROCm 7.0 / HIP 7.0.5; round 2 had met the same with a fourth stream).
+enum { ST_MAIN = 0, ST_AHEAD = 1, ST_SIDE = 2, ST_TAB = 3, ST_SIDE2 = 4, ST_COUNT = 5 };
+enum { EV_FORK = 0, EV_JOIN = 1, EV_AHEAD = 2, EV_CHAIN = 3, EV_TAB = 4, EV_KINDS = 5 };
+
+struct Sched {
+    v2e_emu *h;
+    hipStream_t st[ST_COUNT];
+    hipGraph_t graph = nullptr; // non-null: build nodes instead of launching
+    std::vector<hipGraphNode_t> pos[ST_COUNT];                  // what the next node of a logical stream depends on
+    std::vector<std::vector<hipGraphNode_t>> evdeps;     // graph mode: the dependencies an event stands for
+    int ev_cap = 0;
+
+    hipEvent_t real_event(int kind, int idx) const
+    {
+        switch (kind) {
+        case EV_FORK: return h->ev_fork[idx];
+        case EV_JOIN: return h->ev_join[idx];
+        case EV_AHEAD: return h->ev_ahead[idx];
+        case EV_CHAIN: return h->ev_chain[idx];
+        default: return h->ev_tab[idx];
+        }
+    }
+    static void merge(std::vector<hipGraphNode_t> &dst, const std::vector<hipGraphNode_t> &src)
+    {
+        for (hipGraphNode_t n : src) {
+            bool dup = false;
+            for (hipGraphNode_t d : dst) dup = dup || d == n;
+            if (!dup) dst.push_back(n);
+        }
+    }
+    int kernel(int s, const void *fn, dim3 grid, dim3 block, size_t lds, void **args)
+    {
+        if (!graph) {
+            V2E_HIP(hipLaunchKernel(fn, grid, block, args, lds, st[s]));
+            return 0;
+        }
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        kp.func = const_cast<void *>(fn);
+        kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = (unsigned)lds;
+        kp.kernelParams = args; kp.extra = nullptr;
+        hipGraphNode_t node;
+        V2E_HIP(hipGraphAddKernelNode(&node, graph, pos[s].empty() ? nullptr : pos[s].data(), pos[s].size(), &kp));
+        pos[s].assign(1, node);
+        return 0;
+    }
+    int zero(int s, void *ptr, size_t bytes)
+    {
+        size_t n = (bytes + 3) / 4;
+        if (n == 0) return 0;
+        uint32_t *p32 = (uint32_t *)ptr;
+        void *args[] = {(void *)&p32, (void *)&n};
+        return kernel(s, (const void *)k_zero_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, args);
+    }
+    int record(int kind, int idx, int s)
+    {
+        if (!graph) { V2E_HIP(hipEventRecord(real_event(kind, idx), st[s])); return 0; }
+        evdeps[(size_t)kind * ev_cap + idx] = pos[s];
+        return 0;
+    }
+    int wait(int s, int kind, int idx)
+    {
+        if (!graph) { V2E_HIP(hipStreamWaitEvent(st[s], real_event(kind, idx), 0)); return 0; }
+        merge(pos[s], evdeps[(size_t)kind * ev_cap + idx]);
+        return 0;
+    }
+};
+
 // ------------------------------------------------------------------ K frames per launch (emu_chain.h)
 static bool chain_small_grid(const v2e_emu *h) { return (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu; }
 
@@ -1205,9 +1282,11 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
     const int inst = (p->f64_state ? 1 : 0) | ((dtype & 3) << 1) | (fused ? 8 : 0);
     const int max_blocks = chain_blocks_per_cu(h, p->f64_state != 0, dtype, fused) * h->n_cu;
     const int K = chain_frames_per_launch(h, has_refr, use_graph, max_blocks);
-    // frames per k_ahead launch and per emission batch: a multiple of K (measured at 346x260: K = 32 with batches of 32
-    // frames 4.86 us/frame, of 64 frames 5.18); small grids 32 frames, large ones max(K, 8) (their ring is what costs memory)
-    int m = std::max(1, (chain_small_grid(h) ? 32 : std::max(K, 8)) / K);
+    // frames per k_ahead launch and per emission batch: a multiple of K.  Small grids 64 frames (the emission kernels are
+    // bound by per-wave latency and by the launch gaps between them, and this runtime runs the captured graph's chain and
+    // emission kernels one after the other: fewer, larger batches -- 346x260, round 3: 64 frames 8.7 Gev/s, 32 frames 7.7);
+    // large ones max(K, 8) (their ring is what costs memory)
+    int m = std::max(1, (chain_small_grid(h) ? 64 : std::max(K, 8)) / K);
     if (const char *ev = getenv("V2E_AMD_CHAIN_M")) { const int v = atoi(ev); if (v >= 1 && v <= 64) m = v; }
     m = std::max(1, std::min(m, 64 / K)); // k_cemit sums a batch's per-frame event counts one frame per lane
     const int E = m * K;
@@ -1236,27 +1315,34 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         V2E_HIP(hipMalloc(&h->ch_cnt, sizeof(uint32_t) * h->ch_D * nc * h->npx_pad));
         V2E_HIP(hipMalloc(&h->ch_ruleM, sizeof(uint32_t) * h->ch_D * nc));
         V2E_HIP(hipMemset(h->ch_ruleM, 0, sizeof(uint32_t) * h->ch_D * nc));
-        // two sets of emission tables: a batch's tables are rebuilt while nothing else reads them, alternating keeps the
-        // option of overlapping k_cframe(b + 1) with k_cemit(b)
-        V2E_HIP(hipMalloc(&h->ch_wmax, 2 * sizeof(uint16_t) * E * nc * h->ch_nwp));
-        V2E_HIP(hipMemset(h->ch_wmax, 0, 2 * sizeof(uint16_t) * E * nc * h->ch_nwp));
-        V2E_HIP(hipMalloc(&h->ch_wtot, (size_t)2 * E * nc * h->nkeys_cap * h->ch_nwp));
-        V2E_HIP(hipMemset(h->ch_wtot, 0, (size_t)2 * E * nc * h->nkeys_cap * h->ch_nwp));
-        V2E_HIP(hipMalloc(&h->ch_cf, 2 * sizeof(CFrame) * E * nc));
-        V2E_HIP(hipMemset(h->ch_cf, 0, 2 * sizeof(CFrame) * E * nc));
-        V2E_HIP(hipMalloc(&h->ch_cdone, 2 * sizeof(unsigned) * E * nc));
-        V2E_HIP(hipMemset(h->ch_cdone, 0, 2 * sizeof(unsigned) * E * nc));
-        V2E_HIP(hipMalloc(&h->ch_cT, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap));
-        V2E_HIP(hipMalloc(&h->ch_ckbase, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap));
-        V2E_HIP(hipMalloc(&h->ch_cperm, 2 * sizeof(uint32_t) * E * nc * h->max_iters * 8));
-        V2E_HIP(hipMalloc(&h->ch_cpre, 2 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp));
+        // three sets of emission tables in rotation: the tables of batches b + 1, b + 2 are built while k_cemit(b) reads its own
+        V2E_HIP(hipMalloc(&h->ch_wmax, 3 * sizeof(uint16_t) * E * nc * h->ch_nwp));
+        V2E_HIP(hipMemset(h->ch_wmax, 0, 3 * sizeof(uint16_t) * E * nc * h->ch_nwp));
+        V2E_HIP(hipMalloc(&h->ch_wtot, (size_t)3 * E * nc * h->nkeys_cap * h->ch_nwp));
+        V2E_HIP(hipMemset(h->ch_wtot, 0, (size_t)3 * E * nc * h->nkeys_cap * h->ch_nwp));
+        V2E_HIP(hipMalloc(&h->ch_cf, 3 * sizeof(CFrame) * E * nc));
+        V2E_HIP(hipMemset(h->ch_cf, 0, 3 * sizeof(CFrame) * E * nc));
+        V2E_HIP(hipMalloc(&h->ch_cdone, 3 * sizeof(unsigned) * E * nc));
+        V2E_HIP(hipMemset(h->ch_cdone, 0, 3 * sizeof(unsigned) * E * nc));
+        V2E_HIP(hipMalloc(&h->ch_cT, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap));
+        V2E_HIP(hipMalloc(&h->ch_ckbase, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap));
+        V2E_HIP(hipMalloc(&h->ch_cperm, 3 * sizeof(uint32_t) * E * nc * h->max_iters * 8));
+        V2E_HIP(hipMalloc(&h->ch_cpre, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp));
         if (!fused) V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
         h->drop_graphs();
     }
     h->ch_max_blocks = max_blocks;
     h->ch_inst = inst;
     const int n_launch = (n_frames + K - 1) / K + 1;
+    if (n_launch + 2 > h->run_off_cap) {
+        hipFree(h->run_off);
+        h->run_off_cap = n_launch + 2;
+        V2E_HIP(hipMalloc(&h->run_off, sizeof(unsigned long long) * (size_t)h->run_off_cap * h->n_clips));
+        h->drop_graphs();
+    }
     if (!h->ahead) V2E_HIP(hipStreamCreateWithFlags(&h->ahead, hipStreamNonBlocking));
+    if (!h->tabs) V2E_HIP(hipStreamCreateWithFlags(&h->tabs, hipStreamNonBlocking));
+    if (!h->side2) V2E_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     auto grow = [&](std::vector<hipEvent_t> &v, size_t n) -> int {
         while (v.size() < n) {
             hipEvent_t e;
@@ -1266,7 +1352,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         return 0;
     };
     if (grow(h->ev_ahead, n_launch + 1) || grow(h->ev_chain, n_launch + 1) || grow(h->ev_fork, n_launch + 1) ||
-        grow(h->ev_join, n_launch + 1)) return V2E_EHIP;
+        grow(h->ev_join, n_launch + 1) || grow(h->ev_tab, n_launch + 1)) return V2E_EHIP;
     if (has_refr) {
         if (!h->ch_tsold) V2E_HIP(hipMalloc(&h->ch_tsold, sizeof(float) * (size_t)h->ch_D * h->n_clips * h->npx_pad));
         if (!h->ch_ck) V2E_HIP(hipMalloc(&h->ch_ck, (size_t)2 * 3 * 20 * h->n_clips * h->npx_pad)); // see ChainArgs::ckc_base
@@ -1299,15 +1385,17 @@ static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p, int dtype)
     return true;
 }
 
-static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, const void *frames, int dtype, int n_frames,
-                             float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, std::vector<hipEvent_t> *ev_main = nullptr,
-                             std::vector<hipEvent_t> *ev_side = nullptr)
+static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a_in, const void *frames, int dtype, int n_frames,
+                             float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, hipGraph_t graph = nullptr,
+                             std::vector<hipEvent_t> *ev_main = nullptr, std::vector<hipEvent_t> *ev_side = nullptr,
+                             bool capturing = false)
 {
-    // Three streams: `s` the chain (k_chain, K frames per launch); h->ahead k_ahead; h->side k_ctot, k_cframe, k_cemit; the
-    // last two in batches of E = m K frames (batch b = frames [b E, (b + 1) E) = chain launches [b m, (b + 1) m)).
+    // Three logical streams: the chain (k_chain, K frames per launch); k_ahead and the emission tables (k_ctot, k_cframe);
+    // the event writer k_cemit; the last two in batches of E = m K frames (batch b = frames [b E, (b + 1) E) = chain
+    // launches [b m, (b + 1) m)).  The emission of a batch is a pipeline of its own: tables of batch b + 1 beside the rows of b.
     //   k_ahead(b)  before chain launch b m; overwrites the records of batch b - nD, last read by launch (b - nD + 1) m (its redo)
-    //   emission(b) once batch b is final: after the launch that validated its last K frames (or, without a refractory
-    //               period, after its last launch)
+    //   tables(b)   once batch b is final: after the launch that validated its last K frames (or, without a refractory
+    //               period, after its last launch); k_cemit(b) after tables(b) and k_cemit(b - 1) (running event offset)
     //   chain launch b m overwrites the ring slots of batch b - nD: after k_cemit(b - nD)   (nD = ch_D / E batches in the ring)
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
     const bool has_refr = p->refractory_period_s > 0;
@@ -1317,18 +1405,25 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     const int nL = (int)plan.size();
     const int nB = (n_frames + K - 1) / K;
     const int nEB = (n_frames + E - 1) / E;
-    V2E_HIP(zero_async(recs, sizeof(v2e_frame_rec) * (size_t)n_frames * NC, s));
-    V2E_HIP(zero_async(h->run_off, sizeof(unsigned long long) * 2 * NC, s));
-    if (has_refr) {
-        V2E_HIP(zero_async(h->ch_gM, sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K, s));
-        V2E_HIP(zero_async(h->ch_bar, sizeof(unsigned) * (size_t)nL * K * NC, s));
+    KArgs a = a_in; // kernel arguments are passed by address (hipLaunchKernel / kernel nodes copy them at the call)
+    Sched sc;
+    sc.h = h; sc.st[ST_MAIN] = s; sc.st[ST_AHEAD] = h->ahead; sc.st[ST_SIDE] = h->side; sc.st[ST_TAB] = h->tabs; sc.st[ST_SIDE2] = h->side2; sc.graph = graph;
+    if (graph) {
+        sc.ev_cap = nL + 2;
+        sc.evdeps.assign((size_t)EV_KINDS * sc.ev_cap, std::vector<hipGraphNode_t>());
     }
-    auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t st) -> int {
-        if (!v) return 0;
+    if (sc.zero(ST_MAIN, recs, sizeof(v2e_frame_rec) * (size_t)n_frames * NC)) return V2E_EHIP;
+    if (sc.zero(ST_MAIN, h->run_off, sizeof(unsigned long long) * NC)) return V2E_EHIP; // batch 0 starts at row 0
+    if (has_refr) {
+        if (sc.zero(ST_MAIN, h->ch_gM, sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K)) return V2E_EHIP;
+        if (sc.zero(ST_MAIN, h->ch_bar, sizeof(unsigned) * (size_t)nL * K * NC)) return V2E_EHIP;
+    }
+    auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t stq) -> int { // instrumented runs (never graphs)
+        if (!v || graph) return 0;
         hipEvent_t e;
         V2E_HIP(hipEventCreate(&e));
         v->push_back(e);
-        V2E_HIP(hipEventRecord(e, st));
+        V2E_HIP(hipEventRecord(e, stq));
         return 0;
     };
     // clips resident at once: with a refractory period every workgroup of a clip must be resident for the redo rendezvous
@@ -1337,40 +1432,67 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     if (has_refr && K > 1) gy = std::max(1, std::min(NC, h->ch_max_blocks / std::max(h->ngroups, 1)));
     dim3 grid(h->ngroups, gy);
     static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
-    auto launch_emission = [&](int b) -> int { // fork event ev_fork[b] has been recorded on `s`
+    static const int chain_prio = getenv("V2E_AMD_CHAIN_PRIO") ? atoi(getenv("V2E_AMD_CHAIN_PRIO")) : 3; // dev: 0 = no raised wave priority
+    // Under stream capture only edges between the origin stream and a forked stream are safe (edges between two forked
+    // streams crash hipStreamEndCapture on this runtime): tables and rows then share the side stream.
+    static const int tab_env = getenv("V2E_AMD_TABLES_ON_SIDE") ? ST_SIDE : (getenv("V2E_AMD_TABLES_ON_AHEAD") ? ST_AHEAD : ST_TAB); // dev
+    const int tab_stream = capturing ? ST_SIDE : tab_env;
+    constexpr int NSET = 3; // emission table sets (chain_alloc sizes them)
+    static const bool one_row_stream = getenv("V2E_AMD_ONE_ROW_STREAM") != nullptr; // dev
+    auto launch_emission = [&](int b) -> int { // EV_FORK[b] has been recorded on the chain stream
         CEmitArgs ea;
         memset(&ea, 0, sizeof(ea));
         ea.ctl = h->run_ctl; ea.recs = recs; ea.fidx_base = h->run_fidx;
         ea.f0 = b * E; ea.nE = std::min((b + 1) * E, n_frames) - ea.f0; ea.D = D; ea.n_clips = NC;
         ea.nwp = h->ch_nwp; ea.nwaves = h->ngroups * (BLOCK / WAVE); ea.E = E;
         ea.cnt = h->ch_cnt; ea.tsold = has_refr ? h->ch_tsold : nullptr; ea.ruleM = has_refr ? h->ch_ruleM : nullptr;
-        const size_t set = (size_t)(b & 1) * E * NC; // table set of this batch
+        const size_t set = (size_t)(b % NSET) * E * NC; // table set of this batch
         ea.wmax = h->ch_wmax + set * h->ch_nwp; ea.wtot = h->ch_wtot + set * h->nkeys_cap * h->ch_nwp;
         ea.cf = h->ch_cf + set; ea.cT = h->ch_cT + set * h->nkeys_cap; ea.ckbase = h->ch_ckbase + set * h->nkeys_cap;
         ea.cperm = h->ch_cperm + set * h->max_iters * 8; ea.cpre = h->ch_cpre + set * h->nkeys_cap * h->ch_nwp;
         ea.cdone = h->ch_cdone + set;
         ea.events = (float4 *)events; ea.cap = cap;
-        ea.off_in = h->run_off + (size_t)(b & 1) * NC;
-        ea.off_out = h->run_off + (size_t)((b + 1) & 1) * NC;
+        ea.off_in = h->run_off + (size_t)b * NC;
+        ea.off_out = h->run_off + (size_t)(b + 1) * NC;
         // event records of k_cemit: 64 x ich per wave and pass.  The chain's workgroups need their LDS (5 KB per frame) on
         // every CU: 15 iterations per pass (most frames have fewer) keep an emission workgroup at 15 KB
         static const int ich_env = getenv("V2E_AMD_CEMIT_ICH") ? atoi(getenv("V2E_AMD_CEMIT_ICH")) : 0;
         ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 15;
         ea.capw = 64 * ea.ich;
+        // frames per workgroup (measured at 346x260, 32-frame batches: k_ctot 4 frames 13 us, 32 frames 37 us; k_cemit 1 frame
+        // 34 us, 8 frames 45 us -- these kernels are bound by the latency of a wave's dependent loads, not by wave dispatch:
+        // more, shorter waves win)
+        static const int zpw_env = getenv("V2E_AMD_EMIT_ZPW") ? atoi(getenv("V2E_AMD_EMIT_ZPW")) : 0;
+        ea.zpw_tot = zpw_env > 0 ? (zpw_env + CTOT_ZF - 1) / CTOT_ZF * CTOT_ZF : CTOT_ZF;
+        ea.zpw_emit = zpw_env > 0 ? zpw_env : 1;
         const int REC_LDS = ea.capw * 4 * (BLOCK / WAVE);
-        V2E_HIP(hipStreamWaitEvent(h->side, h->ev_fork[b], 0));
-        if (mark(ev_side, h->side)) return V2E_EHIP;
+        void *args[] = {(void *)&a, (void *)&ea};
+        // tables on a stream of their own (NSET table sets rotate: tables(b + 1) are built while k_cemit(b) reads those of b;
+        // k_cemit(b - NSET), which read this set last, is waited for), rows on the side stream
+        if (sc.wait(tab_stream, EV_FORK, b)) return V2E_EHIP;
+        if (b >= NSET && tab_stream != ST_SIDE && sc.wait(tab_stream, EV_JOIN, b - NSET)) return V2E_EHIP;
         if (!no_emit) {
-            k_ctot<<<dim3(h->ngroups, NC, ea.nE), BLOCK, 0, h->side>>>(a, ea);
+            if (sc.kernel(tab_stream, (const void *)k_ctot, dim3(h->ngroups, NC, (ea.nE + ea.zpw_tot - 1) / ea.zpw_tot), dim3(BLOCK), 0, args)) return V2E_EHIP;
             // a key row of a small grid is a couple of steps of one wave: one workgroup per frame; of a large grid (1280x720:
             // 14 400 waves) a segmented scan by a workgroup of its own
-            if (h->ch_nwp <= 4096) k_cframe1<<<dim3(1, NC, ea.nE), CFRAME_THREADS, 0, h->side>>>(a, ea);
-            else k_cframe<<<dim3(std::min(h->nkeys_cap, CFRAME_ROWS), NC, ea.nE), CFRAME_THREADS, 0, h->side>>>(a, ea);
-            k_cemit<<<dim3(h->ngroups, NC, ea.nE), BLOCK, REC_LDS, h->side>>>(a, ea);
+            if (h->ch_nwp <= 4096) {
+                if (sc.kernel(tab_stream, (const void *)k_cframe1, dim3(1, NC, ea.nE), dim3(CFRAME_THREADS), 0, args)) return V2E_EHIP;
+            } else if (sc.kernel(tab_stream, (const void *)k_cframe, dim3(std::min(h->nkeys_cap, CFRAME_ROWS), NC, ea.nE), dim3(CFRAME_THREADS), 0, args)) {
+                return V2E_EHIP;
+            }
         }
-        if (mark(ev_side, h->side)) return V2E_EHIP;
-        V2E_HIP(hipEventRecord(h->ev_join[b], h->side));
-        return 0;
+        if (!no_emit) {
+            void *oargs[] = {(void *)&ea};
+            if (sc.kernel(tab_stream, (const void *)k_coff, dim3(NC), dim3(WAVE), 0, oargs)) return V2E_EHIP;
+        }
+        // rows: two batches side by side on two streams (the rows of a batch depend on nothing but its tables)
+        const int row_stream = (tab_stream == ST_SIDE || one_row_stream) ? ST_SIDE : ((b & 1) ? ST_SIDE2 : ST_SIDE);
+        if (sc.record(EV_TAB, b, tab_stream)) return V2E_EHIP;
+        if (row_stream != tab_stream && sc.wait(row_stream, EV_TAB, b)) return V2E_EHIP;
+        if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
+        if (!no_emit && sc.kernel(row_stream, (const void *)k_cemit, dim3(h->ngroups, NC, (ea.nE + ea.zpw_emit - 1) / ea.zpw_emit), dim3(BLOCK), REC_LDS, args)) return V2E_EHIP;
+        if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
+        return sc.record(EV_JOIN, b, row_stream);
     };
     auto launch_ahead = [&](int b) -> int {
         AheadArgs aa;
@@ -1379,23 +1501,25 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         aa.ctl = h->run_ctl; aa.fidx_base = h->run_fidx;
         aa.f0 = b * E; aa.nf = std::min((b + 1) * E, n_frames) - b * E; aa.D = D; aa.n_clips = NC;
         aa.rec = h->ch_rec;
-        if (b >= nD) V2E_HIP(hipStreamWaitEvent(h->ahead, h->ev_chain[(b - nD + 1) * m], 0)); // records of batch b - nD: last read by that launch's redo
-        // frame pairs touched by the batch: at most nf / 2 + 1 (the device knows the run's first frame index, the host's
-        // capture does not: one extra pair covers either alignment; threads of a pair outside the batch return)
-        dim3 ga(h->ngroups, NC, aa.nf / 2 + 1);
-        k_ahead<uint8_t><<<ga, BLOCK, 0, h->ahead>>>(a, aa);
-        V2E_HIP(hipEventRecord(h->ev_ahead[b], h->ahead));
-        return 0;
+        if (b >= nD && sc.wait(ST_AHEAD, EV_CHAIN, (b - nD + 1) * m)) return V2E_EHIP; // records of batch b - nD: last read by that launch's redo
+        // frame pairs touched by the batch: at most nf / 2 + 1 (the device knows the run's first frame index, the host
+        // does not when it builds a graph: one extra pair covers either alignment; threads of a pair outside the batch return)
+        static const int ppt_env = getenv("V2E_AMD_AHEAD_PPT") ? atoi(getenv("V2E_AMD_AHEAD_PPT")) : 0;
+        aa.ppt = ppt_env > 0 ? ppt_env : 1;
+        void *args[] = {(void *)&a, (void *)&aa};
+        if (sc.kernel(ST_AHEAD, (const void *)k_ahead<uint8_t>, dim3(h->ngroups, NC, (aa.nf / 2 + 1 + aa.ppt - 1) / aa.ppt), dim3(BLOCK), 0, args)) return V2E_EHIP;
+        return sc.record(EV_AHEAD, b, ST_AHEAD);
     };
     // state planes: X[0] the caller's (bound) planes, X[1] the engine's second set; launch L reads X[L % 2], writes X[(L + 1) % 2]
     void *xb[2] = {h->base, has_refr ? h->ch_base2 : h->base}, *xl[2] = {h->lp, has_refr ? h->ch_lp2 : h->lp};
     float *xt[2] = {h->ts_mem, has_refr ? h->ch_ts2 : h->ts_mem};
-    if (!fused_rec) {
-        V2E_HIP(hipEventRecord(h->ev_fork[nL], s)); // the run's uploads (frame times, first frame index) precede everything
-        V2E_HIP(hipStreamWaitEvent(h->ahead, h->ev_fork[nL], 0));
-    }
+    // the run's uploads (frame times, first frame index) and the zero fills precede everything
+    if (sc.record(EV_FORK, nL, ST_MAIN) || sc.wait(ST_SIDE, EV_FORK, nL)) return V2E_EHIP;
+    if (!fused_rec && sc.wait(ST_AHEAD, EV_FORK, nL)) return V2E_EHIP;
+    if (!capturing && (sc.wait(ST_TAB, EV_FORK, nL) || sc.wait(ST_SIDE2, EV_FORK, nL))) return V2E_EHIP;
     for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b)
         if (launch_ahead(b)) return V2E_EHIP;
+    const void *kfn = chain_fn(p->f64_state != 0, dtype, fused_rec);
     for (int L = 0; L < nL; ++L) {
         const ChainLaunch &pl = plan[L];
         const bool tail = pl.nf == 0;
@@ -1432,30 +1556,27 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         }
         ca.recs = recs;
         ca.store_out = tail && in != 0;
+        ca.prio = chain_prio;
         ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
-        if (pl.wait_join >= 0) V2E_HIP(hipStreamWaitEvent(s, h->ev_join[pl.wait_join], 0)); // ring slots: read by k_cemit of that batch
-        if (pl.wait_ahead >= 0) V2E_HIP(hipStreamWaitEvent(s, h->ev_ahead[pl.wait_ahead], 0));
-        if (L == 0 && mark(ev_main, s)) return V2E_EHIP;
-        if (fused_rec) {
-            DISPATCH_FT(dtype, {
-                if (p->f64_state) k_chain<double, FT, true><<<grid, BLOCK, 0, s>>>(a, ca);
-                else k_chain<float, FT, true><<<grid, BLOCK, 0, s>>>(a, ca);
-            });
-        } else {
-            const size_t lds = chain_dyn_lds(false);
-            if (p->f64_state) k_chain<double, uint8_t, false><<<grid, BLOCK, lds, s>>>(a, ca);
-            else k_chain<float, uint8_t, false><<<grid, BLOCK, lds, s>>>(a, ca);
-        }
-        if (L % m == 0) V2E_HIP(hipEventRecord(h->ev_chain[L], s));
-        if (pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
-        if (pl.emit_batch >= 0) {
-            V2E_HIP(hipEventRecord(h->ev_fork[pl.emit_batch], s));
+        if (pl.wait_join >= 0 && sc.wait(ST_MAIN, EV_JOIN, pl.wait_join)) return V2E_EHIP; // ring slots: read by k_cemit of that batch
+        if (pl.wait_ahead >= 0 && sc.wait(ST_MAIN, EV_AHEAD, pl.wait_ahead)) return V2E_EHIP;
+        if (mark(ev_main, s)) return V2E_EHIP; // instrumented runs: an event before and after every chain launch
+        void *args[] = {(void *)&a, (void *)&ca};
+        if (sc.kernel(ST_MAIN, kfn, grid, dim3(BLOCK), chain_dyn_lds(fused_rec), args)) return V2E_EHIP;
+        if (mark(ev_main, s)) return V2E_EHIP;
+        if (L % m == 0 && sc.record(EV_CHAIN, L, ST_MAIN)) return V2E_EHIP;
+        if (pl.emit_batch >= 0) { // (before k_ahead on their common stream: the ring slots this frees are what the chain waits for)
+            if (sc.record(EV_FORK, pl.emit_batch, ST_MAIN)) return V2E_EHIP;
             if (launch_emission(pl.emit_batch)) return V2E_EHIP;
         }
+        if (pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
     }
-    if (mark(ev_main, s)) return V2E_EHIP;
-    V2E_HIP(hipStreamWaitEvent(s, h->ev_join[nEB - 1], 0)); // join: the run is complete on `s`
-    if (!fused_rec) V2E_HIP(hipStreamWaitEvent(s, h->ev_ahead[nEB - 1], 0));
+    if (!graph) { // join: the run is complete on `s` (a graph is complete when all its nodes are)
+        if (sc.wait(ST_MAIN, EV_JOIN, nEB - 1)) return V2E_EHIP;
+        if (!capturing && sc.wait(ST_MAIN, EV_TAB, nEB - 1)) return V2E_EHIP;
+        if (!capturing && nEB >= 2 && sc.wait(ST_MAIN, EV_JOIN, nEB - 2)) return V2E_EHIP;
+        if (!fused_rec && sc.wait(ST_MAIN, EV_AHEAD, nEB - 1)) return V2E_EHIP;
+    }
     V2E_HIP(hipGetLastError());
     return 0;
 }
@@ -1515,14 +1636,18 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     }
     if (mode == 2 && chain) { // instrumented: chain time from events on `s`, emission batches from events on the side stream
         std::vector<hipEvent_t> em, es;
-        rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, &em, &es);
+        rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, nullptr, &em, &es);
         if (rc == 0) {
             V2E_HIP(hipStreamSynchronize(s));
             for (int k = 0; k < 4; ++k) h->prof_ms[k] = 0.0;
             float ms = 0.f;
             V2E_HIP(hipEventElapsedTime(&ms, em.front(), em.back()));
-            h->prof_ms[0] = ms;
-            h->prof_step_launches = (n_frames + h->ch_K - 1) / h->ch_K + (p->refractory_period_s > 0 ? 1 : 0);
+            h->prof_ms[0] = ms; // first launch's start to last launch's end: the chain's launch-to-launch period x launches
+            for (size_t i = 0; i + 1 < em.size(); i += 2) { // the kernels alone
+                V2E_HIP(hipEventElapsedTime(&ms, em[i], em[i + 1]));
+                h->prof_ms[1] += ms;
+            }
+            h->prof_step_launches = (int)(em.size() / 2);
             for (size_t i = 0; i + 1 < es.size(); i += 2) {
                 V2E_HIP(hipEventElapsedTime(&ms, es[i], es[i + 1]));
                 h->prof_ms[3] += ms;
@@ -1577,16 +1702,30 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
             hipGraphExecDestroy(h->graphs[lru].exec);
             h->graphs.erase(h->graphs.begin() + lru);
         }
-        hipStream_t cs;
-        V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        if (legacy) rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs, nullptr);
-        else rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs);
         hipGraph_t g = nullptr;
-        hipError_t e = hipStreamEndCapture(cs, &g);
-        hipStreamDestroy(cs);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        V2E_HIP(e);
+        if (legacy) { // one stream: plain stream capture
+            hipStream_t cs;
+            V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs, nullptr);
+            hipError_t e = hipStreamEndCapture(cs, &g);
+            hipStreamDestroy(cs);
+            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            V2E_HIP(e);
+        } else if (getenv("V2E_AMD_GRAPH_EXPLICIT")) { // dev: the graph node by node (see Sched); this runtime then runs it serially
+            V2E_HIP(hipGraphCreate(&g, 0));
+            rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, g);
+            if (rc) { hipGraphDestroy(g); return rc; }
+        } else { // stream capture, with edges between the origin and the forked streams only
+            hipStream_t cs;
+            V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs, nullptr, nullptr, nullptr, true);
+            hipError_t e = hipStreamEndCapture(cs, &g);
+            hipStreamDestroy(cs);
+            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            V2E_HIP(e);
+        }
         V2E_HIP(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
         V2E_HIP(hipGraphDestroy(g));
         h->graphs.push_back({key, exec, ++h->graph_clock});

@@ -145,6 +145,7 @@ struct ChainArgs {
     float *ckp_ts;
     v2e_frame_rec *recs;              // [n_frames][n_clips]
     int store_out;                    // tail launch: state must be copied to *_out even without a redo
+    int prio;                         // wave priority of the chain (3: it outranks the emission waves sharing its SIMDs)
     unsigned long long *dbg;          // dev tool: [ngroups][16] wall-clock stamps of one launch, or nullptr
 };
 
@@ -210,6 +211,7 @@ struct AheadArgs {
     const FrameCtl *ctl;
     const uint32_t *fidx_base;
     int f0, nf, D, n_clips;
+    int ppt;    // frame pairs per thread (grid z = ceil(pairs / ppt))
     uint4 *rec; // [D][n_clips][npx_pad]
 };
 
@@ -228,28 +230,30 @@ __global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
     const int clip = blockIdx.y, p = blockIdx.x * BLOCK + tid;
     if (p >= a.npx) return;
     const uint32_t fbase = *aa.fidx_base;
-    // pair z of the launch: global frames 2q-1 (odd) and 2q (even), q = pair of the launch's first frame + z
-    const uint32_t q = v2e_frame_pair(fbase + (uint32_t)aa.f0) + blockIdx.z;
-    const long long f_odd = 2ll * q - 1 - (long long)fbase; // run-relative
-    const bool in0 = f_odd >= aa.f0 && f_odd < aa.f0 + aa.nf, in1 = f_odd + 1 >= aa.f0 && f_odd + 1 < aa.f0 + aa.nf;
-    if (!in0 && !in1) return;
     const size_t sp = (size_t)clip * a.npx_pad + p;
     const bool need_r = a.do_leak && a.jit_f != 0.f;
-    float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f;
-    if (need_r || a.do_shot) v2e_draw_pair(a.seed, (uint32_t)clip, q, (uint32_t)p, need_r, &r_odd, &u_odd, &r_even, &u_even);
     const float thp = a.pos_thres[sp], thn = a.neg_thres[sp];
     const float lk = a.do_leak ? a.leak_hz_f * a.noise_rate[sp] : 0.f;
     const float ppre = a.scalar_thres ? a.pos_pre_scalar : a.pos_nom_f / thp; // emulator.py:475-478
     const float npre = a.scalar_thres ? a.neg_pre_scalar : a.neg_nom_f / thn;
+    for (int zz = 0; zz < aa.ppt; ++zz) {
+        // pair z of the launch: global frames 2q-1 (odd) and 2q (even), q = pair of the launch's first frame + z
+        const uint32_t q = v2e_frame_pair(fbase + (uint32_t)aa.f0) + blockIdx.z * (uint32_t)aa.ppt + (uint32_t)zz;
+        const long long f_odd = 2ll * q - 1 - (long long)fbase; // run-relative
+        const bool in0 = f_odd >= aa.f0 && f_odd < aa.f0 + aa.nf, in1 = f_odd + 1 >= aa.f0 && f_odd + 1 < aa.f0 + aa.nf;
+        if (!in0 && !in1) continue;
+        float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f;
+        if (need_r || a.do_shot) v2e_draw_pair(a.seed, (uint32_t)clip, q, (uint32_t)p, need_r, &r_odd, &u_odd, &r_even, &u_even);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (!(half ? in1 : in0)) continue;
-        const long long f = f_odd + half;
-        const FrameCtl *c = aa.ctl + (size_t)f * aa.n_clips + clip;
-        const FT px = ((const FT *)((const char *)aa.frames + (size_t)f * aa.frame_stride))[(size_t)clip * a.npx + p];
-        const uint4 r = make_frame_record<FT>(a, px, s_lutL, s_lutI, c->dt_over_tau, c->shot_base, (float)(c->t_frame - c->t_prev), lk, thp,
-                                              ppre, npre, half ? r_even : r_odd, half ? u_even : u_odd);
-        aa.rec[((size_t)(f % aa.D) * aa.n_clips + clip) * a.npx_pad + p] = r;
+        for (int half = 0; half < 2; ++half) {
+            if (!(half ? in1 : in0)) continue;
+            const long long f = f_odd + half;
+            const FrameCtl *c = aa.ctl + (size_t)f * aa.n_clips + clip;
+            const FT px = ((const FT *)((const char *)aa.frames + (size_t)f * aa.frame_stride))[(size_t)clip * a.npx + p];
+            const uint4 r = make_frame_record<FT>(a, px, s_lutL, s_lutI, c->dt_over_tau, c->shot_base, (float)(c->t_frame - c->t_prev), lk, thp,
+                                                  ppre, npre, half ? r_even : r_odd, half ? u_even : u_odd);
+            aa.rec[((size_t)(f % aa.D) * aa.n_clips + clip) * a.npx_pad + p] = r;
+        }
     }
 }
 
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
     // and the counter covers stores too, so a store inside the frame loop would stand between the loop and the arrival
     // of the next sub-pass's records
     uint32_t *const s_cw = (uint32_t *)(s_arec + (size_t)CHAIN_SUB * BLOCK);
-    __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
+    if (ca.prio) __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
     V2E_STAMP_C(0);
     uint32_t fbase = 0u;
     if (FUSED) {
@@ -309,10 +313,12 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
         auto stage = [&](const int fs, const int fn) __attribute__((always_inline)) { // the first CHAIN_SUB frames of a pass
             if (FUSED || !valid) return;
             uint4 t[CHAIN_SUB];
+            int sl = fs % ca.D;
 #pragma unroll
             for (int j = 0; j < CHAIN_SUB; ++j) {
                 t[j] = make_uint4(0u, 0u, 0u, 0u);
-                if (j < fn) t[j] = ca.rec[((size_t)((fs + j) % ca.D) * ca.n_clips + clip) * a.npx_pad + p];
+                if (j < fn) t[j] = ca.rec[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p];
+                if (++sl == ca.D) sl = 0;
             }
 #pragma unroll
             for (int j = 0; j < CHAIN_SUB; ++j)
@@ -525,20 +531,25 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 if (++slot == ca.D) slot = 0;
                 if (own && k < 12) V2E_STAMP_C(3 + k);
             };
+            // records of the pass's frames [kn, kn + CHAIN_SUB) into registers (in flight while the frames before them compute)
+            uint4 nx[CHAIN_SUB];
+            auto fetch_next = [&](const int kn) __attribute__((always_inline)) {
+                const int cn = min(CHAIN_SUB, fn - kn); // <= 0: none
+                int sl = cn > 0 ? (fs + kn) % ca.D : 0;
+#pragma unroll
+                for (int j = 0; j < CHAIN_SUB; ++j) {
+                    nx[j] = make_uint4(0u, 0u, 0u, 0u);
+                    if (!FUSED && valid && j < cn) nx[j] = ca.rec[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p];
+                    if (++sl == ca.D) sl = 0;
+                }
+            };
+            fetch_next(c0 + CHAIN_SUB);
             for (int k0 = c0; k0 < fn; k0 += CHAIN_SUB) {
                 if (ck_base && k0 > c0 && valid) { // state before frame k0
                     const size_t cs = ((size_t)(k0 / CHAIN_SUB - 1) * ca.n_clips + clip) * a.npx_pad + p;
                     ((R *)ck_base)[cs] = b;
                     if (lp_state) ((R *)ck_lp)[cs] = lp;
                     ck_ts[cs] = tsm;
-                }
-                uint4 nx[CHAIN_SUB];
-                const int nnext = min(CHAIN_SUB, fn - k0 - CHAIN_SUB); // frames of the next sub-pass (<= 0: none)
-#pragma unroll
-                for (int j = 0; j < CHAIN_SUB; ++j) {
-                    nx[j] = make_uint4(0u, 0u, 0u, 0u);
-                    if (!FUSED && valid && j < nnext)
-                        nx[j] = ca.rec[((size_t)((fs + k0 + CHAIN_SUB + j) % ca.D) * ca.n_clips + clip) * a.npx_pad + p];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int kend = min(k0 + CHAIN_SUB, fn);
@@ -553,14 +564,22 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     frame_body(k, rc_cur);
                     rc_cur = rc_nxt;
                 }
-                if (!FUSED && valid) {
+                if (!FUSED) {
+                    const int nnext = min(CHAIN_SUB, fn - k0 - CHAIN_SUB); // frames of the next sub-pass (<= 0: none)
+                    if (valid) {
 #pragma unroll
-                    for (int j = 0; j < CHAIN_SUB; ++j)
-                        if (j < nnext) s_arec[(size_t)j * BLOCK + tid] = nx[j];
-                    int sl = slot0;
-                    for (int k = k0; k < kend; ++k) { // the sub-pass's count words, behind the arrival of the next records
-                        WT_STORE(&ca.cnt[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p], s_cw[(size_t)(k % CHAIN_SUB) * BLOCK + tid]);
-                        if (++sl == ca.D) sl = 0;
+                        for (int j = 0; j < CHAIN_SUB; ++j)
+                            if (j < nnext) s_arec[(size_t)j * BLOCK + tid] = nx[j];
+                    }
+                    // the sub-pass after the next: its loads go out BEFORE this sub-pass's count words (vector memory operations
+                    // retire in order; the wait above then only ever covers operations a whole sub-pass old)
+                    fetch_next(k0 + 2 * CHAIN_SUB);
+                    if (valid) {
+                        int sl = slot0;
+                        for (int k = k0; k < kend; ++k) { // the sub-pass's count words
+                            WT_STORE(&ca.cnt[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p], s_cw[(size_t)(k % CHAIN_SUB) * BLOCK + tid]);
+                            if (++sl == ca.D) sl = 0;
+                        }
                     }
                 }
             }
@@ -577,7 +596,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             // finishing, and the workgroups this one waits for may need their slots)
             __builtin_amdgcn_s_setprio(0);
             const bool ok = clip_barrier(ca.bar_prev + (size_t)(round - 1) * ca.n_clips + clip, (unsigned)ca.ngroups);
-            __builtin_amdgcn_s_setprio(3);
+            if (ca.prio) __builtin_amdgcn_s_setprio(3);
             if (!ok && tid == 0) atomicOr(&ca.recs[(size_t)ca.pf0 * ca.n_clips + clip].flags, V2E_FLAG_SYNC_TIMEOUT);
         }
         if (valid && (ca.nf > 0 || ca.store_out || redone)) {
@@ -616,63 +635,93 @@ struct CEmitArgs {
     unsigned long long *off_out;
     unsigned *cdone;     // [E][n_clips] k_cframe: row workgroups done per frame (self-resetting)
     int capw, ich; // event records per wave in LDS; iterations per pass of k_cemit (64 * ich <= capw, 2 * ich <= 62)
+    int zpw_tot, zpw_emit; // frames a workgroup of k_ctot / k_cemit walks (grid z = ceil(nE / that)); see enqueue_run_chain
 };
 
 // What the event list needs from a frame's count words beyond the words themselves, per WAVE (every wave on its own, no
 // workgroup barrier): the wave's max count and its (iteration, polarity) event totals (ballot / popcount) as key-major u8
 // rows [key][wave]: key 0/1 shot ON/OFF, key 2+2i / 3+2i iteration i ON/OFF -- after the refractory filter on the frames
 // the chain finalised by the rule (ruleM != 0: the recurrence against ts_mem as it was, emulator.py:836-842).  A prefix
-// over waves (k_cframe) turns them into row offsets; k_cemit writes the rows.
+// over waves (k_cframe) turns them into row offsets; k_cemit writes the rows.  A workgroup takes CTOT_ZF frames of its 256
+// pixels (their count words in flight together: a wave's work per frame is a few dozen instructions, so what this kernel
+// costs is workgroup dispatch and one memory round trip).
+constexpr int CTOT_ZF = 4;
+
 __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
 {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int clip = blockIdx.y, g = blockIdx.x;
     const int wave_g = g * (BLOCK / WAVE) + wave;
     const int p = g * BLOCK + tid;
     const bool valid = p < a.npx;
-    const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
-    const size_t zc = (size_t)z * ea.n_clips + clip;
-    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
-    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
-    const uint32_t rM_v = ea.ruleM ? ea.ruleM[(size_t)slot * ea.n_clips + clip] : 0u;
-    const FrameTab ftb(c, lane);
-    float tsm = (valid && ea.tsold) ? ea.tsold[sp] : 0.f; // meaningful on rule-on frames only
-    const uint32_t rM = (uint32_t)__builtin_amdgcn_readfirstlane((int)rM_v);
-    const int magv = (int)(cw & CNT_MASK);
-    const bool neg = (cw & CNT_NEG) != 0;
-    const int wm = wave_max_i32(magv);
-    if (lane == 0) ea.wmax[zc * ea.nwp + wave_g] = (uint16_t)min(wm, 65535);
-    uint8_t *trow = ea.wtot + (zc * a.nkeys_cap) * ea.nwp + wave_g;
-    const int wmc = min(wm, a.max_iters); // beyond max_iters the frame is flagged and not emitted
-    const int nkw = 2 + 2 * wmc;
-    const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
-    const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
-    bool ruled = false;
-    TsGen tg(0.f, 0.f, 0.f, 1);
-    if (rM != 0u) tg = frame_tsgen(a, c, ftb, (int)rM, ruled);
-    for (int kb = 0; kb < nkw; kb += WAVE) {
-        uint32_t mine = 0;
-        const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
-        const int i_hi = min((kb + WAVE - 2) / 2, wmc);
-        for (int i = i_lo; i < i_hi; ++i) {
-            bool pass = magv > i;
-            if (ruled && pass) {
-                const float t = tg(i);
-                const float pt = 1.0f * t - tsm;
-                pass = pt > a.refr_f;
-                if (pass) tsm = t;
+    const int z_end = min(ea.nE, ((int)blockIdx.z + 1) * ea.zpw_tot);
+    for (int zb = (int)blockIdx.z * ea.zpw_tot; zb < z_end; zb += CTOT_ZF) { // CTOT_ZF frames' count words in flight together
+    uint32_t cwq[CTOT_ZF], rMq[CTOT_ZF];
+    int slotq[CTOT_ZF];
+    {
+        int sl = (ea.f0 + zb) % ea.D;
+#pragma unroll
+        for (int q = 0; q < CTOT_ZF; ++q) {
+            slotq[q] = sl;
+            cwq[q] = 0u;
+            rMq[q] = 0u;
+            if (zb + q < z_end) {
+                if (valid) cwq[q] = ea.cnt[((size_t)sl * ea.n_clips + clip) * a.npx_pad + p];
+                if (ea.ruleM) rMq[q] = ea.ruleM[(size_t)sl * ea.n_clips + clip];
             }
-            const unsigned long long bo = __ballot(pass && !neg);
-            const unsigned long long bf = __ballot(pass && neg);
-            const int kl = 2 + 2 * i - kb;
-            if (lane == kl) mine = (uint32_t)__popcll(bo);
-            if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+            if (++sl == ea.D) sl = 0;
         }
-        if (kb == 0) {
-            if (lane == 0) mine = (uint32_t)__popcll(so);
-            if (lane == 1) mine = (uint32_t)__popcll(sf);
+    }
+#pragma unroll
+    for (int q = 0; q < CTOT_ZF; ++q) {
+        const int z = zb + q;
+        if (z >= z_end) break;
+        const size_t zc = (size_t)z * ea.n_clips + clip;
+        const uint32_t cw = cwq[q];
+        const uint32_t rM = (uint32_t)__builtin_amdgcn_readfirstlane((int)rMq[q]);
+        const int magv = (int)(cw & CNT_MASK);
+        const bool neg = (cw & CNT_NEG) != 0;
+        const int wm = wave_max_i32(magv);
+        if (lane == 0) ea.wmax[zc * ea.nwp + wave_g] = (uint16_t)min(wm, 65535);
+        uint8_t *trow = ea.wtot + (zc * a.nkeys_cap) * ea.nwp + wave_g;
+        const int wmc = min(wm, a.max_iters); // beyond max_iters the frame is flagged and not emitted
+        const int nkw = 2 + 2 * wmc;
+        const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
+        const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
+        bool ruled = false;
+        TsGen tg(0.f, 0.f, 0.f, 1);
+        float tsm = 0.f;
+        if (rM != 0u) { // rule-on frame (rare): the filter needs the frame's time stamps and ts_mem as it was
+            const FrameCtl *c = ea.ctl + (size_t)(ea.f0 + z) * ea.n_clips + clip;
+            const FrameTab ftb(c, lane);
+            tg = frame_tsgen(a, c, ftb, (int)rM, ruled);
+            if (valid && ea.tsold) tsm = ea.tsold[((size_t)slotq[q] * ea.n_clips + clip) * a.npx_pad + p];
         }
-        if (kb + lane < nkw) trow[(size_t)(kb + lane) * ea.nwp] = (uint8_t)mine;
+        for (int kb = 0; kb < nkw; kb += WAVE) {
+            uint32_t mine = 0;
+            const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
+            const int i_hi = min((kb + WAVE - 2) / 2, wmc);
+            for (int i = i_lo; i < i_hi; ++i) {
+                bool pass = magv > i;
+                if (ruled && pass) {
+                    const float t = tg(i);
+                    const float pt = 1.0f * t - tsm;
+                    pass = pt > a.refr_f;
+                    if (pass) tsm = t;
+                }
+                const unsigned long long bo = __ballot(pass && !neg);
+                const unsigned long long bf = __ballot(pass && neg);
+                const int kl = 2 + 2 * i - kb;
+                if (lane == kl) mine = (uint32_t)__popcll(bo);
+                if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+            }
+            if (kb == 0) {
+                if (lane == 0) mine = (uint32_t)__popcll(so);
+                if (lane == 1) mine = (uint32_t)__popcll(sf);
+            }
+            if (kb + lane < nkw) trow[(size_t)(kb + lane) * ea.nwp] = (uint8_t)mine;
+        }
+    }
     }
 }
 
@@ -944,14 +993,24 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
     }
 }
 
+// Event offset of the next batch: this batch's plus its frames' event counts (one wave per clip; behind k_cframe on the tables
+// stream, so that k_cemit of batch b + 1 needs nothing from k_cemit of batch b).
+__global__ __launch_bounds__(WAVE) void k_coff(CEmitArgs ea)
+{
+    const int clip = blockIdx.x, lane = threadIdx.x;
+    unsigned long long tot = 0;
+    for (int z = lane; z < ea.nE; z += WAVE) tot += ea.cf[(size_t)z * ea.n_clips + clip].n_events;
+    const uint32_t lo = wave_sum_u32((uint32_t)(tot & 0xFFFFFFu)), hi = wave_sum_u32((uint32_t)(tot >> 24));
+    if (lane == 0) ea.off_out[clip] = ea.off_in[clip] + lo + ((unsigned long long)hi << 24);
+}
+
 // Event rows of one frame, every wave on its own: which of my iterations pass (the refractory recurrence against
 // tsold on rule-on frames), ballot ranks, one 4-byte record per event in LDS; then one event per lane: row =
 // frame offset + iteration base + shuffle(ON/OFF block offset + prefix over earlier waves + rank in wave).
-__global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
+__device__ __forceinline__ void cemit_frame(const KArgs &a, const CEmitArgs &ea, const int z, uint32_t *s_crec)
 {
-    extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw]
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int clip = blockIdx.y, g = blockIdx.x, fe = ea.f0 + z, slot = fe % ea.D;
     const size_t zc = (size_t)z * ea.n_clips + clip;
     const CFrame *cf = ea.cf + zc;
     const int wave_g = g * (BLOCK / WAVE) + wave;
@@ -996,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
     const uint32_t n_events = __builtin_amdgcn_readfirstlane((int)nev_v);
     if (g == 0 && tid == 0) {
         rec[clip].ev_offset = ev0;
-        if (z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events;
+        // (the next batch's offset is k_coff's: the event writers of consecutive batches do not wait for each other)
     }
     if (__builtin_amdgcn_readfirstlane((int)disc_v)) return;
     const int wmw = __builtin_amdgcn_readfirstlane(wm_v);
@@ -1102,4 +1161,11 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
         }
     }
     if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
+{
+    extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw]
+    const int z_end = min(ea.nE, ((int)blockIdx.z + 1) * ea.zpw_emit);
+    for (int z = (int)blockIdx.z * ea.zpw_emit; z < z_end; ++z) cemit_frame(a, ea, z, s_crec); // (a wave reads back only its own records)
 }

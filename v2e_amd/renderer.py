@@ -1,14 +1,21 @@
-"""Drop-in `EventRenderer`: DVS frames from events, the histograms on the GPU.
+"""Drop-in `EventRenderer`: DVS frames from events, rendered on the GPU a packet at a time.
 
-Mirrors v2ecore/renderer.py: `ExposureMode`, constructor signature (:37-99), `render_events_to_frames(event_arr,
-height, width, return_frames) -> frames or None` (:161-366) with the frame being filled held between packets, and
-`accumulate_event_frame` (:368-400).  What is re-built: the ON/OFF 2-D histograms and the clipped running frame
-(`hist2d_numba_seq`, v2e_utils.py:474-486) as HIP kernels on the device-resident event packet, and the 0..1
-normalisation.  What is kept on the host, statement for statement, is the exposure bookkeeping -- which events belong to
-which frame (duration / count / area-count / source), including the reference's own edge behaviour (the last event of a
-packet is never accumulated, renderer.py:303-306; `searchsorted` on the remaining time stamps) -- so that the frames
-are the reference's frames.  AVI output and the preview window (cv2) are outside the hot path: `dvs_vid` / `preview`
-raise NotImplementedError.
+Mirrors the surface of v2ecore/renderer.py: `ExposureMode`, the constructor signature (:37-99),
+`render_events_to_frames(event_arr, height, width, return_frames) -> frames or None` (:161-366) with the frame the packet
+ends in left behind in `currentFrame`, and `accumulate_event_frame` (:368-400).
+
+How a packet is rendered here (v2e_amd/csrc/render.hip): the reference walks the packet window by window; this class
+never walks it.  The host only works out the packet's window boundaries -- DURATION: the frame start times, the same
+scalar additions the reference makes, until they pass the packet's second-to-last time stamp (the only two values read
+back from the device); COUNT: plain index arithmetic; AREA_COUNT: the segment ends found by one single-wave scan kernel
+(per-cell counters in LDS, the trigger event re-counted in the next window as renderer.py:253-266 does) -- and ONE
+launch then drops every event into the frame(s) its window rule assigns it to (binary search over the boundaries; an
+event exactly on a DURATION boundary belongs to both neighbours, as the reference's searchsorted left / right pair gives
+it), one more clips and normalises all frames of the packet.  The reference's edge behaviour is part of the contract and
+kept: the running frame is reset at every packet (:273), the last event of a packet is never accumulated (:303-306), the
+frame a packet ends in is not emitted (except SOURCE).  Pinned by frames of the reference's own class in every mode
+(tests/golden/make_golden_renderer.py).  AVI output and the preview window (cv2) are outside the hot path: `dvs_vid` /
+`preview` raise NotImplementedError.
 """
 import ctypes as C
 import logging
@@ -95,10 +102,28 @@ class EventRenderer(object):
         acc.accumulate(events_dev)
         self.currentFrame = acc.currentFrame
 
+    def _duration_bounds(self, ts_first, ts_second_last, n):
+        """Start times T_0 .. T_m of the frames this packet touches (frame k = [T_k, T_k+1], k < m complete; T_m opens the
+        frame the packet ends in), advancing `currentFrameStartTime` as the reference does (renderer.py:209-213, 315-318):
+        a frame is complete while events beyond its end remain besides the packet's last one, i.e. while the
+        second-to-last time stamp lies past the next frame's start."""
+        if self.currentFrameStartTime is None:
+            self.currentFrameStartTime = ts_first
+        bounds = [self.currentFrameStartTime]
+        if n >= 2:
+            while ts_second_last > self.currentFrameStartTime + self.frameIntevalS:
+                nxt = self.currentFrameStartTime + self.frameIntevalS
+                if not nxt > self.currentFrameStartTime:
+                    raise ValueError("exposure duration %g s does not advance the frame time %r (float32 time stamps)"
+                                     % (self.frameIntevalS, self.currentFrameStartTime))
+                self.currentFrameStartTime += self.frameIntevalS
+                bounds.append(self.currentFrameStartTime)
+        return bounds
+
     def render_events_to_frames(self, event_arr, height: int, width: int, return_frames=False):
-        """Incrementally render event frames (renderer.py:161-366).  `event_arr`: [n,4] events (ts, x, y, pol) as a host
-        array or a device tensor.  Returns the frames filled by this packet as a float64 [n,h,w] numpy array in 0..1 (only
-        if return_frames), or None."""
+        """Render the frames this packet completes (renderer.py:161-366).  `event_arr`: [n,4] events (ts, x, y, pol) as a
+        host array or a device tensor.  Returns the completed frames as a float64 [m,h,w] numpy array in 0..1 (only if
+        return_frames), or None; the frame the packet ends in stays in `currentFrame` (device float64 [h,w])."""
         self.width = width
         self.height = height
         if event_arr is None or event_arr.shape[0] == 0:
@@ -106,82 +131,57 @@ class EventRenderer(object):
                 logger.info('event_arr is None or there are no events, doing nothing, supressing further warnings')
                 self.printed_empty_packet_warning = True
             return None
+        dev = self.device
         if torch.is_tensor(event_arr):
-            ev_dev = event_arr.to(self.device, torch.float32).contiguous()
-            ev_host = None
-            ts = ev_dev[:, 0].cpu().numpy()
+            ev = event_arr.to(dev, torch.float32).contiguous()
+            n = int(ev.shape[0])
+            edge = ev[[0, max(n - 2, 0)], 0].cpu().numpy() if self.exposure_mode == ExposureMode.DURATION else None
         else:
-            ev_host = np.ascontiguousarray(event_arr, dtype=np.float32)
-            ev_dev = torch.from_numpy(ev_host).to(self.device)
-            ts = ev_host[:, 0]
-        if self.exposure_mode == ExposureMode.DURATION:
-            if self.currentFrameStartTime is None:
-                self.currentFrameStartTime = ts[0]
-            nextFrameStartTs = self.currentFrameStartTime + self.frameIntevalS
-        if self.exposure_mode == ExposureMode.AREA_COUNT and self.area_counts is None:
+            host = np.ascontiguousarray(event_arr, dtype=np.float32)
+            n = int(host.shape[0])
+            ev = torch.from_numpy(host).to(dev)
+            edge = host[[0, max(n - 2, 0)], 0] if self.exposure_mode == ExposureMode.DURATION else None
+        lib = _capi.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        mode = self.exposure_mode
+        bounds_dev = seg_dev = None
+        n_bounds = n_seg = 0
+        count_per_frame = 1
+        has_open = 1
+        if mode == ExposureMode.DURATION:
+            bounds = self._duration_bounds(edge[0], edge[1], n)
+            n_complete = len(bounds) - 1
+            bounds_dev = torch.tensor([float(b) for b in bounds], dtype=torch.float64).to(dev)
+            n_bounds = len(bounds)
+        elif mode == ExposureMode.COUNT:
+            count_per_frame = int(self.event_count)
+            n_complete = (n - 2) // count_per_frame if n >= 2 else 0  # frames [k c, (k + 1) c) with (k + 1) c < n - 1
+        elif mode == ExposureMode.AREA_COUNT:
             nw = 1 + self.width // self.area_dimension
             nh = 1 + self.height // self.area_dimension
-            self.area_counts = np.zeros(shape=(nw, nh), dtype=int)
-        returned = []
-        thisFrameIdx = 0
-        numEvents = len(ts)
-        histrange = np.asarray([(0, v) for v in (self.height, self.width)], dtype=np.int64)
-        doneWithTheseEvents = False
-        start, end = 0, numEvents
-        self.currentFrame = None  # (renderer.py:273: reset at every packet, as the reference does)
-        while not doneWithTheseEvents:
-            if self.exposure_mode == ExposureMode.DURATION:
-                rest = ts[thisFrameIdx:]
-                start = int(np.searchsorted(rest, self.currentFrameStartTime, side="left"))
-                end = int(np.searchsorted(rest, nextFrameStartTs, side="right"))
-            elif self.exposure_mode == ExposureMode.COUNT:
-                start = thisFrameIdx
-                end = start + self.event_count
-            elif self.exposure_mode == ExposureMode.AREA_COUNT:
-                start = thisFrameIdx
-                if ev_host is None:
-                    ev_host = ev_dev.cpu().numpy()
-                self.area_counts, end = self._compute_area_counts(ev_host, self.area_counts, self.area_count,
-                                                                  self.area_dimension, start)
-            elif self.exposure_mode == ExposureMode.SOURCE:
-                start = 0
-                end = numEvents
-            if end >= numEvents - 1:
-                doneWithTheseEvents = True
-                end = numEvents - 1
-            self.accumulate_event_frame(ev_dev[start:end], histrange)
-            if not doneWithTheseEvents or self.exposure_mode == ExposureMode.SOURCE:
-                if self.exposure_mode == ExposureMode.DURATION:
-                    self.currentFrameStartTime += self.frameIntevalS
-                    nextFrameStartTs = self.currentFrameStartTime + self.frameIntevalS
-                elif self.exposure_mode == ExposureMode.COUNT or self.exposure_mode == ExposureMode.AREA_COUNT:
-                    thisFrameIdx = end
-                # img output is 0-1 range (renderer.py:245-247)
-                img = torch.empty_like(self.currentFrame)
-                check(_capi.lib().v2e_frame_normalize(C.c_void_p(self.currentFrame.data_ptr()), C.c_void_p(img.data_ptr()),
-                                                      img.numel(), float(self.full_scale_count),
-                                                      C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
-                      "v2e_frame_normalize")
-                self.currentFrame = None
-                if return_frames:
-                    returned.append(img)
-                self.numFramesWritten += 0  # only a video file advances the reference's counter
-        if self.currentFrame is not None:
-            self.currentFrame = self.currentFrame.clone()  # detach from the accumulator, which the next packet zeroes
-        if not returned:
+            if self.area_counts is None or tuple(self.area_counts.shape) != (nw, nh):
+                self.area_counts = torch.zeros((nw, nh), dtype=torch.int32, device=dev)
+            seg_dev = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+            out2 = torch.zeros((2,), dtype=torch.int32, device=dev)
+            check(lib.v2e_render_area_segments(C.c_void_p(ev.data_ptr()), n, C.c_void_p(self.area_counts.data_ptr()), nw, nh,
+                                               float(self.area_dimension), int(self.area_count), C.c_void_p(seg_dev.data_ptr()),
+                                               int(seg_dev.numel()), C.c_void_p(out2.data_ptr()), stream), "v2e_render_area_segments")
+            n_seg = n_complete = int(out2[0].item())
+        else:  # SOURCE: the whole packet is one frame, and it is emitted
+            n_complete, has_open = 1, 0
+        npx = height * width
+        diff = torch.empty((n_complete + has_open, npx), dtype=torch.int32, device=dev)
+        frames = torch.empty((n_complete, height, width), dtype=torch.float64, device=dev)
+        cur = torch.empty((height, width), dtype=torch.float64, device=dev) if has_open else None
+        check(lib.v2e_render_packet(C.c_void_p(ev.data_ptr()), n - 1, mode.value,
+                                    C.c_void_p(bounds_dev.data_ptr()) if bounds_dev is not None else None, n_bounds,
+                                    count_per_frame, C.c_void_p(seg_dev.data_ptr()) if seg_dev is not None else None, n_seg,
+                                    n_complete, has_open, C.c_void_p(diff.data_ptr()),
+                                    C.c_void_p(frames.data_ptr()) if n_complete else None,
+                                    C.c_void_p(cur.data_ptr()) if cur is not None else None, height, width,
+                                    0.0, float(self.height), 0.0, float(self.width), float(self.full_scale_count), stream),
+              "v2e_render_packet")
+        self.currentFrame = cur
+        if n_complete == 0 or not return_frames:
             return None
-        return torch.stack(returned).cpu().numpy()
-
-    @staticmethod
-    def _compute_area_counts(events, area_counts, area_count, area_dimension, start):
-        """renderer.py:253-266 (a sequential scan by definition: host loop)."""
-        ev_idx = start
-        for ev_idx in range(start, events.shape[0]):
-            x = int(events[ev_idx, 1] // area_dimension)
-            y = int(events[ev_idx, 2] // area_dimension)
-            count = 1 + area_counts[x, y]
-            area_counts[x, y] = count
-            if count >= area_count:
-                area_counts = np.zeros_like(area_counts)
-                break
-        return area_counts, ev_idx
+        return frames.cpu().numpy()
