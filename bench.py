@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the slomo / batched / frame-API side measurements")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--force-allgather", action="store_true", help="run the RCCL gather path even with one rank (self-test)")
+    ap.add_argument("--gather-algo", choices=["allgather", "p2p"], default="allgather",
+                    help="event-stream exchange: ncclAllGather on padded payloads, or grouped point-to-point sends of exact sizes")
+    ap.add_argument("--gather-wire", choices=["auto", "pack32", "pack64"], default="auto")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -277,7 +280,7 @@ def main():
         return res[order[len(order) // 2]]
 
     emu = make_emu()
-    gather = EventStreamGatherer(device, world) if use_gather else None
+    gather = EventStreamGatherer(device, world, wire=args.gather_wire, algo=args.gather_algo, sensor=(H, W)) if use_gather else None
     blocks = timed_blocks(emu, gather)
     elapsed, tot_events = median_block(blocks)
     compute_only = None
@@ -314,7 +317,9 @@ def main():
                                    "note": "same loop, no event-stream exchange"}
             out["with_allgather"] = {"value": out["value"], "unit": "Mevents/s",
                                      "bytes_gathered_per_rank_per_step": int(gather.bytes_gathered / max(nblocks * K + Wm, 1)),
-                                     "wire_format": "8 B per event (v2e_events_pack64)"}
+                                     "algo": args.gather_algo,
+                                     "wire_format": ("4 B per event + 8 B per block of one time stamp (v2e_events_pack32)"
+                                                     if gather.wire == "pack32" else "8 B per event (v2e_events_pack64)")}
 
     # ---------------- roofline of the dominant emulator kernel (rank 0, HIP events, same workload)
     if rank == 0:
@@ -338,7 +343,7 @@ def main():
         # base 16 + thresholds 8 + noise rate 4 + ts_mem 8) + 16 B/event; the chain kernel also writes the 4-byte count word the
         # event writer reads.  A launch covers `fpl` frames.
         n_step = max(prof.get("step_launches", 0), 1)
-        period_us = prof["count"] / n_step * 1e3   # first launch's start to last launch's end / launches
+        period_us = elapsed / K / n_step * 1e6     # the driver-timed region: one step = n_step chain launches
         kernel_us = prof["rank"] / n_step * 1e3    # HIP events before and after every chain launch, on its stream: the kernels alone
         step_bytes = bpp * npx * fpl               # 53 B per pixel and frame x the frames one launch advances
         emit_bytes = 16 * ev_per_frame + 4 * npx
@@ -357,7 +362,8 @@ def main():
             "launch_period_us": round(period_us, 3),
             "as_delivered": {"achieved_GBps": round(step_bytes / (period_us * 1e-6) / 1e9, 2),
                              "frac": round(step_bytes / (period_us * 1e-6) / HBM_PEAK, 5),
-                             "note": "the same bytes against the chain's launch-to-launch period (gaps, ring waits and redo passes included)"},
+                             "note": "the same bytes against the timed region's time per chain launch (ms_per_step / launches per step: "
+                                     "everything the step does -- k_ahead, the emission kernels, gaps, redo passes -- included)"},
             "rocprof_recorded": (lambda us: None if us is None else {
                 "avg_kernel_us": us, "source": "profiles/r03_emulator_chain_kernel_trace.txt",
                 "frac": round(step_bytes / (us * 1e-6) / HBM_PEAK, 5)})(rocprof_kernel_us(kname.split("(")[0])),
@@ -367,7 +373,8 @@ def main():
                            "achieved_GBps": round(whole * K * F / elapsed / 1e9, 2),
                            "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
             "note": "achieved = algorithmic bytes of the frames a chain launch advances / the launch's own duration, HIP events "
-                    "before and after every launch of an instrumented re-run of the last step's frames on the chain's stream; "
+                    "before and after every launch of an instrumented re-run of the last step's frames (all kernels of the run on the "
+                    "one stream, i.e. each running alone, which is also how the captured graph of the timed runs executes on this runtime); "
                     "the per-pixel state (2.9 MB at 346x260) stays in registers for the launch's frames and one frame is only "
                     "1408 waves, so the chain is bounded by instruction latency, not HBM (DESIGN.md section 3); whole_step prices "
                     "the complete frame (state traffic + event rows) against the driver-timed region",

@@ -316,6 +316,17 @@ int v2e_events_pack_h5(const float *events, uint32_t *out, int64_t n, void *stre
 int v2e_events_pack64(const float *events, uint64_t *out, int64_t n, void *stream);
 int v2e_events_unpack64(const uint64_t *in, float *events, int64_t n, void *stream);
 
+/* Lossless 4-byte wire format for sensors up to 2048 x 1024: the rows of a run come in blocks of one time stamp (all events
+ * of one (frame, iteration) share it: emulator.py:793-796, 861-870), so t travels once per block.  payload[i] = x | y << 11
+ * | (p > 0) << 21; runs[0] = number of blocks R, runs[1 + r] = float32 bits of t << 32 | index of the block's first event
+ * (in order).  cap_runs: entries the run table holds besides runs[0] (a bound is sum over frames of max(iterations, 1));
+ * scratch: device uint32 [v2e_events_pack32_scratch_words(n)], scratch[0] after the call: bit 0 a coordinate did not fit,
+ * bit 1 the run table was too small (the caller then sends pack64).  unpack32 restores the float32 rows bit for bit. */
+int v2e_events_pack32(const float *events, int64_t n, uint32_t *payload, uint64_t *runs, int64_t cap_runs,
+                      uint32_t *scratch, void *stream);
+int64_t v2e_events_pack32_scratch_words(int64_t n);
+int v2e_events_unpack32(const uint32_t *payload, int64_t n, const uint64_t *runs, float *events, void *stream);
+
 /* EventRenderer.accumulate_event_frame (renderer.py:368-400, hist2d_numba_seq v2e_utils.py:474-486):
  * current_frame (float64 [bins_y][bins_x], device) = clip(current_frame + hist(ON) - hist(OFF), +-full_scale).
  * scratch_diff: device int32 [bins_y][bins_x], zero on entry, left zero. */

@@ -23,44 +23,96 @@ def _rows(n, rank, step):
     return torch.stack([k * 1e-3 - 0.002 + rank + 0.1 * step, (k + 13 * rank) % 346, (k * 7 + step) % 260, (k % 2) * 2 - 1], dim=1).contiguous()
 
 
-def _worker(rank, world, port, q):
+def _rows_runs(n, rank, step):
+    """n event rows in blocks of one time stamp (as an emulator emits them: all events of one (frame, iteration) share t),
+    block lengths 1..7, x up to 1279, y up to 719, a negative and a zero time stamp among them."""
+    k = torch.arange(n, dtype=torch.int64)
+    blk = torch.div(k * 3 + rank, 7 + step, rounding_mode="floor")
+    t = (blk.to(torch.float32) - 2.0) * 1.25e-4 * (1 + rank)
+    return torch.stack([t, ((k * 37 + 13 * rank) % 1280).to(torch.float32), ((k * 7 + step) % 720).to(torch.float32),
+                        ((k % 3 == 0).to(torch.float32)) * 2 - 1], dim=1).contiguous()
+
+
+def _counts(world, rank, step):
+    n = 5 + 7 * rank + 3 * step           # ragged, different per rank and step
+    if step == 2 and rank == 1:
+        n = 0                              # empty stream on one rank
+    if step == 1 and rank == world - 1:
+        n = 0
+    return n
+
+
+def _worker(rank, world, port, q, wire="pack64", algo="allgather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from v2e_amd.dist import EventStreamGatherer, clips_of_rank
-    g = EventStreamGatherer("cpu", world)
+    g = EventStreamGatherer("cpu", world, wire=wire, algo=algo, sensor=(720, 1280))
     ok = True
+    rows = _rows if wire == "pack64" else _rows_runs
     for step in range(3):
-        n = 5 + 7 * rank + 3 * step           # ragged, different per rank and step
-        if step == 2 and rank == 1:
-            n = 0                              # empty stream on one rank
-        ev = _rows(n + 4, rank, step)
-        g.submit(ev, n)
+        n = _counts(world, rank, step)
+        ev = rows(n + 4, rank, step)
+        g.submit(ev, n, run_bound=(n if wire == "pack32" else None))
         parts = g.result()
         for r in range(world):
-            nr = 5 + 7 * r + 3 * step
-            if step == 2 and r == 1:
-                nr = 0
-            exp = _rows(nr + 4, r, step)[:nr]
-            ok &= parts[r].shape == exp.shape and torch.equal(parts[r], exp)
+            nr = _counts(world, r, step)
+            exp = rows(nr + 4, r, step)[:nr]
+            ok &= parts[r].shape == exp.shape and torch.equal(parts[r].view(torch.int32), exp.view(torch.int32))
     ok &= clips_of_rank(8, world, rank) == list(range(rank, 8, world))
+    ok &= g.bytes_gathered > 0
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_event_stream_allgather_gloo_world2():
-    world = 2
+def _run_gloo(world, wire, algo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, wire, algo)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(world))
+    res = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
-    assert res == {0: True, 1: True}
+    assert res == {r: True for r in range(world)}
+
+
+def test_event_stream_allgather_gloo_world2():
+    _run_gloo(2, "pack64", "allgather")
+
+
+@pytest.mark.parametrize("wire,algo", [("pack64", "allgather"), ("pack32", "allgather"), ("pack32", "p2p"), ("pack64", "p2p")])
+def test_event_stream_exchange_gloo_world4_unequal_counts(wire, algo):
+    """Four ranks, ragged streams incl. empty ones, both wire formats (8 bytes per event; 4 bytes per event + one time stamp
+    per block), both exchange algorithms (padded all-gather; grouped point-to-point sends of exact sizes)."""
+    _run_gloo(4, wire, algo)
+
+
+def test_wire_formats_round_trip_and_agree():
+    """pack32 (payload + run table) and pack64 restore the same float32 rows bit for bit: blocks of one time stamp, a
+    negative time stamp, -0.0 next to +0.0 (different bits: two blocks), coordinates up to 2047 x 1023; a coordinate beyond
+    that is flagged."""
+    from v2e_amd.dist import pack_events32, pack_events64, unpack_events32, unpack_events64
+    ev = _rows_runs(5000, 1, 2)
+    ev[10:20, 0] = -0.0
+    ev[20:30, 0] = 0.0
+    ev[100, 1], ev[100, 2] = 2047.0, 1023.0
+    pl, runs, fl = pack_events32(ev)
+    assert int(fl[0]) == 0 and int(runs[0]) == runs.numel() - 1
+    back32 = unpack_events32(pl, runs)
+    back64 = unpack_events64(pack_events64(ev))
+    assert torch.equal(back32.view(torch.int32), ev.view(torch.int32))
+    assert torch.equal(back64.view(torch.int32), ev.view(torch.int32))
+    # an emulator's blocks hold thousands of events: the run table is noise, the stream half of pack64's
+    big = _rows_runs(60000, 0, 0)
+    big[:, 0] = torch.div(torch.arange(60000), 500, rounding_mode="floor").to(torch.float32) * 1e-4
+    pl2, runs2, _ = pack_events32(big)
+    assert 4 * pl2.numel() + 8 * runs2.numel() < 0.51 * 8 * big.shape[0]
+    assert torch.equal(unpack_events32(pl2, runs2).view(torch.int32), big.view(torch.int32))
+    ev[7, 1] = 2048.0
+    assert int(pack_events32(ev)[2][0]) != 0
 
 
 def test_clip_sharding_covers_all_clips():
@@ -70,7 +122,7 @@ def test_clip_sharding_covers_all_clips():
         assert allc == list(range(8))
 
 
-def _nccl_worker(rank, world, port, q):
+def _nccl_worker(rank, world, port, q, wire="pack64", algo="allgather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -78,7 +130,7 @@ def _nccl_worker(rank, world, port, q):
     dev = torch.device("cuda", rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from v2e_amd.dist import EventStreamGatherer
-    g = EventStreamGatherer(dev, world)
+    g = EventStreamGatherer(dev, world, wire=wire, algo=algo, sensor=(260, 346))
     ok = True
     for step in range(4):
         n = 1000 + 50000 * rank + 7 * step     # unequal per rank: the padded size must come from the gathered counts
@@ -87,7 +139,7 @@ def _nccl_worker(rank, world, port, q):
         ev = _rows(n + 4, rank, step).to(dev)
         # keep the main stream busy so that a count read on the wrong stream would race the collective
         _ = torch.randn(2048, 2048, device=dev) @ torch.randn(2048, 2048, device=dev)
-        g.submit(ev, n)
+        g.submit(ev, n, run_bound=(n if wire == "pack32" else None))
         parts = g.result()
         for r in range(world):
             nr = 1000 + 50000 * r + 7 * step
@@ -101,7 +153,8 @@ def _nccl_worker(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_event_stream_allgather_nccl_world2_unequal_counts():
+@pytest.mark.parametrize("wire,algo", [("pack64", "allgather"), ("pack32", "allgather"), ("pack32", "p2p")])
+def test_event_stream_allgather_nccl_world2_unequal_counts(wire, algo):
     """RCCL path with two ranks and rank-dependent row counts (needs two GPUs; the 1-GPU test box skips it)."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
@@ -109,7 +162,7 @@ def test_event_stream_allgather_nccl_world2_unequal_counts():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q, wire, algo)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))

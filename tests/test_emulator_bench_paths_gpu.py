@@ -127,7 +127,7 @@ class _DigestSink:
     def __init__(self):
         self.steps = []
 
-    def submit(self, ev, n):
+    def submit(self, ev, n, ready_event=None, run_bound=None):
         self.steps.append((int(n), sha(ev[:n].cpu().numpy())))
 
     def wait(self):

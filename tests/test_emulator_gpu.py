@@ -435,6 +435,19 @@ def test_event_wire_format_roundtrip():
     assert torch.equal(w.cpu(), pack_events64(torch.from_numpy(ev)))
     back = unpack_events64(w)
     assert np.array_equal(back.cpu().numpy().view(np.uint32), ev.view(np.uint32))
+    # the 4-byte format (payload + one time stamp per block): device kernels == the CPU implementation == the rows
+    from v2e_amd.dist import pack_events32, unpack_events32
+    ev32 = ev[:-1].copy()  # (the 16383 corner value does not fit 11 + 10 bits)
+    d32 = torch.from_numpy(ev32).cuda()
+    pl, runs, flags = pack_events32(d32, cap_runs=len(ev32))
+    plc, runsc, _ = pack_events32(torch.from_numpy(ev32))
+    assert int(flags[0].item()) == 0 and int(runs[0].item()) == int(runsc[0])
+    R = int(runsc[0])
+    assert torch.equal(pl[:len(ev32)].cpu(), plc) and torch.equal(runs[:R + 1].cpu(), runsc)
+    back32 = unpack_events32(pl, runs, len(ev32))
+    assert np.array_equal(back32.cpu().numpy().view(np.uint32), ev32.view(np.uint32))
+    assert int(pack_events32(d, cap_runs=len(ev))[2][0].item()) & 1  # 16383 flagged
+    assert int(pack_events32(d32, cap_runs=3)[2][0].item()) & 2      # run table too small flagged
 
 
 def test_event_stream_gatherer_nccl_single_rank():

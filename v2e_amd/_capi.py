@@ -110,6 +110,9 @@ SIGNATURES = {
     "v2e_events_pack_h5": (_i, [_vp, _vp, _i64, _vp]),
     "v2e_events_pack64": (_i, [_vp, _vp, _i64, _vp]),
     "v2e_events_unpack64": (_i, [_vp, _vp, _i64, _vp]),
+    "v2e_events_pack32": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "v2e_events_pack32_scratch_words": (_i64, [_i64]),
+    "v2e_events_unpack32": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "v2e_events_accumulate_frame": (_i, [_vp, _i64, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _vp]),
     "v2e_frame_normalize": (_i, [_vp, _vp, _i, _d, _vp]),
     "v2e_render_area_segments": (_i, [_vp, _i64, _vp, _i, _i, _d, _i, _vp, _i64, _vp, _vp]),

@@ -33,7 +33,11 @@ def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device, first
         ev, counts = pend.result()
         n = int(counts.sum())
         if gather is not None:
-            gather.submit(ev, n)  # all-gather of this step's stream overlaps the next step
+            # all-gather of this step's stream overlaps the next step: the side stream waits for THIS run's completion event
+            # only; the blocks of one time stamp are bounded by the frames' iteration counts (4-byte wire format)
+            rh = getattr(pend, "rec_host", None)
+            rb = int(np.maximum(rh["max_events"], 1).sum()) if rh is not None else None
+            gather.submit(ev, n, ready_event=getattr(pend, "done", None), run_bound=rb)
         return n
 
     def sync():

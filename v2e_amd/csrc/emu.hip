@@ -1408,6 +1408,8 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     KArgs a = a_in; // kernel arguments are passed by address (hipLaunchKernel / kernel nodes copy them at the call)
     Sched sc;
     sc.h = h; sc.st[ST_MAIN] = s; sc.st[ST_AHEAD] = h->ahead; sc.st[ST_SIDE] = h->side; sc.st[ST_TAB] = h->tabs; sc.st[ST_SIDE2] = h->side2; sc.graph = graph;
+    if (ev_main) // instrumented run: every kernel on the one stream, so that a launch's HIP events bracket that kernel running alone --
+        for (int q = 0; q < ST_COUNT; ++q) sc.st[q] = s; // which is how the captured graph of the timed runs executes on this runtime
     if (graph) {
         sc.ev_cap = nL + 2;
         sc.evdeps.assign((size_t)EV_KINDS * sc.ev_cap, std::vector<hipGraphNode_t>());

@@ -86,6 +86,105 @@ __global__ __launch_bounds__(256) void k_unpack64(const unsigned long long *__re
                         (v & 1ull) ? 1.0f : -1.0f);
 }
 
+
+// ---- 4-byte wire format of an event stream (include/v2e_amd.h: v2e_events_pack32).  The rows of a run come in blocks of
+// one time stamp -- all events of one (frame, iteration) carry the same t, emulator.py:793-796, 861-870 -- so t travels once
+// per block: run table {float32 bits of t, index of the block's first event} + one word per event (x | y << 11 | p << 21).
+constexpr int P32_BLOCK = 1024;
+
+__device__ __forceinline__ bool p32_starts_run(const float4 *__restrict__ ev, int64_t i)
+{
+    return i == 0 || __float_as_uint(ev[i].x) != __float_as_uint(ev[i - 1].x);
+}
+
+// pass 1: payload words + run starts per block of 1024 events
+__global__ __launch_bounds__(P32_BLOCK) void k_pack32_words(const float4 *__restrict__ ev, int64_t n, uint32_t *__restrict__ payload,
+                                                            uint32_t *__restrict__ blk_runs, uint32_t *__restrict__ overflow)
+{
+    __shared__ uint32_t s_cnt[P32_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * P32_BLOCK + threadIdx.x;
+    bool start = false;
+    if (i < n) {
+        const float4 e = ev[i];
+        const uint32_t x = (uint32_t)e.y, y = (uint32_t)e.z;
+        if (x >= 2048u || y >= 1024u) atomicOr(overflow, 1u); // does not fit 11 + 10 bits: the caller falls back to pack64
+        payload[i] = (x & 0x7FFu) | ((y & 0x3FFu) << 11) | (e.w > 0.f ? 1u << 21 : 0u);
+        start = p32_starts_run(ev, i);
+    }
+    const unsigned long long b = __ballot(start);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < P32_BLOCK / 64; ++w) t += s_cnt[w];
+        blk_runs[blockIdx.x] = t;
+    }
+}
+
+// pass 2: exclusive scan of the per-block run counts (one workgroup; nblk <= 2^22), total to runs[0]
+__global__ __launch_bounds__(1024) void k_pack32_scan(uint32_t *__restrict__ blk_runs, int nblk, unsigned long long *__restrict__ runs,
+                                                      int64_t cap_runs, uint32_t *__restrict__ overflow)
+{
+    __shared__ uint32_t s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nblk + 1023) / 1024;
+    uint32_t sum = 0;
+    for (int k = 0; k < per; ++k) { const int j = tid * per + k; if (j < nblk) sum += blk_runs[j]; }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int k = 0; k < per; ++k) {
+        const int j = tid * per + k;
+        if (j < nblk) { const uint32_t c = blk_runs[j]; blk_runs[j] = run; run += c; }
+    }
+    if (tid == 1023) {
+        const uint32_t total = s_part[1023];
+        runs[0] = total;
+        if ((int64_t)total > cap_runs) atomicOr(overflow, 2u); // run table too small
+    }
+}
+
+// pass 3: run table entries (t bits << 32 | first event index), in order
+__global__ __launch_bounds__(P32_BLOCK) void k_pack32_runs(const float4 *__restrict__ ev, int64_t n, const uint32_t *__restrict__ blk_base,
+                                                           unsigned long long *__restrict__ runs, int64_t cap_runs)
+{
+    __shared__ uint32_t s_cnt[P32_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * P32_BLOCK + threadIdx.x;
+    const bool start = i < n && p32_starts_run(ev, i);
+    const unsigned long long b = __ballot(start);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t before = blk_base[blockIdx.x];
+    for (int w = 0; w < wave; ++w) before += s_cnt[w];
+    if (start) {
+        const uint32_t r = before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if ((int64_t)r < cap_runs) runs[1 + r] = ((unsigned long long)__float_as_uint(ev[i].x) << 32) | (unsigned long long)(uint32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unpack32(const uint32_t *__restrict__ payload, int64_t n, const unsigned long long *__restrict__ runs,
+                                                  float4 *__restrict__ ev)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int nr = (int)runs[0];
+    int lo = 0, hi = nr; // last run whose first event index is <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)(uint32_t)runs[1 + mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint32_t w = payload[i];
+    ev[i] = make_float4(__uint_as_float((uint32_t)(runs[1 + lo] >> 32)), (float)(w & 0x7FFu), (float)((w >> 11) & 0x3FFu),
+                        (w >> 21) & 1u ? 1.0f : -1.0f);
+}
+
 } // namespace
 
 extern "C" {
@@ -124,6 +223,33 @@ int v2e_events_unpack64(const uint64_t *in, float *events, int64_t n, void *stre
     V2E_REQUIRE((events && in) || n == 0, "null");
     if (n <= 0) return 0;
     k_unpack64<<<v2e_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>((const unsigned long long *)in, (float4 *)events, n);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_events_pack32(const float *events, int64_t n, uint32_t *payload, uint64_t *runs, int64_t cap_runs, uint32_t *scratch, void *stream)
+{
+    V2E_REQUIRE(runs && scratch && cap_runs >= 0 && (n == 0 || (events && payload)), "null");
+    V2E_REQUIRE(n < ((int64_t)1 << 32), "too many events for 32-bit run starts");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (int)((n + P32_BLOCK - 1) / P32_BLOCK);
+    // scratch: [0] overflow flags, [1 .. 1 + nblk) per-block run counts / bases
+    V2E_HIP(hipMemsetAsync(scratch, 0, sizeof(uint32_t), s));
+    if (n == 0) { V2E_HIP(hipMemsetAsync(runs, 0, sizeof(uint64_t), s)); return 0; }
+    k_pack32_words<<<nblk, P32_BLOCK, 0, s>>>((const float4 *)events, n, payload, scratch + 1, scratch);
+    k_pack32_scan<<<1, 1024, 0, s>>>(scratch + 1, nblk, (unsigned long long *)runs, cap_runs, scratch);
+    k_pack32_runs<<<nblk, P32_BLOCK, 0, s>>>((const float4 *)events, n, scratch + 1, (unsigned long long *)runs, cap_runs);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int64_t v2e_events_pack32_scratch_words(int64_t n) { return 2 + (n + P32_BLOCK - 1) / P32_BLOCK; }
+
+int v2e_events_unpack32(const uint32_t *payload, int64_t n, const uint64_t *runs, float *events, void *stream)
+{
+    V2E_REQUIRE(runs && (n == 0 || (payload && events)), "null");
+    if (n <= 0) return 0;
+    k_unpack32<<<v2e_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(payload, n, (const unsigned long long *)runs, (float4 *)events);
     V2E_HIP(hipGetLastError());
     return 0;
 }
