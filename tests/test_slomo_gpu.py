@@ -248,27 +248,26 @@ def test_interpolation_matches_reference_at_benchmark_shape(conv_math):
     assert np.array_equal(Ft[:, :b], Ft[:, b:2 * b]) and np.array_equal(intrp[:, :b], intrp[:, 3 * b:])
 
 
+@pytest.mark.parametrize("fixture", ["slomo_trained_scale_64x96", "slomo_allscale_64x96"])
 @pytest.mark.parametrize("conv_math", CONV_MATHS)
-def test_interpolation_matches_reference_at_trained_scale(conv_math):
-    """conv3 heads scaled so |flow| reaches 30 px and the visibility logit 100 (fixture generated by the reference);
-    tolerance as in tests/test_slomo_oracle_golden.py: 1e-5 of each tensor's scale (the scaled heads magnify the
-    reference's own f32 summation-order noise), 1e-4 absolute on Ft."""
-    from test_slomo_oracle_golden import TRAINED_SCALE_FT_TOL, close_scaled
+def test_interpolation_within_reference_float32_noise(conv_math, fixture):
+    """Two stress fixtures generated by the reference in float32 AND float64 (make_golden_slomo_allscale.py): the conv3
+    heads scaled so that |flow| reaches 30 px and the visibility logit 100; every layer scaled so that the trunk's
+    activations run to 20 .. 200.  Per tensor, both conv maths: max|HIP - f64| <= 1.5 max|ref_f32 - f64| -- the HIP path
+    (incl. the split-bf16 kernel's dropped products) is no further from the exact result than the reference itself."""
+    from test_slomo_oracle_golden import REF_NOISE_FACTOR, _scaled_state_dicts, noise_ratio
     from v2e_amd.slomo import SloMoEngine
-    from v2e_amd.synth import portable_unet_state_dict
-    z = np.load(os.path.join(GOLDEN, "slomo_trained_scale_64x96.npz"))
+    z = np.load(os.path.join(GOLDEN, fixture + ".npz"))
     I0, I1 = _pairs(z)
     ts = list(z["ts"])
-    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
-    for sd, s in zip((sd_f, sd_i), z["conv3_scale"]):
-        sd["conv3.weight"] = sd["conv3.weight"] * np.float32(s)
-        sd["conv3.bias"] = sd["conv3.bias"] * np.float32(s)
+    sd_f, sd_i = _scaled_state_dicts(z)
     eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
                       {k: torch.from_numpy(v) for k, v in sd_i.items()}, "cuda", conv_math=conv_math)
     Ft = eng.interpolate(torch.from_numpy(I0).cuda(), torch.from_numpy(I1).cuda(), ts).cpu().numpy()
-    assert close_scaled(eng.last["flow"].cpu().numpy(), z["flow"]) < TOL
-    assert close_scaled(eng.last["intrp"].cpu().numpy().reshape(len(ts), I0.shape[0], 5, 64, 96), z["intrp"]) < TOL
-    assert np.max(np.abs(Ft.astype(np.float64) - z["Ft"])) < TRAINED_SCALE_FT_TOL
+    r = {"flow": noise_ratio(eng.last["flow"].cpu().numpy(), z, "flow"),
+         "intrp": noise_ratio(eng.last["intrp"].cpu().numpy().reshape(len(ts), I0.shape[0], 5, 64, 96), z, "intrp"),
+         "Ft": noise_ratio(Ft, z, "Ft")}
+    assert max(r.values()) <= REF_NOISE_FACTOR, r
 
 
 def test_warp_blend_fusion_match_reference_golden():

@@ -16,18 +16,18 @@ def close(a, b, tol=TOL):
     return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
 
 
-def close_scaled(a, b):
-    """error relative to the tensor's scale, max|b|.  For the trained-scale fixture only: its conv3 heads are
-    scaled x200 / x40, which magnifies the f32 summation-order noise of their inputs (~1.5e-7, present in the
-    reference's own MKL-DNN result) to 3e-5 absolute on outputs near zero, so a per-element bound relative to
-    max(1,|b|) is below the noise floor of the reference itself; relative to the tensor's scale (30 px, 100)
-    the 1e-5 bar stands."""
-    a = np.asarray(a, np.float64)
-    b = np.asarray(b, np.float64)
-    return np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))
+def noise_ratio(a, z, key):
+    """max|a - f64| / max|ref_f32 - f64| for one tensor of a fixture that stores the reference's float32 result `key` and
+    the same computation in float64 `key_f64` (tests/golden/make_golden_slomo_allscale.py): how far `a` is from the exact
+    result, in units of how far the reference itself is.  The fixtures this is used on magnify float32 summation-order
+    noise (scaled weights), so a fixed 1e-5 per element would sit below the reference's own noise floor; this criterion
+    carries its justification with it."""
+    f64 = z[key + "_f64"]
+    ref = np.max(np.abs(z[key].astype(np.float64) - f64))
+    return float(np.max(np.abs(np.asarray(a, np.float64) - f64)) / ref)
 
 
-TRAINED_SCALE_FT_TOL = 1e-4  # Ft of the trained-scale fixture: flows carry up to 4e-5 px of that noise into the warps
+REF_NOISE_FACTOR = 1.5  # |ours - f64| <= 1.5 |ref_f32 - f64| per tensor
 
 
 def load_pairs(z):
@@ -89,21 +89,47 @@ def test_oracle_matches_reference_at_benchmark_shape(oracle_lib):
     assert close(o["Ft"], z["Ft"][pick][:, pair]) < TOL
 
 
-def test_oracle_matches_reference_at_trained_scale(oracle_lib):
-    """|flow| up to 30 px, visibility logits up to 100: warps far outside the image, saturated sigmoid."""
+def _scaled_state_dicts(z):
     from v2e_amd.synth import portable_unet_state_dict
+    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
+    if "gain" in z.files:  # every layer scaled
+        g = np.float32(z["gain"])
+        for sd in (sd_f, sd_i):
+            for k in sd:
+                sd[k] = (sd[k] * g).astype(np.float32)
+    else:  # the output heads scaled
+        for sd, s in zip((sd_f, sd_i), z["conv3_scale"]):
+            sd["conv3.weight"] = (sd["conv3.weight"] * np.float32(s)).astype(np.float32)
+            sd["conv3.bias"] = (sd["conv3.bias"] * np.float32(s)).astype(np.float32)
+    return sd_f, sd_i
+
+
+def test_oracle_matches_reference_at_trained_scale(oracle_lib):
+    """|flow| up to 30 px, visibility logits up to 100: warps far outside the image, saturated sigmoid.  No further from the
+    float64 result than 1.5 x the reference's own float32 result is."""
     z = np.load(os.path.join(GOLDEN, "slomo_trained_scale_64x96.npz"))
     I0, I1 = load_pairs(z)
     ts = list(z["ts"])
-    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
-    for sd, s in zip((sd_f, sd_i), z["conv3_scale"]):
-        sd["conv3.weight"] = sd["conv3.weight"] * np.float32(s)
-        sd["conv3.bias"] = sd["conv3.bias"] * np.float32(s)
+    sd_f, sd_i = _scaled_state_dicts(z)
     o = oracle_lib.slomo_interpolate(I0, I1, ts, sd_f, sd_i)
     assert np.abs(z["flow"]).max() > 25 and np.abs(z["intrp"]).max() > 50
-    assert close_scaled(o["flow"], z["flow"]) < TOL
-    assert close_scaled(o["intrp"].reshape(len(ts), I0.shape[0], 5, 64, 96), z["intrp"]) < TOL
-    assert np.max(np.abs(o["Ft"].astype(np.float64) - z["Ft"])) < TRAINED_SCALE_FT_TOL
+    assert noise_ratio(o["flow"], z, "flow") <= REF_NOISE_FACTOR
+    assert noise_ratio(o["intrp"].reshape(len(ts), I0.shape[0], 5, 64, 96), z, "intrp") <= REF_NOISE_FACTOR
+    assert noise_ratio(o["Ft"], z, "Ft") <= REF_NOISE_FACTOR
+
+
+def test_oracle_matches_reference_with_every_layer_scaled(oracle_lib):
+    """Every layer's weights x 1.9: activations of 20 .. 200 in every layer of the trunk (where a product-relative error
+    could hide behind cancellation), flows to 13 px."""
+    z = np.load(os.path.join(GOLDEN, "slomo_allscale_64x96.npz"))
+    I0, I1 = load_pairs(z)
+    ts = list(z["ts"])
+    sd_f, sd_i = _scaled_state_dicts(z)
+    o = oracle_lib.slomo_interpolate(I0, I1, ts, sd_f, sd_i)
+    assert z["act_max"].min() > 10
+    assert noise_ratio(o["flow"], z, "flow") <= REF_NOISE_FACTOR
+    assert noise_ratio(o["intrp"].reshape(len(ts), I0.shape[0], 5, 64, 96), z, "intrp") <= REF_NOISE_FACTOR
+    assert noise_ratio(o["Ft"], z, "Ft") <= REF_NOISE_FACTOR
 
 
 def test_oracle_pipeline_matches_reference_class_pngs(oracle_lib):
