@@ -123,6 +123,12 @@ int v2e_emu_init_state(v2e_emu *h, const v2e_emu_params *p, const void *frame, i
  * `photoreceptor_noise_arr` (caller-owned, zero on the first frame); randn_tape the float32 draws
  * torch.randn(shape) of the coming frame in tape mode (NULL in Philox mode).  Both are consumed by the next
  * v2e_emu_count when params.photoreceptor_noise is set; NULL pn_arr switches the feature off. */
+/* SCIDVS pixel (emulator.py:56-80, 719-725, 747; float64 state only): device planes [n_clips][npx_pad] scidvs_highpass and
+ * scidvs_previous_photo (state dtype) and scidvs_tau_arr (float32; filled by v2e_emu_init_state in Philox mode, by the
+ * caller in tape mode).  first_frame_idx: the frame index at which scidvs_previous_photo is taken from the frame itself
+ * (emulator.py:720-722).  All NULL switches it off.  Runs on the count / rank / scan / emit kernels. */
+int v2e_emu_set_scidvs(v2e_emu *h, void *highpass, void *previous_photo, float *tau, uint32_t first_frame_idx);
+
 int v2e_emu_set_pnoise(v2e_emu *h, void *pn_arr, const float *randn_tape);
 
 /*
@@ -175,6 +181,17 @@ int v2e_emu_read_iter_counts(v2e_emu *h, uint32_t frame_idx, int n_iters, uint32
 /* out[dst0 + j] = in[src0 + idx[j]], j < n   (events_curr_iter[idx], emulator.py:869) */
 int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const int32_t *idx,
                     uint64_t row0, uint64_t n, void *stream);
+
+/* One frame of the frame-at-a-time API in one call (Philox mode, one clip; replaces the sequence v2e_emu_count /
+ * read_rec / rank / read_iter_counts / emit + the row copy of EventEmulator.generate_events, emulator.py:619-1022): the
+ * frame (host pointer if frame_on_host, else device) is counted, ranked and scanned, the frame record and per-key totals
+ * come back in ONE read, the rows are emitted into events_dev[0 .. n) and copied to pinned host memory owned by the
+ * handle (*events_host, valid until the next call; NULL when n = 0).  out8 = {n_events, n_on, n_off, n_signal, M, 0, 0, 0}.
+ * Returns 0; 1 if M > the handle's max_iters (counted, nothing emitted: grow with v2e_emu_reserve_iters, then
+ * v2e_emu_rank / v2e_emu_emit); 2 if n_events > cap (same); negative on error.  Synchronises `stream`. */
+int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int frame_on_host, int dtype, double t_prev,
+                  double t_frame, uint32_t frame_idx, float *events_dev, uint64_t cap, uint32_t *out8,
+                  const float **events_host, void *stream);
 
 /*
  * Philox-mode, fully device-resident multi-frame run: frames [n_frames][n_clips][H*W],

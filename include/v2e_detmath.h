@@ -211,6 +211,14 @@ V2E_HD void v2e_draw_init(uint64_t seed, uint32_t clip, uint32_t pixel,
     *n_rate = v2e_normal(o[0], o[1]);
 }
 
+/* SCIDVS per-pixel time-constant normal (emulator.py:480-483 in philox mode): the second pair of the noise-rate call. */
+V2E_HD float v2e_draw_scidvs(uint64_t seed, uint32_t clip, uint32_t pixel)
+{
+    uint32_t o[4];
+    v2e_philox4x32(pixel, 0u, V2E_STREAM_RATE, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return v2e_normal(o[2], o[3]);
+}
+
 /* ------------------------------------------------ keyed bijection (shuffle) */
 /*
  * Philox-mode replacement for `idx = torch.randperm(n_i)` (emulator.py:868): a keyed

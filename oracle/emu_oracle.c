@@ -101,6 +101,12 @@ EXPORT void v2e_oracle_philox_init(uint64_t seed, uint32_t clip, int64_t npx, fl
     }
 }
 
+/* SCIDVS time constants in philox mode: tau = 0.01f * exp(0.5f * n) with the deterministic expf (emulator.py:480-483) */
+EXPORT void v2e_oracle_philox_scidvs_tau(uint64_t seed, uint32_t clip, int64_t npx, float *tau)
+{
+    for (int64_t p = 0; p < npx; ++p) tau[p] = 0.01f * v2e_det_expf(0.5f * v2e_draw_scidvs(seed, clip, (uint32_t)p));
+}
+
 /* idx with idx[sigma(c)] = c, i.e. what `torch.randperm` must return for the
  * reference's `events[idx]` to equal the philox-mode order. */
 EXPORT void v2e_oracle_perm_idx(uint64_t seed, uint32_t clip, uint32_t frame, uint32_t iter,

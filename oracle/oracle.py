@@ -114,6 +114,9 @@ class RecordedTape:
     def exp_noise_rate(self, cov, randn):
         return self._next("noise_rate").reshape(randn.shape)
 
+    def exp_scidvs(self, draw):  # torch.exp of the SCIDVS time-constant draw (recorded like every torch.exp on the path)
+        return self._next("noise_rate").reshape(draw.shape)
+
 
 def philox_frame(seed, clip, frame, npx):
     a = np.empty(npx, np.float32)
@@ -135,6 +138,12 @@ def philox_init(seed, clip, npx):
     c = np.empty(npx, np.float32)
     lib().v2e_oracle_philox_init(C.c_uint64(seed), C.c_uint32(clip), C.c_int64(npx), _p(a), _p(b), _p(c))
     return a, b, c
+
+
+def philox_scidvs_tau(seed, clip, npx):
+    a = np.empty(npx, np.float32)
+    lib().v2e_oracle_philox_scidvs_tau(C.c_uint64(seed), C.c_uint32(clip), C.c_int64(npx), _p(a))
+    return a
 
 
 def perm_idx(seed, clip, frame, it, n):

@@ -122,6 +122,9 @@ def make_tape_fixture(name, frames, times, kw, preset=None, seed=42):
     }
     if getattr(ref, "timestamp_mem", None) is not None and ref.refractory_period_s > 0:
         out["ts_mem_final"] = ref.timestamp_mem.numpy()
+    if getattr(ref, "scidvs", False):
+        out["scidvs_highpass_final"] = ref.scidvs_highpass.numpy()
+        out["scidvs_tau"] = ref.scidvs_tau_arr.numpy()
     for k, (kind, arr) in enumerate(items):
         out["tape_%05d_%s" % (k, kind)] = arr
     for k, e in enumerate(evs):
@@ -200,6 +203,8 @@ def run_reference_philox(frames, times, kw, preset, seed):
         ref.neg_thres = torch.clamp(torch.from_numpy(tn.reshape(H, W)), min=0.01)
         ref.pos_thres_pre_prob = torch.div(ref.pos_thres_nominal, ref.pos_thres)
         ref.neg_thres_pre_prob = torch.div(ref.neg_thres_nominal, ref.neg_thres)
+    if getattr(ref, "scidvs", False):  # emulator.py:480-483 with the Philox normal and the deterministic expf
+        ref.scidvs_tau_arr = torch.from_numpy(orc.philox_scidvs_tau(seed, 0, H * W).reshape(H, W))
     if ref.leak_rate_hz > 0:
         lnc = np.float32(math.log(10) * ref.noise_rate_cov_decades)
         nr = np.array([orc.lib().v2e_oracle_det_expf(float(np.float32(lnc * v))) for v in n_rate], np.float32)
@@ -232,6 +237,9 @@ def make_philox_fixture(name, frames, times, kw, preset=None, seed=7, store_fram
     }
     if ref.refractory_period_s > 0:
         out["ts_mem_sha"] = sha(ref.timestamp_mem.numpy())
+    if getattr(ref, "scidvs", False):
+        out["scidvs_highpass_final"] = ref.scidvs_highpass.numpy()
+        out["base_final"] = ref.base_log_frame.numpy()
     if store_frames:
         out["frames"] = np.stack(frames)
     if store_events:

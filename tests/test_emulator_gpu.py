@@ -150,6 +150,60 @@ def test_hip_philox_device_resident_photoreceptor_noise(use_graph):
         emu.generate_events_batch(fx.frames[-2:], [fx.times[-1] + 0.01, fx.times[-1] + 0.02], use_graph=257)
 
 
+def test_scidvs_replays_reference_tape(oracle_lib):
+    """scidvs=True (emulator.py:56-80, 719-725, 747; float64 state): the reference's recorded torch draws (incl. the
+    per-pixel time-constant normal and its exp) -> the reference's events, frame by frame, bit for bit; base / lp planes bit
+    for bit; scidvs_highpass to 1e-12 (torch's vectorised float64 sinh and the device's differ in the last bit)."""
+    import os
+    from fixtures import GOLDEN
+    fx = TapeFixture("tape_scidvs_40x48")
+    emu = _mk(fx, seed=0, rng_mode="tape", tape=oracle_lib.RecordedTape(fx.items))
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        ev = emu.generate_events(f, float(t))
+        assert events_equal(ev, fx.events[k]), "frame %d differs from the reference" % k
+    assert emu._tape.pos == len(fx.items)
+    st = _state(emu)
+    assert np.array_equal(st["base_log_frame"], fx.base_final) and np.array_equal(st["lp_log_frame"], fx.lp_final)
+    z = np.load(os.path.join(GOLDEN, "tape_scidvs_40x48.npz"))
+    assert np.array_equal(emu.scidvs_tau_arr.cpu().numpy(), z["scidvs_tau"])
+    hp = emu.scidvs_highpass.cpu().numpy()
+    assert np.max(np.abs(hp - z["scidvs_highpass_final"])) <= 1e-12 * max(1.0, np.max(np.abs(z["scidvs_highpass_final"])))
+    assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
+@pytest.mark.parametrize("api", ["frame", "clip", "clip_graph"])
+def test_scidvs_philox_matches_reference(api):
+    """scidvs=True in Philox mode (time constants from the portable streams), frame-at-a-time and device-resident (the count /
+    rank / scan / emit kernels carry the two extra state planes), against the reference fed the same numbers."""
+    import os
+    from fixtures import GOLDEN
+    from v2e_amd._capi import V2EAmdError
+    fx = PhiloxFixture("philox_scidvs_97x131")
+    emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+    if api == "frame":
+        evs = [emu.generate_events(f, float(t)) for f, t in zip(fx.frames, fx.times)]
+        counts = [0 if e is None else len(e) for e in evs]
+        ev = np.concatenate([e for e in evs if e is not None])
+    else:
+        ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=(api == "clip_graph"))
+        assert emu._engine.last_pipeline()[0] == "k_count/k_rank/k_scan/k_emit"
+    assert list(counts) == list(fx.n_events)
+    assert np.array_equal(ev, np.concatenate([e for e in fx.events if len(e)]))
+    z = np.load(os.path.join(GOLDEN, "philox_scidvs_97x131.npz"))
+    assert np.array_equal(emu.base_log_frame.cpu().numpy(), z["base_final"])
+    hp = emu.scidvs_highpass.cpu().numpy()
+    assert np.max(np.abs(hp - z["scidvs_highpass_final"])) <= 1e-12 * max(1.0, np.max(np.abs(z["scidvs_highpass_final"])))
+    if api == "clip":
+        with pytest.raises(V2EAmdError):  # k_chain does not carry the SCIDVS planes: refused, not silently a plain DVS
+            emu.generate_events_batch(fx.frames[-2:], [fx.times[-1] + 0.01, fx.times[-1] + 0.02], use_graph=257)
+
+
+def test_scidvs_float32_state_is_refused():
+    from v2e_amd import EventEmulator
+    with pytest.raises(NotImplementedError):
+        EventEmulator(device="cuda", scidvs=True, cutoff_hz=0)
+
+
 @pytest.mark.parametrize("chain_k", [1, 2, 3, 5, 8, 11, 16, 32])
 @pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260", "philox_defaults_346x260"])
 def test_chain_launch_lengths_and_ring_wrap(name, chain_k, monkeypatch):

@@ -81,6 +81,7 @@ SIGNATURES = {
     "v2e_emu_bind_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v2e_emu_init_state": (_i, [_vp, _PP, _vp, _i, _d, _vp, _vp, _vp, _vp]),
     "v2e_emu_set_pnoise": (_i, [_vp, _vp, _vp]),
+    "v2e_emu_set_scidvs": (_i, [_vp, _vp, _vp, _vp, _u32]),
     "v2e_emu_count": (_i, [_vp, _PP, _vp, _i, C.POINTER(_d), C.POINTER(_d), _u32, _vp, _vp, _vp]),
     "v2e_emu_read_rec": (_i, [_vp, _u32, C.POINTER(FrameRec), _vp]),
     "v2e_emu_shot": (_i, [_vp, _PP, _vp, _i, _u32, _vp, _vp]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "v2e_emu_emit": (_i, [_vp, _PP, _u32, _vp, _i, _vp, _u64, C.POINTER(_u64), _vp]),
     "v2e_emu_read_iter_counts": (_i, [_vp, _u32, _i, C.POINTER(_u32), _vp]),
     "v2e_emu_permute": (_i, [_vp, _vp, _vp, _vp, _u64, _u64, _vp]),
+    "v2e_emu_frame": (_i, [_vp, _PP, _vp, _i, _i, _d, _d, _u32, _vp, _u64, C.POINTER(_u32), C.POINTER(C.POINTER(C.c_float)), _vp]),
     "v2e_emu_run": (_i, [_vp, _PP, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d), _u32, _vp, _u64,
                          _vp, _i, _vp]),
     "v2e_emu_last_profile": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),

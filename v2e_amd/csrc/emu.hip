@@ -119,7 +119,13 @@ struct KArgs {
     void *pn_arr;
     const float *pn_tape;
     float pn_vrms_f;
+    // SCIDVS (emulator.py:56-80, 719-725; float64 state only): high-pass state, previous photoreceptor value, time constants
+    void *sc_hp, *sc_prev;
+    float *sc_tau;
+    uint32_t sc_first_frame; // frame index at which scidvs_previous_photo is taken from the frame itself
 };
+
+__device__ constexpr double SCIDVS_EFOLD = 1 / 0.7; // efold of the sinh conductance (emulator.py:78)
 
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ float lin_log(double x)
@@ -301,6 +307,11 @@ __global__ __launch_bounds__(BLOCK) void k_init(KArgs a, const FT *__restrict__ 
     if (a.do_leak)
         a.noise_rate[sp] = (a.rng_mode == V2E_RNG_PHILOX) ? v2e_det_expf(a.ln10cov_f * n_rate) : nr_tape[fp];
     if (a.has_refr) a.ts_mem[sp] = 0.0f - a.refr_f;
+    if (a.sc_hp) { // scidvs_highpass = zeros_like(lp); tau = SCIDVS_TAU_S * exp(normal(0, SCIDVS_TAU_COV)) (emulator.py:480-483, 719-722)
+        ((R *)a.sc_hp)[sp] = (R)0;
+        ((R *)a.sc_prev)[sp] = (R)0;
+        if (a.rng_mode == V2E_RNG_PHILOX) a.sc_tau[sp] = 0.01f * v2e_det_expf(0.5f * v2e_draw_scidvs(a.seed, (uint32_t)clip, (uint32_t)p));
+    }
 }
 
 // ----------------------------------------------------------------- k_count
@@ -365,7 +376,19 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
             ((R *)a.pn_arr)[sp] = (R)pnn;
             pn = (R)pnn;
         }
-        R diff = (lpn + pn) - b; // photoreceptor + photoreceptor_noise_arr - base_log_frame (emulator.py:751)
+        R photo = lpn;
+        if (a.sc_hp) { // SCIDVS: nonlinear CR high-pass of the photoreceptor, amplified (emulator.py:719-725, 747; R == double)
+            const R prev = frame_idx == a.sc_first_frame ? lpn : ((R *)a.sc_prev)[sp]; // first frame: clone of lp_log_frame
+            R hp = ((R *)a.sc_hp)[sp];
+            const float inv_tau = 1.0f / a.sc_tau[sp];                  // torch.div(1, tau): float32
+            const R sh = (R)sinh((double)hp / SCIDVS_EFOLD);             // torch.sinh(v / efold)
+            const R dvdt = (R)inv_tau * sh;
+            hp = hp + ((lpn - prev) - (R)(delta_time * (double)dvdt));
+            ((R *)a.sc_hp)[sp] = hp;
+            ((R *)a.sc_prev)[sp] = lpn;
+            photo = (R)2 * hp;                                           // SCIDVS_GAIN * scidvs_highpass
+        }
+        R diff = (photo + pn) - b; // photoreceptor + photoreceptor_noise_arr - base_log_frame (emulator.py:747-751)
         R pf = diff > (R)0 ? diff : (R)0;
         R nf = (-diff) > (R)0 ? -diff : (R)0;
         R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;
@@ -675,6 +698,9 @@ struct v2e_emu {
     uint32_t *cnt = nullptr, *hist = nullptr, *tot = nullptr;
     void *pn_arr = nullptr;           // photoreceptor_noise_arr plane (v2e_emu_set_pnoise)
     const float *pn_tape = nullptr;
+    void *sc_hp = nullptr, *sc_prev = nullptr; // SCIDVS planes (v2e_emu_set_scidvs)
+    float *sc_tau = nullptr;
+    uint32_t sc_first_frame = 0;
     int ngroups = 0;
     float *lut_L = nullptr;
     double *lut_I = nullptr;
@@ -682,7 +708,14 @@ struct v2e_emu {
     FrameCtl *ctl_ring = nullptr;      // [RING][n_clips]
     FrameCtl *ctl_host = nullptr;      // pinned staging [RING][n_clips]
     unsigned long long *off_dev = nullptr, *off_host = nullptr; // [n_clips] explicit event offsets
-    uint32_t *frame_out = nullptr, *frame_out_host = nullptr;   // v2e_emu_frame: {n_events, n_on, n_off, M, flags} per clip
+    // v2e_emu_frame (one call per frame): pinned staging for the frame, the frame record + per-key totals, the event rows
+    void *fr_stage = nullptr, *fr_dev = nullptr;
+    size_t fr_bytes = 0;
+    unsigned char *fr_rec_host = nullptr; // v2e_frame_rec + nkeys_cap totals
+    int fr_rec_keys = 0;
+    float *fr_ev_host = nullptr;
+    uint64_t fr_ev_cap = 0;
+    unsigned long long *off_zero = nullptr; // [n_clips] zeros
     // multi-frame run
     FrameCtl *run_ctl = nullptr;       // device [run_cap][n_clips]
     FrameCtl *run_ctl_host2[2] = {nullptr, nullptr}; // pinned staging, two sets
@@ -770,12 +803,14 @@ static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
     a.cnt = h->cnt; a.hist = h->hist; a.tot = h->tot;
     a.lut_L = h->lut_L; a.lut_I = h->lut_I;
     if (p->photoreceptor_noise) { a.pn_arr = h->pn_arr; a.pn_tape = h->pn_tape; a.pn_vrms_f = (float)p->photoreceptor_noise_vrms; }
+    if (h->sc_hp) { a.sc_hp = h->sc_hp; a.sc_prev = h->sc_prev; a.sc_tau = h->sc_tau; a.sc_first_frame = h->sc_first_frame; }
     return a;
 }
 
 static int check_params(const v2e_emu *h, const v2e_emu_params *p)
 {
     V2E_REQUIRE(h && p, "null handle/params");
+    V2E_REQUIRE(!h->sc_hp || p->f64_state, "SCIDVS is built for float64 state (cutoff_hz > 0 or hdr)");
     V2E_REQUIRE(h->lp && h->base && h->pos_thres && h->neg_thres, "state not bound (v2e_emu_bind_state)");
     V2E_REQUIRE((p->f64_state != 0) == (p->cutoff_hz > 0 || p->log_input != 0), "f64_state must equal (cutoff_hz > 0 || log_input)");
     V2E_REQUIRE(!(p->leak_rate_hz > 0) || h->noise_rate, "leak enabled but noise_rate plane not bound");
@@ -842,6 +877,8 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
     V2E_HIP(hipMalloc(&h->ctl_ring, sizeof(FrameCtl) * RING * n_clips));
     V2E_HIP(hipHostMalloc(&h->ctl_host, sizeof(FrameCtl) * RING * n_clips));
     V2E_HIP(hipMalloc(&h->off_dev, sizeof(unsigned long long) * n_clips));
+    V2E_HIP(hipMalloc(&h->off_zero, sizeof(unsigned long long) * n_clips));
+    V2E_HIP(hipMemset(h->off_zero, 0, sizeof(unsigned long long) * n_clips));
     V2E_HIP(hipHostMalloc(&h->off_host, sizeof(unsigned long long) * n_clips));
     V2E_HIP(hipMalloc(&h->run_fidx, sizeof(uint32_t)));
     V2E_HIP(hipHostMalloc(&h->run_fidx_host, 2 * sizeof(uint32_t)));
@@ -876,8 +913,10 @@ int v2e_emu_destroy(v2e_emu *h)
     for (int q = 0; q < 2; ++q) { if (h->run_ctl_host2[q]) hipHostFree(h->run_ctl_host2[q]); if (h->ev_stage[q]) hipEventDestroy(h->ev_stage[q]); }
     hipFree(h->run_fidx);
     if (h->run_fidx_host) hipHostFree(h->run_fidx_host);
-    hipFree(h->frame_out);
-    if (h->frame_out_host) hipHostFree(h->frame_out_host);
+    hipFree(h->fr_dev); hipFree(h->off_zero);
+    if (h->fr_stage) hipHostFree(h->fr_stage);
+    if (h->fr_rec_host) hipHostFree(h->fr_rec_host);
+    if (h->fr_ev_host) hipHostFree(h->fr_ev_host);
     delete h;
     return 0;
 }
@@ -941,6 +980,14 @@ static int launch_count(v2e_emu *h, const KArgs &a, int f64_state, const void *f
         if (f64_state) k_count<double, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, fidx_base, fidx_off, leak, shot, rec);
         else k_count<float, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, fidx_base, fidx_off, leak, shot, rec);
     });
+    return 0;
+}
+
+int v2e_emu_set_scidvs(v2e_emu *h, void *highpass, void *previous_photo, float *tau, uint32_t first_frame_idx)
+{
+    V2E_REQUIRE(h && ((highpass && previous_photo && tau) || (!highpass && !previous_photo && !tau)), "set_scidvs: all three planes or none");
+    h->sc_hp = highpass; h->sc_prev = previous_photo; h->sc_tau = tau; h->sc_first_frame = first_frame_idx;
+    h->drop_graphs();
     return 0;
 }
 
@@ -1086,6 +1133,91 @@ int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const
     k_permute<<<v2e_cdiv((int64_t)n, BLOCK), BLOCK, 0, (hipStream_t)stream>>>((const float4 *)events_in, (float4 *)events_out,
                                                                               idx, row0, n);
     V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+// One frame of the frame-at-a-time API in ONE call (Philox mode, one clip): what a v2e.py caller of generate_events pays
+// per frame used to be five C calls with three stream synchronisations between them.  Here: frame -> pinned staging ->
+// device, count / rank / scan enqueued back to back, ONE read-back of the frame record and the per-key totals (which
+// gives M and the event count), emit, ONE read-back of exactly that many rows into pinned memory.
+// Returns 0, or 1 when the frame needs more iteration scratch than the handle has (M > max_iters; the caller grows it
+// with v2e_emu_reserve_iters and finishes the frame with v2e_emu_rank / v2e_emu_emit: the count is done and stays valid),
+// or 2 when the rows do not fit `cap` (same: nothing was emitted).
+int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int frame_on_host, int dtype, double t_prev, double t_frame,
+                  uint32_t frame_idx, float *events_dev, uint64_t cap, uint32_t *out8, const float **events_host, void *stream)
+{
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    V2E_REQUIRE(frame && out8 && events_host && events_dev, "null");
+    V2E_REQUIRE(h->n_clips == 1 && p->rng_mode == V2E_RNG_PHILOX && !p->photoreceptor_noise, "v2e_emu_frame: one clip, Philox mode, no photoreceptor noise");
+    V2E_REQUIRE(dtype == V2E_DT_U8 || dtype == V2E_DT_F32 || dtype == V2E_DT_F64, "bad frame dtype");
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
+    const size_t fbytes = esz * (size_t)h->npx;
+    const void *frame_dev = frame;
+    if (frame_on_host) {
+        if (fbytes > h->fr_bytes) {
+            V2E_HIP(hipStreamSynchronize(s));
+            if (h->fr_stage) V2E_HIP(hipHostFree(h->fr_stage));
+            if (h->fr_dev) V2E_HIP(hipFree(h->fr_dev));
+            V2E_HIP(hipHostMalloc(&h->fr_stage, fbytes));
+            V2E_HIP(hipMalloc(&h->fr_dev, fbytes));
+            h->fr_bytes = fbytes;
+        }
+        memcpy(h->fr_stage, frame, fbytes); // (the previous frame's upload has completed: every call ends synchronised)
+        V2E_HIP(hipMemcpyAsync(h->fr_dev, h->fr_stage, fbytes, hipMemcpyHostToDevice, s));
+        frame_dev = h->fr_dev;
+    }
+    if (h->fr_rec_keys != h->nkeys_cap) {
+        if (h->fr_rec_host) V2E_HIP(hipHostFree(h->fr_rec_host));
+        V2E_HIP(hipHostMalloc((void **)&h->fr_rec_host, sizeof(v2e_frame_rec) + sizeof(uint32_t) * h->nkeys_cap));
+        h->fr_rec_keys = h->nkeys_cap;
+    }
+    rc = stage_ctl(h, p, frame_idx, &t_prev, &t_frame, s);
+    if (rc) return rc;
+    const int slot = frame_idx % RING;
+    v2e_frame_rec *rec = h->rec_ring + slot;
+    const FrameCtl *ctl = h->ctl_ring + slot;
+    V2E_HIP(zero_async(rec, sizeof(v2e_frame_rec), s));
+    KArgs a = make_kargs(h, p);
+    rc = launch_count(h, a, p->f64_state, frame_dev, dtype, ctl, nullptr, frame_idx, nullptr, nullptr, rec, s);
+    if (rc) return rc;
+    dim3 gridw(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), 1);
+    k_rank<<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, 0);
+    k_scan<<<dim3(SCAN_BLOCKS, 1), BLOCK, 0, s>>>(a, rec);
+    v2e_frame_rec *rh = (v2e_frame_rec *)h->fr_rec_host;
+    uint32_t *th = (uint32_t *)(h->fr_rec_host + sizeof(v2e_frame_rec));
+    V2E_HIP(hipMemcpyAsync(rh, rec, sizeof(v2e_frame_rec), hipMemcpyDeviceToHost, s));
+    V2E_HIP(hipMemcpyAsync(th, h->tot, sizeof(uint32_t) * h->nkeys_cap, hipMemcpyDeviceToHost, s));
+    V2E_HIP(hipStreamSynchronize(s));
+    const int M = rh->max_events;
+    memset(out8, 0, sizeof(uint32_t) * 8);
+    out8[4] = (uint32_t)M;
+    if (M > h->max_iters) return 1;
+    uint64_t n_on = 0, n_off = 0, n_sig = 0;
+    for (int k = 0; k < 2 * M + 2; ++k) {
+        ((k & 1) ? n_off : n_on) += th[k];
+        if (k < 2 * M) n_sig += th[k];
+    }
+    const uint64_t n = n_on + n_off;
+    out8[0] = (uint32_t)n; out8[1] = (uint32_t)n_on; out8[2] = (uint32_t)n_off; out8[3] = (uint32_t)n_sig;
+    if (n > cap) return 2;
+    const v2e_frame_rec *rec_prev = h->rec_ring + (frame_idx + RING - 1) % RING;
+    if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
+    else k_emit<float><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
+    V2E_HIP(hipGetLastError());
+    *events_host = nullptr;
+    if (n > 0) {
+        if (n > h->fr_ev_cap) {
+            if (h->fr_ev_host) V2E_HIP(hipHostFree(h->fr_ev_host));
+            h->fr_ev_cap = std::max<uint64_t>(2 * n, 1u << 16);
+            V2E_HIP(hipHostMalloc((void **)&h->fr_ev_host, sizeof(float) * 4 * h->fr_ev_cap));
+        }
+        V2E_HIP(hipMemcpyAsync(h->fr_ev_host, events_dev, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, s));
+        V2E_HIP(hipStreamSynchronize(s));
+        *events_host = h->fr_ev_host;
+    }
     return 0;
 }
 
@@ -1382,6 +1514,7 @@ static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p, int dtype)
     if (h->max_iters > CHAIN_MAX_ITERS) return false;
     if (dtype == V2E_DT_F64 && p->log_input) return false; // the frame record carries the lin-log value as float32
     if (p->photoreceptor_noise) return false;              // one more state plane and normal per pixel
+    if (h->sc_hp) return false;                            // SCIDVS: two more state planes
     return true;
 }
 

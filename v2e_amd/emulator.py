@@ -61,6 +61,9 @@ class _TorchTape:
     def exp_noise_rate(self, cov, randn):
         return torch.exp(math.log(10) * cov * randn)  # emulator.py:504-505
 
+    def exp_scidvs(self, draw):
+        return torch.exp(draw)  # emulator.py:481-483
+
 
 def photoreceptor_noise_vrms(shot_noise_rate_hz, f3db, sample_rate_hz, pos_thr, neg_thr, sigma_thr):
     """Gaussian RMS amplitude (ln units) to inject before the photoreceptor low-pass so that threshold crossings of
@@ -88,10 +91,16 @@ def _limit_host_threads(n):
     """Tape mode issues a handful of small torch CPU ops per frame (randn / rand of one frame, a randperm per
     iteration).  Their values do not depend on the intra-op thread count, but on a many-core host fanning each of
     them out over the OpenMP pool costs milliseconds: 250 -> 1 170 frames/s on the MI355X box with one thread.
-    The setting is process-global in torch, so it is applied ONCE, when a tape-mode emulator is constructed
-    (`tape_host_threads`, default 1; None leaves torch alone), not toggled around calls."""
-    if n is not None and torch.get_num_threads() != int(n):
-        torch.set_num_threads(int(n))
+    The setting is process-global in torch, so it is applied once, when a tape-mode emulator is constructed
+    (`tape_host_threads`, default 1; None leaves torch alone), said so in the log, and put back by cleanup().
+    Returns the previous value (None if nothing was changed)."""
+    if n is None or torch.get_num_threads() == int(n):
+        return None
+    prev = torch.get_num_threads()
+    logger.warning("v2e_amd.EventEmulator (tape mode): torch.set_num_threads(%d) for this process (was %d; restored by "
+                   "cleanup(); pass tape_host_threads=None to leave torch alone)", int(n), prev)
+    torch.set_num_threads(int(n))
+    return prev
 
 
 def _as_f32_tensor(a):
@@ -172,7 +181,6 @@ class EventEmulator(object):
     ):
         unsupported = []
         if cs_lambda_pixels is not None: unsupported.append("cs_lambda_pixels (CSDVS)")
-        if scidvs: unsupported.append("scidvs")
         if show_dvs_model_state is not None: unsupported.append("show_dvs_model_state")
         if record_single_pixel_states is not None: unsupported.append("record_single_pixel_states")
         if unsupported:
@@ -212,7 +220,12 @@ class EventEmulator(object):
         self.save_dvs_model_state = save_dvs_model_state
         self.label_signal_noise = label_signal_noise
         self.log_input = bool(hdr)  # emulator.py:304: frames are log-encoded already
-        self.scidvs = False
+        self.scidvs = bool(scidvs)  # emulator.py:307-309: nonlinear CR high-pass amplified log intensity
+        self.scidvs_highpass = self.scidvs_previous_photo = self.scidvs_tau_arr = None
+        if self.scidvs and not (cutoff_hz > 0 or hdr):
+            raise NotImplementedError(
+                "v2e_amd.EventEmulator(scidvs=True) is built for float64 pixel state (cutoff_hz > 0 or hdr): with float32 state "
+                "torch's vectorised sinh and the device's differ in the last bit often enough to move events (DESIGN.md section 7)")
         self.csdvs_enabled = False
         self.seed = seed
 
@@ -221,8 +234,9 @@ class EventEmulator(object):
             raise ValueError("rng_mode must be 'tape' or 'philox', got %r" % (self.rng_mode,))
         self.shuffle = bool(shuffle)
         self._tape = tape if tape is not None else _TorchTape()
+        self._host_threads_prev = None
         if self.rng_mode == "tape":
-            _limit_host_threads(tape_host_threads)
+            self._host_threads_prev = _limit_host_threads(tape_host_threads)
         self._max_iters = max_iters
         if seed != 0:  # emulator.py:221-224
             torch.manual_seed(seed)
@@ -292,6 +306,9 @@ class EventEmulator(object):
             self.frame_h5_dataset = self.frame_ts_dataset = self.frame_ev_idx_dataset = None
 
     def cleanup(self):  # emulator.py:402-429
+        if getattr(self, "_host_threads_prev", None) is not None:
+            torch.set_num_threads(self._host_threads_prev)
+            self._host_threads_prev = None
         for w in ("dvs_h5", "dvs_aedat2", "dvs_aedat4", "dvs_text"):
             o = getattr(self, w, None)
             if o is not None:
@@ -339,6 +356,8 @@ class EventEmulator(object):
         self.timestamp_mem = None
         self.noise_rate_array = None
         self.photoreceptor_noise_arr = None
+        self.scidvs_highpass = self.scidvs_previous_photo = self.scidvs_tau_arr = None
+        self._pn_last_rate = None  # the noise amplitude is recomputed for the first frame pair of the next clip
         self._initialized = False
 
     # ------------------------------------------------------------- parameters
@@ -397,15 +416,31 @@ class EventEmulator(object):
         eng.alloc_state(self.cutoff_hz > 0 or self.log_input)
         P = self._params()
         tp = tn = nr = None
+        sc_tau_host = None
+        if self.scidvs:  # two more state planes + per-pixel time constants (emulator.py:480-483, 719-722)
+            sd = torch.float64
+            self._sc_planes = [torch.zeros((1, eng.npx_pad), dtype=sd, device=eng.device) for _ in range(2)]
+            self._sc_tau = torch.zeros((1, eng.npx_pad), dtype=torch.float32, device=eng.device)
+            _capi.check(eng.lib.v2e_emu_set_scidvs(eng._h, self._sc_planes[0].data_ptr(), self._sc_planes[1].data_ptr(),
+                                                   self._sc_tau.data_ptr(), int(self.frame_counter)), "v2e_emu_set_scidvs")
         if self.rng_mode == "tape":
             dev = eng.device
             if self.sigma_thres > 0:
                 tp = _as_f32_tensor(self._tape.normal(self.pos_thres, self.sigma_thres, (H, W))).to(dev)
                 tn = _as_f32_tensor(self._tape.normal(self.neg_thres, self.sigma_thres, (H, W))).to(dev)
+            if self.scidvs and self.SCIDVS_TAU_COV > 0:  # drawn between the thresholds and the noise rates
+                d = _as_f32_tensor(self._tape.normal(0, self.SCIDVS_TAU_COV, (H, W)))
+                sc_tau_host = self.SCIDVS_TAU_S * _as_f32_tensor(self._tape.exp_scidvs(d))
             if self.leak_rate_hz > 0:
                 r = _as_f32_tensor(self._tape.randn((H, W)))
                 nr = _as_f32_tensor(self._tape.exp_noise_rate(self.noise_rate_cov_decades, r)).to(dev)
         eng.init_state(P, frame_dev, t_frame, tp, tn, nr)
+        if self.scidvs:
+            if sc_tau_host is not None:
+                self._sc_tau[0, :H * W] = sc_tau_host.reshape(-1).to(eng.device)
+            self.scidvs_highpass = eng.plane(self._sc_planes[0])
+            self.scidvs_previous_photo = eng.plane(self._sc_planes[1])
+            self.scidvs_tau_arr = eng.plane(self._sc_tau)
         # public state attributes, as [H,W] device views
         self.lp_log_frame = eng.plane(eng.lp)
         self.base_log_frame = eng.plane(eng.base)
@@ -442,7 +477,13 @@ class EventEmulator(object):
             raise ValueError("new_frame must be [height, width], got shape %r" % (shape,))
         H, W = shape
         eng = self._ensure_engine(H, W)
-        frame_dev = eng.to_device_frame(new_frame)
+        # Philox mode after the first frame: the whole frame is ONE C call (v2e_emu_frame), the host frame goes through
+        # the handle's pinned staging instead of a torch tensor
+        fast = self._initialized and self.rng_mode == "philox" and not self.photoreceptor_noise
+        host_frame = None
+        if fast and isinstance(new_frame, np.ndarray) and new_frame.dtype in (np.uint8, np.float32, np.float64):
+            host_frame = np.ascontiguousarray(new_frame)
+        frame_dev = None if host_frame is not None else eng.to_device_frame(new_frame)
 
         if not self._initialized:
             self._first_frame(frame_dev, H, W, float(t_frame))
@@ -457,6 +498,32 @@ class EventEmulator(object):
                              "(float64 iff cutoff_hz > 0 or hdr) is fixed by the first frame")
         tape = self.rng_mode == "tape"
         dev = eng.device
+
+        counted = False
+        if fast:
+            ev = eng.event_buffer(max(4 * H * W, 1 << 16))
+            rc, out8, events = eng.frame(P, host_frame if host_frame is not None else frame_dev, t_prev, t_frame, fidx, ev)
+            n_events, n_on, n_off, n_signal, M = (int(out8[k]) for k in range(5))
+            if rc == 0:
+                if M > 100:
+                    logger.warning(f'Too many events generated for this frame: num_iter={M}>100 events')
+                if M == 0 and self.no_events_warning_count < 100:
+                    logger.warning(f'no signal events generated for frame #{self.frame_counter:,} at t={t_frame:.4f}s')
+                    self.no_events_warning_count += 1
+                self.num_events_on += n_on
+                self.num_events_off += n_off
+                self.num_events_total += n_events
+                if events is not None:
+                    self._write_events(events, n_signal, events_dev=ev[0, :n_events])
+                if self.frame_ev_idx_dataset is not None:
+                    self.frame_ev_idx_dataset[self.frame_counter - 1] = self.dvs_h5_dataset.shape[0]
+                self.t_previous = t_frame
+                return events
+            # rc 1: more iterations than the scratch holds; rc 2: more rows than the buffer: the frame is counted, the general
+            # path below grows what is needed and finishes it
+            counted = True
+            if frame_dev is None:
+                frame_dev = eng.to_device_frame(new_frame)
 
         pn_draw = None
         if self.photoreceptor_noise:  # emulator.py:694-703
@@ -477,7 +544,8 @@ class EventEmulator(object):
         leak = None
         if tape and self.leak_rate_hz > 0:
             leak = _as_f32_tensor(self._tape.randn((H, W))).to(dev)
-        eng.count(P, frame_dev, [t_prev], [t_frame], fidx, leak_randn=leak)
+        if not counted:
+            eng.count(P, frame_dev, [t_prev], [t_frame], fidx, leak_randn=leak)
         rec = eng.read_rec(fidx)[0]
         M = int(rec.max_events)
         if M > 100:
@@ -641,25 +709,31 @@ class EventEmulator(object):
             if self.photoreceptor_noise_vrms is not None:
                 self._pn_vrms = float(self.photoreceptor_noise_vrms)
             else:
-                # the reference recomputes the amplitude when the sample rate moves by 10 % (emulator_utils.py:217-220);
-                # inside one device-resident run the amplitude is one number
-                if any(abs(r / rates[0] - 1) >= 0.1 for r in rates):
-                    raise ValueError("photoreceptor_noise: the frame interval changes by more than 10 % inside this run; "
-                                     "split the run there (or use generate_events per frame)")
+                # the reference recomputes the amplitude when the sample rate has moved by 10 % from the rate it was last
+                # computed for (emulator_utils.py:217-220); inside one device-resident run the amplitude is one number, so
+                # every frame of the run must stay within 10 % of the rate that number belongs to
                 if self._pn_last_rate is None or abs(rates[0] / self._pn_last_rate - 1) >= 0.1:
                     self._pn_vrms = photoreceptor_noise_vrms(self.shot_noise_rate_hz, self.cutoff_hz, rates[0],
                                                              self.pos_thres_nominal, self.neg_thres_nominal, self.sigma_thres)
                     self._pn_last_rate = rates[0]
+                if any(abs(r / self._pn_last_rate - 1) >= 0.1 for r in rates):
+                    raise ValueError("photoreceptor_noise: the frame interval moves by more than 10 % from the rate the noise "
+                                     "amplitude was computed for inside this run; split the run there (or use generate_events "
+                                     "per frame)")
             eng.set_pnoise(self._pn_plane, None)
             if isinstance(use_graph, bool) or use_graph in (0, 1):
                 use_graph = int(use_graph) | 16  # the pipeline that carries the noise plane
+        if self.scidvs and (isinstance(use_graph, bool) or use_graph in (0, 1)):
+            use_graph = int(use_graph) | 16  # the kernels that carry the SCIDVS planes
         P = self._params()
         if cap is None:
             # 4 events per pixel and frame (the reference never drops events; a clip that exceeds this raises below and
             # leaves the instance unusable until reset()), bounded to 4 GiB of rows for very long runs
             per_frame = max(4 * H * W, 1 << 16)
             cap = per_frame * min(nrun, max(64, (4 << 30) // (16 * per_frame)))
-        which = 0 if _single_buffer else self.__dict__.setdefault("_async_flip", 0)
+        # two buffer sets alternate between asynchronous runs; the synchronous call has a third of its own, so that a pending
+        # handle whose result() has not been read yet is never overwritten by it
+        which = 2 if _single_buffer else self.__dict__.setdefault("_async_flip", 0)
         if not _single_buffer:
             self._async_flip = which ^ 1
         ev = eng.event_buffer(cap, which)
@@ -677,6 +751,9 @@ class EventEmulator(object):
 
     def _finish_run(self, pend):
         eng = self._engine
+        if getattr(self, "_failed", None):  # an earlier pending run failed: the state this run started from is not the clip's
+            raise _capi.V2EAmdError("a previous device-resident run failed (%s); this run started from its state: call reset()"
+                                    % self._failed)
         r = eng.read_recs_after(pend.recs, pend.done)[:, 0]
         if self.refractory_period_s > 0:  # emulator.py:830 on the frames just run: how often was the rule active?
             m = np.maximum(r["max_events"], 1)

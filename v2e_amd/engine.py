@@ -153,14 +153,15 @@ class EmuEngine:
         return np.frombuffer(out, dtype=np.uint32).reshape(self.n_clips, n_iters + 1, 2).copy()
 
     def event_buffer(self, cap, which=0):
-        """Device [n_clips][cap][4] float32 buffer, grown geometrically (`which`: one of two sets, so that the events of a
-        run can still be read while the next run writes the other set)."""
+        """Device [n_clips][cap][4] float32 buffer, grown geometrically (`which`: one of several sets, so that the events of
+        a run can still be read while the next run writes another set; set 0 is also the frame-at-a-time API's)."""
         if which:
-            cur = self.__dict__.get("_events_b")
+            sets = self.__dict__.setdefault("_events_sets", {})
+            cur = sets.get(which)
             if cur is None or cur.shape[1] < cap:
                 ncap = max(int(cap), 1024) if cur is None else max(int(cap), 2 * cur.shape[1])
-                self._events_b = torch.empty((self.n_clips, ncap, 4), dtype=torch.float32, device=self.device)
-            return self._events_b
+                cur = sets[which] = torch.empty((self.n_clips, ncap, 4), dtype=torch.float32, device=self.device)
+            return cur
         if self._events is None or self._events.shape[1] < cap:
             ncap = max(int(cap), 1024)
             if self._events is not None:
@@ -180,6 +181,30 @@ class EmuEngine:
     def permute(self, events_in, events_out, idx_dev, row0, n):
         check(self.lib.v2e_emu_permute(self._h, _ptr(events_in), _ptr(events_out), _ptr(idx_dev), int(row0),
                                        int(n), self.stream), "v2e_emu_permute")
+
+    def frame(self, P, frame, t_prev, t_frame, frame_idx, events):
+        """One frame in one C call (v2e_emu_frame; Philox mode, one clip): `frame` a C-contiguous uint8/float32/float64
+        numpy array (copied through the handle's pinned staging) or a device tensor.  Returns (rc, out8, rows) with rows a
+        fresh host [n,4] float32 array (or None): rc 0 done; 1 more iteration scratch needed (M = out8[4]); 2 the event
+        buffer is too small for out8[0] rows -- in both cases the frame is counted and nothing was emitted."""
+        if isinstance(frame, np.ndarray):
+            fp, on_host, dt = C.c_void_p(frame.ctypes.data), 1, {np.dtype(np.uint8): _capi.DT_U8, np.dtype(np.float32): _capi.DT_F32,
+                                                                 np.dtype(np.float64): _capi.DT_F64}[frame.dtype]
+            n_el = frame.size
+        else:
+            fp, on_host, dt, n_el = _ptr(frame), 0, _DT[frame.dtype], frame.numel()
+        if n_el != self.npx:
+            raise ValueError("frame has %d elements, expected %d x %d" % (n_el, self.H, self.W))
+        out8 = (C.c_uint32 * 8)()
+        rows = C.POINTER(C.c_float)()
+        rc = self.lib.v2e_emu_frame(self._h, C.byref(P), fp, on_host, dt, float(t_prev), float(t_frame), int(frame_idx),
+                                    _ptr(events), int(events.shape[1]), out8, C.byref(rows), self.stream)
+        if rc < 0:
+            check(rc, "v2e_emu_frame")
+        ev = None
+        if rc == 0 and out8[0] > 0:
+            ev = np.ctypeslib.as_array(rows, shape=(int(out8[0]), 4)).copy()  # the pinned rows are reused by the next call
+        return rc, out8, ev
 
     def run(self, P, frames_dev, t_prev, t_frame, frame_idx0, events, recs_dev, use_graph=True):
         """Device-resident Philox run over frames_dev [F][n_clips][H*W]; no host sync."""
