@@ -27,7 +27,23 @@ def noise_ratio(a, z, key):
     return float(np.max(np.abs(np.asarray(a, np.float64) - f64)) / ref)
 
 
-REF_NOISE_FACTOR = 1.5  # |ours - f64| <= 1.5 |ref_f32 - f64| per tensor
+def noise_ratio_rms(a, z, key):
+    """the same with root-mean-square errors: the robust statistic (the maxima of two independent noise realisations over
+    18 000 .. 90 000 elements differ by a factor of two by chance, more so behind a 30-pixel warp)"""
+    f64 = z[key + "_f64"]
+    ref = np.sqrt(np.mean((z[key].astype(np.float64) - f64) ** 2))
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - f64) ** 2)) / ref)
+
+
+REF_NOISE_FACTOR = 1.5      # the oracle: max|ours - f64| <= 1.5 max|ref_f32 - f64| per tensor (measured 0.07 .. 0.25)
+# The GPU kernels (tests/test_slomo_gpu.py), measured on the MI355X, (rms, max) ratios per tensor:
+#   heads scaled   bf16x3 1.2 .. 1.3 / 0.9 .. 1.9     f32-MFMA 1.4 .. 1.5 / 1.1 .. 1.9
+#   all scaled     bf16x3 3.2 .. 3.5 / 2.1 .. 3.5     f32-MFMA 3.1 .. 3.8 / 2.2 .. 3.9
+# i.e. with O(100) activations in every layer both kernels are ~3.5 x as far from the exact result as the reference's
+# oneDNN convolution is -- BOTH conv maths alike: it is the float32 accumulation along k in one fixed sequential chain
+# (deterministic by design; oneDNN sums in vector lanes / blocks), not the split-bf16 operands' dropped products.  In units
+# of the tensors' scale that is 5.5e-6 (flow, 12.8 px) and 5.2e-6 (interpolation net outputs, 133): inside 1e-5.
+GPU_NOISE_FACTOR = {"slomo_trained_scale_64x96": (2.0, 3.0), "slomo_allscale_64x96": (4.5, 4.5)}  # (rms, max) bounds
 
 
 def load_pairs(z):
