@@ -1571,7 +1571,8 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // Under stream capture only edges between the origin stream and a forked stream are safe (edges between two forked
     // streams crash hipStreamEndCapture on this runtime): tables and rows then share the side stream.
     static const int tab_env = getenv("V2E_AMD_TABLES_ON_SIDE") ? ST_SIDE : (getenv("V2E_AMD_TABLES_ON_AHEAD") ? ST_AHEAD : ST_TAB); // dev
-    const int tab_stream = capturing ? ST_SIDE : tab_env;
+    static const bool tabs_on_main = getenv("V2E_AMD_TABLES_ON_MAIN") != nullptr; // dev: tables on the chain's stream, rows on the side stream
+    const int tab_stream = capturing ? (tabs_on_main ? ST_MAIN : ST_SIDE) : tab_env;
     constexpr int NSET = 3; // emission table sets (chain_alloc sizes them)
     static const bool one_row_stream = getenv("V2E_AMD_ONE_ROW_STREAM") != nullptr; // dev
     auto launch_emission = [&](int b) -> int { // EV_FORK[b] has been recorded on the chain stream
@@ -1594,17 +1595,19 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         static const int ich_env = getenv("V2E_AMD_CEMIT_ICH") ? atoi(getenv("V2E_AMD_CEMIT_ICH")) : 0;
         ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 15;
         ea.capw = 64 * ea.ich;
+        ea.coff_in_cemit = (tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream) ? 1 : 0;
         // frames per workgroup (measured at 346x260, 32-frame batches: k_ctot 4 frames 13 us, 32 frames 37 us; k_cemit 1 frame
         // 34 us, 8 frames 45 us -- these kernels are bound by the latency of a wave's dependent loads, not by wave dispatch:
         // more, shorter waves win)
         static const int zpw_env = getenv("V2E_AMD_EMIT_ZPW") ? atoi(getenv("V2E_AMD_EMIT_ZPW")) : 0;
-        ea.zpw_tot = zpw_env > 0 ? (zpw_env + CTOT_ZF - 1) / CTOT_ZF * CTOT_ZF : CTOT_ZF;
-        ea.zpw_emit = zpw_env > 0 ? zpw_env : 1;
+        (void)zpw_env;
+        ea.zpw_tot = CTOT_ZF;
+        ea.zpw_emit = 1; // (k_cemit: one frame per workgroup; several per workgroup measured slower and cost 25 % more instructions)
         const int REC_LDS = ea.capw * 4 * (BLOCK / WAVE);
         void *args[] = {(void *)&a, (void *)&ea};
         // tables on a stream of their own (NSET table sets rotate: tables(b + 1) are built while k_cemit(b) reads those of b;
         // k_cemit(b - NSET), which read this set last, is waited for), rows on the side stream
-        if (sc.wait(tab_stream, EV_FORK, b)) return V2E_EHIP;
+        if (tab_stream != ST_MAIN && sc.wait(tab_stream, EV_FORK, b)) return V2E_EHIP;
         if (b >= NSET && tab_stream != ST_SIDE && sc.wait(tab_stream, EV_JOIN, b - NSET)) return V2E_EHIP;
         if (!no_emit) {
             if (sc.kernel(tab_stream, (const void *)k_ctot, dim3(h->ngroups, NC, (ea.nE + ea.zpw_tot - 1) / ea.zpw_tot), dim3(BLOCK), 0, args)) return V2E_EHIP;
@@ -1616,12 +1619,13 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
                 return V2E_EHIP;
             }
         }
-        if (!no_emit) {
+        // rows: two batches side by side on two streams (the rows of a batch depend on nothing but its tables; the batch's
+        // event offset then comes from k_coff behind the tables); on one stream with the tables the rows carry it forward
+        const int row_stream = (tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream) ? ST_SIDE : ((b & 1) ? ST_SIDE2 : ST_SIDE);
+        if (!no_emit && !ea.coff_in_cemit) {
             void *oargs[] = {(void *)&ea};
             if (sc.kernel(tab_stream, (const void *)k_coff, dim3(NC), dim3(WAVE), 0, oargs)) return V2E_EHIP;
         }
-        // rows: two batches side by side on two streams (the rows of a batch depend on nothing but its tables)
-        const int row_stream = (tab_stream == ST_SIDE || one_row_stream) ? ST_SIDE : ((b & 1) ? ST_SIDE2 : ST_SIDE);
         if (sc.record(EV_TAB, b, tab_stream)) return V2E_EHIP;
         if (row_stream != tab_stream && sc.wait(row_stream, EV_TAB, b)) return V2E_EHIP;
         if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
@@ -1649,7 +1653,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     void *xb[2] = {h->base, has_refr ? h->ch_base2 : h->base}, *xl[2] = {h->lp, has_refr ? h->ch_lp2 : h->lp};
     float *xt[2] = {h->ts_mem, has_refr ? h->ch_ts2 : h->ts_mem};
     // the run's uploads (frame times, first frame index) and the zero fills precede everything
-    if (sc.record(EV_FORK, nL, ST_MAIN) || sc.wait(ST_SIDE, EV_FORK, nL)) return V2E_EHIP;
+    static const bool no_side_fork = getenv("V2E_AMD_INITIAL_SIDE_FORK") == nullptr; // under capture the side stream joins at its first batch
+    if (sc.record(EV_FORK, nL, ST_MAIN)) return V2E_EHIP;
+    if (!(capturing && no_side_fork) && sc.wait(ST_SIDE, EV_FORK, nL)) return V2E_EHIP;
     if (!fused_rec && sc.wait(ST_AHEAD, EV_FORK, nL)) return V2E_EHIP;
     if (!capturing && (sc.wait(ST_TAB, EV_FORK, nL) || sc.wait(ST_SIDE2, EV_FORK, nL))) return V2E_EHIP;
     for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b)
@@ -1700,11 +1706,16 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (sc.kernel(ST_MAIN, kfn, grid, dim3(BLOCK), chain_dyn_lds(fused_rec), args)) return V2E_EHIP;
         if (mark(ev_main, s)) return V2E_EHIP;
         if (L % m == 0 && sc.record(EV_CHAIN, L, ST_MAIN)) return V2E_EHIP;
-        if (pl.emit_batch >= 0) { // (before k_ahead on their common stream: the ring slots this frees are what the chain waits for)
+        // Enqueue order of the two side branches: k_ahead first.  It decides how this runtime executes the captured graph:
+        // with the emission enqueued first the chain's next launch runs BEHIND the emission kernels (measured, profiles/
+        // r03_graph_scheduling.txt), with k_ahead first it runs beside them.
+        static const bool ahead_first = getenv("V2E_AMD_ORDER_EMISSION_FIRST") == nullptr;
+        if (ahead_first && pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
+        if (pl.emit_batch >= 0) {
             if (sc.record(EV_FORK, pl.emit_batch, ST_MAIN)) return V2E_EHIP;
             if (launch_emission(pl.emit_batch)) return V2E_EHIP;
         }
-        if (pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
+        if (!ahead_first && pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
     }
     if (!graph) { // join: the run is complete on `s` (a graph is complete when all its nodes are)
         if (sc.wait(ST_MAIN, EV_JOIN, nEB - 1)) return V2E_EHIP;

@@ -636,6 +636,7 @@ struct CEmitArgs {
     unsigned *cdone;     // [E][n_clips] k_cframe: row workgroups done per frame (self-resetting)
     int capw, ich; // event records per wave in LDS; iterations per pass of k_cemit (64 * ich <= capw, 2 * ich <= 62)
     int zpw_tot, zpw_emit; // frames a workgroup of k_ctot / k_cemit walks (grid z = ceil(nE / that)); see enqueue_run_chain
+    int coff_in_cemit;     // the next batch's event offset is written by k_cemit (one stream for tables and rows) instead of k_coff
 };
 
 // What the event list needs from a frame's count words beyond the words themselves, per WAVE (every wave on its own, no
@@ -654,8 +655,7 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
     const int wave_g = g * (BLOCK / WAVE) + wave;
     const int p = g * BLOCK + tid;
     const bool valid = p < a.npx;
-    const int z_end = min(ea.nE, ((int)blockIdx.z + 1) * ea.zpw_tot);
-    for (int zb = (int)blockIdx.z * ea.zpw_tot; zb < z_end; zb += CTOT_ZF) { // CTOT_ZF frames' count words in flight together
+    const int zb = (int)blockIdx.z * CTOT_ZF, z_end = ea.nE; // CTOT_ZF frames' count words in flight together
     uint32_t cwq[CTOT_ZF], rMq[CTOT_ZF];
     int slotq[CTOT_ZF];
     {
@@ -721,7 +721,6 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
             }
             if (kb + lane < nkw) trow[(size_t)(kb + lane) * ea.nwp] = (uint8_t)mine;
         }
-    }
     }
 }
 
@@ -1007,10 +1006,11 @@ __global__ __launch_bounds__(WAVE) void k_coff(CEmitArgs ea)
 // Event rows of one frame, every wave on its own: which of my iterations pass (the refractory recurrence against
 // tsold on rule-on frames), ballot ranks, one 4-byte record per event in LDS; then one event per lane: row =
 // frame offset + iteration base + shuffle(ON/OFF block offset + prefix over earlier waves + rank in wave).
-__device__ __forceinline__ void cemit_frame(const KArgs &a, const CEmitArgs &ea, const int z, uint32_t *s_crec)
+__global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
 {
+    extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw]
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int clip = blockIdx.y, g = blockIdx.x, fe = ea.f0 + z, slot = fe % ea.D;
+    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
     const size_t zc = (size_t)z * ea.n_clips + clip;
     const CFrame *cf = ea.cf + zc;
     const int wave_g = g * (BLOCK / WAVE) + wave;
@@ -1055,7 +1055,7 @@ __device__ __forceinline__ void cemit_frame(const KArgs &a, const CEmitArgs &ea,
     const uint32_t n_events = __builtin_amdgcn_readfirstlane((int)nev_v);
     if (g == 0 && tid == 0) {
         rec[clip].ev_offset = ev0;
-        // (the next batch's offset is k_coff's: the event writers of consecutive batches do not wait for each other)
+        if (ea.coff_in_cemit && z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events; // else k_coff's
     }
     if (__builtin_amdgcn_readfirstlane((int)disc_v)) return;
     const int wmw = __builtin_amdgcn_readfirstlane(wm_v);
@@ -1161,11 +1161,4 @@ __device__ __forceinline__ void cemit_frame(const KArgs &a, const CEmitArgs &ea,
         }
     }
     if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
-}
-
-__global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
-{
-    extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw]
-    const int z_end = min(ea.nE, ((int)blockIdx.z + 1) * ea.zpw_emit);
-    for (int z = (int)blockIdx.z * ea.zpw_emit; z < z_end; ++z) cemit_frame(a, ea, z, s_crec); // (a wave reads back only its own records)
 }
