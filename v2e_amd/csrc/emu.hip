@@ -744,7 +744,7 @@ struct v2e_emu {
     uint32_t *ch_cnt = nullptr;     // [ch_D][n_clips][npx_pad]
     uint32_t *ch_ruleM = nullptr;   // [ch_D][n_clips]
     uint16_t *ch_wmax = nullptr;    // [2][ch_E][n_clips][ch_nwp]
-    uint8_t *ch_wtot = nullptr;     // [2][ch_E][n_clips][nkeys_cap][ch_nwp]
+    uint16_t *ch_wtot = nullptr;    // [3][ch_E][n_clips][nkeys_cap][ch_nwp]
     float *ch_tsold = nullptr;      // [ch_D][n_clips][npx_pad] (refractory runs)
     void *ch_ck = nullptr;          // refractory runs: 2 launch parities x 3 checkpoints x (base 8 B, lp 8 B, ts 4 B) planes
     uint4 *ch_rec = nullptr;        // [ch_D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
@@ -1441,7 +1441,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         if (const char *ev = getenv("V2E_AMD_CHAIN_RING")) { const int v = atoi(ev); if (v >= 3 && v <= 16) nD = v; }
         h->ch_nD = nD;
         h->ch_D = nD * E;
-        h->ch_nwp = (h->ngroups * (BLOCK / WAVE) + 15) / 16 * 16;
+        h->ch_nwp = (h->ngroups + 15) / 16 * 16; // emission groups of 256 pixels (one wave each), padded to the 16 a lane of k_cframe takes
         h->ch_nkeys_cap = h->nkeys_cap;
         const size_t nc = (size_t)h->n_clips;
         V2E_HIP(hipMalloc(&h->ch_cnt, sizeof(uint32_t) * h->ch_D * nc * h->npx_pad));
@@ -1450,8 +1450,8 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         // three sets of emission tables in rotation: the tables of batches b + 1, b + 2 are built while k_cemit(b) reads its own
         V2E_HIP(hipMalloc(&h->ch_wmax, 3 * sizeof(uint16_t) * E * nc * h->ch_nwp));
         V2E_HIP(hipMemset(h->ch_wmax, 0, 3 * sizeof(uint16_t) * E * nc * h->ch_nwp));
-        V2E_HIP(hipMalloc(&h->ch_wtot, (size_t)3 * E * nc * h->nkeys_cap * h->ch_nwp));
-        V2E_HIP(hipMemset(h->ch_wtot, 0, (size_t)3 * E * nc * h->nkeys_cap * h->ch_nwp));
+        V2E_HIP(hipMalloc(&h->ch_wtot, sizeof(uint16_t) * 3 * E * nc * h->nkeys_cap * h->ch_nwp));
+        V2E_HIP(hipMemset(h->ch_wtot, 0, sizeof(uint16_t) * 3 * E * nc * h->nkeys_cap * h->ch_nwp));
         V2E_HIP(hipMalloc(&h->ch_cf, 3 * sizeof(CFrame) * E * nc));
         V2E_HIP(hipMemset(h->ch_cf, 0, 3 * sizeof(CFrame) * E * nc));
         V2E_HIP(hipMalloc(&h->ch_cdone, 3 * sizeof(unsigned) * E * nc));
@@ -1580,7 +1580,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         memset(&ea, 0, sizeof(ea));
         ea.ctl = h->run_ctl; ea.recs = recs; ea.fidx_base = h->run_fidx;
         ea.f0 = b * E; ea.nE = std::min((b + 1) * E, n_frames) - ea.f0; ea.D = D; ea.n_clips = NC;
-        ea.nwp = h->ch_nwp; ea.nwaves = h->ngroups * (BLOCK / WAVE); ea.E = E;
+        ea.nwp = h->ch_nwp; ea.nwaves = h->ngroups; ea.E = E; // emission groups (256 pixels, one wave each)
         ea.cnt = h->ch_cnt; ea.tsold = has_refr ? h->ch_tsold : nullptr; ea.ruleM = has_refr ? h->ch_ruleM : nullptr;
         const size_t set = (size_t)(b % NSET) * E * NC; // table set of this batch
         ea.wmax = h->ch_wmax + set * h->ch_nwp; ea.wtot = h->ch_wtot + set * h->nkeys_cap * h->ch_nwp;
@@ -1590,11 +1590,11 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ea.events = (float4 *)events; ea.cap = cap;
         ea.off_in = h->run_off + (size_t)b * NC;
         ea.off_out = h->run_off + (size_t)(b + 1) * NC;
-        // event records of k_cemit: 64 x ich per wave and pass.  The chain's workgroups need their LDS (5 KB per frame) on
-        // every CU: 15 iterations per pass (most frames have fewer) keep an emission workgroup at 15 KB
+        // event records of k_cemit: 256 x ich per group (wave) and pass.  The chain's workgroups need their LDS (5 KB per frame)
+        // on every CU: 6 iterations per pass (most frames have fewer) keep an emission workgroup of four groups at 24 KB
         static const int ich_env = getenv("V2E_AMD_CEMIT_ICH") ? atoi(getenv("V2E_AMD_CEMIT_ICH")) : 0;
-        ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 15;
-        ea.capw = 64 * ea.ich;
+        ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 6;
+        ea.capw = GROUP_PX * ea.ich;
         ea.coff_in_cemit = (tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream) ? 1 : 0;
         // frames per workgroup (measured at 346x260, 32-frame batches: k_ctot 4 frames 13 us, 32 frames 37 us; k_cemit 1 frame
         // 34 us, 8 frames 45 us -- these kernels are bound by the latency of a wave's dependent loads, not by wave dispatch:
@@ -1604,13 +1604,14 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ea.zpw_tot = CTOT_ZF;
         ea.zpw_emit = 1; // (k_cemit: one frame per workgroup; several per workgroup measured slower and cost 25 % more instructions)
         const int REC_LDS = ea.capw * 4 * (BLOCK / WAVE);
+        const int egx = (h->ngroups + BLOCK / WAVE - 1) / (BLOCK / WAVE); // workgroups of four emission groups
         void *args[] = {(void *)&a, (void *)&ea};
         // tables on a stream of their own (NSET table sets rotate: tables(b + 1) are built while k_cemit(b) reads those of b;
         // k_cemit(b - NSET), which read this set last, is waited for), rows on the side stream
         if (tab_stream != ST_MAIN && sc.wait(tab_stream, EV_FORK, b)) return V2E_EHIP;
         if (b >= NSET && tab_stream != ST_SIDE && sc.wait(tab_stream, EV_JOIN, b - NSET)) return V2E_EHIP;
         if (!no_emit) {
-            if (sc.kernel(tab_stream, (const void *)k_ctot, dim3(h->ngroups, NC, (ea.nE + ea.zpw_tot - 1) / ea.zpw_tot), dim3(BLOCK), 0, args)) return V2E_EHIP;
+            if (sc.kernel(tab_stream, (const void *)k_ctot, dim3(egx, NC, (ea.nE + CTOT_ZF - 1) / CTOT_ZF), dim3(BLOCK), 0, args)) return V2E_EHIP;
             // a key row of a small grid is a couple of steps of one wave: one workgroup per frame; of a large grid (1280x720:
             // 14 400 waves) a segmented scan by a workgroup of its own
             if (h->ch_nwp <= 4096) {
@@ -1629,7 +1630,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (sc.record(EV_TAB, b, tab_stream)) return V2E_EHIP;
         if (row_stream != tab_stream && sc.wait(row_stream, EV_TAB, b)) return V2E_EHIP;
         if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
-        if (!no_emit && sc.kernel(row_stream, (const void *)k_cemit, dim3(h->ngroups, NC, (ea.nE + ea.zpw_emit - 1) / ea.zpw_emit), dim3(BLOCK), REC_LDS, args)) return V2E_EHIP;
+        if (!no_emit && sc.kernel(row_stream, (const void *)k_cemit, dim3(egx, NC, ea.nE), dim3(BLOCK), REC_LDS, args)) return V2E_EHIP;
         if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
         return sc.record(EV_JOIN, b, row_stream);
     };

@@ -621,8 +621,8 @@ struct CEmitArgs {
     int f0, nE, D, n_clips, nwp, nwaves, E;
     const uint32_t *cnt;
     const uint32_t *ruleM; // [D][n_clips] (refractory runs) or nullptr
-    uint16_t *wmax;      // [E][n_clips][nwp] per-wave max count (k_ctot)
-    uint8_t *wtot;       // [E][n_clips][nkeys_cap][nwp] per-wave key totals, <= 64 each (k_ctot)
+    uint16_t *wmax;      // [E][n_clips][nwp] per-group max count (k_ctot); nwaves = groups of 256 pixels, nwp = that padded to 16
+    uint16_t *wtot;      // [E][n_clips][nkeys_cap][nwp] per-group key totals, <= 256 each (k_ctot)
     const float *tsold;
     CFrame *cf;          // [E][n_clips]
     uint32_t *cT;        // [E][n_clips][nkeys_cap] events per key over all waves
@@ -639,88 +639,129 @@ struct CEmitArgs {
     int coff_in_cemit;     // the next batch's event offset is written by k_cemit (one stream for tables and rows) instead of k_coff
 };
 
-// What the event list needs from a frame's count words beyond the words themselves, per WAVE (every wave on its own, no
-// workgroup barrier): the wave's max count and its (iteration, polarity) event totals (ballot / popcount) as key-major u8
-// rows [key][wave]: key 0/1 shot ON/OFF, key 2+2i / 3+2i iteration i ON/OFF -- after the refractory filter on the frames
+// ---- Emission groups.  The event list is assembled per GROUP of 256 consecutive pixels, one wave per group (GPX = 4 pixels
+// per lane: sub-group j = pixels [64 j, 64 j + 64) of the group).  A frame of the benchmark clip has ~25 events per 64
+// pixels (9 at 1280x720 noisy): with one wave per 64 pixels most of what the emission kernels executed was per-wave set-up
+// and a 64-lane event pass that was a third full; with 256 pixels per wave the set-up, the per-key tables (352 entries per
+// frame and key at 346x260 instead of 1 408) and the prefix over them shrink fourfold and the event pass runs full.
+constexpr int GPX = 4;
+constexpr int GROUP_PX = GPX * WAVE;
+
+// What the event list needs from a frame's count words beyond the words themselves, per group (every wave on its own, no
+// workgroup barrier): the group's max count and its (iteration, polarity) event totals (ballot / popcount) as key-major u16
+// rows [key][group]: key 0/1 shot ON/OFF, key 2+2i / 3+2i iteration i ON/OFF -- after the refractory filter on the frames
 // the chain finalised by the rule (ruleM != 0: the recurrence against ts_mem as it was, emulator.py:836-842).  A prefix
-// over waves (k_cframe) turns them into row offsets; k_cemit writes the rows.  A workgroup takes CTOT_ZF frames of its 256
-// pixels (their count words in flight together: a wave's work per frame is a few dozen instructions, so what this kernel
-// costs is workgroup dispatch and one memory round trip).
-constexpr int CTOT_ZF = 4;
+// over groups (k_cframe) turns them into row offsets; k_cemit writes the rows.  A wave takes CTOT_ZF frames of its group
+// (their count words in flight together).
+constexpr int CTOT_ZF = 2;
 
 __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
 {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int clip = blockIdx.y, g = blockIdx.x;
-    const int wave_g = g * (BLOCK / WAVE) + wave;
-    const int p = g * BLOCK + tid;
-    const bool valid = p < a.npx;
-    const int zb = (int)blockIdx.z * CTOT_ZF, z_end = ea.nE; // CTOT_ZF frames' count words in flight together
-    uint32_t cwq[CTOT_ZF], rMq[CTOT_ZF];
+    const int clip = blockIdx.y;
+    const int grp = blockIdx.x * (BLOCK / WAVE) + wave;
+    if (grp >= ea.nwaves) return;
+    const int p0 = grp * GROUP_PX + lane;
+    const int zb = (int)blockIdx.z * CTOT_ZF;
+    uint32_t cwq[CTOT_ZF][GPX], rMq[CTOT_ZF];
     int slotq[CTOT_ZF];
     {
         int sl = (ea.f0 + zb) % ea.D;
 #pragma unroll
         for (int q = 0; q < CTOT_ZF; ++q) {
             slotq[q] = sl;
-            cwq[q] = 0u;
             rMq[q] = 0u;
-            if (zb + q < z_end) {
-                if (valid) cwq[q] = ea.cnt[((size_t)sl * ea.n_clips + clip) * a.npx_pad + p];
-                if (ea.ruleM) rMq[q] = ea.ruleM[(size_t)sl * ea.n_clips + clip];
+#pragma unroll
+            for (int j = 0; j < GPX; ++j) {
+                cwq[q][j] = 0u;
+                if (zb + q < ea.nE && p0 + j * WAVE < a.npx) cwq[q][j] = ea.cnt[((size_t)sl * ea.n_clips + clip) * a.npx_pad + p0 + j * WAVE];
             }
+            if (zb + q < ea.nE && ea.ruleM) rMq[q] = ea.ruleM[(size_t)sl * ea.n_clips + clip];
             if (++sl == ea.D) sl = 0;
         }
     }
 #pragma unroll
     for (int q = 0; q < CTOT_ZF; ++q) {
         const int z = zb + q;
-        if (z >= z_end) break;
+        if (z >= ea.nE) break;
         const size_t zc = (size_t)z * ea.n_clips + clip;
-        const uint32_t cw = cwq[q];
         const uint32_t rM = (uint32_t)__builtin_amdgcn_readfirstlane((int)rMq[q]);
-        const int magv = (int)(cw & CNT_MASK);
-        const bool neg = (cw & CNT_NEG) != 0;
-        const int wm = wave_max_i32(magv);
-        if (lane == 0) ea.wmax[zc * ea.nwp + wave_g] = (uint16_t)min(wm, 65535);
-        uint8_t *trow = ea.wtot + (zc * a.nkeys_cap) * ea.nwp + wave_g;
+        int magv[GPX];
+        bool neg[GPX];
+        int mmax = 0;
+        uint32_t son = 0, soff = 0;
+#pragma unroll
+        for (int j = 0; j < GPX; ++j) {
+            const uint32_t cw = cwq[q][j];
+            magv[j] = (int)(cw & CNT_MASK);
+            neg[j] = (cw & CNT_NEG) != 0;
+            mmax = max(mmax, magv[j]);
+            son += (uint32_t)__popcll(__ballot((cw & CNT_SHOT_ON) != 0));
+            soff += (uint32_t)__popcll(__ballot((cw & CNT_SHOT_OFF) != 0));
+        }
+        const int wm = wave_max_i32(mmax);
+        if (lane == 0) ea.wmax[zc * ea.nwp + grp] = (uint16_t)min(wm, 65535);
+        uint16_t *trow = ea.wtot + (zc * a.nkeys_cap) * ea.nwp + grp;
         const int wmc = min(wm, a.max_iters); // beyond max_iters the frame is flagged and not emitted
         const int nkw = 2 + 2 * wmc;
-        const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0);
-        const unsigned long long sf = __ballot((cw & CNT_SHOT_OFF) != 0);
         bool ruled = false;
         TsGen tg(0.f, 0.f, 0.f, 1);
-        float tsm = 0.f;
+        float tsm[GPX];
+#pragma unroll
+        for (int j = 0; j < GPX; ++j) tsm[j] = 0.f;
         if (rM != 0u) { // rule-on frame (rare): the filter needs the frame's time stamps and ts_mem as it was
             const FrameCtl *c = ea.ctl + (size_t)(ea.f0 + z) * ea.n_clips + clip;
             const FrameTab ftb(c, lane);
             tg = frame_tsgen(a, c, ftb, (int)rM, ruled);
-            if (valid && ea.tsold) tsm = ea.tsold[((size_t)slotq[q] * ea.n_clips + clip) * a.npx_pad + p];
+            if (ea.tsold) {
+#pragma unroll
+                for (int j = 0; j < GPX; ++j)
+                    if (p0 + j * WAVE < a.npx) tsm[j] = ea.tsold[((size_t)slotq[q] * ea.n_clips + clip) * a.npx_pad + p0 + j * WAVE];
+            }
         }
         for (int kb = 0; kb < nkw; kb += WAVE) {
             uint32_t mine = 0;
             const int i_lo = kb == 0 ? 0 : (kb - 2) / 2;
             const int i_hi = min((kb + WAVE - 2) / 2, wmc);
             for (int i = i_lo; i < i_hi; ++i) {
-                bool pass = magv > i;
-                if (ruled && pass) {
-                    const float t = tg(i);
-                    const float pt = 1.0f * t - tsm;
-                    pass = pt > a.refr_f;
-                    if (pass) tsm = t;
+                uint32_t on = 0, off = 0;
+#pragma unroll
+                for (int j = 0; j < GPX; ++j) {
+                    bool pass = magv[j] > i;
+                    if (ruled && pass) {
+                        const float t = tg(i);
+                        const float pt = 1.0f * t - tsm[j];
+                        pass = pt > a.refr_f;
+                        if (pass) tsm[j] = t;
+                    }
+                    on += (uint32_t)__popcll(__ballot(pass && !neg[j]));
+                    off += (uint32_t)__popcll(__ballot(pass && neg[j]));
                 }
-                const unsigned long long bo = __ballot(pass && !neg);
-                const unsigned long long bf = __ballot(pass && neg);
                 const int kl = 2 + 2 * i - kb;
-                if (lane == kl) mine = (uint32_t)__popcll(bo);
-                if (lane == kl + 1) mine = (uint32_t)__popcll(bf);
+                if (lane == kl) mine = on;
+                if (lane == kl + 1) mine = off;
             }
             if (kb == 0) {
-                if (lane == 0) mine = (uint32_t)__popcll(so);
-                if (lane == 1) mine = (uint32_t)__popcll(sf);
+                if (lane == 0) mine = son;
+                if (lane == 1) mine = soff;
             }
-            if (kb + lane < nkw) trow[(size_t)(kb + lane) * ea.nwp] = (uint8_t)mine;
+            if (kb + lane < nkw) trow[(size_t)(kb + lane) * ea.nwp] = (uint16_t)mine;
         }
+    }
+}
+
+// 16 consecutive entries of a key row (u16 totals of 16 groups) with the rows a group did not write masked: a group writes
+// only the rows of its own iterations; above them the table holds an older frame's values
+__device__ __forceinline__ void key_row16(const uint16_t *__restrict__ row_at, const uint16_t *__restrict__ wm_at, uint32_t k, uint32_t v[16])
+{
+    const uint4 t0 = *(const uint4 *)row_at, t1 = *(const uint4 *)(row_at + 8);
+    const uint4 m0 = *(const uint4 *)wm_at, m1 = *(const uint4 *)(wm_at + 8);
+    const uint32_t tw[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        v[j] = k < 2u + 2u * wmj ? ((tw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) : 0u;
     }
 }
 
@@ -753,7 +794,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe1(KArgs a, CEmitArgs e
         return;
     }
     const int nk = 2 + 2 * M;
-    const uint8_t *tot = ea.wtot + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
+    const uint16_t *tot = ea.wtot + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
     uint32_t *pre = ea.cpre + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
     for (int k = wave; k < nk; k += NW) { // one wave per key row, 16 waves' totals per lane and step
         uint32_t carry = 0;
@@ -763,16 +804,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe1(KArgs a, CEmitArgs e
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = 0u;
             if (wi < ea.nwp) {
-                const uint4 t4 = *(const uint4 *)(tot + (size_t)k * ea.nwp + wi);
-                const uint4 m0 = *(const uint4 *)(wm + wi), m1 = *(const uint4 *)(wm + wi + 8);
-                const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
-                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                    // a wave writes only the rows of its own iterations; above them the table holds an older frame's bytes
-                    v[j] = (uint32_t)k < 2u + 2u * wmj ? ((tw[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 0u;
-                }
+                key_row16(tot + (size_t)k * ea.nwp + wi, wm + wi, (uint32_t)k, v);
             }
             uint32_t lane_tot = 0;
 #pragma unroll
@@ -863,7 +895,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
     v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips + clip;
     const bool discard = M > a.max_iters; // the frame is not emitted; the caller sees the flag
     const int nk = discard ? 0 : 2 + 2 * M;
-    const uint8_t *tot = ea.wtot + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
+    const uint16_t *tot = ea.wtot + ((size_t)z * ea.n_clips + clip) * a.nkeys_cap * ea.nwp;
     uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp;
     uint32_t *cT = ea.cT + zc * a.nkeys_cap;
     // this workgroup's row(s): r0, and for the last row workgroup every row beyond the grid
@@ -875,16 +907,10 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
             const int wi = w0 + lane * 16;
             uint32_t lane_tot = 0;
             if (wi < hi) {
-                const uint4 t4 = *(const uint4 *)(tot + (size_t)k * ea.nwp + wi);
-                const uint4 m0 = *(const uint4 *)(wm + wi), m1 = *(const uint4 *)(wm + wi + 8);
-                const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
-                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                uint32_t v[16];
+                key_row16(tot + (size_t)k * ea.nwp + wi, wm + wi, (uint32_t)k, v);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                    // a wave writes only the rows of its own iterations; above them the table holds an older frame's bytes
-                    lane_tot += (uint32_t)k < 2u + 2u * wmj ? ((tw[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 0u;
-                }
+                for (int j = 0; j < 16; ++j) lane_tot += v[j];
             }
             wsum += wave_sum_u32(lane_tot);
         }
@@ -903,15 +929,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = 0u;
             if (wi < hi) {
-                const uint4 t4 = *(const uint4 *)(tot + (size_t)k * ea.nwp + wi);
-                const uint4 m0 = *(const uint4 *)(wm + wi), m1 = *(const uint4 *)(wm + wi + 8);
-                const uint32_t tw[4] = {t4.x, t4.y, t4.z, t4.w};
-                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t wmj = (mw[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                    v[j] = (uint32_t)k < 2u + 2u * wmj ? ((tw[j >> 2] >> (8 * (j & 3))) & 0xFFu) : 0u;
-                }
+                key_row16(tot + (size_t)k * ea.nwp + wi, wm + wi, (uint32_t)k, v);
             }
             uint32_t lane_tot = 0;
 #pragma unroll
@@ -1003,39 +1021,40 @@ __global__ __launch_bounds__(WAVE) void k_coff(CEmitArgs ea)
     if (lane == 0) ea.off_out[clip] = ea.off_in[clip] + lo + ((unsigned long long)hi << 24);
 }
 
-// Event rows of one frame, every wave on its own: which of my iterations pass (the refractory recurrence against
-// tsold on rule-on frames), ballot ranks, one 4-byte record per event in LDS; then one event per lane: row =
-// frame offset + iteration base + shuffle(ON/OFF block offset + prefix over earlier waves + rank in wave).
+// Event rows of one frame, every group (256 pixels, one wave) on its own: which of its pixels' iterations pass (the
+// refractory recurrence against tsold on rule-on frames), ballot ranks, one 4-byte record per event in LDS; then one event per
+// lane: row = frame offset + iteration base + shuffle(ON/OFF block offset + prefix over earlier groups + rank in group).
 __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
 {
     extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw]
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int clip = blockIdx.y, g = blockIdx.x, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int grp = blockIdx.x * (BLOCK / WAVE) + wave;
+    if (grp >= ea.nwaves) return;
     const size_t zc = (size_t)z * ea.n_clips + clip;
     const CFrame *cf = ea.cf + zc;
-    const int wave_g = g * (BLOCK / WAVE) + wave;
-    const int p = g * BLOCK + tid;
-    const bool valid = p < a.npx;
-    const size_t sp = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p;
+    const int p0 = grp * GROUP_PX + lane; // this lane's pixels: p0 + 64 j
+    const size_t sp0 = ((size_t)slot * ea.n_clips + clip) * a.npx_pad + p0;
     v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips;
     const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
     const uint32_t *cT = ea.cT + zc * a.nkeys_cap, *ckb = ea.ckbase + zc * a.nkeys_cap;
-    const uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp + wave_g;
+    const uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp + grp;
     const uint32_t *perm = ea.cperm + zc * a.max_iters * 8;
     const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
-    const int ICH = ea.ich; // iterations per pass: their 2 * ICH keys in the wave's lanes, at most 64 * ICH records
+    const int ICH = ea.ich; // iterations per pass: their 2 * ICH keys in the wave's lanes, at most GROUP_PX * ICH records
     // ------------------------------------------------------------ every load of the common case, issued back to back (one
-    // memory round trip per wave instead of one per early-exit test): frame table, offsets, count word, wave max, timestamp
-    // tables, ts_mem as it was, and the first pass's per-key totals / prefixes / shuffle parameters (rows beyond the
-    // frame's keys hold older frames' values: masked once M is known)
+    // memory round trip per wave instead of one per early-exit test): frame table, offsets, count words, group max, timestamp
+    // tables, and the first pass's per-key totals / prefixes / shuffle parameters (rows beyond the frame's keys hold older
+    // frames' values: masked once M is known)
     const uint32_t off_lo = (uint32_t)ea.off_in[clip], off_hi = (uint32_t)(ea.off_in[clip] >> 32);
     const uint32_t nj = lane < z ? ea.cf[(size_t)lane * ea.n_clips + clip].n_events : 0u; // lane j: frame j of the batch (E <= 64)
     const int M_v = cf->M;
     const uint32_t nsig_v = cf->n_signal, nev_v = cf->n_events, disc_v = cf->discarded;
-    const uint32_t cw = valid ? ea.cnt[sp] : 0u;
-    const int wm_v = (int)ea.wmax[zc * ea.nwp + wave_g];
+    uint32_t cw[GPX];
+#pragma unroll
+    for (int j = 0; j < GPX; ++j) cw[j] = p0 + j * WAVE < a.npx ? ea.cnt[sp0 + j * WAVE] : 0u;
+    const int wm_v = (int)ea.wmax[zc * ea.nwp + grp];
     const FrameTab ftb(c, lane);
-    float tsm = (valid && a.has_refr && ea.tsold) ? ea.tsold[sp] : 0.f; // meaningful on rule-on frames only
     uint32_t T_0 = 0, kbase_0 = 0, P_0 = 0;
     if (lane < 2 * ICH && 2 + lane < a.nkeys_cap) {
         T_0 = cT[2 + lane];
@@ -1053,22 +1072,53 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
     const int M = __builtin_amdgcn_readfirstlane(M_v);
     const uint32_t n_signal = __builtin_amdgcn_readfirstlane((int)nsig_v);
     const uint32_t n_events = __builtin_amdgcn_readfirstlane((int)nev_v);
-    if (g == 0 && tid == 0) {
+    if (grp == 0 && lane == 0) {
         rec[clip].ev_offset = ev0;
         if (ea.coff_in_cemit && z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events; // else k_coff's
     }
     if (__builtin_amdgcn_readfirstlane((int)disc_v)) return;
     const int wmw = __builtin_amdgcn_readfirstlane(wm_v);
-    const unsigned long long so = __ballot((cw & CNT_SHOT_ON) != 0), sf = __ballot((cw & CNT_SHOT_OFF) != 0);
-    if (wmw == 0 && (so | sf) == 0ull) return; // nothing of this wave in the frame
+    unsigned long long so[GPX], sf[GPX];
+    unsigned long long any_shot = 0ull;
+#pragma unroll
+    for (int j = 0; j < GPX; ++j) {
+        so[j] = __ballot((cw[j] & CNT_SHOT_ON) != 0);
+        sf[j] = __ballot((cw[j] & CNT_SHOT_OFF) != 0);
+        any_shot |= so[j] | sf[j];
+    }
+    if (wmw == 0 && any_shot == 0ull) return; // nothing of this group in the frame
     const int n = M > 0 ? M : 1;
     bool use_refr;
     const TsGen tg = frame_tsgen(a, c, ftb, n, use_refr);
-    const int mag = (int)(cw & CNT_MASK);
-    const bool neg = (cw & CNT_NEG) != 0;
+    int mag[GPX];
+    bool neg[GPX];
+    float tsm[GPX];
+#pragma unroll
+    for (int j = 0; j < GPX; ++j) {
+        mag[j] = (int)(cw[j] & CNT_MASK);
+        neg[j] = (cw[j] & CNT_NEG) != 0;
+        tsm[j] = 0.f;
+    }
+    if (use_refr && ea.tsold) { // ts_mem as it was before the frame (rule-on frames only)
+#pragma unroll
+        for (int j = 0; j < GPX; ++j)
+            if (p0 + j * WAVE < a.npx) tsm[j] = ea.tsold[sp0 + j * WAVE];
+    }
     float4 *ev = ea.events + (size_t)clip * ea.cap;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const float fx = (float)(p % a.W), fy = (float)(p / a.W);
+    const float rcpW = 1.0f / (float)a.W;
+    auto pixel_xy = [&](const uint32_t p, float &x, float &y) __attribute__((always_inline)) { // y = p / W, x = p % W, exactly
+        uint32_t q;
+        if (a.npx < (1 << 24)) { // float32 holds p exactly: the quotient estimate is the true one or one off
+            q = (uint32_t)((float)p * rcpW);
+            if (q * (uint32_t)a.W > p) --q;
+            else if ((q + 1u) * (uint32_t)a.W <= p) ++q;
+        } else {
+            q = p / (uint32_t)a.W;
+        }
+        y = (float)q;
+        x = (float)(p - q * (uint32_t)a.W);
+    };
     uint32_t *rec_w = s_crec + (size_t)wave * ea.capw;
     bool dropped = false;
     const int iters = min(wmw, M);
@@ -1092,40 +1142,52 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
                 pb = ((const uint4 *)(perm + (size_t)(i0 + lane) * 8))[1];
             }
         }
-        // pass 1
+        // pass 1: a record per passing (pixel, iteration): source pixel of the group, iteration, polarity, rank within the group's
+        // (iteration, polarity) block in pixel order (sub-group by sub-group)
         uint32_t nrec = 0;
         bool alive = true;
         for (int i = i0; i < i1; ++i) {
-            const bool cand = mag > i;
-            if (__ballot(cand) == 0ull) { alive = false; break; }
-            bool pass = cand;
-            if (use_refr) {
-                const float t = tg(i);
-                const float pt = (cand ? 1.0f : 0.0f) * t - tsm;
-                pass = pt > a.refr_f;
-                if (pass) tsm = t;
+            unsigned long long cand_any = 0ull;
+#pragma unroll
+            for (int j = 0; j < GPX; ++j) cand_any |= __ballot(mag[j] > i);
+            if (cand_any == 0ull) { alive = false; break; }
+            uint32_t run_on = 0, run_off = 0;
+#pragma unroll
+            for (int j = 0; j < GPX; ++j) {
+                const bool cand = mag[j] > i;
+                bool pass = cand;
+                if (use_refr) {
+                    const float t = tg(i);
+                    const float pt = (cand ? 1.0f : 0.0f) * t - tsm[j];
+                    pass = pt > a.refr_f;
+                    if (pass) tsm[j] = t;
+                }
+                const unsigned long long bo = __ballot(pass && !neg[j]);
+                const unsigned long long bf = __ballot(pass && neg[j]);
+                if (pass) {
+                    const uint32_t rank = neg[j] ? run_off + (uint32_t)__popcll(bf & lt) : run_on + (uint32_t)__popcll(bo & lt);
+                    const uint32_t pos = nrec + (uint32_t)__popcll((bo | bf) & lt);
+                    rec_w[pos] = (uint32_t)(j * WAVE + lane) | ((uint32_t)(i - i0) << 8) | ((neg[j] ? 1u : 0u) << 13) | (rank << 14);
+                }
+                nrec += (uint32_t)__popcll(bo | bf);
+                run_on += (uint32_t)__popcll(bo);
+                run_off += (uint32_t)__popcll(bf);
             }
-            const unsigned long long bo = __ballot(pass && !neg);
-            const unsigned long long bf = __ballot(pass && neg);
-            if (pass) {
-                const uint32_t rank = (uint32_t)__popcll((neg ? bf : bo) & lt);
-                const uint32_t pos = nrec + (uint32_t)__popcll((bo | bf) & lt);
-                rec_w[pos] = (uint32_t)lane | ((uint32_t)(i - i0) << 6) | ((neg ? 1u : 0u) << 11) | (rank << 12);
-            }
-            nrec += (uint32_t)__popcll(bo | bf);
         }
         // pass 2: one event per lane
         for (uint32_t e0 = 0; e0 < nrec; e0 += WAVE) {
             const bool has = e0 + lane < nrec;
             const uint32_t r = has ? rec_w[e0 + lane] : 0u;
-            const int src = (int)(r & 63u), il = (int)((r >> 6) & 31u);
-            const bool eneg = (r >> 11) & 1u;
-            const uint32_t rank = r >> 12;
+            const uint32_t src = r & 255u;
+            const int il = (int)((r >> 8) & 31u);
+            const bool eneg = (r >> 13) & 1u;
+            const uint32_t rank = r >> 14;
             const int kl = 2 * il;
             const uint32_t it_base = (uint32_t)__shfl((int)kbase_k, kl);
             const uint32_t tot_on = (uint32_t)__shfl((int)T_k, kl);
             const uint32_t off = (uint32_t)__shfl((int)P_k, kl + (eneg ? 1 : 0));
-            const float ex = __shfl(fx, src), ey = __shfl(fy, src);
+            float ex, ey;
+            pixel_xy((uint32_t)(grp * GROUP_PX) + src, ex, ey);
             uint32_t cidx = (eneg ? tot_on : 0u) + off + rank;
             if (shuf) {
                 v2e_perm_t pm;
@@ -1145,19 +1207,26 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
         if (!alive) break;
     }
     // shot-noise events after all signal events (ON block, OFF block), ts[-1], unshuffled
-    if (a.do_shot && (so | sf)) {
+    if (a.do_shot && any_shot) {
         const uint32_t son_tot = cT[0];
-        const uint32_t son_off = pre[0], soff_off = pre[(size_t)ea.nwp];
+        uint32_t son_off = pre[0], soff_off = pre[(size_t)ea.nwp];
         const float tl = tg(n - 1);
-        if (cw & CNT_SHOT_ON) {
-            const unsigned long long row = ev0 + n_signal + son_off + (uint32_t)__popcll(so & lt);
-            if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, 1.0f);
-            else dropped = true;
-        }
-        if (cw & CNT_SHOT_OFF) {
-            const unsigned long long row = ev0 + n_signal + son_tot + soff_off + (uint32_t)__popcll(sf & lt);
-            if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, -1.0f);
-            else dropped = true;
+#pragma unroll
+        for (int j = 0; j < GPX; ++j) {
+            float fx, fy;
+            pixel_xy((uint32_t)(p0 + j * WAVE), fx, fy);
+            if (cw[j] & CNT_SHOT_ON) {
+                const unsigned long long row = ev0 + n_signal + son_off + (uint32_t)__popcll(so[j] & lt);
+                if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, 1.0f);
+                else dropped = true;
+            }
+            if (cw[j] & CNT_SHOT_OFF) {
+                const unsigned long long row = ev0 + n_signal + son_tot + soff_off + (uint32_t)__popcll(sf[j] & lt);
+                if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, -1.0f);
+                else dropped = true;
+            }
+            son_off += (uint32_t)__popcll(so[j]);
+            soff_off += (uint32_t)__popcll(sf[j]);
         }
     }
     if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
