@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libv2e_amd.so")
+LIB_PATH = os.environ.get("V2E_AMD_LIB") or os.path.join(_HERE, "csrc", "libv2e_amd.so")  # (V2E_AMD_LIB: dev builds for A/B)
 
 DT_U8, DT_F32, DT_F64 = 0, 1, 2
 RNG_TAPE, RNG_PHILOX = 0, 1

@@ -1325,6 +1325,7 @@ struct Sched {
 };
 
 // ------------------------------------------------------------------ K frames per launch (emu_chain.h)
+static int chain_egroups(const v2e_emu *h) { return (h->npx + GROUP_PX - 1) / GROUP_PX; }
 static bool chain_small_grid(const v2e_emu *h) { return (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu; }
 
 // records built inside the chain (large grids) or by k_ahead (small grids); V2E_AMD_CHAIN_FUSED=0/1 overrides (dev / tests)
@@ -1441,7 +1442,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         if (const char *ev = getenv("V2E_AMD_CHAIN_RING")) { const int v = atoi(ev); if (v >= 3 && v <= 16) nD = v; }
         h->ch_nD = nD;
         h->ch_D = nD * E;
-        h->ch_nwp = (h->ngroups + 15) / 16 * 16; // emission groups of 256 pixels (one wave each), padded to the 16 a lane of k_cframe takes
+        h->ch_nwp = (chain_egroups(h) + 15) / 16 * 16; // emission groups (one wave each), padded to the 16 a lane of k_cframe takes
         h->ch_nkeys_cap = h->nkeys_cap;
         const size_t nc = (size_t)h->n_clips;
         V2E_HIP(hipMalloc(&h->ch_cnt, sizeof(uint32_t) * h->ch_D * nc * h->npx_pad));
@@ -1580,7 +1581,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         memset(&ea, 0, sizeof(ea));
         ea.ctl = h->run_ctl; ea.recs = recs; ea.fidx_base = h->run_fidx;
         ea.f0 = b * E; ea.nE = std::min((b + 1) * E, n_frames) - ea.f0; ea.D = D; ea.n_clips = NC;
-        ea.nwp = h->ch_nwp; ea.nwaves = h->ngroups; ea.E = E; // emission groups (256 pixels, one wave each)
+        ea.nwp = h->ch_nwp; ea.nwaves = chain_egroups(h); ea.E = E; // emission groups (GROUP_PX pixels, one wave each)
         ea.cnt = h->ch_cnt; ea.tsold = has_refr ? h->ch_tsold : nullptr; ea.ruleM = has_refr ? h->ch_ruleM : nullptr;
         const size_t set = (size_t)(b % NSET) * E * NC; // table set of this batch
         ea.wmax = h->ch_wmax + set * h->ch_nwp; ea.wtot = h->ch_wtot + set * h->nkeys_cap * h->ch_nwp;
@@ -1591,9 +1592,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ea.off_in = h->run_off + (size_t)b * NC;
         ea.off_out = h->run_off + (size_t)(b + 1) * NC;
         // event records of k_cemit: 256 x ich per group (wave) and pass.  The chain's workgroups need their LDS (5 KB per frame)
-        // on every CU: 6 iterations per pass (most frames have fewer) keep an emission workgroup of four groups at 24 KB
+        // on every CU: 4 iterations per pass (measured at 346x260: 3 / 6 / 10 per pass 10.47 / 10.30 / 10.31 Gev/s) keep an emission workgroup of four groups at 16 KB
         static const int ich_env = getenv("V2E_AMD_CEMIT_ICH") ? atoi(getenv("V2E_AMD_CEMIT_ICH")) : 0;
-        ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 6;
+        ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 4;
         ea.capw = GROUP_PX * ea.ich;
         ea.coff_in_cemit = (tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream) ? 1 : 0;
         // frames per workgroup (measured at 346x260, 32-frame batches: k_ctot 4 frames 13 us, 32 frames 37 us; k_cemit 1 frame
@@ -1604,7 +1605,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ea.zpw_tot = CTOT_ZF;
         ea.zpw_emit = 1; // (k_cemit: one frame per workgroup; several per workgroup measured slower and cost 25 % more instructions)
         const int REC_LDS = ea.capw * 4 * (BLOCK / WAVE);
-        const int egx = (h->ngroups + BLOCK / WAVE - 1) / (BLOCK / WAVE); // workgroups of four emission groups
+        const int egx = (chain_egroups(h) + BLOCK / WAVE - 1) / (BLOCK / WAVE); // workgroups of four emission groups
         void *args[] = {(void *)&a, (void *)&ea};
         // tables on a stream of their own (NSET table sets rotate: tables(b + 1) are built while k_cemit(b) reads those of b;
         // k_cemit(b - NSET), which read this set last, is waited for), rows on the side stream

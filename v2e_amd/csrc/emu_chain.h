@@ -644,8 +644,12 @@ struct CEmitArgs {
 // pixels (9 at 1280x720 noisy): with one wave per 64 pixels most of what the emission kernels executed was per-wave set-up
 // and a 64-lane event pass that was a third full; with 256 pixels per wave the set-up, the per-key tables (352 entries per
 // frame and key at 346x260 instead of 1 408) and the prefix over them shrink fourfold and the event pass runs full.
-constexpr int GPX = 4;
+#ifndef V2E_GPX
+#define V2E_GPX 4
+#endif
+constexpr int GPX = V2E_GPX;
 constexpr int GROUP_PX = GPX * WAVE;
+constexpr int GROUP_SRC_BITS = GPX <= 4 ? 8 : (GPX <= 8 ? 9 : 10); // bits of a pixel's index within its group
 
 // What the event list needs from a frame's count words beyond the words themselves, per group (every wave on its own, no
 // workgroup barrier): the group's max count and its (iteration, polarity) event totals (ballot / popcount) as key-major u16
@@ -1167,7 +1171,8 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
                 if (pass) {
                     const uint32_t rank = neg[j] ? run_off + (uint32_t)__popcll(bf & lt) : run_on + (uint32_t)__popcll(bo & lt);
                     const uint32_t pos = nrec + (uint32_t)__popcll((bo | bf) & lt);
-                    rec_w[pos] = (uint32_t)(j * WAVE + lane) | ((uint32_t)(i - i0) << 8) | ((neg[j] ? 1u : 0u) << 13) | (rank << 14);
+                    rec_w[pos] = (uint32_t)(j * WAVE + lane) | ((uint32_t)(i - i0) << GROUP_SRC_BITS) | ((neg[j] ? 1u : 0u) << (GROUP_SRC_BITS + 5)) |
+                                 (rank << (GROUP_SRC_BITS + 6));
                 }
                 nrec += (uint32_t)__popcll(bo | bf);
                 run_on += (uint32_t)__popcll(bo);
@@ -1178,10 +1183,10 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
         for (uint32_t e0 = 0; e0 < nrec; e0 += WAVE) {
             const bool has = e0 + lane < nrec;
             const uint32_t r = has ? rec_w[e0 + lane] : 0u;
-            const uint32_t src = r & 255u;
-            const int il = (int)((r >> 8) & 31u);
-            const bool eneg = (r >> 13) & 1u;
-            const uint32_t rank = r >> 14;
+            const uint32_t src = r & ((1u << GROUP_SRC_BITS) - 1u);
+            const int il = (int)((r >> GROUP_SRC_BITS) & 31u);
+            const bool eneg = (r >> (GROUP_SRC_BITS + 5)) & 1u;
+            const uint32_t rank = r >> (GROUP_SRC_BITS + 6);
             const int kl = 2 * il;
             const uint32_t it_base = (uint32_t)__shfl((int)kbase_k, kl);
             const uint32_t tot_on = (uint32_t)__shfl((int)T_k, kl);
