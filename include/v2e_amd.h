@@ -131,6 +131,27 @@ int v2e_emu_set_scidvs(v2e_emu *h, void *highpass, void *previous_photo, float *
 
 int v2e_emu_set_pnoise(v2e_emu *h, void *pn_arr, const float *randn_tape);
 
+/* Centre-surround DVS (cs_lambda_pixels; emulator.py:245-272, 707-716, 753-754, 1061-1124).  The surround plane
+ * cs_surround_frame [n_clips][npx_pad] (state dtype, caller-owned) is what v2e_emu_count subtracts from the photoreceptor
+ * output: diff = (photoreceptor + noise - surround) - base; NULL switches the feature off.  Per frame the caller
+ *   1. v2e_emu_lp_preview: the frame's lp_log_frame (the low-pass of emulator.py:685-690 applied to the state as it is,
+ *      written to lp_out, the state untouched),
+ *   2. v2e_csdvs_update:   steps the diffuser against it (below),
+ *   3. v2e_emu_count ...:  the frame itself (recomputes the same lp_log_frame).
+ * On the first frame the surround is a copy of lp_log_frame and base_log_frame is zero (emulator.py:1062-1063, 715). */
+int v2e_emu_set_csdvs(v2e_emu *h, const void *surround);
+int v2e_emu_lp_preview(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, const double *t_prev,
+                       const double *t_frame, uint32_t frame_idx, void *lp_out, void *stream);
+/* EventEmulator._update_csdvs (emulator.py:1098-1124) on device planes of H x W values (float64 if f64 else float32):
+ * up to num_steps Euler steps  h += alpha_p (p - h) + alpha_h conv2d(ReplicationPad2d(1)(h.float()), [[0,1,0],[1,-4,1],[0,1,0]])
+ * stopping after the first step whose max |change| is <= max_change_to_stop (1e-5 in the reference).  The float32 5-point
+ * sum is taken in kernel order ((((top + left) - 4 centre) + right) + bottom) -- what torch's CPU convolution does on planes
+ * of 200 x 200 and more (DAVIS346 included; on small planes its backend sums in another order, see csdvs.hip).  h_scratch: a
+ * second plane of the same size.  steps_taken: the reference's `steps`; last_max_change (may be NULL): its `max_change`.
+ * Synchronises the stream once per 32 steps. */
+int v2e_csdvs_update(const void *p_plane, void *h_plane, void *h_scratch, int H, int W, int f64, double alpha_p, double alpha_h,
+                     int num_steps, double max_change_to_stop, int *steps_taken, double *last_max_change, void *stream);
+
 /*
  * Front half of one time step for all clips: photoreceptor, IIR, leak, event
  * counts, shot-noise decisions, global max.  leak_randn/shot_rand: [n_clips][npx_pad]

@@ -107,6 +107,61 @@ EXPORT void v2e_oracle_philox_scidvs_tau(uint64_t seed, uint32_t clip, int64_t n
     for (int64_t p = 0; p < npx; ++p) tau[p] = 0.01f * v2e_det_expf(0.5f * v2e_draw_scidvs(seed, clip, (uint32_t)p));
 }
 
+/* EventEmulator._update_csdvs's stepping loop (emulator.py:1102-1124) on planes of H x W values, R = float64 (f64) or
+ * float32: diff = p - h; p_term = alpha_p * diff (the Python scalar takes the tensor's type); h_conv = conv2d of
+ * ReplicationPad2d(1)(h.float()) with [[0,1,0],[1,-4,1],[0,1,0]] in float32; h_term = alpha_h * h_conv in float32;
+ * change = p_term + h_term in R; max_change = max |change|; h += change; until steps == num_steps or max_change <= stop.
+ * The float32 sum is taken in kernel order ((((top + left) - 4 centre) + right) + bottom): the order of torch's CPU
+ * convolution on planes of 200 x 200 and more (tests/golden/make_golden_csdvs.py measures it).  Returns the steps taken. */
+static float cs_conv(const float *hf, int H, int W, int y, int x)
+{
+    const float t = hf[(y > 0 ? y - 1 : 0) * W + x], b = hf[(y < H - 1 ? y + 1 : H - 1) * W + x];
+    const float l = hf[y * W + (x > 0 ? x - 1 : 0)], r = hf[y * W + (x < W - 1 ? x + 1 : W - 1)];
+    float acc = t + l;
+    acc = acc + -4.0f * hf[y * W + x];
+    acc = acc + r;
+    acc = acc + b;
+    return acc;
+}
+
+EXPORT int v2e_oracle_csdvs_update(const void *p_plane, void *h_plane, int H, int W, int f64, double alpha_p, double alpha_h,
+                                   int num_steps, double stop, double *last_max_change)
+{
+    const int n = H * W;
+    float *hf = (float *)malloc(sizeof(float) * (size_t)n);
+    double max_change = 2 * stop;
+    int steps = 0;
+    while (steps < num_steps && max_change > stop) {
+        if (f64) { const double *h = (const double *)h_plane; for (int i = 0; i < n; ++i) hf[i] = (float)h[i]; }
+        else memcpy(hf, h_plane, sizeof(float) * (size_t)n);
+        max_change = 0.0;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const int i = y * W + x;
+                const float h_term = (float)alpha_h * cs_conv(hf, H, W, y, x);
+                if (f64) {
+                    double *h = (double *)h_plane;
+                    const double diff = ((const double *)p_plane)[i] - h[i];
+                    const double p_term = alpha_p * diff;
+                    const double change = p_term + (double)h_term;
+                    if (fabs(change) > max_change) max_change = fabs(change);
+                    h[i] = h[i] + change;
+                } else {
+                    float *h = (float *)h_plane;
+                    const float diff = ((const float *)p_plane)[i] - h[i];
+                    const float p_term = (float)alpha_p * diff;
+                    const float change = p_term + h_term;
+                    if (fabs((double)change) > max_change) max_change = fabs((double)change);
+                    h[i] = h[i] + change;
+                }
+            }
+        ++steps;
+    }
+    free(hf);
+    if (last_max_change) *last_max_change = max_change;
+    return steps;
+}
+
 /* idx with idx[sigma(c)] = c, i.e. what `torch.randperm` must return for the
  * reference's `events[idx]` to equal the philox-mode order. */
 EXPORT void v2e_oracle_perm_idx(uint64_t seed, uint32_t clip, uint32_t frame, uint32_t iter,

@@ -28,8 +28,12 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.isfile(_LIB):
-        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    """make is a no-op when the library is newer than its sources; a stale library (a symbol added since) is rebuilt."""
+    try:
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.isfile(_LIB):
+            raise
 
 
 def lib():
@@ -144,6 +148,20 @@ def philox_scidvs_tau(seed, clip, npx):
     a = np.empty(npx, np.float32)
     lib().v2e_oracle_philox_scidvs_tau(C.c_uint64(seed), C.c_uint32(clip), C.c_int64(npx), _p(a))
     return a
+
+
+def csdvs_update(p_plane, h_plane, alpha_p, alpha_h, num_steps, stop=1e-5):
+    """EventEmulator._update_csdvs's stepping loop (emulator.py:1102-1124) on host planes; h_plane is updated in place.
+    Returns (steps, last max_change)."""
+    assert p_plane.dtype == h_plane.dtype and p_plane.shape == h_plane.shape and h_plane.flags.c_contiguous
+    H, W = h_plane.shape
+    last = C.c_double(0)
+    L = lib()
+    L.v2e_oracle_csdvs_update.restype = C.c_int
+    steps = L.v2e_oracle_csdvs_update(_p(np.ascontiguousarray(p_plane)), _p(h_plane), C.c_int(H), C.c_int(W),
+                                      C.c_int(1 if h_plane.dtype == np.float64 else 0), C.c_double(alpha_p), C.c_double(alpha_h),
+                                      C.c_int(num_steps), C.c_double(stop), C.byref(last))
+    return int(steps), float(last.value)
 
 
 def perm_idx(seed, clip, frame, it, n):

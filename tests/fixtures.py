@@ -119,3 +119,25 @@ def events_equal(a, b):
     if b is None:
         b = np.zeros((0, 4), np.float32)
     return a.shape == b.shape and np.array_equal(a, b)
+
+
+# ---- `_update_csdvs` in isolation (tests/golden/make_golden_csdvs.py: csdvs_steps.npz holds the reference's digests)
+CSDVS_STEP_SHAPE = (200, 208)
+CSDVS_STEP_CASES = ["f32", "f64", "f32_early", "f64_early"]
+
+
+def csdvs_step_case(name):
+    """(photoreceptor plane p, surround plane h0) of a step case: seeded noise, or (`*_early`) a nearly settled diffuser
+    whose loop ends on max_change <= 1e-5 well before num_steps."""
+    H, W = CSDVS_STEP_SHAPE
+    dt = np.float32 if name.startswith("f32") else np.float64
+    if name.endswith("early"):
+        yy, xx = np.mgrid[0:H, 0:W]
+        # (+ - * / only: correctly rounded everywhere, unlike numpy's vectorised sin / exp)
+        p = (3 + 0.002 * ((xx % 34) / 17.0 - 1) * ((yy % 46) / 23.0 - 1)).astype(dt)
+        h0 = (p + 2e-4 / (1 + ((xx - 90) ** 2 + (yy - 70) ** 2) / 50.0)).astype(dt)
+    else:
+        rng = np.random.default_rng(5 if dt == np.float32 else 6)
+        p = (rng.standard_normal((H, W)) * 0.5 + 3).astype(dt)
+        h0 = (p + rng.standard_normal((H, W)) * 0.05).astype(dt)
+    return p, h0

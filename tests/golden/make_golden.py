@@ -240,6 +240,12 @@ def make_philox_fixture(name, frames, times, kw, preset=None, seed=7, store_fram
     if getattr(ref, "scidvs", False):
         out["scidvs_highpass_final"] = ref.scidvs_highpass.numpy()
         out["base_final"] = ref.base_log_frame.numpy()
+    if getattr(ref, "csdvs_enabled", False):
+        out["cs_surround_sha"] = sha(ref.cs_surround_frame.numpy())
+        out["cs_steps"] = np.asarray(ref.cs_steps_taken, np.int64)
+        if store_events:
+            out["cs_surround_final"] = ref.cs_surround_frame.numpy()
+            out["base_final"] = ref.base_log_frame.numpy()
     if store_frames:
         out["frames"] = np.stack(frames)
     if store_events:

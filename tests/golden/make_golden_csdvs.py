@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Golden vectors for the centre-surround DVS (cs_lambda_pixels; emulator.py:245-272, 707-716, 753-754, 1061-1124), generated
+by running the REFERENCE (/root/reference, torch CPU) here.
+
+The one thing torch leaves open in `_update_csdvs` is the order of the float32 sum inside conv2d.  `conv_orders()` measures
+it on this machine (printed, and asserted for the sizes the fixtures use): planes of 200 x 200 and more -- DAVIS346 included
+-- sum in kernel order ((((t + l) - 4 c) + r) + b), which is the order csdvs.hip and the oracle fix; small planes
+(40 x 48 ... 128 x 128) sum ((t + l) + ((b + r) - 4 c)), and odd sizes such as 97 x 131 follow neither everywhere (vector body
+and scalar tail of the backend differ).  Hence:
+
+  csdvs_steps.npz                   `_update_csdvs` alone on seeded planes of 200 x 208 (float32 and float64 state): surround
+                                    digests + step counts; the oracle's restatement is asserted equal at generation time
+  philox_csdvs_346x260.npz          DAVIS346, float64 state (cutoff 300 Hz), Philox source: event digests per frame, final
+                                    planes' digests, surround digest, steps per frame -- to be matched BIT FOR BIT
+  philox_csdvs_f32_346x260.npz      the same with float32 state (no cutoff)
+  philox_csdvs_97x131.npz           a size where the backend's order differs: events and planes stored; the tests bound the
+                                    surround plane by 1e-5 and the event count by 1 %
+"""
+import itertools
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import make_golden as mg  # noqa: E402
+import ref_harness as rh  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from v2e_amd.synth import int_gradient_frames  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+from fixtures import CSDVS_STEP_CASES, CSDVS_STEP_SHAPE, csdvs_step_case  # noqa: E402
+
+CS = dict(cs_lambda_pixels=3.0, cs_tau_p_ms=2.0)
+
+
+def conv_orders():
+    k = torch.tensor([[[[0, 1, 0], [1, -4, 1], [0, 1, 0]]]], dtype=torch.float32)
+    g = torch.Generator().manual_seed(0)
+    res = {}
+    for (H, W) in ((40, 48), (64, 64), (97, 131), (128, 128), (200, 200), (200, 208), (260, 346), (480, 640), (720, 1280)):
+        h = (torch.randn(1, 1, H, W, generator=g) * 3).float()
+        hp = torch.nn.ReplicationPad2d(1)(h)
+        ref = torch.conv2d(hp, k)[0, 0].numpy()
+        x = hp[0, 0].numpy()
+        t, l, c, r, b = x[:-2, 1:-1], x[1:-1, :-2], np.float32(-4) * x[1:-1, 1:-1], x[1:-1, 2:], x[2:, 1:-1]
+        kernel_order = (((t + l) + c) + r) + b
+        small_order = (t + l) + ((b + r) + c)
+        res[(H, W)] = ("kernel order" if np.array_equal(kernel_order, ref) else
+                       "small-plane order" if np.array_equal(small_order, ref) else
+                       "mixed (%d px off kernel order)" % int((kernel_order != ref).sum()))
+        print("   conv2d float32 sum at %4d x %-4d : %s" % (H, W, res[(H, W)]))
+    return res
+
+
+def steps_fixture():
+    """`_update_csdvs` in isolation: seeded planes, one call, against the oracle restatement."""
+    EE = rh.ref_emulator_cls()
+    out = {}
+    H, W = CSDVS_STEP_SHAPE
+    for name in CSDVS_STEP_CASES:
+        p, h0 = csdvs_step_case(name)
+        ref = EE(seed=1, device="cpu", pos_thres=.2, neg_thres=.2, sigma_thres=0.03, **CS)
+        ref.lp_log_frame = torch.from_numpy(p.copy())
+        ref.cs_surround_frame = torch.from_numpy(h0.copy())
+        delta_time = 1 / 300
+        ref._update_csdvs(delta_time)
+        steps = ref.cs_steps_taken[-1]
+        h_ref = ref.cs_surround_frame.numpy()
+        # the host arithmetic of emulator.py:1066-1090
+        tau_p = CS["cs_tau_p_ms"] * 1e-3
+        tau_h = (CS["cs_tau_p_ms"] / CS["cs_lambda_pixels"] ** 2) * 1e-3
+        num_steps = int(np.ceil((delta_time / min(tau_p, tau_h)) * 5))
+        adt = delta_time / num_steps
+        h_or = h0.copy()
+        osteps, _ = orc.csdvs_update(p, h_or, adt / tau_p, adt / tau_h, num_steps)
+        assert osteps == steps and np.array_equal(h_or, h_ref), "oracle csdvs_update != reference (%s)" % name
+        out["%s_sha" % name] = mg.sha(h_ref)
+        if name.endswith("early"):
+            assert 1 < steps < num_steps
+        out["%s_steps" % name] = steps
+        out["%s_num_steps" % name] = num_steps
+        out["%s_alpha" % name] = np.asarray([adt / tau_p, adt / tau_h])
+        print("   _update_csdvs %s: %d of %d steps, oracle bit-equal" % (name, steps, num_steps))
+    out["shape"] = np.asarray([H, W])
+    out["torch_version"] = torch.__version__
+    np.savez_compressed(os.path.join(HERE, "csdvs_steps.npz"), **out)
+
+
+def main():
+    mg.logging_off()
+    torch.set_num_threads(1)
+    orders = conv_orders()
+    assert orders[(260, 346)] == "kernel order" and orders[(200, 208)] == "kernel order"
+    steps_fixture()
+    kw = dict(mg.DEFAULTS); kw.update(CS); kw["shot_noise_rate_hz"] = 2.0; kw["leak_rate_hz"] = 0.2
+    n = 8
+    spec = dict(gen="int_gradient_frames", n=n, H=260, W=346, seed=41, noise=6)
+    fr = int_gradient_frames(n, 260, 346, seed=41, noise=6)
+    ts = [i / 300 for i in range(n)]
+    mg.make_philox_fixture("philox_csdvs_346x260", fr, ts, kw, seed=21, frame_spec=spec)
+    kw32 = dict(kw); kw32["cutoff_hz"] = 0; kw32["shot_noise_rate_hz"] = 0.0
+    mg.make_philox_fixture("philox_csdvs_f32_346x260", fr, ts, kw32, seed=22, frame_spec=spec)
+    fr = int_gradient_frames(8, 97, 131, seed=42, noise=6)
+    mg.make_philox_fixture("philox_csdvs_97x131", fr, [i / 300 for i in range(8)], kw, seed=23, store_frames=True, store_events=True)
+
+
+if __name__ == "__main__":
+    main()

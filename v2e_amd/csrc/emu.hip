@@ -123,6 +123,8 @@ struct KArgs {
     void *sc_hp, *sc_prev;
     float *sc_tau;
     uint32_t sc_first_frame; // frame index at which scidvs_previous_photo is taken from the frame itself
+    const void *cs_sur; // CSDVS: the surround plane the frame's photoreceptor output is compared against (emulator.py:753-754)
+    int emit_guard; // k_emit: leave everything untouched (flag the record) when the frame's rows do not fit the buffer
 };
 
 __device__ constexpr double SCIDVS_EFOLD = 1 / 0.7; // efold of the sinh conductance (emulator.py:78)
@@ -314,6 +316,36 @@ __global__ __launch_bounds__(BLOCK) void k_init(KArgs a, const FT *__restrict__ 
     }
 }
 
+// low_pass_filter (emulator_utils.py:69-104) of one pixel: the new lp_log_frame value
+template <typename R>
+__device__ __forceinline__ R lp_next(const KArgs &a, double L, double inten01, double delta_time, size_t sp)
+{
+    if (a.has_cutoff) { // R == double
+        double tau = 1.0 / a.cutoff_two_pi;
+        double dt_over_tau = delta_time / tau;
+        double eps = inten01 * dt_over_tau;
+        if (eps > 1.0) eps = 1.0;
+        return (R)((1.0 - eps) * (double)((R *)a.lp)[sp] + eps * (double)L);
+    }
+    return (R)L;
+}
+
+// CSDVS: the frame's lp_log_frame BEFORE the frame is counted -- the surround's diffuser is stepped against it
+// (emulator.py:707-708 sits between the low-pass and the event computation); k_count recomputes the same value
+template <typename R, typename FT>
+__global__ __launch_bounds__(BLOCK) void k_cs_lp(KArgs a, const FT *__restrict__ frame, const FrameCtl *__restrict__ ctl, R *__restrict__ out)
+{
+    const int clip = blockIdx.y;
+    const int p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= a.npx) return;
+    const FrameCtl c = ctl[clip];
+    const size_t sp = (size_t)clip * a.npx_pad + p;
+    const double x = (double)frame[(size_t)clip * a.npx + p];
+    const double L = a.log_input ? x : (double)lin_log(x);
+    const double inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
+    out[sp] = lp_next<R>(a, L, inten01, c.t_frame - c.t_prev, sp);
+}
+
 // ----------------------------------------------------------------- k_count
 template <typename R, typename FT>
 __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__ frame,
@@ -350,16 +382,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
             float rate = (a.leak_hz_f * a.noise_rate[sp]) * (1.0f - a.jit_f * r);
             delta_leak = ((float)delta_time * rate) * thp;
         }
-        R lpn;
-        if (a.has_cutoff) { // R == double
-            double tau = 1.0 / a.cutoff_two_pi;
-            double dt_over_tau = delta_time / tau;
-            double eps = inten01 * dt_over_tau;
-            if (eps > 1.0) eps = 1.0;
-            lpn = (R)((1.0 - eps) * (double)((R *)a.lp)[sp] + eps * (double)L);
-        } else {
-            lpn = (R)L;
-        }
+        const R lpn = lp_next<R>(a, L, inten01, delta_time, sp);
         ((R *)a.lp)[sp] = lpn;
         R b = ((R *)a.base)[sp];
         if (a.do_leak) {
@@ -389,6 +412,7 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
             photo = (R)2 * hp;                                           // SCIDVS_GAIN * scidvs_highpass
         }
         R diff = (photo + pn) - b; // photoreceptor + photoreceptor_noise_arr - base_log_frame (emulator.py:747-751)
+        if (a.cs_sur) diff = ((photo + pn) - ((const R *)a.cs_sur)[sp]) - b; // c_minus_s_frame - base_log_frame (:753-754)
         R pf = diff > (R)0 ? diff : (R)0;
         R nf = (-diff) > (R)0 ? -diff : (R)0;
         R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;
@@ -549,6 +573,18 @@ __global__ __launch_bounds__(BLOCK) void k_emit(KArgs a, const FrameCtl *__restr
         }
         return;
     }
+    const uint32_t *trow = a.tot + (size_t)clip * a.nkeys_cap;
+    if (a.emit_guard) { // speculative launch (v2e_emu_frame): the host has not seen the totals yet
+        uint32_t tsum = 0;
+        for (int kb = 0; kb < 2 * M + 2; kb += WAVE) tsum += kb + lane < 2 * M + 2 ? trow[kb + lane] : 0u;
+        if (ev0 + wave_sum_u32(tsum) > cap) {
+            if (w == 0 && lane == 0) {
+                rec[clip].flags |= V2E_FLAG_EVENTS_DROPPED;
+                rec[clip].ev_offset = ev0;
+            }
+            return;
+        }
+    }
     const int n = M > 0 ? M : 1;
     const FrameCtl c = ctl[clip];
     const TsGen tg(c, n, ts_tab ? ts_tab + (size_t)clip * n_ts : nullptr);
@@ -560,7 +596,6 @@ __global__ __launch_bounds__(BLOCK) void k_emit(KArgs a, const FrameCtl *__restr
     const bool neg = (cw & CNT_NEG) != 0;
     float tsm = (use_refr && valid) ? a.ts_mem[sp] : 0.f;
     const uint32_t *hrow = a.hist + (size_t)clip * a.nkeys_cap * a.nwaves;
-    const uint32_t *trow = a.tot + (size_t)clip * a.nkeys_cap;
     float4 *ev = events + (size_t)clip * cap;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float fx = (float)(p % a.W), fy = (float)(p / a.W);
@@ -699,6 +734,7 @@ struct v2e_emu {
     void *pn_arr = nullptr;           // photoreceptor_noise_arr plane (v2e_emu_set_pnoise)
     const float *pn_tape = nullptr;
     void *sc_hp = nullptr, *sc_prev = nullptr; // SCIDVS planes (v2e_emu_set_scidvs)
+    const void *cs_sur = nullptr;              // CSDVS surround plane (v2e_emu_set_csdvs)
     float *sc_tau = nullptr;
     uint32_t sc_first_frame = 0;
     int ngroups = 0;
@@ -709,12 +745,13 @@ struct v2e_emu {
     FrameCtl *ctl_host = nullptr;      // pinned staging [RING][n_clips]
     unsigned long long *off_dev = nullptr, *off_host = nullptr; // [n_clips] explicit event offsets
     // v2e_emu_frame (one call per frame): pinned staging for the frame, the frame record + per-key totals, the event rows
-    void *fr_stage = nullptr, *fr_dev = nullptr;
+    // [v2e_frame_rec zeros | FrameCtl | frame] goes up in ONE copy; the record and an estimated number of rows come back
+    unsigned char *fr_stage = nullptr, *fr_dev = nullptr;
     size_t fr_bytes = 0;
     unsigned char *fr_rec_host = nullptr; // v2e_frame_rec + nkeys_cap totals
     int fr_rec_keys = 0;
     float *fr_ev_host = nullptr;
-    uint64_t fr_ev_cap = 0;
+    uint64_t fr_ev_cap = 0, fr_est = 0;
     unsigned long long *off_zero = nullptr; // [n_clips] zeros
     // multi-frame run
     FrameCtl *run_ctl = nullptr;       // device [run_cap][n_clips]
@@ -803,6 +840,7 @@ static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
     a.cnt = h->cnt; a.hist = h->hist; a.tot = h->tot;
     a.lut_L = h->lut_L; a.lut_I = h->lut_I;
     if (p->photoreceptor_noise) { a.pn_arr = h->pn_arr; a.pn_tape = h->pn_tape; a.pn_vrms_f = (float)p->photoreceptor_noise_vrms; }
+    a.cs_sur = h->cs_sur;
     if (h->sc_hp) { a.sc_hp = h->sc_hp; a.sc_prev = h->sc_prev; a.sc_tau = h->sc_tau; a.sc_first_frame = h->sc_first_frame; }
     return a;
 }
@@ -991,6 +1029,36 @@ int v2e_emu_set_scidvs(v2e_emu *h, void *highpass, void *previous_photo, float *
     return 0;
 }
 
+int v2e_emu_set_csdvs(v2e_emu *h, const void *surround)
+{
+    V2E_REQUIRE(h, "null");
+    h->cs_sur = surround;
+    h->drop_graphs();
+    return 0;
+}
+
+int v2e_emu_lp_preview(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, const double *t_prev, const double *t_frame,
+                       uint32_t frame_idx, void *lp_out, void *stream)
+{
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    V2E_REQUIRE(frame && t_prev && t_frame && lp_out, "null");
+    V2E_REQUIRE(dtype == V2E_DT_U8 || dtype == V2E_DT_F32 || dtype == V2E_DT_F64, "bad frame dtype");
+    V2E_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = stage_ctl(h, p, frame_idx, t_prev, t_frame, s); // the frame's own slot: v2e_emu_count stages the same values again
+    if (rc) return rc;
+    const FrameCtl *ctl = h->ctl_ring + (size_t)(frame_idx % RING) * h->n_clips;
+    KArgs a = make_kargs(h, p);
+    dim3 grid(v2e_cdiv(h->npx, BLOCK), h->n_clips);
+    DISPATCH_FT(dtype, {
+        if (p->f64_state) k_cs_lp<double, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, (double *)lp_out);
+        else k_cs_lp<float, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, (float *)lp_out);
+    });
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
 int v2e_emu_set_pnoise(v2e_emu *h, void *pn_arr, const float *randn_tape)
 {
     V2E_REQUIRE(h, "null");
@@ -1155,69 +1223,100 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
     const size_t fbytes = esz * (size_t)h->npx;
-    const void *frame_dev = frame;
-    if (frame_on_host) {
-        if (fbytes > h->fr_bytes) {
-            V2E_HIP(hipStreamSynchronize(s));
-            if (h->fr_stage) V2E_HIP(hipHostFree(h->fr_stage));
-            if (h->fr_dev) V2E_HIP(hipFree(h->fr_dev));
-            V2E_HIP(hipHostMalloc(&h->fr_stage, fbytes));
-            V2E_HIP(hipMalloc(&h->fr_dev, fbytes));
-            h->fr_bytes = fbytes;
-        }
-        memcpy(h->fr_stage, frame, fbytes); // (the previous frame's upload has completed: every call ends synchronised)
-        V2E_HIP(hipMemcpyAsync(h->fr_dev, h->fr_stage, fbytes, hipMemcpyHostToDevice, s));
-        frame_dev = h->fr_dev;
+    // One upload: the zeroed frame record, the frame's scalars and (a host frame) its pixels
+    constexpr size_t FR_CTL = 64, FR_PIX = 384;
+    static_assert(sizeof(v2e_frame_rec) <= FR_CTL && FR_CTL + sizeof(FrameCtl) <= FR_PIX, "v2e_emu_frame staging layout");
+    const size_t up_bytes = FR_PIX + (frame_on_host ? fbytes : 0);
+    if (up_bytes > h->fr_bytes) {
+        V2E_HIP(hipStreamSynchronize(s));
+        if (h->fr_stage) V2E_HIP(hipHostFree(h->fr_stage));
+        if (h->fr_dev) V2E_HIP(hipFree(h->fr_dev));
+        h->fr_stage = h->fr_dev = nullptr; h->fr_bytes = 0;
+        V2E_HIP(hipHostMalloc((void **)&h->fr_stage, up_bytes));
+        V2E_HIP(hipMalloc((void **)&h->fr_dev, up_bytes));
+        h->fr_bytes = up_bytes;
     }
     if (h->fr_rec_keys != h->nkeys_cap) {
         if (h->fr_rec_host) V2E_HIP(hipHostFree(h->fr_rec_host));
         V2E_HIP(hipHostMalloc((void **)&h->fr_rec_host, sizeof(v2e_frame_rec) + sizeof(uint32_t) * h->nkeys_cap));
         h->fr_rec_keys = h->nkeys_cap;
     }
-    rc = stage_ctl(h, p, frame_idx, &t_prev, &t_frame, s);
-    if (rc) return rc;
-    const int slot = frame_idx % RING;
-    v2e_frame_rec *rec = h->rec_ring + slot;
-    const FrameCtl *ctl = h->ctl_ring + slot;
-    V2E_HIP(zero_async(rec, sizeof(v2e_frame_rec), s));
+    // (the previous frame's upload has completed: every call ends synchronised)
+    memset(h->fr_stage, 0, FR_CTL);
+    *(FrameCtl *)(h->fr_stage + FR_CTL) = make_ctl(t_prev, t_frame, p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
+    const void *frame_dev = frame;
+    if (frame_on_host) {
+        memcpy(h->fr_stage + FR_PIX, frame, fbytes);
+        frame_dev = h->fr_dev + FR_PIX;
+    }
+    V2E_HIP(hipMemcpyAsync(h->fr_dev, h->fr_stage, up_bytes, hipMemcpyHostToDevice, s));
+    v2e_frame_rec *rec = (v2e_frame_rec *)h->fr_dev;
+    const FrameCtl *ctl = (const FrameCtl *)(h->fr_dev + FR_CTL);
     KArgs a = make_kargs(h, p);
+    a.emit_guard = 1;
     rc = launch_count(h, a, p->f64_state, frame_dev, dtype, ctl, nullptr, frame_idx, nullptr, nullptr, rec, s);
     if (rc) return rc;
     dim3 gridw(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), 1);
     k_rank<<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, 0);
     k_scan<<<dim3(SCAN_BLOCKS, 1), BLOCK, 0, s>>>(a, rec);
+    // The event writer goes out before the host has seen the totals (k_emit checks them against cap itself), and with it
+    // the rows the frame is expected to have: one synchronisation per frame unless the estimate was short
+    if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
+    else k_emit<float><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
+    V2E_HIP(hipGetLastError());
+    const uint64_t est = std::min<uint64_t>(std::max<uint64_t>(h->fr_est, 1024), cap);
+    if (est > h->fr_ev_cap) {
+        V2E_HIP(hipStreamSynchronize(s));
+        if (h->fr_ev_host) V2E_HIP(hipHostFree(h->fr_ev_host));
+        h->fr_ev_host = nullptr; h->fr_ev_cap = 0;
+        const uint64_t want = std::max<uint64_t>(2 * est, 1u << 16);
+        V2E_HIP(hipHostMalloc((void **)&h->fr_ev_host, sizeof(float) * 4 * want));
+        h->fr_ev_cap = want;
+    }
     v2e_frame_rec *rh = (v2e_frame_rec *)h->fr_rec_host;
-    uint32_t *th = (uint32_t *)(h->fr_rec_host + sizeof(v2e_frame_rec));
     V2E_HIP(hipMemcpyAsync(rh, rec, sizeof(v2e_frame_rec), hipMemcpyDeviceToHost, s));
-    V2E_HIP(hipMemcpyAsync(th, h->tot, sizeof(uint32_t) * h->nkeys_cap, hipMemcpyDeviceToHost, s));
+    V2E_HIP(hipMemcpyAsync(h->fr_ev_host, events_dev, sizeof(float) * 4 * est, hipMemcpyDeviceToHost, s));
     V2E_HIP(hipStreamSynchronize(s));
     const int M = rh->max_events;
     memset(out8, 0, sizeof(uint32_t) * 8);
     out8[4] = (uint32_t)M;
-    if (M > h->max_iters) return 1;
-    uint64_t n_on = 0, n_off = 0, n_sig = 0;
-    for (int k = 0; k < 2 * M + 2; ++k) {
-        ((k & 1) ? n_off : n_on) += th[k];
-        if (k < 2 * M) n_sig += th[k];
-    }
-    const uint64_t n = n_on + n_off;
-    out8[0] = (uint32_t)n; out8[1] = (uint32_t)n_on; out8[2] = (uint32_t)n_off; out8[3] = (uint32_t)n_sig;
-    if (n > cap) return 2;
-    const v2e_frame_rec *rec_prev = h->rec_ring + (frame_idx + RING - 1) % RING;
-    if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
-    else k_emit<float><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, rec_prev, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
-    V2E_HIP(hipGetLastError());
     *events_host = nullptr;
-    if (n > 0) {
-        if (n > h->fr_ev_cap) {
-            if (h->fr_ev_host) V2E_HIP(hipHostFree(h->fr_ev_host));
-            h->fr_ev_cap = std::max<uint64_t>(2 * n, 1u << 16);
-            V2E_HIP(hipHostMalloc((void **)&h->fr_ev_host, sizeof(float) * 4 * h->fr_ev_cap));
-        }
-        V2E_HIP(hipMemcpyAsync(h->fr_ev_host, events_dev, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, s));
+    if (M > h->max_iters || (rh->flags & V2E_FLAG_EVENTS_DROPPED)) {
+        // not emitted (nothing of the state touched): hand the counted frame to the step-wise entry points, which read
+        // the ring's record and scalars
+        const int slot = frame_idx % RING;
+        V2E_HIP(hipMemcpyAsync(h->rec_ring + slot, rec, sizeof(v2e_frame_rec), hipMemcpyDeviceToDevice, s));
+        V2E_HIP(zero_async(&h->rec_ring[slot].flags, sizeof(uint32_t), s));
+        V2E_HIP(hipMemcpyAsync(h->ctl_ring + slot, ctl, sizeof(FrameCtl), hipMemcpyDeviceToDevice, s));
+        h->ctl_host[slot] = *(const FrameCtl *)(h->fr_stage + FR_CTL);
+        if (M > h->max_iters) { V2E_HIP(hipStreamSynchronize(s)); return 1; }
+        uint32_t *th = (uint32_t *)(h->fr_rec_host + sizeof(v2e_frame_rec));
+        V2E_HIP(hipMemcpyAsync(th, h->tot, sizeof(uint32_t) * (2 * M + 2), hipMemcpyDeviceToHost, s));
         V2E_HIP(hipStreamSynchronize(s));
-        *events_host = h->fr_ev_host;
+        uint64_t n_on = 0, n_off = 0, n_sig = 0;
+        for (int k = 0; k < 2 * M + 2; ++k) {
+            ((k & 1) ? n_off : n_on) += th[k];
+            if (k < 2 * M) n_sig += th[k];
+        }
+        out8[0] = (uint32_t)(n_on + n_off); out8[1] = (uint32_t)n_on; out8[2] = (uint32_t)n_off; out8[3] = (uint32_t)n_sig;
+        return 2;
     }
+    const uint64_t n = rh->n_events;
+    out8[0] = (uint32_t)n; out8[1] = rh->n_on; out8[2] = rh->n_off; out8[3] = rh->n_signal;
+    h->fr_est = n + n / 4 + 256;
+    if (n > est) { // the estimate was short: the rest of the rows
+        if (n > h->fr_ev_cap) {
+            float *grown = nullptr;
+            const uint64_t want = std::max<uint64_t>(2 * n, 1u << 16);
+            V2E_HIP(hipHostMalloc((void **)&grown, sizeof(float) * 4 * want));
+            memcpy(grown, h->fr_ev_host, sizeof(float) * 4 * est);
+            V2E_HIP(hipHostFree(h->fr_ev_host));
+            h->fr_ev_host = grown; h->fr_ev_cap = want;
+        }
+        V2E_HIP(hipMemcpyAsync(h->fr_ev_host + 4 * est, events_dev + 4 * est, sizeof(float) * 4 * (n - est), hipMemcpyDeviceToHost, s));
+        V2E_HIP(hipStreamSynchronize(s));
+    }
+    if (n > 0) *events_host = h->fr_ev_host;
     return 0;
 }
 
@@ -1516,6 +1615,7 @@ static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p, int dtype)
     if (dtype == V2E_DT_F64 && p->log_input) return false; // the frame record carries the lin-log value as float32
     if (p->photoreceptor_noise) return false;              // one more state plane and normal per pixel
     if (h->sc_hp) return false;                            // SCIDVS: two more state planes
+    if (h->cs_sur) return false;                           // CSDVS: the surround is stepped between frames
     return true;
 }
 

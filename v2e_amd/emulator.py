@@ -18,10 +18,10 @@ Random numbers come in two modes, selected with the extra key
            per-iteration shuffle computed on device; no host round trip except the final
            copy of the event list.  `generate_events_batch` keeps a whole clip on device.
 
-The reference's research-only pixel variants are not part of the hot path and raise
-NotImplementedError here: CSDVS (cs_lambda_pixels), SCIDVS, show_dvs_model_state,
-record_single_pixel_states.  `hdr=True` (log-encoded input, emulator.py:304, 666) is supported, and so is
-`photoreceptor_noise=True` (emulator.py:694-703) in the frame-at-a-time API.
+Not part of the hot path, NotImplementedError here: show_dvs_model_state, record_single_pixel_states.  `hdr=True`
+(log-encoded input, emulator.py:304, 666), `photoreceptor_noise=True` (emulator.py:694-703), `scidvs=True` (float64 state)
+and the centre-surround pixel (`cs_lambda_pixels`, emulator.py:1061-1124: the diffuser is stepped on the device between
+frames, csrc/csdvs.hip) are supported.
 """
 import atexit
 import logging
@@ -180,7 +180,6 @@ class EventEmulator(object):
             tape_host_threads: Optional[int] = 1,
     ):
         unsupported = []
-        if cs_lambda_pixels is not None: unsupported.append("cs_lambda_pixels (CSDVS)")
         if show_dvs_model_state is not None: unsupported.append("show_dvs_model_state")
         if record_single_pixel_states is not None: unsupported.append("record_single_pixel_states")
         if unsupported:
@@ -226,7 +225,18 @@ class EventEmulator(object):
             raise NotImplementedError(
                 "v2e_amd.EventEmulator(scidvs=True) is built for float64 pixel state (cutoff_hz > 0 or hdr): with float32 state "
                 "torch's vectorised sinh and the device's differ in the last bit often enough to move events (DESIGN.md section 7)")
-        self.csdvs_enabled = False
+        # CSDVS (emulator.py:245-272)
+        self.cs_steps_warning_printed = False
+        self.cs_steps_taken = []
+        self.cs_alpha_warning_printed = False
+        self.cs_tau_p_ms = cs_tau_p_ms
+        self.cs_lambda_pixels = cs_lambda_pixels
+        self.cs_surround_frame = None
+        self.csdvs_enabled = cs_lambda_pixels is not None
+        if self.csdvs_enabled:
+            self.cs_tau_h_ms = 0 if (cs_tau_p_ms is None or cs_tau_p_ms == 0) else cs_tau_p_ms / (cs_lambda_pixels ** 2)
+            logger.info(f'Center-surround parameters:\n\tcs_tau_p_ms: {self.cs_tau_p_ms}\n\tcs_tau_h_ms:  {self.cs_tau_h_ms}\n\t'
+                        f'cs_lambda_pixels:  {self.cs_lambda_pixels:.2f}\n\t')
         self.seed = seed
 
         self.rng_mode = (rng_mode or os.environ.get("V2E_AMD_RNG", "tape")).lower()
@@ -306,6 +316,9 @@ class EventEmulator(object):
             self.frame_h5_dataset = self.frame_ts_dataset = self.frame_ev_idx_dataset = None
 
     def cleanup(self):  # emulator.py:402-429
+        if len(getattr(self, "cs_steps_taken", ())) > 1:
+            logger.info(f'CSDVS steps statistics: mean+std= {np.mean(self.cs_steps_taken):.0f} + {np.std(self.cs_steps_taken):.0f} '
+                        f'(median= {np.median(self.cs_steps_taken):.0f})')
         if getattr(self, "_host_threads_prev", None) is not None:
             torch.set_num_threads(self._host_threads_prev)
             self._host_threads_prev = None
@@ -357,6 +370,7 @@ class EventEmulator(object):
         self.noise_rate_array = None
         self.photoreceptor_noise_arr = None
         self.scidvs_highpass = self.scidvs_previous_photo = self.scidvs_tau_arr = None
+        self.cs_surround_frame = None
         self._pn_last_rate = None  # the noise amplitude is recomputed for the first frame pair of the next clip
         self._initialized = False
 
@@ -441,6 +455,15 @@ class EventEmulator(object):
             self.scidvs_highpass = eng.plane(self._sc_planes[0])
             self.scidvs_previous_photo = eng.plane(self._sc_planes[1])
             self.scidvs_tau_arr = eng.plane(self._sc_tau)
+        if self.csdvs_enabled:
+            # emulator.py:1062-1063 and :715: the surround starts as a copy of lp_log_frame, so base_log_frame =
+            # lp_log_frame - cs_surround_frame is zero; [surround, ping-pong scratch, the coming frame's lp_log_frame]
+            self._cs_planes = [eng.lp.clone(), torch.empty_like(eng.lp), torch.empty_like(eng.lp)]
+            eng.base.zero_()
+            eng.set_csdvs(self._cs_planes[0])
+            self.cs_surround_frame = eng.plane(self._cs_planes[0])
+        else:
+            eng.set_csdvs(None)
         # public state attributes, as [H,W] device views
         self.lp_log_frame = eng.plane(eng.lp)
         self.base_log_frame = eng.plane(eng.base)
@@ -479,7 +502,7 @@ class EventEmulator(object):
         eng = self._ensure_engine(H, W)
         # Philox mode after the first frame: the whole frame is ONE C call (v2e_emu_frame), the host frame goes through
         # the handle's pinned staging instead of a torch tensor
-        fast = self._initialized and self.rng_mode == "philox" and not self.photoreceptor_noise
+        fast = self._initialized and self.rng_mode == "philox" and not self.photoreceptor_noise and not self.csdvs_enabled
         host_frame = None
         if fast and isinstance(new_frame, np.ndarray) and new_frame.dtype in (np.uint8, np.float32, np.float64):
             host_frame = np.ascontiguousarray(new_frame)
@@ -544,6 +567,8 @@ class EventEmulator(object):
         leak = None
         if tape and self.leak_rate_hz > 0:
             leak = _as_f32_tensor(self._tape.randn((H, W))).to(dev)
+        if self.csdvs_enabled:  # emulator.py:707-708: between the low-pass and the event computation
+            self._update_csdvs(P, frame_dev, t_prev, t_frame, fidx)
         if not counted:
             eng.count(P, frame_dev, [t_prev], [t_frame], fidx, leak_randn=leak)
         rec = eng.read_rec(fidx)[0]
@@ -647,6 +672,46 @@ class EventEmulator(object):
         if self.dvs_text is not None:
             self.dvs_text.appendEvents(ev_dev, n_signal=sig)
 
+    # ------------------------------------------------------------- centre-surround
+    MAX_CHANGE_TO_TERMINATE_EULER_SURROUND_STEPPING = 1e-5  # emulator.py:52
+
+    def _update_csdvs(self, P, frame_dev, t_prev, t_frame, fidx):
+        """emulator.py:1061-1124.  The host part (step count, IIR coefficients, warnings, the refusal of a diverging
+        diffuser) as the reference writes it; the stepping loop is v2e_csdvs_update on the device planes, driven by the
+        coming frame's lp_log_frame (v2e_emu_lp_preview: the low-pass applied to the state as it is)."""
+        eng = self._engine
+        delta_time = t_frame - t_prev
+        abs_min_tau_p = 1e-9
+        tau_p = abs_min_tau_p if (self.cs_tau_p_ms is None or self.cs_tau_p_ms == 0) else self.cs_tau_p_ms * 1e-3
+        tau_h = abs_min_tau_p / (self.cs_lambda_pixels ** 2) if (self.cs_tau_h_ms is None or self.cs_tau_h_ms == 0) \
+            else self.cs_tau_h_ms * 1e-3
+        min_tau = min(tau_p, tau_h)
+        NUM_STEPS_PER_TAU = 5
+        num_steps = int(np.ceil((delta_time / min_tau) * NUM_STEPS_PER_TAU))
+        actual_delta_time = delta_time / num_steps
+        if num_steps > 1000 and not self.cs_steps_warning_printed:
+            if self.cs_tau_p_ms == 0:
+                logger.warning(f'You set time constant cs_tau_p_ms to zero which set the minimum tau of {abs_min_tau_p}s')
+            logger.warning(f'CSDVS timestepping of diffuser could take up to {num_steps} steps per frame for Euler delta time '
+                           f'{actual_delta_time:.3g}s; simulation of each frame will terminate when max change is smaller than '
+                           f'{self.MAX_CHANGE_TO_TERMINATE_EULER_SURROUND_STEPPING}')
+            self.cs_steps_warning_printed = True
+        alpha_p = actual_delta_time / tau_p
+        alpha_h = actual_delta_time / tau_h
+        if alpha_p >= 1 or alpha_h >= 1:
+            logger.error(f'CSDVS update alpha (of IIR update) is too large; simulation would explode: '
+                         f'alpha_p={alpha_p:.3f} alpha_h={alpha_h:.3f}')
+            self.cs_alpha_warning_printed = True
+            raise SystemExit(1)  # v2e_quit(1)
+        if alpha_p > .25 or alpha_h > .25:
+            logger.warning(f'CSDVS update alpha (of IIR update) is too large; simulation will be inaccurate: '
+                           f'alpha_p={alpha_p:.3f} alpha_h={alpha_h:.3f}')
+            self.cs_alpha_warning_printed = True
+        sur, scratch, lp_new = self._cs_planes
+        eng.lp_preview(P, frame_dev, [t_prev], [t_frame], fidx, lp_new)
+        steps = eng.csdvs_update(lp_new, sur, scratch, alpha_p, alpha_h, num_steps, self.MAX_CHANGE_TO_TERMINATE_EULER_SURROUND_STEPPING)
+        self.cs_steps_taken.append(steps)
+
     # ------------------------------------------------------------- device-resident clip
     def generate_events_batch(self, frames, t_frames, return_device=False, use_graph=True, cap=None):
         """Philox mode: run a whole clip [F,H,W] with timestamps t_frames[F] on device.
@@ -671,6 +736,9 @@ class EventEmulator(object):
             raise _capi.V2EAmdError("a previous device-resident run failed (%s); call reset()" % self._failed)
         if self.rng_mode != "philox":
             raise ValueError("generate_events_batch needs rng_mode='philox' (tape mode needs the host per frame)")
+        if self.csdvs_enabled:
+            raise NotImplementedError("generate_events_batch with cs_lambda_pixels: the surround's stepping loop ends on a "
+                                      "host-visible maximum per frame (emulator.py:1107); use generate_events per frame")
         if isinstance(frames, np.ndarray):
             if frames.dtype not in (np.uint8, np.float32, np.float64):
                 frames = frames.astype(np.float64)

@@ -123,6 +123,24 @@ class EmuEngine:
                                      _dbl_array(t_prev), _dbl_array(t_frame), int(frame_idx),
                                      _ptr(leak_randn), _ptr(shot_rand), self.stream), "v2e_emu_count")
 
+    def set_csdvs(self, surround_plane):
+        """cs_surround_frame plane [n_clips][npx_pad] (state dtype) that count() subtracts; None switches CSDVS off."""
+        check(self.lib.v2e_emu_set_csdvs(self._h, _ptr(surround_plane)), "v2e_emu_set_csdvs")
+
+    def lp_preview(self, P, frame_dev, t_prev, t_frame, frame_idx, lp_out):
+        """The coming frame's lp_log_frame into lp_out, the state untouched (v2e_emu_lp_preview)."""
+        self._check_frame(frame_dev, self.n_clips)
+        check(self.lib.v2e_emu_lp_preview(self._h, C.byref(P), _ptr(frame_dev), _DT[frame_dev.dtype], _dbl_array(t_prev),
+                                          _dbl_array(t_frame), int(frame_idx), _ptr(lp_out), self.stream), "v2e_emu_lp_preview")
+
+    def csdvs_update(self, p_plane, h_plane, h_scratch, alpha_p, alpha_h, num_steps, stop):
+        """EventEmulator._update_csdvs's stepping loop on device planes (v2e_csdvs_update); returns the steps taken."""
+        steps = C.c_int(0)
+        check(self.lib.v2e_csdvs_update(_ptr(p_plane), _ptr(h_plane), _ptr(h_scratch), self.H, self.W, 1 if self.f64_state else 0,
+                                        float(alpha_p), float(alpha_h), int(num_steps), float(stop), C.byref(steps), None,
+                                        self.stream), "v2e_csdvs_update")
+        return int(steps.value)
+
     def set_pnoise(self, pn_plane, randn_tape=None):
         """photoreceptor_noise_arr plane [n_clips][npx_pad] float64 (+ the frame's torch.randn draws in tape mode) for
         the next count(); None switches the feature off."""
@@ -203,7 +221,10 @@ class EmuEngine:
             check(rc, "v2e_emu_frame")
         ev = None
         if rc == 0 and out8[0] > 0:
-            ev = np.ctypeslib.as_array(rows, shape=(int(out8[0]), 4)).copy()  # the pinned rows are reused by the next call
+            # the pinned rows are reused by the next call (memmove, not ctypeslib.as_array: that builds a ctypes array
+            # type per distinct row count, ~100 us a frame)
+            ev = np.empty((int(out8[0]), 4), dtype=np.float32)
+            C.memmove(ev.ctypes.data, rows, 16 * int(out8[0]))
         return rc, out8, ev
 
     def run(self, P, frames_dev, t_prev, t_frame, frame_idx0, events, recs_dev, use_graph=True):
