@@ -65,7 +65,7 @@ def _device_update(p, h0, alpha_p, alpha_h, num_steps):
     import ctypes as C
     import torch
     from v2e_amd import _capi
-    lib = _capi.load()
+    lib = _capi.lib()
     dev = torch.device("cuda")
     pd, hd = torch.from_numpy(p).to(dev), torch.from_numpy(h0).to(dev)
     scratch = torch.empty_like(hd)

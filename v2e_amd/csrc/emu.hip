@@ -25,6 +25,7 @@
 
 #include <cstdarg>
 #include <cstdlib>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -701,6 +702,54 @@ __global__ __launch_bounds__(BLOCK) void k_permute(const float4 *__restrict__ in
     if (j < n) out[row0 + j] = in[row0 + (unsigned long long)idx[j]];
 }
 
+// ------------------------------------------------------------------ v2e_emu_frame's two ends
+// Everything a frame needs goes through the compute queue: a copy engine between kernels costs a cross-queue dependency at
+// either end (~20 us each on this runtime), more than the whole frame's kernels.  The frame's scalars arrive as a kernel
+// argument, its pixels are read by k_count straight from the pinned staging buffer, and the rows go back by a kernel writing
+// pinned host memory.
+// What changes from frame to frame, in pinned host memory the first kernel reads: the kernels of a frame are then the same
+// launch every time and can be replayed as one hipGraph (V2E_AMD_FRAME_GRAPH=1).
+struct FramePar {
+    FrameCtl ctl;
+    uint32_t frame_idx, pad_;
+    unsigned long long est_rows;
+};
+struct FrameScratch { // device
+    v2e_frame_rec rec;
+    uint32_t frame_idx, pad_;
+    unsigned long long est_rows;
+    FrameCtl ctl;
+};
+
+__global__ void k_frame_begin(const FramePar *__restrict__ par /* host */, FrameScratch *sc)
+{
+    static_assert(sizeof(FrameCtl) % 4 == 0 && sizeof(FrameCtl) / 4 <= 128, "one word per thread");
+    const int t = threadIdx.x;
+    if (t < (int)(sizeof(FrameCtl) / 4)) ((uint32_t *)&sc->ctl)[t] = ((const uint32_t *)&par->ctl)[t];
+    if (t == 127) {
+        v2e_frame_rec z;
+        memset(&z, 0, sizeof(z));
+        sc->rec = z;
+        sc->frame_idx = par->frame_idx;
+        sc->est_rows = par->est_rows;
+    }
+}
+
+// rows [row0, min(n_events, row0 + max_rows)) of the frame to the pinned host buffer, and the frame record with them
+__global__ __launch_bounds__(256) void k_frame_rows_to_host(const float4 *__restrict__ ev, const v2e_frame_rec *__restrict__ rec,
+                                                            float4 *__restrict__ out_rows, v2e_frame_rec *__restrict__ out_rec,
+                                                            unsigned long long row0, unsigned long long max_rows,
+                                                            const unsigned long long *__restrict__ max_rows_dev)
+{
+    if (max_rows_dev) max_rows = *max_rows_dev;
+    const v2e_frame_rec r = *rec;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out_rec) *out_rec = r;
+    if (r.flags & (V2E_FLAG_EVENTS_DROPPED | V2E_FLAG_ITERS_CLAMPED)) return;
+    const unsigned long long n = r.n_events < row0 + max_rows ? r.n_events : row0 + max_rows;
+    for (unsigned long long i = row0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256)
+        out_rows[i] = ev[i];
+}
+
 #include "emu_chain.h"
 
 } // namespace
@@ -745,8 +794,13 @@ struct v2e_emu {
     FrameCtl *ctl_host = nullptr;      // pinned staging [RING][n_clips]
     unsigned long long *off_dev = nullptr, *off_host = nullptr; // [n_clips] explicit event offsets
     // v2e_emu_frame (one call per frame): pinned staging for the frame, the frame record + per-key totals, the event rows
-    // [v2e_frame_rec zeros | FrameCtl | frame] goes up in ONE copy; the record and an estimated number of rows come back
-    unsigned char *fr_stage = nullptr, *fr_dev = nullptr;
+    // pinned staging of a host frame (read by k_count in place), device scratch [v2e_frame_rec | FrameCtl], pinned record and
+    // rows (written by k_frame_rows_to_host); *_dev: the device-side addresses of the pinned buffers
+    unsigned char *fr_stage = nullptr, *fr_stage_dev = nullptr, *fr_dev = nullptr, *fr_rec_host_dev = nullptr;
+    unsigned char *fr_par = nullptr, *fr_par_dev = nullptr; // FramePar, pinned
+    hipGraphExec_t fr_graph = nullptr;                      // the frame's kernels, replayed (key: everything baked in)
+    std::vector<unsigned char> fr_graph_key;
+    float *fr_ev_host_dev = nullptr;
     size_t fr_bytes = 0;
     unsigned char *fr_rec_host = nullptr; // v2e_frame_rec + nkeys_cap totals
     int fr_rec_keys = 0;
@@ -766,7 +820,12 @@ struct v2e_emu {
     struct CachedGraph { std::vector<unsigned char> key; hipGraphExec_t exec; unsigned long long used; };
     std::vector<CachedGraph> graphs;
     unsigned long long graph_clock = 0;
-    void drop_graphs() { for (auto &g : graphs) hipGraphExecDestroy(g.exec); graphs.clear(); }
+    void drop_graphs()
+    {
+        for (auto &g : graphs) hipGraphExecDestroy(g.exec);
+        graphs.clear();
+        if (fr_graph) { hipGraphExecDestroy(fr_graph); fr_graph = nullptr; }
+    }
     unsigned long long *dbg = nullptr; // dev tool (v2e_emu_debug_timeline)
     int n_cu = 256;
     double prof_ms[4] = {0, 0, 0, 0}; // count, rank, scan, emit (use_graph == 2)
@@ -953,6 +1012,7 @@ int v2e_emu_destroy(v2e_emu *h)
     if (h->run_fidx_host) hipHostFree(h->run_fidx_host);
     hipFree(h->fr_dev); hipFree(h->off_zero);
     if (h->fr_stage) hipHostFree(h->fr_stage);
+    if (h->fr_par) hipHostFree(h->fr_par);
     if (h->fr_rec_host) hipHostFree(h->fr_rec_host);
     if (h->fr_ev_host) hipHostFree(h->fr_ev_host);
     delete h;
@@ -1223,60 +1283,109 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == V2E_DT_U8 ? 1 : (dtype == V2E_DT_F32 ? 4 : 8);
     const size_t fbytes = esz * (size_t)h->npx;
-    // One upload: the zeroed frame record, the frame's scalars and (a host frame) its pixels
-    constexpr size_t FR_CTL = 64, FR_PIX = 384;
-    static_assert(sizeof(v2e_frame_rec) <= FR_CTL && FR_CTL + sizeof(FrameCtl) <= FR_PIX, "v2e_emu_frame staging layout");
-    const size_t up_bytes = FR_PIX + (frame_on_host ? fbytes : 0);
-    if (up_bytes > h->fr_bytes) {
+    const auto tp0 = std::chrono::steady_clock::now();
+    // (see k_frame_begin: no copy engine on the way in or out)
+    if (frame_on_host && fbytes > h->fr_bytes) {
         V2E_HIP(hipStreamSynchronize(s));
         if (h->fr_stage) V2E_HIP(hipHostFree(h->fr_stage));
-        if (h->fr_dev) V2E_HIP(hipFree(h->fr_dev));
-        h->fr_stage = h->fr_dev = nullptr; h->fr_bytes = 0;
-        V2E_HIP(hipHostMalloc((void **)&h->fr_stage, up_bytes));
-        V2E_HIP(hipMalloc((void **)&h->fr_dev, up_bytes));
-        h->fr_bytes = up_bytes;
+        h->fr_stage = nullptr; h->fr_bytes = 0;
+        V2E_HIP(hipHostMalloc((void **)&h->fr_stage, fbytes, hipHostMallocMapped));
+        V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_stage_dev, h->fr_stage, 0));
+        h->fr_bytes = fbytes;
+    }
+    if (!h->fr_dev) {
+        V2E_HIP(hipMalloc((void **)&h->fr_dev, sizeof(FrameScratch)));
+        V2E_HIP(hipHostMalloc((void **)&h->fr_par, sizeof(FramePar), hipHostMallocMapped));
+        V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_par_dev, h->fr_par, 0));
     }
     if (h->fr_rec_keys != h->nkeys_cap) {
         if (h->fr_rec_host) V2E_HIP(hipHostFree(h->fr_rec_host));
-        V2E_HIP(hipHostMalloc((void **)&h->fr_rec_host, sizeof(v2e_frame_rec) + sizeof(uint32_t) * h->nkeys_cap));
+        V2E_HIP(hipHostMalloc((void **)&h->fr_rec_host, sizeof(v2e_frame_rec) + sizeof(uint32_t) * h->nkeys_cap, hipHostMallocMapped));
+        V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_rec_host_dev, h->fr_rec_host, 0));
         h->fr_rec_keys = h->nkeys_cap;
     }
-    // (the previous frame's upload has completed: every call ends synchronised)
-    memset(h->fr_stage, 0, FR_CTL);
-    *(FrameCtl *)(h->fr_stage + FR_CTL) = make_ctl(t_prev, t_frame, p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
     const void *frame_dev = frame;
     if (frame_on_host) {
-        memcpy(h->fr_stage + FR_PIX, frame, fbytes);
-        frame_dev = h->fr_dev + FR_PIX;
+        memcpy(h->fr_stage, frame, fbytes); // (the previous frame's kernels have completed: every call ends synchronised)
+        frame_dev = h->fr_stage_dev;
     }
-    V2E_HIP(hipMemcpyAsync(h->fr_dev, h->fr_stage, up_bytes, hipMemcpyHostToDevice, s));
-    v2e_frame_rec *rec = (v2e_frame_rec *)h->fr_dev;
-    const FrameCtl *ctl = (const FrameCtl *)(h->fr_dev + FR_CTL);
-    KArgs a = make_kargs(h, p);
-    a.emit_guard = 1;
-    rc = launch_count(h, a, p->f64_state, frame_dev, dtype, ctl, nullptr, frame_idx, nullptr, nullptr, rec, s);
-    if (rc) return rc;
-    dim3 gridw(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), 1);
-    k_rank<<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, 0);
-    k_scan<<<dim3(SCAN_BLOCKS, 1), BLOCK, 0, s>>>(a, rec);
-    // The event writer goes out before the host has seen the totals (k_emit checks them against cap itself), and with it
-    // the rows the frame is expected to have: one synchronisation per frame unless the estimate was short
-    if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
-    else k_emit<float><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
-    V2E_HIP(hipGetLastError());
     const uint64_t est = std::min<uint64_t>(std::max<uint64_t>(h->fr_est, 1024), cap);
     if (est > h->fr_ev_cap) {
         V2E_HIP(hipStreamSynchronize(s));
         if (h->fr_ev_host) V2E_HIP(hipHostFree(h->fr_ev_host));
         h->fr_ev_host = nullptr; h->fr_ev_cap = 0;
         const uint64_t want = std::max<uint64_t>(2 * est, 1u << 16);
-        V2E_HIP(hipHostMalloc((void **)&h->fr_ev_host, sizeof(float) * 4 * want));
+        V2E_HIP(hipHostMalloc((void **)&h->fr_ev_host, sizeof(float) * 4 * want, hipHostMallocMapped));
+        V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_ev_host_dev, h->fr_ev_host, 0));
         h->fr_ev_cap = want;
     }
+    FramePar *par = (FramePar *)h->fr_par;
+    par->ctl = make_ctl(t_prev, t_frame, p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
+    par->frame_idx = frame_idx;
+    par->est_rows = est;
+    const FrameCtl ctl_host = par->ctl;
+    FrameScratch *sc = (FrameScratch *)h->fr_dev;
+    v2e_frame_rec *rec = &sc->rec;
+    FrameCtl *ctl = &sc->ctl;
+    KArgs a = make_kargs(h, p);
+    a.emit_guard = 1;
     v2e_frame_rec *rh = (v2e_frame_rec *)h->fr_rec_host;
-    V2E_HIP(hipMemcpyAsync(rh, rec, sizeof(v2e_frame_rec), hipMemcpyDeviceToHost, s));
-    V2E_HIP(hipMemcpyAsync(h->fr_ev_host, events_dev, sizeof(float) * 4 * est, hipMemcpyDeviceToHost, s));
+    // The event writer goes out before the host has seen the totals (k_emit checks them against cap itself), and with it
+    // the copy of the rows the frame is expected to have: one synchronisation per frame unless the estimate was short
+    auto enqueue = [&](hipStream_t q) -> int {
+        k_frame_begin<<<1, 128, 0, q>>>((const FramePar *)h->fr_par_dev, sc);
+        int r = launch_count(h, a, p->f64_state, frame_dev, dtype, ctl, &sc->frame_idx, 0u, nullptr, nullptr, rec, q);
+        if (r) return r;
+        dim3 gridw(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), 1);
+        k_rank<<<gridw, BLOCK, 0, q>>>(a, ctl, rec, nullptr, 0);
+        k_scan<<<dim3(SCAN_BLOCKS, 1), BLOCK, 0, q>>>(a, rec);
+        if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, q>>>(a, ctl, rec, nullptr, h->off_zero, &sc->frame_idx, 0u, nullptr, 0, (float4 *)events_dev, cap);
+        else k_emit<float><<<gridw, BLOCK, 0, q>>>(a, ctl, rec, nullptr, h->off_zero, &sc->frame_idx, 0u, nullptr, 0, (float4 *)events_dev, cap);
+        k_frame_rows_to_host<<<256, 256, 0, q>>>((const float4 *)events_dev, rec, (float4 *)h->fr_ev_host_dev,
+                                                 (v2e_frame_rec *)h->fr_rec_host_dev, 0ull, 0ull, &sc->est_rows);
+        return 0;
+    };
+    // measured (346x260, 35 k events a frame): replayed as a graph the host spends 10 us instead of 19 us enqueueing, but the
+    // graph's start latency leaves the frame's wall time where it was (56 vs 53 us): plain launches unless asked
+    static const bool use_graph = getenv("V2E_AMD_FRAME_GRAPH") && atoi(getenv("V2E_AMD_FRAME_GRAPH")) != 0;
+    if (use_graph) {
+        std::vector<unsigned char> key;
+        auto push = [&key](const void *ptr, size_t n) { const unsigned char *b = (const unsigned char *)ptr; key.insert(key.end(), b, b + n); };
+        int f64 = p->f64_state;
+        push(&a, sizeof(a)); push(&frame_dev, sizeof(frame_dev)); push(&dtype, sizeof(dtype)); push(&f64, sizeof(f64));
+        push(&events_dev, sizeof(events_dev)); push(&cap, sizeof(cap)); push(&h->fr_ev_host_dev, sizeof(void *));
+        push(&h->fr_rec_host_dev, sizeof(void *)); push(&h->fr_dev, sizeof(void *)); push(&h->fr_par_dev, sizeof(void *));
+        if (!h->fr_graph || key != h->fr_graph_key) {
+            if (h->fr_graph) { hipGraphExecDestroy(h->fr_graph); h->fr_graph = nullptr; }
+            hipStream_t cs;
+            hipGraph_t g = nullptr;
+            V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            rc = enqueue(cs);
+            hipError_t e = hipStreamEndCapture(cs, &g);
+            hipStreamDestroy(cs);
+            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            V2E_HIP(e);
+            V2E_HIP(hipGraphInstantiate(&h->fr_graph, g, nullptr, nullptr, 0));
+            V2E_HIP(hipGraphDestroy(g));
+            h->fr_graph_key = key;
+        }
+        V2E_HIP(hipGraphLaunch(h->fr_graph, s));
+    } else {
+        rc = enqueue(s);
+        if (rc) return rc;
+    }
+    V2E_HIP(hipGetLastError());
+    static const bool timing = getenv("V2E_AMD_FRAME_TIMING") != nullptr; // dev: where a frame's host time goes
+    static double t_enq = 0, t_sync = 0; static int t_n = 0;
+    const auto tp1 = std::chrono::steady_clock::now();
     V2E_HIP(hipStreamSynchronize(s));
+    if (timing) {
+        const auto tp2 = std::chrono::steady_clock::now();
+        t_enq += std::chrono::duration<double, std::micro>(tp1 - tp0).count();
+        t_sync += std::chrono::duration<double, std::micro>(tp2 - tp1).count();
+        if (++t_n == 100) { fprintf(stderr, "v2e_emu_frame: enqueue %.1f us, synchronise %.1f us per frame\n", t_enq / 100, t_sync / 100); t_enq = t_sync = 0; t_n = 0; }
+    }
     const int M = rh->max_events;
     memset(out8, 0, sizeof(uint32_t) * 8);
     out8[4] = (uint32_t)M;
@@ -1288,7 +1397,7 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
         V2E_HIP(hipMemcpyAsync(h->rec_ring + slot, rec, sizeof(v2e_frame_rec), hipMemcpyDeviceToDevice, s));
         V2E_HIP(zero_async(&h->rec_ring[slot].flags, sizeof(uint32_t), s));
         V2E_HIP(hipMemcpyAsync(h->ctl_ring + slot, ctl, sizeof(FrameCtl), hipMemcpyDeviceToDevice, s));
-        h->ctl_host[slot] = *(const FrameCtl *)(h->fr_stage + FR_CTL);
+        h->ctl_host[slot] = ctl_host;
         if (M > h->max_iters) { V2E_HIP(hipStreamSynchronize(s)); return 1; }
         uint32_t *th = (uint32_t *)(h->fr_rec_host + sizeof(v2e_frame_rec));
         V2E_HIP(hipMemcpyAsync(th, h->tot, sizeof(uint32_t) * (2 * M + 2), hipMemcpyDeviceToHost, s));
@@ -1308,12 +1417,15 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
         if (n > h->fr_ev_cap) {
             float *grown = nullptr;
             const uint64_t want = std::max<uint64_t>(2 * n, 1u << 16);
-            V2E_HIP(hipHostMalloc((void **)&grown, sizeof(float) * 4 * want));
+            V2E_HIP(hipHostMalloc((void **)&grown, sizeof(float) * 4 * want, hipHostMallocMapped));
             memcpy(grown, h->fr_ev_host, sizeof(float) * 4 * est);
             V2E_HIP(hipHostFree(h->fr_ev_host));
             h->fr_ev_host = grown; h->fr_ev_cap = want;
+            V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_ev_host_dev, h->fr_ev_host, 0));
         }
-        V2E_HIP(hipMemcpyAsync(h->fr_ev_host + 4 * est, events_dev + 4 * est, sizeof(float) * 4 * (n - est), hipMemcpyDeviceToHost, s));
+        k_frame_rows_to_host<<<(unsigned)std::min<uint64_t>(v2e_cdiv((int64_t)(n - est), 256), 4096), 256, 0, s>>>(
+            (const float4 *)events_dev, rec, (float4 *)h->fr_ev_host_dev, nullptr, est, n - est, nullptr);
+        V2E_HIP(hipGetLastError());
         V2E_HIP(hipStreamSynchronize(s));
     }
     if (n > 0) *events_host = h->fr_ev_host;
