@@ -116,12 +116,32 @@ static int run_case(const Case &c, int reps)
     return (nbad == 0 && e3 < 1e-5 && dscaled < 5e-5) ? 0 : 1; // both kernels against the double-precision sums
 }
 
+extern "C" int v2e_slomo_debug_s3p_timeline(unsigned long long *out, int n_pairs); // dev entry point, not in the header
+
+// S3P_TIMELINE=1: k_conv_s3p's workgroup 0, step by step (shader clocks per step, and the shader clock rate itself from the
+// 100 MHz wall clock read at the same points)
+static void print_s3p_timeline()
+{
+    std::vector<unsigned long long> tl(2 * 512);
+    if (v2e_slomo_debug_s3p_timeline(tl.data(), 512)) return;
+    int n = 0;
+    while (n < 511 && tl[2 * n]) ++n;
+    if (n < 3) { printf("   (no k_conv_s3p timeline)\n"); return; }
+    const double clk = (double)(tl[2 * (n - 1)] - tl[0]), wall = (double)(tl[2 * (n - 1) + 1] - tl[1]);
+    printf("   k_conv_s3p workgroup 0: %d steps, %.0f shader clocks per step, shader clock %.0f MHz (per step:", n, clk / (n - 1), clk / wall * 100.0);
+    for (int i = 1; i < n && i < 14; ++i) printf(" %llu", tl[2 * i] - tl[2 * (i - 1)]);
+    printf(" ...)\n");
+}
+
 int main(int argc, char **argv)
 {
     int bad = 0;
+    if (getenv("S3P_TIMELINE")) v2e_slomo_debug_s3p_timeline(nullptr, 0);
     if (argc >= 7) {
         Case c = {atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6])};
-        return run_case(c, argc > 7 ? atoi(argv[7]) : 5);
+        const int r = run_case(c, argc > 7 ? atoi(argv[7]) : 5);
+        if (getenv("S3P_TIMELINE")) print_s3p_timeline();
+        return r;
     }
     const int full = getenv("S3_FULL") ? atoi(getenv("S3_FULL")) : 0;
     const int N = getenv("S3_N") ? atoi(getenv("S3_N")) : (full ? 80 : 8);

@@ -35,9 +35,11 @@ __global__ __launch_bounds__(256) void k_mfma(const uint4 *__restrict__ opnd, fl
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters; it += 8) { // unrolled: no branch between multiplies
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[(i + 1) % NACC], acc[i], 0, 0, 0);
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[(i + 1) % NACC], acc[i], 0, 0, 0);
     }
     float s = 0.f;
 #pragma unroll

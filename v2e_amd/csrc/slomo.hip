@@ -35,6 +35,7 @@ struct ConvArgs {
     const void *ws3; // split-bf16 weights (slomo_s3.h) or nullptr
     int ncb;         // slomo_s3.h: channel blocks when the grid is 1-D in XCD order, else 0
     long long xs_plane; // slomo_s3.h, pre-split input: 16-byte units per piece plane (n * C/8 * h * w)
+    int tl_on;          // slomo_s3p.h, dev: record workgroup 0's per-step timeline
 };
 
 // element fetch with the producer op fused: PRE 0 plain, 1 avg_pool2d(2) of a [2H][2W] source,
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
 }
 
 #include "slomo_s3.h"
+#include "slomo_s3p.h"
 
 // ... one output per thread, for widths that are not a multiple of 4
 __global__ __launch_bounds__(256) void k_avgpool2_scalar(const float *__restrict__ x, float *__restrict__ y, long long nc, int h, int w)
@@ -617,11 +619,18 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
     static const int variant = getenv("V2E_AMD_S3_VARIANT") ? atoi(getenv("V2E_AMD_S3_VARIANT")) : 0; // dev: tile choice
     const bool c64 = a.cout % 64 == 0 && variant == 6;
     if (ks == 3) {
+        // the software-pipelined one-wave-per-SIMD kernel where the layer has one of its shapes (bit-identical output; 3-6 % less
+        // time per layer, 1.5 % per forward: the chip is at its power limit in these kernels -- the shader clock reads 1.63-1.75 GHz
+        // of 2.4 -- and the 64 x 64 register tile moves fewer LDS bytes per multiply; slomo_s3p.h); variant 12: off
+        if ((variant == 0 || variant == 11) && conv_dispatch_s3p(a, ks, s) == 0) return 0;
         if (a.w_ % 32 == 0) {
             if (variant == 2 && a.cout % 64 == 0) return launch_conv_s3<3, 2, 2, 8, 32>(a, s);
             if (variant == 3) return launch_conv_s3<3, 1, 4, 4, 32>(a, s);
             if (variant == 4 && a.cout % 64 == 0) return launch_conv_s3<3, 2, 4, 4, 32>(a, s);
             if (variant == 7) return launch_conv_s3<3, 1, 2, 4, 32, 2>(a, s);
+            if (variant == 8 && a.cout % 64 == 0) return launch_conv_s3<3, 2, 2, 4, 32, 1, 0, 1>(a, s);
+            if (variant == 9 && a.cout % 64 == 0) return launch_conv_s3<3, 2, 2, 4, 32, 2, 0, 1>(a, s);
+            if (variant == 10) return launch_conv_s3<3, 1, 2, 4, 32, 1, 0, 1>(a, s);
             return c64 ? launch_conv_s3<3, 2, 2, 4, 32>(a, s) : launch_conv_s3<3, 1, 2, 4, 32>(a, s);
         }
         if (a.w_ % 16 == 0) return c64 ? launch_conv_s3<3, 2, 2, 4, 16>(a, s) : (variant == 7 ? launch_conv_s3<3, 1, 2, 4, 16, 2>(a, s) : launch_conv_s3<3, 1, 2, 4, 16>(a, s));
@@ -637,6 +646,19 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
 } // namespace
 
 extern "C" {
+
+// dev tool (not part of the public header; scripts/conv_s3_check): switch k_conv_s3p's per-step timeline of workgroup 0 on
+// (out == NULL) or read it back: pairs (shader clock, 100 MHz wall clock), terminated by a zero
+int v2e_slomo_debug_s3p_timeline(unsigned long long *out, int n_pairs)
+{
+    if (!out) {
+        g_s3p_timeline_on = 1;
+        return 0;
+    }
+    V2E_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s3p_timeline), sizeof(unsigned long long) * 2 * (size_t)(n_pairs < 512 ? n_pairs : 512)));
+    return 0;
+}
+
 
 int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, int k, void *stream)
 {

@@ -84,9 +84,12 @@ __global__ __launch_bounds__(256) void k_split3_nchw(const float *__restrict__ x
 // MODE 1 (PADC): cin is not a multiple of 16 (the 12-channel conv1): channels beyond cin are staged as zeros (their weights
 // are zero too).  MODE 2 (PRES): the input arrives already split, [piece][n][C/8][h][w][8 bf16] (k_split3_nchw or a
 // producer that writes this layout): staging is three 16-byte loads and three 16-byte LDS stores per item, no conversion.
-template <int KS, int CT, int PT, int WP, int TW, int NB, int MODE = 0>
+// RG (3x3 only): the weights of ONE kernel row resident at a time, as 5x5 / 7x7 do (18 KB instead of 55 KB for a 64-channel
+// tile: 50 KB of LDS in all, so two workgroups of 64-channel tiles share a CU, and a 64 x 64 register tile reads half the LDS
+// bytes per multiply of a 32 x 64 one).
+template <int KS, int CT, int PT, int WP, int TW, int NB, int MODE = 0, int RG = 0>
 __global__ __launch_bounds__(WP * 64)
-__attribute__((amdgpu_waves_per_eu(CT * PT * WP <= 5 ? 3 : (CT * PT * WP <= 8 ? 2 : 1), CT * PT * WP <= 5 ? 4 : (CT * PT * WP <= 10 ? 2 : 1))))
+__attribute__((amdgpu_waves_per_eu(CT * PT * WP <= 5 ? 3 : (CT * PT * WP <= 8 || RG ? 2 : 1), CT * PT * WP <= 5 ? 4 : (CT * PT * WP <= 10 || RG ? 2 : 1))))
 void k_conv_s3(ConvArgs a)
 {
     constexpr bool PADC = MODE == 1, PRES = MODE == 2;
@@ -97,8 +100,9 @@ void k_conv_s3(ConvArgs a)
     constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PP = PH * PW;
     constexpr int COT = CT * 32;
     constexpr int KK = KS * KS;
-    constexpr int G = KS == 3 ? 9 : KS; // taps whose weights are resident in LDS at a time (3x3: all; else one kernel row)
+    constexpr int G = (KS == 3 && !RG) ? 9 : KS; // taps whose weights are resident in LDS at a time (3x3: all; else one kernel row)
     constexpr int NG = KK / G;
+    constexpr bool ALLTAPS = G == KK;
     constexpr int NPI = (2 * PP + NT - 1) / NT; // patch items per thread; item = 8 channels of one patch pixel
     constexpr int WU = G * 6 * COT;             // 16-byte weight units per group
     constexpr int NWU = (WU + NT - 1) / NT;
@@ -249,7 +253,7 @@ void k_conv_s3(ConvArgs a)
     // NB operand register sets: with 2, tap t+1 is read from LDS before the multiplies of tap t are issued
     bf16x8 av[NB][3][CT], bv[NB][3][PT];
     auto load_ops = [&](int t, int buf, int ky0) {
-        const int ky = KS == 3 ? t / 3 : 0, kx = KS == 3 ? t % 3 : t;
+        const int ky = ALLTAPS ? t / KS : 0, kx = ALLTAPS ? t % KS : t;
         const int koff_p = (ky0 + ky) * PW + kx;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -329,7 +333,7 @@ void k_conv_s3(ConvArgs a)
                 __syncthreads();
                 if (g + 1 < NG) prefetch_w(0, cb, g + 1);
                 else if (cb + 16 < a.cin) { prefetch_w(0, cb + 16, 0); prefetch_patch(0, cb + 16); }
-                compute_group(KS == 3 ? 0 : g); // G == KS: group g is kernel row g
+                compute_group(ALLTAPS ? 0 : g); // G == KS: group g is kernel row g
             }
         }
     }
@@ -354,18 +358,18 @@ void k_conv_s3(ConvArgs a)
     }
 }
 
-template <int KS, int CT, int PT, int WP, int TW, int NB = 1, int MODE = 0>
+template <int KS, int CT, int PT, int WP, int TW, int NB = 1, int MODE = 0, int RG = 0>
 static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
 {
     ConvArgs a = a0;
     constexpr int TH = WP * PT * 32 / TW;
     constexpr int PP = (TH + KS - 1) * (TW + KS - 1);
-    constexpr int G = KS == 3 ? 9 : KS;
+    constexpr int G = (KS == 3 && !RG) ? 9 : KS;
     constexpr size_t lds = (size_t)(6 * PP + G * 6 * CT * 32) * 16;
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false; // one per instantiation
     if (!attr_set) {
-        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB, MODE, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     a.tiles_x = (a.w_ + TW - 1) / TW;
@@ -376,6 +380,6 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     // noise at 2 blocks, -3 % on the five-wave 20-wide tiles (16 blocks: more workgroups than an XCD holds at once)
     a.ncb = ((order == 1 && KS == 3 && WP == 4 && ncb >= 4) || (order == 2 && ncb > 1)) ? ncb : 0;
     dim3 grid = a.ncb ? dim3((unsigned)((ntiles + 7) / 8 * 8 * ncb)) : dim3((unsigned)ntiles, (unsigned)ncb);
-    k_conv_s3<KS, CT, PT, WP, TW, NB, MODE><<<grid, WP * 64, lds, s>>>(a);
+    k_conv_s3<KS, CT, PT, WP, TW, NB, MODE, RG><<<grid, WP * 64, lds, s>>>(a);
     return 0;
 }
