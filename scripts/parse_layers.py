@@ -19,8 +19,8 @@ for (name, s, e, gx, gy, wx, vg, lds), (lname, co, ci, k) in zip(last, unet_laye
     fl = 2.0 * n * (H >> lvl) * (W >> lvl) * co * ci * k * k
     us = (e - s) / 1e3
     tot_t += us; tot_f += fl
-    kn = "k_conv_s3<" if "k_conv_s3<" in name else ("k_conv<" if "k_conv<" in name else "")
-    tmpl = (("s3 " if "s3" in kn else "") + name[name.find(kn) + len(kn): name.find(">")]) if kn else name[:40]
+    kn = "k_conv_s3p<" if "k_conv_s3p<" in name else ("k_conv_s3<" if "k_conv_s3<" in name else ("k_conv<" if "k_conv<" in name else ""))
+    tmpl = (("s3p " if "s3p" in kn else ("s3 " if "s3" in kn else "")) + name[name.find(kn) + len(kn): name.find(">")]) if kn else name[:40]
     print("%-12s k%d %4d->%4d @%3dx%3d  %8.1f us %6.1f TF  grid %5dx%-3d wg %3d vgpr %3d lds %6d  <%s>" % (
         lname, k, ci, co, H >> lvl, W >> lvl, us, fl / us / 1e6, gx // wx, gy, wx, vg, lds, tmpl))
 print("conv total %.1f us, %.1f TF" % (tot_t, tot_f / tot_t / 1e6))

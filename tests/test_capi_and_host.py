@@ -62,7 +62,8 @@ def test_emulator_errors_like_reference():
     e.t_previous = 1.0
     with pytest.raises(ValueError):  # emulator.py:650-653
         e.generate_events(np.zeros((4, 4), np.uint8), 0.5)
-    for kw in (dict(cs_lambda_pixels=2.0), dict(scidvs=True), dict(show_dvs_model_state=["all"]),
+    EventEmulator(cs_lambda_pixels=2.0, cs_tau_p_ms=2.0)  # CSDVS: built (tests/test_csdvs.py)
+    for kw in (dict(scidvs=True), dict(show_dvs_model_state=["all"]),  # SCIDVS with float32 state (no cutoff): refused
                dict(record_single_pixel_states=(1, 2))):
         with pytest.raises(NotImplementedError):
             EventEmulator(**kw)
