@@ -78,7 +78,7 @@ def emulator_bytes_per_pixel(kw):
 
 def pmc_traffic_per_launch(kernel):
     """HBM bytes per chain-kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r02_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs).  Counters cannot
+    (profiles/r03_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs).  Counters cannot
     be read from inside this process, so the value is the recorded one or null."""
     for name in ("r03_emulator_pmc_hbm.txt", "r02_emulator_pmc_hbm.txt"):
         try:
@@ -93,8 +93,7 @@ def pmc_traffic_per_launch(kernel):
 
 def rocprof_kernel_us(kernel):
     """Average duration (us) of the chain kernel in the committed rocprofv3 kernel trace of this same command
-    (profiles/r02_emulator_chain_kernel_trace.txt), or None: the HIP-event figure measured live is the launch-to-launch
-    PERIOD of the dependency chain (gaps and waits included); the profiler's is the kernel alone."""
+    (profiles/r03_emulator_chain_kernel_trace.txt), or None: bench.py's own figure is measured live with HIP events."""
     try:
         for line in open(os.path.join(ROOT, "profiles", "r03_emulator_chain_kernel_trace.txt")):
             parts = line.split()

@@ -123,7 +123,7 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     # executed matrix-core work: with split-bf16 operands every f32 multiply-add is six bf16 ones (the 12-channel conv1,
     # the 8x10 level and the 5-channel head stay on f32 instructions: ~6 % of the FLOPs)
     ach = fl_u / sec_u
-    roof = {"bound": "mfma", "kernel": ("k_conv_s3" if s3 else "k_conv") + " (23 launches of the interpolation UNet)",
+    roof = {"bound": "mfma", "kernel": ("k_conv_s3 / k_conv_s3p" if s3 else "k_conv") + " (23 launches of the interpolation UNet)",
             "achieved": round(ach * (6 if s3 else 1) / 1e12, 2), "peak": (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK) / 1e12,
             "unit": "TFLOP/s", "frac": round(ach * (6 if s3 else 1) / (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK), 4),
             "traffic": slomo_pmc_traffic(), "f32_equivalent_TFLOPs": round(ach / 1e12, 2),
