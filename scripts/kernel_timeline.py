@@ -1,10 +1,10 @@
 #!/usr/bin/env python
-"""dev tool: from a rocprofv3 --kernel-trace db, the k_step chain's kernel durations and the gaps between
+"""dev tool: from a rocprofv3 --kernel-trace db, a kernel's (default: the chain's) launch durations and the gaps between
 consecutive launches, and what else was running (durations of the other emulator kernels)."""
 import sqlite3, sys, glob
 import numpy as np
 db = glob.glob(sys.argv[1] + "/*/*.db")[0]
-pat = sys.argv[2] if len(sys.argv) > 2 else "k_step"
+pat = sys.argv[2] if len(sys.argv) > 2 else "k_chain"
 con = sqlite3.connect(db)
 rows = list(con.execute("select start, end from kernels where name like ? order by start", ("%" + pat + "%",)))
 a = np.array(rows, dtype=np.int64)

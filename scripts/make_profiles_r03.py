@@ -140,7 +140,7 @@ def slomo():
 # multiply-adds per f32 one).  <s3p TW, DBG> = k_conv_s3p (slomo_s3p.h: 64 x 64 register tile, one software-pipelined wave per
 # SIMD, new this round); <s3 KS, CT, PT, WP, TW, NB, MODE, RG> = k_conv_s3 (slomo_s3.h); <KS, CI_T, ...> = k_conv (f32 MFMA).
 # Box-to-box spread of these kernels is +-3 % (they run at the chip's power limit: r03_slomo_s3p_ablation.txt); on one box,
-# A/B: forward 27.68 ms with k_conv_s3 everywhere, 27.28 ms with k_conv_s3p where it fits (scripts/gpu_r03n.sh).
+# A/B: forward 27.68 ms with k_conv_s3 everywhere, 27.28 ms with k_conv_s3p where it fits (scripts/gpu_slomo_ab.sh).
 #
 """ + rd("p3_slomo_layers.txt"))
     wr("r03_slomo_s3p_ablation.txt", """# k_conv_s3p against k_conv_s3 on single layers, with the pipelined kernel's pieces switched off one at a time, and the

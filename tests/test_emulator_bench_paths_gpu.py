@@ -206,3 +206,29 @@ def test_hd_noisy_enqueue_loop_matches_oracle(oracle_lib):
         assert got[k] == (len(ref), sha(ref)), "run %d differs from the oracle" % k
     assert np.array_equal(emu.base_log_frame.cpu().numpy(), ora.base_log_frame)
     assert np.array_equal(emu.lp_log_frame.cpu().numpy(), ora.lp_log_frame)
+
+
+@pytest.mark.parametrize("nframes", [9, 33, 70])
+@pytest.mark.parametrize("shape", [(64, 96), (260, 346)])
+def test_chain_carries_lp_without_cutoff_or_shot(shape, nframes, oracle_lib):
+    """Refractory period, no photoreceptor cutoff, no shot noise (round-2 advisor finding): lp_log_frame is not part of the
+    chain's arithmetic there, but the state planes ping-pong between launches and the tail launch hands them back, so it
+    must be carried through whatever the number of launches (1, 2 and 3 + tail here)."""
+    from v2e_amd import EventEmulator
+    from v2e_amd.synth import int_gradient_frames
+    H, W = shape
+    frames = int_gradient_frames(nframes, H, W, seed=51, noise=6, as_array=True)
+    times = [i / 300 for i in range(nframes)]
+    kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=0, leak_rate_hz=.2, shot_noise_rate_hz=0.0,
+              refractory_period_s=0.002)
+    emu = EventEmulator(device="cuda", seed=5, rng_mode="philox", **kw)
+    ev, counts = emu.generate_events_batch(frames, times, use_graph=257)
+    assert emu._engine.last_pipeline()[0].startswith("k_chain")
+    ora = oracle_lib.OracleEmulator(seed=5, rng_mode="philox", **kw)
+    oev = [ora.generate_events(f, t) for f, t in zip(frames, times)]
+    assert list(counts) == [0 if e is None else len(e) for e in oev]
+    assert np.array_equal(ev, np.concatenate([e for e in oev if e is not None]))
+    assert emu.lp_log_frame.dtype == torch.float32
+    assert np.array_equal(emu.lp_log_frame.cpu().numpy(), ora.lp_log_frame)
+    assert np.array_equal(emu.base_log_frame.cpu().numpy(), ora.base_log_frame)
+    assert np.array_equal(emu.timestamp_mem.cpu().numpy(), ora.timestamp_mem)
