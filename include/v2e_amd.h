@@ -213,6 +213,11 @@ int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const
 int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int frame_on_host, int dtype, double t_prev,
                   double t_frame, uint32_t frame_idx, float *events_dev, uint64_t cap, uint32_t *out8,
                   const float **events_host, void *stream);
+/* Where the NEXT v2e_emu_frame call puts its rows: a caller-owned PINNED host buffer of cap_rows rows of 4 floats (hipHostMalloc
+ * / hipHostRegister memory, e.g. a torch pin_memory tensor), written by the frame's last kernel directly -- *events_host then
+ * equals pinned_rows and the caller needs no copy.  One frame only; a frame with more rows than cap_rows is delivered in the
+ * handle's own buffer as before (*events_host says which).  NULL / 0 cancels. */
+int v2e_emu_frame_host_rows(v2e_emu *h, float *pinned_rows, uint64_t cap_rows);
 
 /*
  * Philox-mode, fully device-resident multi-frame run: frames [n_frames][n_clips][H*W],

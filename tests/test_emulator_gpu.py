@@ -557,3 +557,48 @@ def test_all_grey_levels_static_scene_and_tensor_input(api, oracle_lib):
     # reset(): the next frame re-initialises the state like a fresh emulator
     hip.reset()
     assert hip.num_events_total == 0 and hip.generate_events(ramp, 1.0) is None
+
+
+def test_frame_api_result_arrays_are_the_callers(oracle_lib):
+    """The frame API hands its rows out in pinned buffers that return to a pool when the caller drops the array (no host
+    copy).  What the caller keeps must stay what it was -- arrays kept across later frames, views derived from an array
+    that itself was dropped -- and what it drops must be reused, not leaked."""
+    import gc
+    from v2e_amd import EventEmulator
+    from v2e_amd.synth import int_gradient_frames
+    F, H, W = 90, 64, 96
+    frames = int_gradient_frames(F, H, W, seed=61, noise=8, as_array=True)
+    kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=200, leak_rate_hz=.2, shot_noise_rate_hz=2.0)
+    emu = EventEmulator(device="cuda", seed=6, rng_mode="philox", **kw)
+    ora = oracle_lib.OracleEmulator(seed=6, rng_mode="philox", **kw)
+    kept, kept_cols, ref = [], [], []
+    for i in range(F):
+        ev = emu.generate_events(frames[i], i / 300)
+        oe = ora.generate_events(frames[i], i / 300)
+        assert events_equal(ev, oe)
+        if ev is None:
+            continue
+        assert ev.dtype == np.float32 and ev.flags.c_contiguous and ev.flags.writeable
+        if i < 75:  # more arrays than the pool has buffers (64): the rest are ordinary copies
+            kept.append(ev)
+            ref.append(oe)
+        elif i < 80:
+            kept_cols.append((ev[:, 0], oe[:, 0].copy()))  # only a view survives this iteration
+        del ev
+    gc.collect()
+    for a, b in zip(kept, ref):
+        assert np.array_equal(a, b)
+    for a, b in kept_cols:
+        assert np.array_equal(a, b)
+    pool = emu._engine._rows_pool
+    assert len(pool.bufs) <= pool.MAX_BUFS
+    busy = sum(not b.free for b in pool.bufs)
+    assert busy >= min(len(kept), pool.MAX_BUFS) - 1
+    # dropped arrays give their buffers back
+    del kept, kept_cols, a
+    gc.collect()
+    assert sum(not b.free for b in pool.bufs) == 0
+    n_bufs = len(pool.bufs)
+    for i in range(F, F + 20):
+        ev = emu.generate_events(frames[i % F], i / 300)
+    assert len(pool.bufs) == n_bufs  # steady state: one buffer in use, none added

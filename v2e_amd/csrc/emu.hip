@@ -801,6 +801,8 @@ struct v2e_emu {
     hipGraphExec_t fr_graph = nullptr;                      // the frame's kernels, replayed (key: everything baked in)
     std::vector<unsigned char> fr_graph_key;
     float *fr_ev_host_dev = nullptr;
+    float *fr_user_rows = nullptr, *fr_user_rows_dev = nullptr; // v2e_emu_frame_host_rows: the next frame's rows go here
+    uint64_t fr_user_cap = 0;
     size_t fr_bytes = 0;
     unsigned char *fr_rec_host = nullptr; // v2e_frame_rec + nkeys_cap totals
     int fr_rec_keys = 0;
@@ -1309,8 +1311,16 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
         memcpy(h->fr_stage, frame, fbytes); // (the previous frame's kernels have completed: every call ends synchronised)
         frame_dev = h->fr_stage_dev;
     }
-    const uint64_t est = std::min<uint64_t>(std::max<uint64_t>(h->fr_est, 1024), cap);
-    if (est > h->fr_ev_cap) {
+    // destination of the rows: the caller's pinned buffer for this frame (v2e_emu_frame_host_rows; one frame only), else the
+    // handle's own
+    float *user_rows = h->fr_user_rows, *user_rows_dev = h->fr_user_rows_dev;
+    const uint64_t user_cap = h->fr_user_cap;
+    h->fr_user_rows = h->fr_user_rows_dev = nullptr; h->fr_user_cap = 0;
+    static const bool use_graph = getenv("V2E_AMD_FRAME_GRAPH") && atoi(getenv("V2E_AMD_FRAME_GRAPH")) != 0;
+    if (use_graph) user_rows = nullptr; // (the replayed graph bakes the handle's buffer)
+    uint64_t est = std::min<uint64_t>(std::max<uint64_t>(h->fr_est, 1024), cap);
+    if (user_rows) est = std::min<uint64_t>(est, user_cap);
+    if (!user_rows && est > h->fr_ev_cap) {
         V2E_HIP(hipStreamSynchronize(s));
         if (h->fr_ev_host) V2E_HIP(hipHostFree(h->fr_ev_host));
         h->fr_ev_host = nullptr; h->fr_ev_cap = 0;
@@ -1341,13 +1351,12 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
         k_scan<<<dim3(SCAN_BLOCKS, 1), BLOCK, 0, q>>>(a, rec);
         if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, q>>>(a, ctl, rec, nullptr, h->off_zero, &sc->frame_idx, 0u, nullptr, 0, (float4 *)events_dev, cap);
         else k_emit<float><<<gridw, BLOCK, 0, q>>>(a, ctl, rec, nullptr, h->off_zero, &sc->frame_idx, 0u, nullptr, 0, (float4 *)events_dev, cap);
-        k_frame_rows_to_host<<<256, 256, 0, q>>>((const float4 *)events_dev, rec, (float4 *)h->fr_ev_host_dev,
+        k_frame_rows_to_host<<<256, 256, 0, q>>>((const float4 *)events_dev, rec, (float4 *)(user_rows ? user_rows_dev : h->fr_ev_host_dev),
                                                  (v2e_frame_rec *)h->fr_rec_host_dev, 0ull, 0ull, &sc->est_rows);
         return 0;
     };
     // measured (346x260, 35 k events a frame): replayed as a graph the host spends 10 us instead of 19 us enqueueing, but the
     // graph's start latency leaves the frame's wall time where it was (56 vs 53 us): plain launches unless asked
-    static const bool use_graph = getenv("V2E_AMD_FRAME_GRAPH") && atoi(getenv("V2E_AMD_FRAME_GRAPH")) != 0;
     if (use_graph) {
         std::vector<unsigned char> key;
         auto push = [&key](const void *ptr, size_t n) { const unsigned char *b = (const unsigned char *)ptr; key.insert(key.end(), b, b + n); };
@@ -1413,6 +1422,32 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
     const uint64_t n = rh->n_events;
     out8[0] = (uint32_t)n; out8[1] = rh->n_on; out8[2] = rh->n_off; out8[3] = rh->n_signal;
     h->fr_est = n + n / 4 + 256;
+    if (user_rows && n > user_cap) { // the caller's buffer cannot hold the frame: all rows into the handle's own
+        if (n > h->fr_ev_cap) {
+            if (h->fr_ev_host) V2E_HIP(hipHostFree(h->fr_ev_host));
+            h->fr_ev_host = nullptr; h->fr_ev_cap = 0;
+            const uint64_t want = std::max<uint64_t>(2 * n, 1u << 16);
+            V2E_HIP(hipHostMalloc((void **)&h->fr_ev_host, sizeof(float) * 4 * want, hipHostMallocMapped));
+            V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_ev_host_dev, h->fr_ev_host, 0));
+            h->fr_ev_cap = want;
+        }
+        k_frame_rows_to_host<<<(unsigned)std::min<uint64_t>(v2e_cdiv((int64_t)n, 256), 4096), 256, 0, s>>>(
+            (const float4 *)events_dev, rec, (float4 *)h->fr_ev_host_dev, nullptr, 0ull, n, nullptr);
+        V2E_HIP(hipGetLastError());
+        V2E_HIP(hipStreamSynchronize(s));
+        *events_host = h->fr_ev_host;
+        return 0;
+    }
+    if (user_rows) {
+        if (n > est) {
+            k_frame_rows_to_host<<<(unsigned)std::min<uint64_t>(v2e_cdiv((int64_t)(n - est), 256), 4096), 256, 0, s>>>(
+                (const float4 *)events_dev, rec, (float4 *)user_rows_dev, nullptr, est, n - est, nullptr);
+            V2E_HIP(hipGetLastError());
+            V2E_HIP(hipStreamSynchronize(s));
+        }
+        if (n > 0) *events_host = user_rows;
+        return 0;
+    }
     if (n > est) { // the estimate was short: the rest of the rows
         if (n > h->fr_ev_cap) {
             float *grown = nullptr;
@@ -1429,6 +1464,18 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
         V2E_HIP(hipStreamSynchronize(s));
     }
     if (n > 0) *events_host = h->fr_ev_host;
+    return 0;
+}
+
+int v2e_emu_frame_host_rows(v2e_emu *h, float *pinned_rows, uint64_t cap_rows)
+{
+    V2E_REQUIRE(h, "null");
+    h->fr_user_rows = h->fr_user_rows_dev = nullptr; h->fr_user_cap = 0;
+    if (!pinned_rows || cap_rows == 0) return 0;
+    V2E_HIP(hipSetDevice(h->device));
+    void *dev = nullptr;
+    V2E_HIP(hipHostGetDevicePointer(&dev, pinned_rows, 0)); // fails for memory that is not pinned (hipHostMalloc / hipHostRegister)
+    h->fr_user_rows = pinned_rows; h->fr_user_rows_dev = (float *)dev; h->fr_user_cap = cap_rows;
     return 0;
 }
 

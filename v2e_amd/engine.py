@@ -6,6 +6,7 @@ advances `n_clips` independent pixel arrays in lock-step; the drop-in
 `EventEmulator` (v2e_amd/emulator.py) uses n_clips = 1.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -14,6 +15,59 @@ from . import _capi
 from ._capi import EmuParams, FrameRec, check
 
 _DT = {torch.uint8: _capi.DT_U8, torch.float32: _capi.DT_F32, torch.float64: _capi.DT_F64}
+
+
+class _RowsOwner:
+    """What a result array of the frame API hangs on: exposes a pinned buffer's first n rows through the array interface
+    and keeps the buffer out of the pool until the array AND every view derived from it are gone (numpy makes derived views
+    hold the first array, which holds this object)."""
+    __slots__ = ("__array_interface__", "buf", "__weakref__")
+
+    def __init__(self, buf, n):
+        self.buf = buf
+        self.__array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (buf.ptr, False), "version": 3}
+
+
+class _RowsBuf:
+    __slots__ = ("tensor", "ptr", "cap", "free")
+
+    def __init__(self, cap):
+        self.tensor = torch.empty((cap, 4), dtype=torch.float32, pin_memory=True)
+        self.ptr, self.cap, self.free = self.tensor.data_ptr(), cap, True
+
+
+class _RowsPool:
+    """Pinned host buffers the frame API's last kernel writes the event rows into, handed out AS the result arrays
+    (`generate_events` returns a fresh array the caller owns: here one whose memory returns to the pool when the caller drops
+    it).  A caller that keeps its arrays makes the pool grow to MAX_BUFS buffers; beyond that, and for frames larger than a
+    buffer, the rows are copied into an ordinary array as before."""
+    MAX_BUFS = 64
+    MIN_ROWS = 1 << 16  # 1 MB
+
+    def __init__(self):
+        self.bufs = []
+
+    def acquire(self, est_rows):
+        want = max(self.MIN_ROWS, 1 << int(2 * est_rows).bit_length())
+        for b in self.bufs:
+            if b.free and b.cap >= want // 2:
+                b.free = False
+                return b
+        if len(self.bufs) >= self.MAX_BUFS:
+            return None
+        b = _RowsBuf(want)
+        b.free = False
+        self.bufs.append(b)
+        return b
+
+    @staticmethod
+    def release(buf):
+        buf.free = True
+
+    def hand_out(self, buf, n):
+        owner = _RowsOwner(buf, n)
+        weakref.finalize(owner, _RowsPool.release, buf)
+        return np.asarray(owner)
 
 
 def _ptr(t):
@@ -215,16 +269,33 @@ class EmuEngine:
             raise ValueError("frame has %d elements, expected %d x %d" % (n_el, self.H, self.W))
         out8 = (C.c_uint32 * 8)()
         rows = C.POINTER(C.c_float)()
+        # the rows land in a pinned buffer of ours that becomes the result array itself (no host copy); see _RowsPool
+        pool = self.__dict__.get("_rows_pool")
+        if pool is None:
+            pool = self._rows_pool = _RowsPool()
+        buf = pool.acquire(self.__dict__.get("_rows_est", 0))
+        if buf is not None:
+            check(self.lib.v2e_emu_frame_host_rows(self._h, C.c_void_p(buf.ptr), buf.cap), "v2e_emu_frame_host_rows")
         rc = self.lib.v2e_emu_frame(self._h, C.byref(P), fp, on_host, dt, float(t_prev), float(t_frame), int(frame_idx),
                                     _ptr(events), int(events.shape[1]), out8, C.byref(rows), self.stream)
         if rc < 0:
+            if buf is not None:
+                pool.release(buf)
             check(rc, "v2e_emu_frame")
         ev = None
-        if rc == 0 and out8[0] > 0:
-            # the pinned rows are reused by the next call (memmove, not ctypeslib.as_array: that builds a ctypes array
-            # type per distinct row count, ~100 us a frame)
-            ev = np.empty((int(out8[0]), 4), dtype=np.float32)
-            C.memmove(ev.ctypes.data, rows, 16 * int(out8[0]))
+        n = int(out8[0])
+        if rc == 0 and n > 0:
+            self._rows_est = n + n // 4 + 256
+            if buf is not None and C.cast(rows, C.c_void_p).value == buf.ptr:
+                ev = pool.hand_out(buf, n)
+                buf = None
+            else:
+                # the handle's own pinned rows are reused by the next call (memmove, not ctypeslib.as_array: that builds a
+                # ctypes array type per distinct row count, ~100 us a frame)
+                ev = np.empty((n, 4), dtype=np.float32)
+                C.memmove(ev.ctypes.data, rows, 16 * n)
+        if buf is not None:
+            pool.release(buf)
         return rc, out8, ev
 
     def run(self, P, frames_dev, t_prev, t_frame, frame_idx0, events, recs_dev, use_graph=True):
