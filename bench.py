@@ -344,9 +344,15 @@ def main():
         n_step = max(prof.get("step_launches", 0), 1)
         period_us = elapsed / K / n_step * 1e6     # the driver-timed region: one step = n_step chain launches
         kernel_us = prof["rank"] / n_step * 1e3    # HIP events before and after every chain launch, on its stream: the kernels alone
-        step_bytes = bpp * npx * fpl               # 53 B per pixel and frame x the frames one launch advances
+        # 53 B per pixel and frame x the frames a launch advances ON AVERAGE: a step's launches are full ones (fpl
+        # frames), one partial one and the tail launch that only validates, and all of them are in the average duration
+        step_bytes = bpp * npx * F / n_step
+        full_bytes = bpp * npx * fpl
         emit_bytes = 16 * ev_per_frame + 4 * npx
         ach = step_bytes / (kernel_us * 1e-6)
+        per_launch = prof.get("chain_launch_us", [])
+        full = sorted(per_launch[:F // fpl])       # the launches that advance fpl frames (the partial and the tail one excluded)
+        p50 = full[len(full) // 2] if full else None
         whole = (bpp * npx + 16 * ev_per_frame)
         prof_file = "profiles/r03_emulator_pmc_hbm.txt"
         out["roofline"] = {
@@ -357,7 +363,14 @@ def main():
             "traffic_source": prof_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; counters cannot be read "
                                           "from inside the process)",
             "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
+            "frames_per_launch_avg": round(F / n_step, 2),
             "avg_kernel_us": round(kernel_us, 3), "launches_timed": n_step,
+            "launch_us": [round(u, 1) for u in per_launch],
+            "median_full_launch": None if p50 is None else {
+                "us": round(p50, 3), "bytes": int(full_bytes), "achieved_GBps": round(full_bytes / (p50 * 1e-6) / 1e9, 2),
+                "frac": round(full_bytes / (p50 * 1e-6) / HBM_PEAK, 5),
+                "note": "the median of the launches that advance %d frames: a launch WITHOUT a redo pass (the average above "
+                        "includes the launches that first redo their predecessor, the partial last launch and the tail launch)" % fpl},
             "launch_period_us": round(period_us, 3),
             "as_delivered": {"achieved_GBps": round(step_bytes / (period_us * 1e-6) / 1e9, 2),
                              "frac": round(step_bytes / (period_us * 1e-6) / HBM_PEAK, 5),
@@ -371,9 +384,10 @@ def main():
             "whole_step": {"algorithmic_bytes_per_frame": int(whole),
                            "achieved_GBps": round(whole * K * F / elapsed / 1e9, 2),
                            "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
-            "note": "achieved = algorithmic bytes of the frames a chain launch advances / the launch's own duration, HIP events "
-                    "before and after every launch of an instrumented re-run of the last step's frames (all kernels of the run on the "
-                    "one stream, i.e. each running alone, which is also how the captured graph of the timed runs executes on this runtime); "
+            "note": "achieved = algorithmic bytes (53 B x pixels x the step's frames / the step's chain launches: what a launch advances "
+                    "on average) / the launches' average duration, HIP events before and after every launch of an instrumented re-run "
+                    "of the last step's frames with all kernels of the run on ONE stream, i.e. each running alone (in the timed runs "
+                    "the three streams overlap and every kernel is stretched: profiles/r03_graph_scheduling.txt); "
                     "the per-pixel state (2.9 MB at 346x260) stays in registers for the launch's frames and one frame is only "
                     "1408 waves, so the chain is bounded by instruction latency, not HBM (DESIGN.md section 3); whole_step prices "
                     "the complete frame (state traffic + event rows) against the driver-timed region",

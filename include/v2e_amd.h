@@ -261,6 +261,9 @@ int v2e_emu_chain_plan(int n_frames, int frames_per_launch, int frames_per_batch
 /* Emission batches timed by the last instrumented run, the frames per emission batch, and the
  * number of chain launches ms_count covers (step_launches may be NULL). */
 int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_batch, int *step_launches);
+/* The chain launches of the last instrumented run one by one, in launch order (microseconds; the last one is the tail launch
+ * that only validates): *n = how many there were, the first min(cap, *n) written to us (may be NULL). */
+int v2e_emu_last_profile_launches(v2e_emu *h, float *us, int cap, int *n);
 
 /* Which pipeline the last v2e_emu_run on this handle used: kind 0 = unfused count/rank/scan/emit, 3 = k_chain (K frames
  * per launch, state in registers; records from k_ahead), 4 = k_chain with the per-frame records built inside the chain;

@@ -13,6 +13,8 @@ and scalar tail of the backend differ).  Hence:
   philox_csdvs_346x260.npz          DAVIS346, float64 state (cutoff 300 Hz), Philox source: event digests per frame, final
                                     planes' digests, surround digest, steps per frame -- to be matched BIT FOR BIT
   philox_csdvs_f32_346x260.npz      the same with float32 state (no cutoff)
+  tape_live_csdvs_346x260.npz       DAVIS346, float64 state, the reference's own seeded torch generator (tape mode, the drop-in's
+                                    default): digests as make_golden_tape_live.py stores them + surround digest + steps
   philox_csdvs_97x131.npz           a size where the backend's order differs: events and planes stored; the tests bound the
                                     surround plane by 1e-5 and the event count by 1 %
 """
@@ -103,6 +105,8 @@ def main():
     mg.make_philox_fixture("philox_csdvs_346x260", fr, ts, kw, seed=21, frame_spec=spec)
     kw32 = dict(kw); kw32["cutoff_hz"] = 0; kw32["shot_noise_rate_hz"] = 0.0
     mg.make_philox_fixture("philox_csdvs_f32_346x260", fr, ts, kw32, seed=22, frame_spec=spec)
+    import make_golden_tape_live as tl
+    tl.make("tape_live_csdvs_346x260", fr, ts, kw, seed=45, frame_spec=spec)  # the reference's own MT19937 stream (the drop-in's default mode)
     fr = int_gradient_frames(8, 97, 131, seed=42, noise=6)
     mg.make_philox_fixture("philox_csdvs_97x131", fr, [i / 300 for i in range(8)], kw, seed=23, store_frames=True, store_events=True)
 

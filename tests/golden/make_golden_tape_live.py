@@ -72,6 +72,9 @@ def make(name, frames, times, kw, preset=None, seed=42, frame_spec=None):
     }
     if getattr(ref, "timestamp_mem", None) is not None and ref.refractory_period_s > 0:
         out["ts_mem_sha"] = mg.sha(ref.timestamp_mem.numpy())
+    if getattr(ref, "csdvs_enabled", False):
+        out["cs_surround_sha"] = mg.sha(ref.cs_surround_frame.numpy())
+        out["cs_steps"] = np.asarray(ref.cs_steps_taken, np.int64)
     if frame_spec is None:
         out["frames"] = np.stack(frames)
     path = os.path.join(HERE, name + ".npz")

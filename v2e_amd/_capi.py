@@ -101,6 +101,7 @@ SIGNATURES = {
                                   C.POINTER(_i)]),
     "v2e_emu_chain_plan": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i]),
     "v2e_emu_last_profile_pipe": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "v2e_emu_last_profile_launches": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "v2e_emu_last_pipeline": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "v2e_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_pack_conv_weight_s3": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -832,6 +832,7 @@ struct v2e_emu {
     int n_cu = 256;
     double prof_ms[4] = {0, 0, 0, 0}; // count, rank, scan, emit (use_graph == 2)
     int prof_launches = 0;
+    std::vector<float> prof_chain_us; // the chain launches of the last instrumented run, one by one
     int prof_emit_batches = 0, prof_step_launches = 0;
     unsigned long long *run_off = nullptr; // [run_off_cap][n_clips] event offset at the start of every emission batch of the run
     int run_off_cap = 0;
@@ -2050,9 +2051,11 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
             float ms = 0.f;
             V2E_HIP(hipEventElapsedTime(&ms, em.front(), em.back()));
             h->prof_ms[0] = ms; // first launch's start to last launch's end: the chain's launch-to-launch period x launches
+            h->prof_chain_us.clear();
             for (size_t i = 0; i + 1 < em.size(); i += 2) { // the kernels alone
                 V2E_HIP(hipEventElapsedTime(&ms, em[i], em[i + 1]));
                 h->prof_ms[1] += ms;
+                h->prof_chain_us.push_back(ms * 1e3f);
             }
             h->prof_step_launches = (int)(em.size() / 2);
             for (size_t i = 0; i + 1 < es.size(); i += 2) {
@@ -2189,6 +2192,14 @@ int v2e_emu_last_pipeline(v2e_emu *h, int *kind, int *frames_per_launch, int *fr
 {
     V2E_REQUIRE(h && kind && frames_per_launch && frames_per_batch, "null");
     *kind = h->last_kind; *frames_per_launch = h->last_fpl; *frames_per_batch = h->last_fpb;
+    return 0;
+}
+
+int v2e_emu_last_profile_launches(v2e_emu *h, float *us, int cap, int *n)
+{
+    V2E_REQUIRE(h && n, "null");
+    *n = (int)h->prof_chain_us.size();
+    for (int i = 0; us && i < cap && i < *n; ++i) us[i] = h->prof_chain_us[i];
     return 0;
 }
 

@@ -317,8 +317,12 @@ class EmuEngine:
         check(self.lib.v2e_emu_last_profile(self._h, *[C.byref(x) for x in v], C.byref(n)), "v2e_emu_last_profile")
         nb, fpb, nsl = C.c_int(), C.c_int(), C.c_int()
         check(self.lib.v2e_emu_last_profile_pipe(self._h, C.byref(nb), C.byref(fpb), C.byref(nsl)), "v2e_emu_last_profile_pipe")
+        nl = C.c_int()
+        us = (C.c_float * 4096)()
+        check(self.lib.v2e_emu_last_profile_launches(self._h, us, 4096, C.byref(nl)), "v2e_emu_last_profile_launches")
         return dict(count=v[0].value, rank=v[1].value, scan=v[2].value, emit=v[3].value, launches=n.value,
-                    emit_batches=nb.value, frames_per_batch=fpb.value, step_launches=nsl.value)
+                    emit_batches=nb.value, frames_per_batch=fpb.value, step_launches=nsl.value,
+                    chain_launch_us=[float(us[i]) for i in range(min(nl.value, 4096))])
 
     def last_pipeline(self):
         """(kind, frames per chain launch, frames per emission batch) of the last run(); see v2e_emu_last_pipeline."""
