@@ -2162,6 +2162,20 @@ int v2e_emu_debug_timeline(v2e_emu *h, unsigned long long *out_host /* [ngroups]
     return 0;
 }
 
+// dev tool (not part of the public header; scripts/chain_rounds.py): the rule-on rows of the last run's chain launches,
+// [launches][K + 1 rows][n_clips][K] -- row 0 what a launch's own pass flagged, row r what the r-th redo pass on it flagged
+int v2e_emu_debug_chain_rows(v2e_emu *h, uint32_t *out, size_t cap_words, int *launches, int *K)
+{
+    V2E_REQUIRE(h && launches && K, "null");
+    *launches = h->ch_launch_cap; *K = h->ch_K;
+    if (!h->ch_gM || !out) return 0;
+    V2E_HIP(hipSetDevice(h->device));
+    V2E_HIP(hipDeviceSynchronize());
+    const size_t n = (size_t)h->ch_launch_cap * (h->ch_K + 1) * h->n_clips * h->ch_K;
+    V2E_HIP(hipMemcpy(out, h->ch_gM, sizeof(uint32_t) * std::min(n, cap_words), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int v2e_emu_last_profile(v2e_emu *h, double *ms_count, double *ms_rank, double *ms_scan, double *ms_emit, int *launches)
 {
     V2E_REQUIRE(h && ms_count && ms_rank && ms_scan && ms_emit && launches, "null");
