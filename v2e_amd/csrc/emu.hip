@@ -353,18 +353,25 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
                                                  const FrameCtl *__restrict__ ctl,
                                                  const uint32_t *__restrict__ fidx_base, uint32_t fidx_off,
                                                  const float *__restrict__ leak_tape,
-                                                 const float *__restrict__ shot_tape, v2e_frame_rec *rec)
+                                                 const float *__restrict__ shot_tape, v2e_frame_rec *rec,
+                                                 const FrameCtl *__restrict__ ctl_host, FrameCtl *ctl_copy,
+                                                 double t_prev_v, double t_frame_v)
 {
     __shared__ int smax[BLOCK / WAVE];
     const int clip = blockIdx.y;
     const int p = blockIdx.x * BLOCK + threadIdx.x;
-    const FrameCtl c = ctl[clip];
+    // ctl == nullptr (v2e_emu_frame): the frame's times arrive by value, and workgroup 0 copies the frame's scalars from pinned
+    // host memory (ctl_host) to device memory (ctl_copy) for the kernels behind this one -- no launch of its own for that
+    double delta_time_v = t_frame_v - t_prev_v;
+    if (ctl) delta_time_v = ctl[clip].t_frame - ctl[clip].t_prev;
+    else if (ctl_host && blockIdx.x == 0 && clip == 0 && threadIdx.x < sizeof(FrameCtl) / 4)
+        ((uint32_t *)ctl_copy)[threadIdx.x] = ((const uint32_t *)ctl_host)[threadIdx.x];
     const uint32_t frame_idx = (fidx_base ? *fidx_base : 0u) + fidx_off;
     int m = 0;
     if (p < a.npx) {
         const size_t sp = (size_t)clip * a.npx_pad + p;
         const size_t fp = (size_t)clip * a.npx + p;
-        const double delta_time = c.t_frame - c.t_prev;
+        const double delta_time = delta_time_v;
         double x = (double)frame[fp];
         const double L = a.log_input ? x : (double)lin_log(x); // emulator.py:666
         double inten01 = a.use_inten ? (x + 20.0) / 275.0 : 0.0;
@@ -707,43 +714,26 @@ __global__ __launch_bounds__(BLOCK) void k_permute(const float4 *__restrict__ in
 // either end (~20 us each on this runtime), more than the whole frame's kernels.  The frame's scalars arrive as a kernel
 // argument, its pixels are read by k_count straight from the pinned staging buffer, and the rows go back by a kernel writing
 // pinned host memory.
-// What changes from frame to frame, in pinned host memory the first kernel reads: the kernels of a frame are then the same
-// launch every time and can be replayed as one hipGraph (V2E_AMD_FRAME_GRAPH=1).
-struct FramePar {
-    FrameCtl ctl;
-    uint32_t frame_idx, pad_;
-    unsigned long long est_rows;
-};
 struct FrameScratch { // device
-    v2e_frame_rec rec;
-    uint32_t frame_idx, pad_;
-    unsigned long long est_rows;
-    FrameCtl ctl;
+    v2e_frame_rec rec[2]; // alternating between calls: a frame's last kernel zeroes the one the next frame counts into
+    FrameCtl ctl;         // the frame's scalars, copied from pinned host memory by k_count's workgroup 0
 };
-
-__global__ void k_frame_begin(const FramePar *__restrict__ par /* host */, FrameScratch *sc)
-{
-    static_assert(sizeof(FrameCtl) % 4 == 0 && sizeof(FrameCtl) / 4 <= 128, "one word per thread");
-    const int t = threadIdx.x;
-    if (t < (int)(sizeof(FrameCtl) / 4)) ((uint32_t *)&sc->ctl)[t] = ((const uint32_t *)&par->ctl)[t];
-    if (t == 127) {
-        v2e_frame_rec z;
-        memset(&z, 0, sizeof(z));
-        sc->rec = z;
-        sc->frame_idx = par->frame_idx;
-        sc->est_rows = par->est_rows;
-    }
-}
 
 // rows [row0, min(n_events, row0 + max_rows)) of the frame to the pinned host buffer, and the frame record with them
 __global__ __launch_bounds__(256) void k_frame_rows_to_host(const float4 *__restrict__ ev, const v2e_frame_rec *__restrict__ rec,
                                                             float4 *__restrict__ out_rows, v2e_frame_rec *__restrict__ out_rec,
                                                             unsigned long long row0, unsigned long long max_rows,
-                                                            const unsigned long long *__restrict__ max_rows_dev)
+                                                            v2e_frame_rec *__restrict__ rec_next)
 {
-    if (max_rows_dev) max_rows = *max_rows_dev;
     const v2e_frame_rec r = *rec;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && out_rec) *out_rec = r;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (out_rec) *out_rec = r;
+        if (rec_next) { // the record the NEXT frame's k_count takes its maximum in (nobody in this launch reads it)
+            v2e_frame_rec z;
+            memset(&z, 0, sizeof(z));
+            *rec_next = z;
+        }
+    }
     if (r.flags & (V2E_FLAG_EVENTS_DROPPED | V2E_FLAG_ITERS_CLAMPED)) return;
     const unsigned long long n = r.n_events < row0 + max_rows ? r.n_events : row0 + max_rows;
     for (unsigned long long i = row0 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256)
@@ -797,9 +787,8 @@ struct v2e_emu {
     // pinned staging of a host frame (read by k_count in place), device scratch [v2e_frame_rec | FrameCtl], pinned record and
     // rows (written by k_frame_rows_to_host); *_dev: the device-side addresses of the pinned buffers
     unsigned char *fr_stage = nullptr, *fr_stage_dev = nullptr, *fr_dev = nullptr, *fr_rec_host_dev = nullptr;
-    unsigned char *fr_par = nullptr, *fr_par_dev = nullptr; // FramePar, pinned
-    hipGraphExec_t fr_graph = nullptr;                      // the frame's kernels, replayed (key: everything baked in)
-    std::vector<unsigned char> fr_graph_key;
+    unsigned char *fr_par = nullptr, *fr_par_dev = nullptr; // the frame's FrameCtl, pinned
+    int fr_flip = 0;                                        // which of the two frame records this call counts into
     float *fr_ev_host_dev = nullptr;
     float *fr_user_rows = nullptr, *fr_user_rows_dev = nullptr; // v2e_emu_frame_host_rows: the next frame's rows go here
     uint64_t fr_user_cap = 0;
@@ -826,7 +815,6 @@ struct v2e_emu {
     {
         for (auto &g : graphs) hipGraphExecDestroy(g.exec);
         graphs.clear();
-        if (fr_graph) { hipGraphExecDestroy(fr_graph); fr_graph = nullptr; }
     }
     unsigned long long *dbg = nullptr; // dev tool (v2e_emu_debug_timeline)
     int n_cu = 256;
@@ -1074,12 +1062,13 @@ static int stage_ctl(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, co
 
 static int launch_count(v2e_emu *h, const KArgs &a, int f64_state, const void *frame, int dtype, const FrameCtl *ctl,
                         const uint32_t *fidx_base, uint32_t fidx_off, const float *leak, const float *shot,
-                        v2e_frame_rec *rec, hipStream_t s)
+                        v2e_frame_rec *rec, hipStream_t s, const FrameCtl *ctl_host = nullptr, FrameCtl *ctl_copy = nullptr,
+                        double t_prev_v = 0.0, double t_frame_v = 0.0)
 {
     dim3 grid(v2e_cdiv(h->npx, BLOCK), h->n_clips);
     DISPATCH_FT(dtype, {
-        if (f64_state) k_count<double, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, fidx_base, fidx_off, leak, shot, rec);
-        else k_count<float, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, fidx_base, fidx_off, leak, shot, rec);
+        if (f64_state) k_count<double, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, fidx_base, fidx_off, leak, shot, rec, ctl_host, ctl_copy, t_prev_v, t_frame_v);
+        else k_count<float, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, fidx_base, fidx_off, leak, shot, rec, ctl_host, ctl_copy, t_prev_v, t_frame_v);
     });
     return 0;
 }
@@ -1298,8 +1287,10 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
     }
     if (!h->fr_dev) {
         V2E_HIP(hipMalloc((void **)&h->fr_dev, sizeof(FrameScratch)));
-        V2E_HIP(hipHostMalloc((void **)&h->fr_par, sizeof(FramePar), hipHostMallocMapped));
+        V2E_HIP(hipMemset(h->fr_dev, 0, sizeof(FrameScratch))); // both records zero: the first frame counts into a clean one
+        V2E_HIP(hipHostMalloc((void **)&h->fr_par, sizeof(FrameCtl), hipHostMallocMapped));
         V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_par_dev, h->fr_par, 0));
+        h->fr_flip = 0;
     }
     if (h->fr_rec_keys != h->nkeys_cap) {
         if (h->fr_rec_host) V2E_HIP(hipHostFree(h->fr_rec_host));
@@ -1317,8 +1308,6 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
     float *user_rows = h->fr_user_rows, *user_rows_dev = h->fr_user_rows_dev;
     const uint64_t user_cap = h->fr_user_cap;
     h->fr_user_rows = h->fr_user_rows_dev = nullptr; h->fr_user_cap = 0;
-    static const bool use_graph = getenv("V2E_AMD_FRAME_GRAPH") && atoi(getenv("V2E_AMD_FRAME_GRAPH")) != 0;
-    if (use_graph) user_rows = nullptr; // (the replayed graph bakes the handle's buffer)
     uint64_t est = std::min<uint64_t>(std::max<uint64_t>(h->fr_est, 1024), cap);
     if (user_rows) est = std::min<uint64_t>(est, user_cap);
     if (!user_rows && est > h->fr_ev_cap) {
@@ -1330,60 +1319,32 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
         V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_ev_host_dev, h->fr_ev_host, 0));
         h->fr_ev_cap = want;
     }
-    FramePar *par = (FramePar *)h->fr_par;
-    par->ctl = make_ctl(t_prev, t_frame, p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
-    par->frame_idx = frame_idx;
-    par->est_rows = est;
-    const FrameCtl ctl_host = par->ctl;
+    // Five launches, no copy engine, no host step between them: the frame's times go to k_count by value, its workgroup 0 copies
+    // the frame's scalars from pinned host memory to the device for the kernels behind it; the record a frame counts into was
+    // zeroed by the frame before (two records alternate); the event writer goes out before the host has seen the totals
+    // (k_emit checks them against cap itself), and with it the copy of the rows the frame is expected to have: one
+    // synchronisation per frame unless the estimate was short.  (Replaying the launches as a hipGraph was measured: the host
+    // spends 10 us instead of 19 us enqueueing, the graph's start latency leaves the frame's wall time where it was.)
+    const FrameCtl ctl_host = make_ctl(t_prev, t_frame, p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
+    *(FrameCtl *)h->fr_par = ctl_host;
     FrameScratch *sc = (FrameScratch *)h->fr_dev;
-    v2e_frame_rec *rec = &sc->rec;
+    v2e_frame_rec *rec = &sc->rec[h->fr_flip], *rec_next = &sc->rec[h->fr_flip ^ 1];
+    h->fr_flip ^= 1;
     FrameCtl *ctl = &sc->ctl;
     KArgs a = make_kargs(h, p);
     a.emit_guard = 1;
     v2e_frame_rec *rh = (v2e_frame_rec *)h->fr_rec_host;
-    // The event writer goes out before the host has seen the totals (k_emit checks them against cap itself), and with it
-    // the copy of the rows the frame is expected to have: one synchronisation per frame unless the estimate was short
-    auto enqueue = [&](hipStream_t q) -> int {
-        k_frame_begin<<<1, 128, 0, q>>>((const FramePar *)h->fr_par_dev, sc);
-        int r = launch_count(h, a, p->f64_state, frame_dev, dtype, ctl, &sc->frame_idx, 0u, nullptr, nullptr, rec, q);
-        if (r) return r;
+    rc = launch_count(h, a, p->f64_state, frame_dev, dtype, nullptr, nullptr, frame_idx, nullptr, nullptr, rec, s,
+                      (const FrameCtl *)h->fr_par_dev, ctl, t_prev, t_frame);
+    if (rc) return rc;
+    {
         dim3 gridw(v2e_cdiv((int64_t)h->nwaves * WAVE, BLOCK), 1);
-        k_rank<<<gridw, BLOCK, 0, q>>>(a, ctl, rec, nullptr, 0);
-        k_scan<<<dim3(SCAN_BLOCKS, 1), BLOCK, 0, q>>>(a, rec);
-        if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, q>>>(a, ctl, rec, nullptr, h->off_zero, &sc->frame_idx, 0u, nullptr, 0, (float4 *)events_dev, cap);
-        else k_emit<float><<<gridw, BLOCK, 0, q>>>(a, ctl, rec, nullptr, h->off_zero, &sc->frame_idx, 0u, nullptr, 0, (float4 *)events_dev, cap);
-        k_frame_rows_to_host<<<256, 256, 0, q>>>((const float4 *)events_dev, rec, (float4 *)(user_rows ? user_rows_dev : h->fr_ev_host_dev),
-                                                 (v2e_frame_rec *)h->fr_rec_host_dev, 0ull, 0ull, &sc->est_rows);
-        return 0;
-    };
-    // measured (346x260, 35 k events a frame): replayed as a graph the host spends 10 us instead of 19 us enqueueing, but the
-    // graph's start latency leaves the frame's wall time where it was (56 vs 53 us): plain launches unless asked
-    if (use_graph) {
-        std::vector<unsigned char> key;
-        auto push = [&key](const void *ptr, size_t n) { const unsigned char *b = (const unsigned char *)ptr; key.insert(key.end(), b, b + n); };
-        int f64 = p->f64_state;
-        push(&a, sizeof(a)); push(&frame_dev, sizeof(frame_dev)); push(&dtype, sizeof(dtype)); push(&f64, sizeof(f64));
-        push(&events_dev, sizeof(events_dev)); push(&cap, sizeof(cap)); push(&h->fr_ev_host_dev, sizeof(void *));
-        push(&h->fr_rec_host_dev, sizeof(void *)); push(&h->fr_dev, sizeof(void *)); push(&h->fr_par_dev, sizeof(void *));
-        if (!h->fr_graph || key != h->fr_graph_key) {
-            if (h->fr_graph) { hipGraphExecDestroy(h->fr_graph); h->fr_graph = nullptr; }
-            hipStream_t cs;
-            hipGraph_t g = nullptr;
-            V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-            V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            rc = enqueue(cs);
-            hipError_t e = hipStreamEndCapture(cs, &g);
-            hipStreamDestroy(cs);
-            if (rc) { if (g) hipGraphDestroy(g); return rc; }
-            V2E_HIP(e);
-            V2E_HIP(hipGraphInstantiate(&h->fr_graph, g, nullptr, nullptr, 0));
-            V2E_HIP(hipGraphDestroy(g));
-            h->fr_graph_key = key;
-        }
-        V2E_HIP(hipGraphLaunch(h->fr_graph, s));
-    } else {
-        rc = enqueue(s);
-        if (rc) return rc;
+        k_rank<<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, 0);
+        k_scan<<<dim3(SCAN_BLOCKS, 1), BLOCK, 0, s>>>(a, rec);
+        if (p->f64_state) k_emit<double><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
+        else k_emit<float><<<gridw, BLOCK, 0, s>>>(a, ctl, rec, nullptr, h->off_zero, nullptr, frame_idx, nullptr, 0, (float4 *)events_dev, cap);
+        k_frame_rows_to_host<<<256, 256, 0, s>>>((const float4 *)events_dev, rec, (float4 *)(user_rows ? user_rows_dev : h->fr_ev_host_dev),
+                                                 (v2e_frame_rec *)h->fr_rec_host_dev, 0ull, est, rec_next);
     }
     V2E_HIP(hipGetLastError());
     static const bool timing = getenv("V2E_AMD_FRAME_TIMING") != nullptr; // dev: where a frame's host time goes

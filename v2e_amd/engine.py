@@ -70,6 +70,12 @@ class _RowsPool:
         return np.asarray(owner)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+if _raw_stream is None:  # older / other torch builds
+    def _raw_stream(idx):
+        return torch.cuda.current_stream(idx).cuda_stream
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -103,6 +109,9 @@ class EmuEngine:
         self.lp = self.base = self.ts_mem = self.pos_thres = self.neg_thres = self.noise_rate = None
         self._events = None
         self._events_tmp = None
+        self._dev_index = self.device.index
+        self._rows_pool = _RowsPool()  # pinned result arrays of the frame API
+        self._rows_est = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -117,7 +126,8 @@ class EmuEngine:
 
     @property
     def stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # (the raw-handle call: torch.cuda.current_stream() builds a Stream object, 2 us a call on the frame API's path)
+        return C.c_void_p(_raw_stream(self._dev_index))
 
     # ------------------------------------------------------------ state
     def alloc_state(self, f64_state):
@@ -270,10 +280,8 @@ class EmuEngine:
         out8 = (C.c_uint32 * 8)()
         rows = C.POINTER(C.c_float)()
         # the rows land in a pinned buffer of ours that becomes the result array itself (no host copy); see _RowsPool
-        pool = self.__dict__.get("_rows_pool")
-        if pool is None:
-            pool = self._rows_pool = _RowsPool()
-        buf = pool.acquire(self.__dict__.get("_rows_est", 0))
+        pool = self._rows_pool
+        buf = pool.acquire(self._rows_est)
         if buf is not None:
             check(self.lib.v2e_emu_frame_host_rows(self._h, C.c_void_p(buf.ptr), buf.cap), "v2e_emu_frame_host_rows")
         rc = self.lib.v2e_emu_frame(self._h, C.byref(P), fp, on_host, dt, float(t_prev), float(t_frame), int(frame_idx),
