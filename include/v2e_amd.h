@@ -277,8 +277,9 @@ typedef struct v2e_conv_desc {
     const float *weight; /* device, pre-packed [Cin][k][k][Cout] (v2e_pack_conv_weight) */
     const float *bias;   /* device [Cout] */
     int32_t cin, cout, ksize;
-    int32_t pad_;
-    const void *weight_s3; /* device, split-bf16 weights (v2e_pack_conv_weight_s3) or NULL: f32-MFMA kernel only */
+    int32_t split_kind;  /* what weight_s3 holds: 0 three bf16 pieces (v2e_pack_conv_weight_s3); 2 | (scale_log2 << 8): two float16
+                          * pieces of the weights times 2^scale_log2 (v2e_pack_conv_weight_h2) */
+    const void *weight_s3; /* device, split weights or NULL: f32-MFMA kernel only */
 } v2e_conv_desc;
 
 /* repack torch [Cout][Cin][k][k] -> [Cin][k][k][Cout] on device */
@@ -291,6 +292,12 @@ int v2e_pack_conv_weight(const float *w_oihw, float *w_packed, int cout, int cin
  * is padded with zero weights): w_s3 must hold ceil(cin/16)*16 * k*k * cout * 6 bytes.
  */
 int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, int k, void *stream);
+/* The same with TWO float16 pieces (w = h0 + h1 + r, |r| <= 2^-22 |w|) for the three-product convolution (conv_math "fp16x2":
+ * half the matrix-core work, a product good to ~2^-21; v2e_amd/csrc/slomo_s3.h): [ceil(Cin/16)][k*k][2][2][Cout][8 f16] =
+ * 4 bytes per weight of the padded tensor.  The weights are split times 2^scale_log2 (choose it so that the layer's largest
+ * |w| 2^scale_log2 is below 2^14: nothing overflows float16 and no weight piece falls into its subnormal range); the
+ * convolution divides it out again exactly.  Set v2e_conv_desc.split_kind = 2 | (scale_log2 << 8) with it. */
+int v2e_pack_conv_weight_h2(const float *w_oihw, void *w_h2, int cout, int cin, int k, int scale_log2, void *stream);
 
 /* activations in the same split form: x [n][c][h][w] f32 -> xs [3 pieces][n][c/8][h][w][8 bf16] (6 bytes per element;
  * c a multiple of 8).  A convolution takes such an input with pre = 3 (3x3 layers with split weights). */

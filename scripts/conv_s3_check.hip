@@ -38,7 +38,7 @@ static int run_case(const Case &c, int reps)
     CV(v2e_pack_conv_weight_s3(dw, dw3, c.cout, c.cin, c.ks, nullptr));
     CK(hipDeviceSynchronize());
     v2e_conv_desc d;
-    d.weight = dwp; d.bias = db; d.cin = c.cin; d.cout = c.cout; d.ksize = c.ks; d.pad_ = 0;
+    d.weight = dwp; d.bias = db; d.cin = c.cin; d.cout = c.cout; d.ksize = c.ks; d.split_kind = 0;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms[3] = {0, 0, 0};

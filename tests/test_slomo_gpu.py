@@ -185,7 +185,8 @@ def test_conv_layer_matches_oracle(case, oracle_lib):
     assert relerr(y, ref) < TOL
 
 
-CONV_MATHS = ("bf16x3", "f32")  # the default (split-bf16 on the bf16 matrix cores) and the f32 matrix-core kernels
+# the default (three bf16 pieces on the bf16 matrix cores), the f32 matrix-core kernels, and the opt-in two-float16-piece mode
+CONV_MATHS = ("bf16x3", "f32", "fp16x2")
 
 
 def _engine(seed_f=101, seed_i=102, conv_math=None):
@@ -257,7 +258,7 @@ def test_interpolation_within_reference_float32_noise(conv_math, fixture):
     reference's own float32 distance (rms and max), bounded by what was measured (test_slomo_oracle_golden.GPU_NOISE_FACTOR:
     1.2 .. 1.5 in rms with the heads scaled, 3.1 .. 3.8 with every layer scaled -- both conv maths alike, so the split-bf16
     operands are not what it comes from), and by 1e-5 of the tensor's scale for the networks' outputs."""
-    from test_slomo_oracle_golden import GPU_NOISE_FACTOR, _scaled_state_dicts, noise_ratio, noise_ratio_rms
+    from test_slomo_oracle_golden import GPU_NOISE_FACTOR, GPU_NOISE_FACTOR_FP16X2, _scaled_state_dicts, noise_ratio, noise_ratio_rms
     from v2e_amd.slomo import SloMoEngine
     z = np.load(os.path.join(GOLDEN, fixture + ".npz"))
     I0, I1 = _pairs(z)
@@ -270,7 +271,7 @@ def test_interpolation_within_reference_float32_noise(conv_math, fixture):
            "Ft": Ft}
     r = {k: (round(noise_ratio_rms(v, z, k), 3), round(noise_ratio(v, z, k), 3)) for k, v in got.items()}
     print("noise ratios (rms, max) %s %s: %s" % (fixture, conv_math, r))
-    b_rms, b_max = GPU_NOISE_FACTOR[fixture]
+    b_rms, b_max = GPU_NOISE_FACTOR[fixture] if conv_math != "fp16x2" else GPU_NOISE_FACTOR_FP16X2[fixture]
     assert max(v[0] for v in r.values()) <= b_rms and max(v[1] for v in r.values()) <= b_max, r
     for k in ("flow", "intrp"):  # the networks' outputs: within 1e-5 of the tensor's scale of the exact result
         assert np.max(np.abs(got[k].astype(np.float64) - z[k + "_f64"])) <= 1e-5 * np.max(np.abs(z[k + "_f64"])), k

@@ -44,6 +44,10 @@ REF_NOISE_FACTOR = 1.5      # the oracle: max|ours - f64| <= 1.5 max|ref_f32 - f
 # (deterministic by design; oneDNN sums in vector lanes / blocks), not the split-bf16 operands' dropped products.  In units
 # of the tensors' scale that is 5.5e-6 (flow, 12.8 px) and 5.2e-6 (interpolation net outputs, 133): inside 1e-5.
 GPU_NOISE_FACTOR = {"slomo_trained_scale_64x96": (2.0, 3.0), "slomo_allscale_64x96": (4.5, 4.5)}  # (rms, max) bounds
+# conv_math "fp16x2" (two float16 pieces, three products: operands good to 2^-22, weights lifted out of float16's subnormal
+# range by an exact power of two): measured 1.10 .. 1.23 / 2.86 .. 3.21 in rms (profiles/r03_slomo_precision.txt) -- the same
+# bounds hold
+GPU_NOISE_FACTOR_FP16X2 = dict(GPU_NOISE_FACTOR)
 
 
 def load_pairs(z):

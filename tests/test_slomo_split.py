@@ -106,3 +106,48 @@ def test_pack_kernel_writes_the_numpy_pieces():
         hi = (pieces[p].view(np.uint32) >> 16).astype(np.uint16)          # [co][ci][ky][kx]
         want = hi.reshape(cout, cin // 16, 2, 8, k * k).transpose(1, 4, 2, 0, 3)  # [chunk][tap][ci/8][co][8]
         assert np.array_equal(got[:, :, p], want), "piece %d" % p
+
+
+# ---- the two-piece float16 split of conv_math "fp16x2" (slomo_s3.h: split2_pair, k_pack_weight_s3<2>)
+def split2(x):
+    x = np.asarray(x, np.float32)
+    h0 = x.astype(np.float16).astype(np.float32)          # round to nearest even, like v_cvt_f16_f32
+    h1 = (x - h0).astype(np.float32).astype(np.float16).astype(np.float32)
+    return h0, h1
+
+
+def test_two_float16_pieces_leave_2_pow_minus_22_in_the_normal_range():
+    rng = np.random.Generator(np.random.PCG64(4))
+    mant = rng.integers(0, 1 << 23, size=200_000, dtype=np.uint32)
+    exp = rng.integers(127 - 3, 127 + 15, size=200_000, dtype=np.uint32)  # 0.125 .. 32768: h1 is a normal float16 too
+    x = ((rng.integers(0, 2, size=200_000, dtype=np.uint32) << 31) | (exp << 23) | mant).view(np.float32)
+    h0, h1 = split2(x)
+    r = x.astype(np.float64) - h0.astype(np.float64) - h1.astype(np.float64)
+    assert np.all(np.abs(r) <= np.abs(x.astype(np.float64)) * 2.0 ** -22)
+    # the three kept products against the f32 product: the dropped h1 g1 and the two residual terms
+    w = x[::-1].copy()
+    g0, g1 = split2(w)
+    kept = h0.astype(np.float64) * g0 + h0.astype(np.float64) * g1 + h1.astype(np.float64) * g0
+    exact = x.astype(np.float64) * w.astype(np.float64)
+    assert np.all(np.abs(kept - exact) <= np.abs(exact) * 2.0 ** -20.4)
+    assert np.sqrt(np.mean(((kept - exact) / exact) ** 2)) < 2.0 ** -22.5
+
+
+def test_two_float16_pieces_below_the_normal_range_are_off_by_an_absolute_6e_8():
+    """Where h1 (or h0) is a float16 subnormal the split loses bits: what is left is an ABSOLUTE error of half a subnormal
+    step, 2^-25 -- which is why the weights are packed times a power of two (their pieces then stay normal) and why the
+    activations' share is bounded by 3e-8 |w| per term."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = (rng.standard_normal(200_000) * np.exp(rng.uniform(np.log(1e-7), np.log(0.125), 200_000))).astype(np.float32)
+    h0, h1 = split2(x)
+    r = x.astype(np.float64) - h0.astype(np.float64) - h1.astype(np.float64)
+    assert np.all(np.abs(r) <= 2.0 ** -25 * (1 + 1e-9) + np.abs(x.astype(np.float64)) * 2.0 ** -22)
+
+
+def test_weight_scale_exponent_keeps_pieces_normal_and_finite():
+    """The exponent SloMoEngine passes to v2e_pack_conv_weight_h2: the layer's largest weight lands in [2^12, 2^13)."""
+    import math
+    for wmax in (1e-4, 0.0123, 0.5, 1.0, 3.7, 100.0):
+        sl2 = max(0, min(40, 12 - math.frexp(wmax)[1] + 1))
+        assert 2.0 ** 12 <= wmax * 2.0 ** sl2 < 2.0 ** 13 or sl2 == 0
+        assert np.isfinite(np.float16(wmax * 2.0 ** sl2))

@@ -63,7 +63,7 @@ class ConvDesc(C.Structure):
         ("cin", C.c_int32),
         ("cout", C.c_int32),
         ("ksize", C.c_int32),
-        ("pad_", C.c_int32),
+        ("split_kind", C.c_int32),
         ("weight_s3", C.c_void_p),
     ]
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "v2e_emu_last_pipeline": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "v2e_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_pack_conv_weight_s3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "v2e_pack_conv_weight_h2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "v2e_split3_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "v2e_conv2d_lrelu": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(ConvDesc), _vp, _i, _i, _i, _vp]),
     "v2e_unet_workspace_bytes": (_i64, [_i, _i, _i, _i]),

@@ -36,6 +36,8 @@ struct ConvArgs {
     int ncb;         // slomo_s3.h: channel blocks when the grid is 1-D in XCD order, else 0
     long long xs_plane; // slomo_s3.h, pre-split input: 16-byte units per piece plane (n * C/8 * h * w)
     int tl_on;          // slomo_s3p.h, dev: record workgroup 0's per-step timeline
+    int np;             // pieces the split weights ws3 hold: 3 (bf16) or 2 (float16)
+    float out_scale;    // np == 2: 2^-s, the inverse of the power of two the weights were packed times
 };
 
 // element fetch with the producer op fused: PRE 0 plain, 1 avg_pool2d(2) of a [2H][2W] source,
@@ -618,6 +620,18 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
     // than 64-channel ones at every level (16 samples: 3x3 143-174 vs 121-153 TF/s, 5x5 172-183 vs 146-160)
     static const int variant = getenv("V2E_AMD_S3_VARIANT") ? atoi(getenv("V2E_AMD_S3_VARIANT")) : 0; // dev: tile choice
     const bool c64 = a.cout % 64 == 0 && variant == 6;
+    if (a.np == 2) { // two float16 pieces, three products (conv_math "fp16x2"): the 32 x 64 tiles, two workgroups per CU
+        if (ks == 3) {
+            if (a.w_ % 32 == 0) return launch_conv_s3<3, 1, 2, 4, 32, 1, 0, 0, 2>(a, s);
+            if (a.w_ % 16 == 0) return launch_conv_s3<3, 1, 2, 4, 16, 1, 0, 0, 2>(a, s);
+            if (a.w_ % 8 == 0) return launch_conv_s3<3, 1, 2, 4, 8, 1, 0, 0, 2>(a, s);
+            if (a.w_ % 20 == 0 && a.h % 8 == 0) return launch_conv_s3<3, 1, 1, 5, 20, 1, 0, 0, 2>(a, s);
+            return 1;
+        }
+        if (ks == 5 && a.w_ % 32 == 0) return launch_conv_s3<5, 1, 2, 4, 32, 1, 0, 0, 2>(a, s);
+        if (ks == 7 && a.w_ % 32 == 0) return a.cin % 16 == 0 ? launch_conv_s3<7, 1, 2, 4, 32, 1, 0, 0, 2>(a, s) : launch_conv_s3<7, 1, 2, 4, 32, 1, 1, 0, 2>(a, s);
+        return 1;
+    }
     if (ks == 3) {
         // the software-pipelined one-wave-per-SIMD kernel where the layer has one of its shapes (bit-identical output; 3-6 % less
         // time per layer, 1.5 % per forward: the chip is at its power limit in these kernels -- the shader clock reads 1.63-1.75 GHz
@@ -665,7 +679,17 @@ int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, 
     V2E_REQUIRE(w_oihw && w_s3 && cout > 0 && cin > 0 && k > 0, "bad pack args");
     const size_t total = (size_t)((cin + 15) / 16) * 2 * k * k * cout; // [ceil(cin/16)][k*k][3][2][cout] 16-byte units / 3
 
-    k_pack_weight_s3<<<v2e_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, (uint4 *)w_s3, cout, cin, k * k);
+    k_pack_weight_s3<3><<<v2e_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, (uint4 *)w_s3, cout, cin, k * k);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_pack_conv_weight_h2(const float *w_oihw, void *w_h2, int cout, int cin, int k, int scale_log2, void *stream)
+{
+    V2E_REQUIRE(w_oihw && w_h2 && cout > 0 && cin > 0 && k > 0 && scale_log2 >= 0 && scale_log2 <= 60, "bad pack args");
+    const size_t total = (size_t)((cin + 15) / 16) * 2 * k * k * cout; // one thread per (chunk, tap, channel group, cout): NP units
+    k_pack_weight_s3<2><<<v2e_cdiv((int64_t)total, 256), 256, 0, (hipStream_t)stream>>>(w_oihw, (uint4 *)w_h2, cout, cin, k * k,
+                                                                                        ldexpf(1.0f, scale_log2));
     V2E_HIP(hipGetLastError());
     return 0;
 }
@@ -699,7 +723,8 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
         ConvArgs a;
         a.x0 = x0; a.x1 = nullptr; a.c0 = c0; a.c1 = 0; a.w = conv->weight; a.bias = conv->bias; a.y = y;
         a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout; a.tiles_x = a.tiles_y = 0;
-        a.ws3 = conv->weight_s3; a.xs_plane = (long long)n * (c0 / 8) * h * w;
+        V2E_REQUIRE((conv->split_kind & 0xFF) != 2, "pre-split input is three bf16 pieces");
+        a.ws3 = conv->weight_s3; a.xs_plane = (long long)n * (c0 / 8) * h * w; a.np = 3; a.tl_on = 0; a.out_scale = 1.0f;
         const int r3 = conv_dispatch_s3_presplit(a, conv->ksize, (hipStream_t)stream);
         V2E_REQUIRE(r3 == 0, "no pre-split tile for this layer shape");
         V2E_HIP(hipGetLastError());
@@ -720,6 +745,9 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout;
     a.tiles_x = a.tiles_y = 0;
     a.ws3 = conv->weight_s3;
+    a.np = (conv->split_kind & 0xFF) == 2 ? 2 : 3;
+    a.out_scale = ldexpf(1.0f, -(conv->split_kind >> 8));
+    a.tl_on = 0;
     if (conv->ksize == 3 && pre == 0 && c1 == 0 && (conv->cout == 4 || conv->cout == 5)) {
         const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;
         dim3 grid((unsigned)(n * tiles_x * tiles_y));

@@ -37,8 +37,44 @@ __device__ __forceinline__ void split3_pair(float a, float b, uint32_t &q0, uint
     q2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2));
 }
 
-// weights: torch [Cout][Cin][k][k] f32 -> [Cin/16][k*k][piece][ci/8 (2)][Cout][8 bf16]; one thread per 16-byte unit triple
-__global__ void k_pack_weight_s3(const float *__restrict__ w, uint4 *__restrict__ ws, int cout, int cin, int kk)
+// ---- the same scheme with TWO float16 pieces (NP = 2, conv_math "fp16x2"): x = h0 + h1 + r, h0 = f16(x), h1 = f16(x - h0)
+// (round-to-nearest), |r| <= 2^-22 |x| while both pieces are normal float16 numbers (11 significant bits each; f16 x f16
+// products are exact in f32), and the three products h0 g0, h0 g1, h1 g0 on v_mfma_f32_32x32x16_f16: HALF the multiplies and
+// two thirds of the operand bytes of the three-piece scheme, for a product that is good to ~2^-21 instead of ~2^-24 -- about
+// the size of the float32 rounding noise of a 2 000-term sum itself.  Pieces below the float16 normal range (|x| < 6e-5 for
+// h0, < 0.06 for the h1 of it) lose bits to float16's subnormals: an ABSOLUTE error <= 6e-8 per operand, which is what the
+// 1e-5 max(1, |y|) bar is about.  Measured against the reference and against float64: tests/test_slomo_gpu.py.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2_pair(float a, float b, uint32_t &q0, uint32_t &q1)
+{
+    const f32x2 v0 = {a, b};
+    const f16x2 h0 = __builtin_convertvector(v0, f16x2); // v_cvt_f16_f32 (RNE)
+    q0 = __builtin_bit_cast(uint32_t, h0);
+    const f32x2 v1 = {a - (float)h0[0], b - (float)h0[1]}; // exact
+    q1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, f16x2));
+}
+
+// NP pieces of a pair of f32 values: q[p] = pieces p of (a, b), packed
+template <int NP> __device__ __forceinline__ void split_pair(float a, float b, uint32_t (&q)[NP])
+{
+    if constexpr (NP == 3) split3_pair(a, b, q[0], q[1], q[2]);
+    else split2_pair(a, b, q[0], q[1]);
+}
+
+// one piece product on the matrix cores: 16-byte operand registers as they come from LDS
+template <int NP> __device__ __forceinline__ f32x16 mfma_pieces(u32x4 a, u32x4 b, f32x16 c)
+{
+    if constexpr (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// weights: torch [Cout][Cin][k][k] f32 -> [Cin/16][k*k][piece][ci/8 (2)][Cout][8 x 16 bit]; one thread per 16-byte unit set
+// wscale (NP = 2): an exact power of two that lifts the layer's weights out of float16's subnormal range before they are
+// split (the convolution's epilogue divides it out again, exactly)
+template <int NP>
+__global__ void k_pack_weight_s3(const float *__restrict__ w, uint4 *__restrict__ ws, int cout, int cin, int kk, float wscale = 1.0f)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nchunk = (cin + 15) / 16; // a last partial chunk is padded with zero weights
@@ -51,16 +87,19 @@ __global__ void k_pack_weight_s3(const float *__restrict__ w, uint4 *__restrict_
     const int chunk = (int)(r / kk);
     const int c0 = chunk * 16 + cig * 8;
     const float *src = w + ((size_t)co * cin + c0) * kk + tap;
-    uint32_t q[3][4];
+    uint32_t q[NP][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float w0 = c0 + 2 * e < cin ? src[(size_t)(2 * e) * kk] : 0.f;
-        const float w1 = c0 + 2 * e + 1 < cin ? src[(size_t)(2 * e + 1) * kk] : 0.f;
-        split3_pair(w0, w1, q[0][e], q[1][e], q[2][e]);
-    }
-    const size_t base = ((size_t)chunk * kk + tap) * 6;
+        const float w0 = c0 + 2 * e < cin ? src[(size_t)(2 * e) * kk] * wscale : 0.f;
+        const float w1 = c0 + 2 * e + 1 < cin ? src[(size_t)(2 * e + 1) * kk] * wscale : 0.f;
+        uint32_t qe[NP];
+        split_pair<NP>(w0, w1, qe);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) ws[(base + p * 2 + cig) * cout + co] = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
+        for (int p = 0; p < NP; ++p) q[p][e] = qe[p];
+    }
+    const size_t base = ((size_t)chunk * kk + tap) * 2 * NP;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) ws[(base + p * 2 + cig) * cout + co] = make_uint4(q[p][0], q[p][1], q[p][2], q[p][3]);
 }
 
 // activations: [n][C][h][w] f32 -> [piece][n][C/8][h][w][8 bf16] (C a multiple of 8); one thread per (n, c/8, pixel)
@@ -87,7 +126,7 @@ __global__ __launch_bounds__(256) void k_split3_nchw(const float *__restrict__ x
 // RG (3x3 only): the weights of ONE kernel row resident at a time, as 5x5 / 7x7 do (18 KB instead of 55 KB for a 64-channel
 // tile: 50 KB of LDS in all, so two workgroups of 64-channel tiles share a CU, and a 64 x 64 register tile reads half the LDS
 // bytes per multiply of a 32 x 64 one).
-template <int KS, int CT, int PT, int WP, int TW, int NB, int MODE = 0, int RG = 0>
+template <int KS, int CT, int PT, int WP, int TW, int NB, int MODE = 0, int RG = 0, int NP = 3>
 __global__ __launch_bounds__(WP * 64)
 __attribute__((amdgpu_waves_per_eu(CT * PT * WP <= 5 ? 3 : (CT * PT * WP <= 8 || RG ? 2 : 1), CT * PT * WP <= 5 ? 4 : (CT * PT * WP <= 10 || RG ? 2 : 1))))
 void k_conv_s3(ConvArgs a)
@@ -104,12 +143,13 @@ void k_conv_s3(ConvArgs a)
     constexpr int NG = KK / G;
     constexpr bool ALLTAPS = G == KK;
     constexpr int NPI = (2 * PP + NT - 1) / NT; // patch items per thread; item = 8 channels of one patch pixel
-    constexpr int WU = G * 6 * COT;             // 16-byte weight units per group
+    constexpr int WU = G * 2 * NP * COT;        // 16-byte weight units per group
+    static_assert(NP == 3 || (NP == 2 && MODE != 2), "two-piece float16 operands: no pre-split input");
     constexpr int NWU = (WU + NT - 1) / NT;
     static_assert(NPX % TW == 0, "tile");
     extern __shared__ u32x4 s3_smem[];
-    u32x4 *sp = s3_smem;          // [3][2][PP]
-    u32x4 *sw = s3_smem + 6 * PP; // [G][3][2][COT]
+    u32x4 *sp = s3_smem;               // [NP][2][PP]
+    u32x4 *sw = s3_smem + 2 * NP * PP; // [G][NP][2][COT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hsel = lane >> 5, l31 = lane & 31;
@@ -215,7 +255,7 @@ void k_conv_s3(ConvArgs a)
         }
     };
     auto prefetch_w = [&](int set, int cb, int g) {
-        const u32x4 *wb = wsrc + ((size_t)(cb >> 4) * KK + g * G) * 6 * a.cout;
+        const u32x4 *wb = wsrc + ((size_t)(cb >> 4) * KK + g * G) * 2 * NP * a.cout;
 #pragma unroll
         for (int j = 0; j < NWU; ++j) wv[set][j] = wb[woff[j]];
     };
@@ -232,13 +272,16 @@ void k_conv_s3(ConvArgs a)
             } else if (i < 2 * PP) {
                 const bool ok = pinfo[j] >= 0;
                 const int nv = PADC ? a.cin - cbs - pcig[j] * 8 : 8;
-                uint32_t q[3][4];
+                uint32_t q[NP][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    split3_pair(ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f,
-                                q[0][e], q[1][e], q[2][e]);
+                for (int e = 0; e < 4; ++e) {
+                    uint32_t qe[NP];
+                    split_pair<NP>(ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f, qe);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) sp[p * 2 * PP + i] = u32x4{q[p][0], q[p][1], q[p][2], q[p][3]};
+                    for (int p = 0; p < NP; ++p) q[p][e] = qe[p];
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) sp[p * 2 * PP + i] = u32x4{q[p][0], q[p][1], q[p][2], q[p][3]};
             }
         }
     };
@@ -251,16 +294,16 @@ void k_conv_s3(ConvArgs a)
     };
 
     // NB operand register sets: with 2, tap t+1 is read from LDS before the multiplies of tap t are issued
-    bf16x8 av[NB][3][CT], bv[NB][3][PT];
+    u32x4 av[NB][NP][CT], bv[NB][NP][PT];
     auto load_ops = [&](int t, int buf, int ky0) {
         const int ky = ALLTAPS ? t / KS : 0, kx = ALLTAPS ? t % KS : t;
         const int koff_p = (ky0 + ky) * PW + kx;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) av[buf][p][ct] = __builtin_bit_cast(bf16x8, sw[aofs + (t * 6 + p * 2) * COT + ct * 32]);
+            for (int ct = 0; ct < CT; ++ct) av[buf][p][ct] = sw[aofs + (t * 2 * NP + p * 2) * COT + ct * 32];
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) bv[buf][p][pt] = __builtin_bit_cast(bf16x8, sp[bofs[pt] + p * 2 * PP + koff_p]);
+            for (int pt = 0; pt < PT; ++pt) bv[buf][p][pt] = sp[bofs[pt] + p * 2 * PP + koff_p];
         }
     };
     auto compute_group = [&](int ky0) { // the G taps whose weights are in LDS
@@ -274,8 +317,9 @@ void k_conv_s3(ConvArgs a)
             // six piece products, small ones first; consecutive multiplies go to different accumulators
 #define S3_MFMA(PA, PB)                                                                                              \
     _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)               \
-        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][PA][ct], bv[cur][PB][pt], acc[ct][pt], 0, 0, 0);
-            S3_MFMA(2, 0) S3_MFMA(0, 2) S3_MFMA(1, 1) S3_MFMA(1, 0) S3_MFMA(0, 1) S3_MFMA(0, 0)
+        acc[ct][pt] = mfma_pieces<NP>(av[cur][PA][ct], bv[cur][PB][pt], acc[ct][pt]);
+            if constexpr (NP == 3) { S3_MFMA(2, 0) S3_MFMA(0, 2) S3_MFMA(1, 1) }
+            S3_MFMA(1, 0) S3_MFMA(0, 1) S3_MFMA(0, 0)
 #undef S3_MFMA
             if (NB == 2) __builtin_amdgcn_sched_barrier(0);
         }
@@ -349,7 +393,9 @@ void k_conv_s3(ConvArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int ch = cobase + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
                 if (pok) {
-                    float v = acc[ct][pt][r] + a.bias[ch];
+                    float s = acc[ct][pt][r];
+                    if constexpr (NP == 2) s *= a.out_scale; // the weights were packed times an exact power of two
+                    float v = s + a.bias[ch];
                     v = v > 0.f ? v : v * 0.1f;
                     a.y[(((size_t)n * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
                 }
@@ -358,18 +404,18 @@ void k_conv_s3(ConvArgs a)
     }
 }
 
-template <int KS, int CT, int PT, int WP, int TW, int NB = 1, int MODE = 0, int RG = 0>
+template <int KS, int CT, int PT, int WP, int TW, int NB = 1, int MODE = 0, int RG = 0, int NP = 3>
 static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
 {
     ConvArgs a = a0;
     constexpr int TH = WP * PT * 32 / TW;
     constexpr int PP = (TH + KS - 1) * (TW + KS - 1);
     constexpr int G = (KS == 3 && !RG) ? 9 : KS;
-    constexpr size_t lds = (size_t)(6 * PP + G * 6 * CT * 32) * 16;
+    constexpr size_t lds = (size_t)(2 * NP * PP + G * 2 * NP * CT * 32) * 16;
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false; // one per instantiation
     if (!attr_set) {
-        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB, MODE, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        V2E_HIP(hipFuncSetAttribute((const void *)k_conv_s3<KS, CT, PT, WP, TW, NB, MODE, RG, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     a.tiles_x = (a.w_ + TW - 1) / TW;
@@ -380,6 +426,6 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     // noise at 2 blocks, -3 % on the five-wave 20-wide tiles (16 blocks: more workgroups than an XCD holds at once)
     a.ncb = ((order == 1 && KS == 3 && WP == 4 && ncb >= 4) || (order == 2 && ncb > 1)) ? ncb : 0;
     dim3 grid = a.ncb ? dim3((unsigned)((ntiles + 7) / 8 * 8 * ncb)) : dim3((unsigned)ntiles, (unsigned)ncb);
-    k_conv_s3<KS, CT, PT, WP, TW, NB, MODE, RG><<<grid, WP * 64, lds, s>>>(a);
+    k_conv_s3<KS, CT, PT, WP, TW, NB, MODE, RG, NP><<<grid, WP * 64, lds, s>>>(a);
     return 0;
 }

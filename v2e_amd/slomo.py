@@ -16,6 +16,7 @@ Differences from the reference, all at the edges of the hot path:
 import atexit
 import glob
 import logging
+import math
 import os
 
 import numpy as np
@@ -41,9 +42,10 @@ class HipUNet:
 
     def __init__(self, state_dict, cin, cout, device, conv_math="bf16x3"):
         import ctypes as C
-        if conv_math not in ("bf16x3", "f32"):
+        if conv_math not in ("bf16x3", "f32", "fp16x2"):
             raise ValueError("conv_math must be 'bf16x3' (f32 operands split exactly into three bf16 pieces, six piece "
-                             "products on the bf16 matrix cores, f32 accumulation) or 'f32' (f32 matrix-core instructions)")
+                             "products on the bf16 matrix cores, f32 accumulation), 'fp16x2' (two float16 pieces, three products: "
+                             "half the matrix-core work, products good to ~2^-21) or 'f32' (f32 matrix-core instructions)")
         self.conv_math = conv_math
         self.lib = _capi.lib()
         self.device = torch.device(device)
@@ -62,6 +64,19 @@ class HipUNet:
             descs[i].weight = wp.data_ptr()
             descs[i].bias = b.data_ptr()
             descs[i].weight_s3 = None
+            descs[i].split_kind = 0
+            if conv_math == "fp16x2" and co % 32 == 0 and (ci % 16 == 0 or (kh == 7 and ci >= 8)):
+                w2 = torch.empty((ci + 15) // 16 * 16 * kh * kw * co * 4, dtype=torch.uint8, device=self.device)
+                # an exact power of two that puts the layer's largest weight in [2^12, 2^13): no piece of a weight that matters
+                # is a float16 subnormal, nothing overflows (65504); the kernel divides it out again
+                wmax = float(w.abs().max())
+                if not wmax < 65504.0:
+                    raise ValueError("conv_math='fp16x2': layer %s has a weight of magnitude %g, beyond float16" % (name, wmax))
+                sl2 = 0 if not wmax > 0.0 else max(0, min(40, 12 - math.frexp(wmax)[1] + 1))
+                check(self.lib.v2e_pack_conv_weight_h2(_ptr(w), _ptr(w2), co, ci, kh, sl2, stream), "v2e_pack_conv_weight_h2")
+                self._keep.append(w2)
+                descs[i].weight_s3 = w2.data_ptr()
+                descs[i].split_kind = 2 | (sl2 << 8)
             if conv_math == "bf16x3" and co % 32 == 0 and (ci % 16 == 0 or (kh == 7 and ci >= 8)):
                 w3 = torch.empty((ci + 15) // 16 * 16 * kh * kw * co * 6, dtype=torch.uint8, device=self.device)
                 check(self.lib.v2e_pack_conv_weight_s3(_ptr(w), _ptr(w3), co, ci, kh, stream), "v2e_pack_conv_weight_s3")
@@ -103,8 +118,11 @@ class SloMoEngine:
 
     def __init__(self, flow_state_dict, interp_state_dict, device="cuda", conv_math=None):
         """conv_math: 'bf16x3' (default; every f32 operand split exactly into three bf16 pieces, six piece products on the
-        bf16 matrix cores, f32 accumulation -- f32 accuracy, v2e_amd/csrc/slomo_s3.h) or 'f32' (f32 matrix-core
-        instructions); the environment variable V2E_AMD_CONV_MATH sets the default."""
+        bf16 matrix cores, f32 accumulation -- f32 accuracy, v2e_amd/csrc/slomo_s3.h), 'fp16x2' (two float16 pieces, three
+        products: 1.4x the frames per second; operands good to 2^-22 and, measured on every fixture, as close to the reference
+        and to float64 as the other two (profiles/r03_slomo_precision.txt) -- but activations beyond float16's range, |x| >
+        65 504, would overflow, which is why it is opt-in) or 'f32' (f32 matrix-core instructions); the environment variable
+        V2E_AMD_CONV_MATH sets the default."""
         if conv_math is None:
             conv_math = os.environ.get("V2E_AMD_CONV_MATH", "bf16x3")
         self.conv_math = conv_math
