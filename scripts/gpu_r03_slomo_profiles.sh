@@ -6,6 +6,12 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/p3_slomo -- python $R/scripts
 cd $R
 python scripts/parse_layers.py $O/p3_slomo 80 > $O/p3_slomo_layers.txt 2>&1
 rm -rf $O/p3_slomo
+cd /tmp
+V2E_AMD_CONV_MATH=fp16x2 timeout 300 rocprofv3 --kernel-trace --stats -d $O/p3_slomo_h2 -- python $R/scripts/slomo_layers.py 80 > $O/p3_slomo_h2.log 2>&1
+cd $R
+python scripts/parse_layers.py $O/p3_slomo_h2 80 > $O/p3_slomo_h2_layers.txt 2>&1
+rm -rf $O/p3_slomo_h2
+python scripts/slomo_precision.py > $O/p3_slomo_precision.txt 2>&1
 timeout 120 ./scripts/ubench_mfma > $O/r03_mfma_bare.txt 2>&1
 {
 export S3P_TIMELINE=1

@@ -142,7 +142,9 @@ def slomo():
 # Box-to-box spread of these kernels is +-3 % (they run at the chip's power limit: r03_slomo_s3p_ablation.txt); on one box,
 # A/B: forward 27.68 ms with k_conv_s3 everywhere, 27.28 ms with k_conv_s3p where it fits (scripts/gpu_slomo_ab.sh).
 #
-""" + rd("p3_slomo_layers.txt"))
+""" + rd("p3_slomo_layers.txt") + (
+        "\n# ---- conv_math fp16x2 (two float16 pieces, three products; <s3 KS, CT, PT, WP, TW, NB, MODE, RG, NP = 2>), same command with\n"
+        "# V2E_AMD_CONV_MATH=fp16x2\n" + rd("p3_slomo_h2_layers.txt") if os.path.exists(os.path.join(G, "p3_slomo_h2_layers.txt")) else ""))
     wr("r03_slomo_s3p_ablation.txt", """# k_conv_s3p against k_conv_s3 on single layers, with the pipelined kernel's pieces switched off one at a time, and the
 # SHADER CLOCK the kernel actually runs at -- round 3
 # command: S3P_TIMELINE=1 V2E_AMD_S3_VARIANT={12: k_conv_s3 | 11: k_conv_s3p} [V2E_AMD_S3P_DBG=d] scripts/conv_s3_check ks cin cout n h w
