@@ -403,7 +403,7 @@ def main():
                 out["hd_noisy"] = hd_noisy_emulator_bench(device)
                 out["slomo"] = slomo_bench(device)
                 out["slomo_f32"] = slomo_bench(device, conv_math="f32")
-                out["slomo_fp16x2"] = slomo_bench(device, conv_math="fp16x2")  # opt-in: half the matrix-core work, products good to 2^-21
+                out["slomo_bf16x3"] = slomo_bench(device, conv_math="bf16x3")  # the exact three-piece split (what the range guard falls back to)
                 ref = recorded_reference()
                 if ref:
                     out["slomo"]["cpu_baseline"] = {

@@ -298,6 +298,11 @@ int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, 
  * |w| 2^scale_log2 is below 2^14: nothing overflows float16 and no weight piece falls into its subnormal range); the
  * convolution divides it out again exactly.  Set v2e_conv_desc.split_kind = 2 | (scale_log2 << 8) with it. */
 int v2e_pack_conv_weight_h2(const float *w_oihw, void *w_h2, int cout, int cin, int k, int scale_log2, void *stream);
+/* Range guard of the two-float16-piece convolutions: while a device flag is set here (per host thread; NULL switches it off),
+ * every such convolution launched ORs 1 into it if an input activation is beyond float16's range (|x| > 65 504: it became
+ * +-inf in the split) or NaN.  The caller zeroes the flag, runs its layers, reads it back, and on 1 redoes them with the exact
+ * three-piece weights -- what SloMoEngine's default conv math "auto" does. */
+int v2e_conv_set_range_flag(int *device_flag);
 
 /* activations in the same split form: x [n][c][h][w] f32 -> xs [3 pieces][n][c/8][h][w][8 bf16] (6 bytes per element;
  * c a multiple of 8).  A convolution takes such an input with pre = 3 (3x3 layers with split weights). */

@@ -186,7 +186,7 @@ def test_conv_layer_matches_oracle(case, oracle_lib):
 
 
 # the default (three bf16 pieces on the bf16 matrix cores), the f32 matrix-core kernels, and the opt-in two-float16-piece mode
-CONV_MATHS = ("bf16x3", "f32", "fp16x2")
+CONV_MATHS = ("auto", "bf16x3", "f32", "fp16x2")
 
 
 def _engine(seed_f=101, seed_i=102, conv_math=None):
@@ -271,7 +271,7 @@ def test_interpolation_within_reference_float32_noise(conv_math, fixture):
            "Ft": Ft}
     r = {k: (round(noise_ratio_rms(v, z, k), 3), round(noise_ratio(v, z, k), 3)) for k, v in got.items()}
     print("noise ratios (rms, max) %s %s: %s" % (fixture, conv_math, r))
-    b_rms, b_max = GPU_NOISE_FACTOR[fixture] if conv_math != "fp16x2" else GPU_NOISE_FACTOR_FP16X2[fixture]
+    b_rms, b_max = GPU_NOISE_FACTOR[fixture] if conv_math not in ("fp16x2", "auto") else GPU_NOISE_FACTOR_FP16X2[fixture]
     assert max(v[0] for v in r.values()) <= b_rms and max(v[1] for v in r.values()) <= b_max, r
     for k in ("flow", "intrp"):  # the networks' outputs: within 1e-5 of the tensor's scale of the exact result
         assert np.max(np.abs(got[k].astype(np.float64) - z[k + "_f64"])) <= 1e-5 * np.max(np.abs(z[k + "_f64"])), k
@@ -396,3 +396,26 @@ def test_auto_upsample_follows_the_flow_magnitude(tmp_path, oracle_lib):
     assert np.allclose(times, exp_times)
     nout = sum(U * min(B, n - 1 - b0) for U, b0 in zip(factors, range(0, n - 1, B)))
     assert sorted(os.listdir(str(dst)), key=lambda s: int(s.split(".")[0])) == ["%d.png" % i for i in range(nout)]
+
+
+def test_range_guard_redoes_a_pass_that_leaves_float16():
+    """conv_math 'auto': an activation beyond 65 504 would become inf in the two-float16-piece split; the convolutions report
+    it and the forward pass is redone with the exact three-bf16-piece split -- bit-identical to conv_math 'bf16x3' -- while
+    a pass that stays in range is the two-piece result and costs no second pass."""
+    from v2e_amd.slomo import HipUNet
+    from v2e_amd.synth import portable_unet_state_dict
+    sd = {k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand((2, 12, 64, 96), generator=g) - 0.4).to(dev)
+    auto, exact, fast = (HipUNet(sd, 12, 5, dev, m) for m in ("auto", "bf16x3", "fp16x2"))
+    y = auto.forward(x)
+    assert auto.fallbacks == 0 and torch.equal(y, fast.forward(x))
+    xb = x * 3.0e5                      # the first layers' activations now exceed float16's 65 504
+    yb = auto.forward(xb)
+    assert auto.fallbacks == 1
+    ye = exact.forward(xb)
+    assert torch.isfinite(ye).all() and torch.equal(yb, ye)
+    assert not torch.isfinite(fast.forward(xb)).all()   # what the unguarded two-piece math makes of it
+    y2 = auto.forward(x)                # and the guard does not stick
+    assert auto.fallbacks == 1 and torch.equal(y2, y)

@@ -106,6 +106,7 @@ SIGNATURES = {
     "v2e_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_pack_conv_weight_s3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_pack_conv_weight_h2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "v2e_conv_set_range_flag": (_i, [_vp]),
     "v2e_split3_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "v2e_conv2d_lrelu": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(ConvDesc), _vp, _i, _i, _i, _vp]),
     "v2e_unet_workspace_bytes": (_i64, [_i, _i, _i, _i]),

@@ -119,8 +119,12 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     torch.cuda.synchronize(device)
     sec_u = e0.elapsed_time(e1) * 1e-3 / iters
     fl_u = U * B * unet_flops(12, 5, H, W)
-    s3 = eng.conv_math in ("bf16x3", "fp16x2")
-    npr = {"bf16x3": 6, "fp16x2": 3}.get(eng.conv_math, 1)  # piece products executed per f32 multiply
+    fallbacks = eng.flow_net.fallbacks + eng.interp_net.fallbacks
+    math_run = eng.conv_math
+    if math_run == "auto":  # what actually ran: the two-piece math, unless the range guard redid passes with the exact split
+        math_run = "fp16x2" if (fallbacks == 0 and eng.interp_net.descs_exact is not None) else "bf16x3"
+    s3 = math_run in ("bf16x3", "fp16x2")
+    npr = {"bf16x3": 6, "fp16x2": 3}.get(math_run, 1)  # piece products executed per f32 multiply
     # executed matrix-core work: with split-bf16 operands every f32 multiply-add is six bf16 ones (the 12-channel conv1,
     # the 8x10 level and the 5-channel head stay on f32 instructions: ~6 % of the FLOPs)
     ach = fl_u / sec_u
@@ -132,10 +136,10 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
             "whole_step_TFLOPs": round(flops / sec / 1e12, 2),
             "note": ("achieved = algorithmic f32 FLOPs of the UNet x 6 (bf16 piece products executed per f32 multiply: x = p0+p1+p2 "
                      "exactly, products with i+j<=2) / time, against the dense bf16 MFMA peak; f32_equivalent is the same time "
-                     "priced in the algorithm's own f32 FLOPs (the f32 matrix-core peak is 157.3 TF/s)") if eng.conv_math == "bf16x3" else
+                     "priced in the algorithm's own f32 FLOPs (the f32 matrix-core peak is 157.3 TF/s)") if math_run == "bf16x3" else
                     ("achieved = algorithmic f32 FLOPs of the UNet x 3 (float16 piece products executed per f32 multiply: x = h0 + h1 + r, "
                      "|r| <= 2^-22 |x|; products h0 g0, h0 g1, h1 g0) / time, against the dense f16 MFMA peak (= the bf16 one)")
-                    if eng.conv_math == "fp16x2" else "f32 matrix-core instructions (v_mfma_f32_32x32x2_f32)"}
+                    if math_run == "fp16x2" else "f32 matrix-core instructions (v_mfma_f32_32x32x2_f32)"}
     return {
         "metric": "interpolated frames/s (SuperSloMo flow UNet + per-t warps + interpolation UNet + fusion)",
         "value": round(U * B / sec, 2), "unit": "frames/s",
@@ -143,8 +147,9 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
                                "seeded random-init weights (checkpoint not available offline)" % (U, B)},
         "dtype": "f32" + ({"bf16x3": " (operands split exactly into 3 bf16 pieces, 6 products on the bf16 matrix cores, f32 accumulation)",
                            "fp16x2": " (operands split into 2 float16 pieces, residual <= 2^-22; 3 products on the f16 matrix cores, f32 accumulation)"}
-                          .get(eng.conv_math, "")),
-        "conv_math": eng.conv_math, "ms_per_batch": round(sec * 1e3, 3),
+                          .get(math_run, "")),
+        "conv_math": eng.conv_math, "conv_math_run": math_run, "range_guard_fallbacks": fallbacks,
+        "ms_per_batch": round(sec * 1e3, 3),
         "gflop_per_frame": round(flops / (U * B) / 1e9, 2),
         "roofline": roof,
     }

@@ -38,7 +38,11 @@ struct ConvArgs {
     int tl_on;          // slomo_s3p.h, dev: record workgroup 0's per-step timeline
     int np;             // pieces the split weights ws3 hold: 3 (bf16) or 2 (float16)
     float out_scale;    // np == 2: 2^-s, the inverse of the power of two the weights were packed times
+    int *ovf;           // np == 2: device flag set when an activation is beyond float16's range (or NaN), or nullptr
 };
+
+// where the two-float16-piece convolutions report an activation beyond float16's range (v2e_conv_set_range_flag), or nullptr
+static thread_local int *g_conv_range_flag = nullptr;
 
 // element fetch with the producer op fused: PRE 0 plain, 1 avg_pool2d(2) of a [2H][2W] source,
 // 2 bilinear x2 upsample (align_corners=False) of a [H/2][W/2] source.
@@ -687,6 +691,12 @@ int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, 
     return 0;
 }
 
+int v2e_conv_set_range_flag(int *device_flag)
+{
+    g_conv_range_flag = device_flag;
+    return 0;
+}
+
 int v2e_pack_conv_weight_h2(const float *w_oihw, void *w_h2, int cout, int cin, int k, int scale_log2, void *stream)
 {
     V2E_REQUIRE(w_oihw && w_h2 && cout > 0 && cin > 0 && k > 0 && scale_log2 >= 0 && scale_log2 <= 60, "bad pack args");
@@ -727,7 +737,7 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
         a.x0 = x0; a.x1 = nullptr; a.c0 = c0; a.c1 = 0; a.w = conv->weight; a.bias = conv->bias; a.y = y;
         a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout; a.tiles_x = a.tiles_y = 0;
         V2E_REQUIRE((conv->split_kind & 0xFF) != 2, "pre-split input is three bf16 pieces");
-        a.ws3 = conv->weight_s3; a.xs_plane = (long long)n * (c0 / 8) * h * w; a.np = 3; a.tl_on = 0; a.out_scale = 1.0f;
+        a.ws3 = conv->weight_s3; a.xs_plane = (long long)n * (c0 / 8) * h * w; a.np = 3; a.tl_on = 0; a.out_scale = 1.0f; a.ovf = nullptr;
         const int r3 = conv_dispatch_s3_presplit(a, conv->ksize, (hipStream_t)stream);
         V2E_REQUIRE(r3 == 0, "no pre-split tile for this layer shape");
         V2E_HIP(hipGetLastError());
@@ -750,6 +760,7 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     a.ws3 = conv->weight_s3;
     a.np = (conv->split_kind & 0xFF) == 2 ? 2 : 3;
     a.out_scale = ldexpf(1.0f, -(conv->split_kind >> 8));
+    a.ovf = g_conv_range_flag;
     a.tl_on = 0;
     if (conv->ksize == 3 && pre == 0 && c1 == 0 && (conv->cout == 4 || conv->cout == 5)) {
         const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;

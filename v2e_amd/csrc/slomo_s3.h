@@ -259,6 +259,7 @@ void k_conv_s3(ConvArgs a)
 #pragma unroll
         for (int j = 0; j < NWU; ++j) wv[set][j] = wb[woff[j]];
     };
+    float amax = 0.f; // NP == 2: the largest |activation| this thread staged (float16 holds up to 65 504: see the range flag)
     auto stage_patch = [&](int set, int cbs = 0) { // split and store this thread's patch items (cbs: the chunk, PADC only)
 #pragma unroll
         for (int j = 0; j < NPI; ++j) {
@@ -276,7 +277,9 @@ void k_conv_s3(ConvArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     uint32_t qe[NP];
-                    split_pair<NP>(ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f, qe);
+                    const float xa = ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, xb = ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f;
+                    if constexpr (NP == 2) amax = fmaxf(amax, fmaxf(fabsf(xa), fabsf(xb)));
+                    split_pair<NP>(xa, xb, qe);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) q[p][e] = qe[p];
                 }
@@ -380,6 +383,11 @@ void k_conv_s3(ConvArgs a)
                 compute_group(ALLTAPS ? 0 : g); // G == KS: group g is kernel row g
             }
         }
+    }
+    // NP == 2: an activation beyond float16's range (it became +-inf in the split) -- or a NaN -- is reported, so that the caller
+    // can redo the layer stack with the exact three-piece split (v2e_conv_set_range_flag)
+    if constexpr (NP == 2) {
+        if (a.ovf && __ballot(!(amax <= 65504.f)) != 0ull && lane == 0) atomicOr(a.ovf, 1);
     }
     // epilogue as k_conv: register r of a lane is channel (r&3)+8(r>>2)+4*hsel of pixel l31
 #pragma unroll

@@ -42,17 +42,24 @@ class HipUNet:
 
     def __init__(self, state_dict, cin, cout, device, conv_math="bf16x3"):
         import ctypes as C
-        if conv_math not in ("bf16x3", "f32", "fp16x2"):
-            raise ValueError("conv_math must be 'bf16x3' (f32 operands split exactly into three bf16 pieces, six piece "
-                             "products on the bf16 matrix cores, f32 accumulation), 'fp16x2' (two float16 pieces, three products: "
-                             "half the matrix-core work, products good to ~2^-21) or 'f32' (f32 matrix-core instructions)")
+        if conv_math not in ("auto", "bf16x3", "f32", "fp16x2"):
+            raise ValueError("conv_math must be 'auto' (two float16 pieces and three products per multiply -- half the "
+                             "matrix-core work, products good to ~2^-21 -- with a range guard: a forward pass in which an activation "
+                             "leaves float16's range is redone with the exact split), 'bf16x3' (f32 operands split exactly into three "
+                             "bf16 pieces, six piece products on the bf16 matrix cores, f32 accumulation), 'fp16x2' (the two-piece "
+                             "math without the guard) or 'f32' (f32 matrix-core instructions)")
         self.conv_math = conv_math
         self.lib = _capi.lib()
         self.device = torch.device(device)
         self.cin, self.cout = cin, cout
         self._keep = []
-        descs = (ConvDesc * 23)()
+        self.fallbacks = 0  # conv_math 'auto': forward passes redone with the exact split
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        want_h2 = conv_math in ("auto", "fp16x2")
+        want_s3 = conv_math in ("auto", "bf16x3")
+        descs = (ConvDesc * 23)()        # what forward() runs first
+        descs_exact = (ConvDesc * 23)() if conv_math == "auto" else None
+        fast_ok = True
         for i, name in enumerate(UNET_LAYERS):
             w = state_dict[name + ".weight"].detach().to(self.device, torch.float32).contiguous()
             b = state_dict[name + ".bias"].detach().to(self.device, torch.float32).contiguous()
@@ -61,31 +68,39 @@ class HipUNet:
             wp = torch.empty((ci, kh, kw, co), dtype=torch.float32, device=self.device)
             check(self.lib.v2e_pack_conv_weight(_ptr(w), _ptr(wp), co, ci, kh, stream), "v2e_pack_conv_weight")
             self._keep += [wp, b]
-            descs[i].weight = wp.data_ptr()
-            descs[i].bias = b.data_ptr()
-            descs[i].weight_s3 = None
-            descs[i].split_kind = 0
-            if conv_math == "fp16x2" and co % 32 == 0 and (ci % 16 == 0 or (kh == 7 and ci >= 8)):
-                w2 = torch.empty((ci + 15) // 16 * 16 * kh * kw * co * 4, dtype=torch.uint8, device=self.device)
+            for d in (descs, descs_exact):
+                if d is not None:
+                    d[i].weight, d[i].bias = wp.data_ptr(), b.data_ptr()
+                    d[i].weight_s3, d[i].split_kind = None, 0
+                    d[i].cin, d[i].cout, d[i].ksize = ci, co, kh
+            splittable = co % 32 == 0 and (ci % 16 == 0 or (kh == 7 and ci >= 8))
+            if want_h2 and splittable:
                 # an exact power of two that puts the layer's largest weight in [2^12, 2^13): no piece of a weight that matters
                 # is a float16 subnormal, nothing overflows (65504); the kernel divides it out again
                 wmax = float(w.abs().max())
                 if not wmax < 65504.0:
-                    raise ValueError("conv_math='fp16x2': layer %s has a weight of magnitude %g, beyond float16" % (name, wmax))
-                sl2 = 0 if not wmax > 0.0 else max(0, min(40, 12 - math.frexp(wmax)[1] + 1))
-                check(self.lib.v2e_pack_conv_weight_h2(_ptr(w), _ptr(w2), co, ci, kh, sl2, stream), "v2e_pack_conv_weight_h2")
-                self._keep.append(w2)
-                descs[i].weight_s3 = w2.data_ptr()
-                descs[i].split_kind = 2 | (sl2 << 8)
-            if conv_math == "bf16x3" and co % 32 == 0 and (ci % 16 == 0 or (kh == 7 and ci >= 8)):
+                    if conv_math == "fp16x2":
+                        raise ValueError("conv_math='fp16x2': layer %s has a weight of magnitude %g, beyond float16" % (name, wmax))
+                    fast_ok = False
+                else:
+                    sl2 = 0 if not wmax > 0.0 else max(0, min(40, 12 - math.frexp(wmax)[1] + 1))
+                    w2 = torch.empty((ci + 15) // 16 * 16 * kh * kw * co * 4, dtype=torch.uint8, device=self.device)
+                    check(self.lib.v2e_pack_conv_weight_h2(_ptr(w), _ptr(w2), co, ci, kh, sl2, stream), "v2e_pack_conv_weight_h2")
+                    self._keep.append(w2)
+                    descs[i].weight_s3 = w2.data_ptr()
+                    descs[i].split_kind = 2 | (sl2 << 8)
+            if want_s3 and splittable:
                 w3 = torch.empty((ci + 15) // 16 * 16 * kh * kw * co * 6, dtype=torch.uint8, device=self.device)
                 check(self.lib.v2e_pack_conv_weight_s3(_ptr(w), _ptr(w3), co, ci, kh, stream), "v2e_pack_conv_weight_s3")
                 self._keep.append(w3)
-                descs[i].weight_s3 = w3.data_ptr()
-            descs[i].cin, descs[i].cout, descs[i].ksize = ci, co, kh
+                d = descs_exact if conv_math == "auto" else descs
+                d[i].weight_s3, d[i].split_kind = w3.data_ptr(), 0
         torch.cuda.synchronize(self.device)
         assert descs[0].cin == cin and descs[22].cout == cout
-        self.descs = descs
+        self.descs, self.descs_exact = descs, descs_exact
+        if conv_math == "auto" and not fast_ok:  # a weight beyond float16: the exact split throughout
+            self.descs, self.descs_exact = descs_exact, None
+        self._flag = torch.zeros(1, dtype=torch.int32, device=self.device) if self.descs_exact is not None else None
         self._ws = None
 
     def forward(self, x, out=None):
@@ -98,8 +113,23 @@ class HipUNet:
         if out is None:
             out = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
-              "v2e_unet_forward")
+        if self._flag is None:
+            check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
+                  "v2e_unet_forward")
+            return out
+        # conv_math 'auto': the two-float16-piece convolutions report an activation beyond float16's range; such a pass is
+        # redone with the exact three-bf16-piece weights (one 4-byte read-back per forward pass)
+        self._flag.zero_()
+        check(self.lib.v2e_conv_set_range_flag(_ptr(self._flag)), "v2e_conv_set_range_flag")
+        try:
+            check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
+                  "v2e_unet_forward")
+        finally:
+            self.lib.v2e_conv_set_range_flag(None)
+        if int(self._flag.item()) != 0:
+            self.fallbacks += 1
+            check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs_exact, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
+                  "v2e_unet_forward")
         return out
 
 
@@ -117,14 +147,15 @@ class SloMoEngine:
     """Flow UNet + interpolation UNet + warps/fusion for batches of frame pairs, on device."""
 
     def __init__(self, flow_state_dict, interp_state_dict, device="cuda", conv_math=None):
-        """conv_math: 'bf16x3' (default; every f32 operand split exactly into three bf16 pieces, six piece products on the
-        bf16 matrix cores, f32 accumulation -- f32 accuracy, v2e_amd/csrc/slomo_s3.h), 'fp16x2' (two float16 pieces, three
-        products: 1.4x the frames per second; operands good to 2^-22 and, measured on every fixture, as close to the reference
-        and to float64 as the other two (profiles/r03_slomo_precision.txt) -- but activations beyond float16's range, |x| >
-        65 504, would overflow, which is why it is opt-in) or 'f32' (f32 matrix-core instructions); the environment variable
+        """conv_math: 'auto' (default) -- every f32 operand split into two float16 pieces, three piece products on the f16 matrix
+        cores, f32 accumulation: operands good to 2^-22 and, measured on every fixture, as close to the reference and to float64
+        as the other maths (profiles/r03_slomo_precision.txt); float16's range is guarded: weights are packed times an exact
+        power of two, and a forward pass in which an activation exceeds 65 504 is redone with the exact split (HipUNet.forward);
+        'bf16x3' -- three bf16 pieces, six products: the exact split (v2e_amd/csrc/slomo_s3.h), 0.7x the frames per second;
+        'fp16x2' -- the two-piece math without the guard; 'f32' -- f32 matrix-core instructions.  The environment variable
         V2E_AMD_CONV_MATH sets the default."""
         if conv_math is None:
-            conv_math = os.environ.get("V2E_AMD_CONV_MATH", "bf16x3")
+            conv_math = os.environ.get("V2E_AMD_CONV_MATH", "auto")
         self.conv_math = conv_math
         if not torch.cuda.is_available():
             raise _capi.V2EAmdError("v2e_amd.SloMoEngine needs a ROCm GPU; there is no CPU fallback")
