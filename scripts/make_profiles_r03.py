@@ -139,6 +139,7 @@ def slomo():
 # TF = algorithmic f32 FLOPs of the layer / its launch duration ("f32-equivalent": the split-bf16 kernels execute 6 bf16
 # multiply-adds per f32 one).  <s3p TW, DBG> = k_conv_s3p (slomo_s3p.h: 64 x 64 register tile, one software-pipelined wave per
 # SIMD, new this round); <s3 KS, CT, PT, WP, TW, NB, MODE, RG> = k_conv_s3 (slomo_s3.h); <KS, CI_T, ...> = k_conv (f32 MFMA).
+# First table: conv_math bf16x3 (the exact three-piece split); second: fp16x2 (what the default "auto" runs, plus its range guard).
 # Box-to-box spread of these kernels is +-3 % (they run at the chip's power limit: r03_slomo_s3p_ablation.txt); on one box,
 # A/B: forward 27.68 ms with k_conv_s3 everywhere, 27.28 ms with k_conv_s3p where it fits (scripts/gpu_slomo_ab.sh).
 #
