@@ -625,6 +625,16 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
     static const int variant = getenv("V2E_AMD_S3_VARIANT") ? atoi(getenv("V2E_AMD_S3_VARIANT")) : 0; // dev: tile choice
     const bool c64 = a.cout % 64 == 0 && variant == 6;
     if (a.np == 2) { // two float16 pieces, three products (conv_math "fp16x2"): the 32 x 64 tiles, two workgroups per CU
+        // 3x3, cout % 64 == 0: 64 x 64 register tiles with one kernel row of weights resident at a time (34 KB of LDS): a third
+        // fewer LDS operand bytes per multiply than the 32 x 64 tile, bit-identical output, 4 % per forward (variant 18: off).
+        // With half the multiplies of the three-piece math the matrix pipe is far from the rate at which four accumulator
+        // chains x two waves per SIMD are slow (slomo_s3p.h), so the tile can keep two workgroups per CU.
+        if (ks == 3 && a.cout % 64 == 0 && variant != 18) {
+            if (a.w_ % 32 == 0) return launch_conv_s3<3, 2, 2, 4, 32, 1, 0, 1, 2>(a, s);
+            if (a.w_ % 16 == 0) return launch_conv_s3<3, 2, 2, 4, 16, 1, 0, 1, 2>(a, s);
+            if (a.w_ % 8 == 0) return launch_conv_s3<3, 2, 2, 4, 8, 1, 0, 1, 2>(a, s);
+            // (the 20-wide level's 5-wave tiles with 64 channels: measured slower, 18.39 against 17.95 ms per forward)
+        }
         if (ks == 3) {
             if (a.w_ % 32 == 0) return launch_conv_s3<3, 1, 2, 4, 32, 1, 0, 0, 2>(a, s);
             if (a.w_ % 16 == 0) return launch_conv_s3<3, 1, 2, 4, 16, 1, 0, 0, 2>(a, s);
@@ -633,6 +643,7 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
             if (a.w_ == 10 && a.h <= 16) return launch_conv_s3<3, 1, 1, 5, 10, 1, 0, 0, 2>(a, s); // the 8 x 10 level: half of a 16-row tile masked
             return 1;
         }
+        if (ks == 5 && a.w_ % 32 == 0 && a.cout % 64 == 0 && variant != 18) return launch_conv_s3<5, 2, 2, 4, 32, 1, 0, 1, 2>(a, s); // 64 x 64 tiles: 1.5 % more
         if (ks == 5 && a.w_ % 32 == 0) return launch_conv_s3<5, 1, 2, 4, 32, 1, 0, 0, 2>(a, s);
         if (ks == 7 && a.w_ % 32 == 0) return a.cin % 16 == 0 ? launch_conv_s3<7, 1, 2, 4, 32, 1, 0, 0, 2>(a, s) : launch_conv_s3<7, 1, 2, 4, 32, 1, 1, 0, 2>(a, s);
         return 1;
