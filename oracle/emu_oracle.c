@@ -259,7 +259,8 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
                             void *base_v, const float *pos_thres, const float *neg_thres,
                             const float *noise_rate, int32_t *pos_cnt, int32_t *neg_cnt,
                             uint8_t *shot_on, uint8_t *shot_off, int32_t *M_out,
-                            double *pn_arr /* photoreceptor_noise_arr or NULL */, const float *pn_randn /* tape draws or NULL */)
+                            double *pn_arr /* photoreceptor_noise_arr or NULL */, const float *pn_randn /* tape draws or NULL */,
+                            const void *cs_surround /* CSDVS: cs_surround_frame (state dtype) or NULL */)
 {
     int64_t npx = (int64_t)H * W;
     double delta_time = t_frame - t_prev;
@@ -316,6 +317,7 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
                 pn_arr[p] = pn;
             }
             double diff = (lpn + pn) - b;
+            if (cs_surround) diff = ((lpn + pn) - ((const double *)cs_surround)[p]) - b; /* emulator.py:753-754 */
             double pf = diff > 0 ? diff : 0.0, nf = (-diff) > 0 ? -diff : 0.0;
             double tp = P->scalar_thres ? P->pos_thres_scalar : (double)pos_thres[p];
             double tn = P->scalar_thres ? P->neg_thres_scalar : (double)neg_thres[p];
@@ -328,6 +330,7 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
             if (do_leak) b = b - delta_leak;
             base[p] = b;
             float diff = (L + 0.0f) - b;
+            if (cs_surround) diff = ((L + 0.0f) - ((const float *)cs_surround)[p]) - b; /* emulator.py:753-754 */
             float pf = diff > 0 ? diff : 0.0f, nf = (-diff) > 0 ? -diff : 0.0f;
             pc = (int32_t)div_floor_f(pf, pos_thres[p]);
             nc = (int32_t)div_floor_f(nf, neg_thres[p]);
@@ -351,6 +354,30 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
         shot_off[p] = sf;
     }
     *M_out = M;
+    return 0;
+}
+
+/* CSDVS: the frame's lp_log_frame before the frame is counted (emulator.py:685-690 applied to the state as it is, which stays
+ * untouched): what _update_csdvs steps the surround against (emulator.py:707-708). */
+EXPORT int v2e_oracle_lp_preview(const v2e_emu_params *P, int H, int W, const double *frame, double t_prev, double t_frame,
+                                 const void *lp_v, void *lp_out)
+{
+    int64_t npx = (int64_t)H * W;
+    double delta_time = t_frame - t_prev;
+    double tau = (P->cutoff_hz > 0) ? 1.0 / (M_PI * 2 * P->cutoff_hz) : 0.0;
+    double dt_over_tau = (P->cutoff_hz > 0) ? delta_time / tau : 0.0;
+    for (int64_t p = 0; p < npx; ++p) {
+        double x = frame[p];
+        double Ld = P->log_input ? x : (double)lin_log(x);
+        if (P->f64_state) {
+            double inten01 = (x + 20.0) / 275.0;
+            double eps = inten01 * dt_over_tau;
+            if (eps > 1.0) eps = 1.0;
+            ((double *)lp_out)[p] = (P->cutoff_hz > 0) ? (1.0 - eps) * ((const double *)lp_v)[p] + eps * Ld : Ld;
+        } else {
+            ((float *)lp_out)[p] = (float)Ld;
+        }
+    }
     return 0;
 }
 

@@ -185,7 +185,13 @@ class OracleEmulator:
                  leak_rate_hz=0.1, refractory_period_s=0.0, shot_noise_rate_hz=0.0,
                  leak_jitter_fraction=0.1, noise_rate_cov_decades=0.1, seed=0,
                  rng_mode="tape", tape=None, shuffle=True, clip=0, hdr=False, photoreceptor_noise=False,
-                 photoreceptor_noise_vrms=None):
+                 photoreceptor_noise_vrms=None, cs_lambda_pixels=None, cs_tau_p_ms=None):
+        # CSDVS (emulator.py:245-272, 707-716, 753-754, 1061-1124)
+        self.cs_lambda_pixels, self.cs_tau_p_ms = cs_lambda_pixels, cs_tau_p_ms
+        self.csdvs_enabled = cs_lambda_pixels is not None
+        self.cs_tau_h_ms = 0 if (not self.csdvs_enabled or cs_tau_p_ms is None or cs_tau_p_ms == 0) else cs_tau_p_ms / (cs_lambda_pixels ** 2)
+        self.cs_surround_frame = None
+        self.cs_steps_taken = []
         self.log_input = bool(hdr)  # emulator.py:304
         # emulator.py:192-205, 694-703; the vrms itself (emulator_utils.py:177-290, unseeded numpy draws in the
         # reference) is an input here
@@ -275,6 +281,25 @@ class OracleEmulator:
         P.seed = self.seed
         return P
 
+    def _update_csdvs(self, P, H, W, frame, t_prev, t_frame):
+        """emulator.py:1061-1124: the host arithmetic as the reference writes it, the stepping loop in C (csdvs_update)."""
+        delta_time = t_frame - t_prev
+        abs_min_tau_p = 1e-9
+        tau_p = abs_min_tau_p if (self.cs_tau_p_ms is None or self.cs_tau_p_ms == 0) else self.cs_tau_p_ms * 1e-3
+        tau_h = abs_min_tau_p / (self.cs_lambda_pixels ** 2) if (self.cs_tau_h_ms is None or self.cs_tau_h_ms == 0) \
+            else self.cs_tau_h_ms * 1e-3
+        num_steps = int(np.ceil((delta_time / min(tau_p, tau_h)) * 5))
+        actual_delta_time = delta_time / num_steps
+        alpha_p, alpha_h = actual_delta_time / tau_p, actual_delta_time / tau_h
+        if alpha_p >= 1 or alpha_h >= 1:
+            raise SystemExit(1)
+        lp_new = np.empty_like(self.lp_log_frame)
+        rc = lib().v2e_oracle_lp_preview(C.byref(P), H, W, _p(frame), C.c_double(t_prev), C.c_double(t_frame),
+                                         _p(self.lp_log_frame), _p(lp_new))
+        assert rc == 0
+        steps, _ = csdvs_update(lp_new, self.cs_surround_frame, alpha_p, alpha_h, num_steps)
+        self.cs_steps_taken.append(steps)
+
     def generate_events(self, new_frame, t_frame):
         L = lib()
         frame = np.ascontiguousarray(np.asarray(new_frame), dtype=np.float64)
@@ -312,6 +337,9 @@ class OracleEmulator:
                                          _p(self.timestamp_mem), _p(self.pos_thres_arr),
                                          _p(self.neg_thres_arr), _p(self.noise_rate_array))
             assert rc == 0
+            if self.csdvs_enabled:  # emulator.py:1062-1063, 715: surround = lp_log_frame, base = lp_log_frame - surround = 0
+                self.cs_surround_frame = self.lp_log_frame.copy()
+                self.base_log_frame[...] = 0
             return None  # t_previous intentionally NOT advanced (emulator.py:717)
 
         P = self._params()
@@ -330,12 +358,15 @@ class OracleEmulator:
         leak = None
         if not philox and self.leak_rate_hz > 0:
             leak = np.ascontiguousarray(self.tape.randn((H, W)))
+        if self.csdvs_enabled:
+            self._update_csdvs(P, H, W, frame, t_prev, t_frame)
         rc = L.v2e_oracle_count(C.byref(P), H, W, _p(frame), C.c_double(t_prev), C.c_double(t_frame),
                                 C.c_uint32(fidx), C.c_uint32(self.clip), _p(leak), None,
                                 _p(self.lp_log_frame), _p(self.base_log_frame), _p(self.pos_thres_arr),
                                 _p(self.neg_thres_arr), _p(self.noise_rate_array), _p(pos_cnt),
                                 _p(neg_cnt), _p(shot_on), _p(shot_off), C.byref(M),
-                                _p(self.photoreceptor_noise_arr) if self.photoreceptor_noise else None, _p(pn_rand))
+                                _p(self.photoreceptor_noise_arr) if self.photoreceptor_noise else None, _p(pn_rand),
+                                _p(self.cs_surround_frame) if self.csdvs_enabled else None)
         assert rc == 0
         M = M.value
         self.last_M = M

@@ -182,3 +182,43 @@ def test_csdvs_default_tape_mode_matches_reference_at_davis346():
         assert sha(emu.base_log_frame.cpu().numpy()) == fx.base_sha
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
     emu.cleanup()
+
+
+@pytest.mark.parametrize("name", ["philox_csdvs_346x260", "philox_csdvs_f32_346x260"])
+def test_oracle_csdvs_emulator_matches_reference_at_davis346(name, oracle_lib):
+    """The oracle's whole centre-surround path (lp preview -> stepping loop -> counts against the surround) against the
+    reference-generated DAVIS346 fixtures, bit for bit (CPU)."""
+    fx = PhiloxFixture(name)
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    ora = oracle_lib.OracleEmulator(seed=fx.seed, rng_mode="philox", **fx.kw)
+    evs = [ora.generate_events(f, float(t)) for f, t in zip(fx.frames, fx.times)]
+    assert ora.cs_steps_taken == list(z["cs_steps"])
+    assert sha(ora.cs_surround_frame) == str(z["cs_surround_sha"])
+    assert [0 if e is None else len(e) for e in evs] == list(fx.n_events)
+    for k, e in enumerate(evs):
+        if e is not None:
+            assert sha(e) == fx.ev_sha[k], "frame %d event digest differs" % k
+    assert sha(ora.lp_log_frame) == fx.lp_sha and sha(ora.base_log_frame) == fx.base_sha
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cutoff", [300, 0])
+@pytest.mark.parametrize("shape", [(33, 37), (97, 131), (64, 96)])
+def test_csdvs_emulator_matches_oracle_at_any_size(shape, cutoff, oracle_lib):
+    """Where the reference's convolution backend sums in another order the HIP path is pinned by the oracle instead (same
+    fixed order): events, surround, state planes bit for bit, float64 and float32 state, ragged sizes."""
+    from v2e_amd import EventEmulator
+    from v2e_amd.synth import int_gradient_frames
+    H, W = shape
+    frames = int_gradient_frames(9, H, W, seed=71, noise=8, as_array=True)
+    kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=cutoff, leak_rate_hz=.2, shot_noise_rate_hz=2.0 if cutoff else 0.0,
+              refractory_period_s=0.0005, cs_lambda_pixels=2.5, cs_tau_p_ms=3.0)
+    emu = EventEmulator(device="cuda", seed=8, rng_mode="philox", **kw)
+    ora = oracle_lib.OracleEmulator(seed=8, rng_mode="philox", **kw)
+    for i in range(9):
+        e, o = emu.generate_events(frames[i], i / 250), ora.generate_events(frames[i], i / 250)
+        assert (e is None) == (o is None) and (e is None or np.array_equal(e, o)), "frame %d" % i
+    assert emu.cs_steps_taken == ora.cs_steps_taken
+    assert np.array_equal(emu.cs_surround_frame.cpu().numpy(), ora.cs_surround_frame)
+    assert np.array_equal(emu.base_log_frame.cpu().numpy(), ora.base_log_frame)
+    assert np.array_equal(emu.lp_log_frame.cpu().numpy(), ora.lp_log_frame)
