@@ -260,7 +260,9 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
                             const float *noise_rate, int32_t *pos_cnt, int32_t *neg_cnt,
                             uint8_t *shot_on, uint8_t *shot_off, int32_t *M_out,
                             double *pn_arr /* photoreceptor_noise_arr or NULL */, const float *pn_randn /* tape draws or NULL */,
-                            const void *cs_surround /* CSDVS: cs_surround_frame (state dtype) or NULL */)
+                            const void *cs_surround /* CSDVS: cs_surround_frame (state dtype) or NULL */,
+                            double *sc_hp /* SCIDVS: scidvs_highpass or NULL (float64 state) */, double *sc_prev /* scidvs_previous_photo */,
+                            const float *sc_tau /* scidvs_tau_arr */, int sc_first /* previous_photo is taken from this frame */)
 {
     int64_t npx = (int64_t)H * W;
     double delta_time = t_frame - t_prev;
@@ -316,8 +318,20 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
                 pn = (1.0 - eps_n) * pn_arr[p] + (double)term2;
                 pn_arr[p] = pn;
             }
-            double diff = (lpn + pn) - b;
-            if (cs_surround) diff = ((lpn + pn) - ((const double *)cs_surround)[p]) - b; /* emulator.py:753-754 */
+            double photo = lpn;
+            if (sc_hp) { /* emulator.py:56-80, 719-725, 747: nonlinear CR high-pass of the photoreceptor, amplified */
+                double prev = sc_first ? lpn : sc_prev[p];
+                double hp = sc_hp[p];
+                float inv_tau = 1.0f / sc_tau[p];            /* torch.div(1, tau): float32 */
+                double sh = sinh(hp / (1 / 0.7));            /* torch.sinh(v / efold) */
+                double dvdt = (double)inv_tau * sh;
+                hp = hp + ((lpn - prev) - delta_time * dvdt);
+                sc_hp[p] = hp;
+                sc_prev[p] = lpn;
+                photo = 2 * hp;                              /* SCIDVS_GAIN * scidvs_highpass */
+            }
+            double diff = (photo + pn) - b;
+            if (cs_surround) diff = ((photo + pn) - ((const double *)cs_surround)[p]) - b; /* emulator.py:753-754 */
             double pf = diff > 0 ? diff : 0.0, nf = (-diff) > 0 ? -diff : 0.0;
             double tp = P->scalar_thres ? P->pos_thres_scalar : (double)pos_thres[p];
             double tn = P->scalar_thres ? P->neg_thres_scalar : (double)neg_thres[p];

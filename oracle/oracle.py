@@ -185,13 +185,16 @@ class OracleEmulator:
                  leak_rate_hz=0.1, refractory_period_s=0.0, shot_noise_rate_hz=0.0,
                  leak_jitter_fraction=0.1, noise_rate_cov_decades=0.1, seed=0,
                  rng_mode="tape", tape=None, shuffle=True, clip=0, hdr=False, photoreceptor_noise=False,
-                 photoreceptor_noise_vrms=None, cs_lambda_pixels=None, cs_tau_p_ms=None):
+                 photoreceptor_noise_vrms=None, cs_lambda_pixels=None, cs_tau_p_ms=None, scidvs=False):
         # CSDVS (emulator.py:245-272, 707-716, 753-754, 1061-1124)
         self.cs_lambda_pixels, self.cs_tau_p_ms = cs_lambda_pixels, cs_tau_p_ms
         self.csdvs_enabled = cs_lambda_pixels is not None
         self.cs_tau_h_ms = 0 if (not self.csdvs_enabled or cs_tau_p_ms is None or cs_tau_p_ms == 0) else cs_tau_p_ms / (cs_lambda_pixels ** 2)
         self.cs_surround_frame = None
         self.cs_steps_taken = []
+        # SCIDVS (emulator.py:56-80, 307-309, 480-483, 719-725, 747); float64 state only, like the HIP path
+        self.scidvs = bool(scidvs)
+        self.scidvs_highpass = self.scidvs_previous_photo = self.scidvs_tau_arr = None
         self.log_input = bool(hdr)  # emulator.py:304
         # emulator.py:192-205, 694-703; the vrms itself (emulator_utils.py:177-290, unseeded numpy draws in the
         # reference) is an input here
@@ -324,10 +327,20 @@ class OracleEmulator:
             self.neg_thres_arr = np.zeros((H, W), np.float32)
             self.noise_rate_array = np.zeros((H, W), np.float32)
             tp = tn = nr = None
+            if self.scidvs:
+                assert P.f64_state, "SCIDVS: float64 state (cutoff_hz > 0 or hdr)"
+                self.scidvs_highpass = np.zeros((H, W), np.float64)       # emulator.py:720
+                self.scidvs_previous_photo = np.zeros((H, W), np.float64)  # taken from the first counted frame (:721)
+                self._sc_first = True
+                if philox:
+                    self.scidvs_tau_arr = philox_scidvs_tau(self.seed, self.clip, npx).reshape(H, W)
             if not philox:
                 if self.sigma_thres > 0:
                     tp = np.ascontiguousarray(self.tape.normal(self.pos_thres, self.sigma_thres, (H, W)))
                     tn = np.ascontiguousarray(self.tape.normal(self.neg_thres, self.sigma_thres, (H, W)))
+                if self.scidvs:  # emulator.py:480-483: drawn between the thresholds and the noise rates
+                    d = np.ascontiguousarray(self.tape.normal(0, 0.5, (H, W)))
+                    self.scidvs_tau_arr = np.ascontiguousarray((np.float32(0.01) * self.tape.exp_scidvs(d)).astype(np.float32))
                 if self.leak_rate_hz > 0:
                     r = np.ascontiguousarray(self.tape.randn((H, W)))
                     nr = np.ascontiguousarray(self.tape.exp_noise_rate(self.noise_rate_cov_decades, r))
@@ -366,7 +379,11 @@ class OracleEmulator:
                                 _p(self.neg_thres_arr), _p(self.noise_rate_array), _p(pos_cnt),
                                 _p(neg_cnt), _p(shot_on), _p(shot_off), C.byref(M),
                                 _p(self.photoreceptor_noise_arr) if self.photoreceptor_noise else None, _p(pn_rand),
-                                _p(self.cs_surround_frame) if self.csdvs_enabled else None)
+                                _p(self.cs_surround_frame) if self.csdvs_enabled else None,
+                                _p(self.scidvs_highpass), _p(self.scidvs_previous_photo), _p(self.scidvs_tau_arr),
+                                C.c_int(1 if (self.scidvs and self._sc_first) else 0))
+        if self.scidvs:
+            self._sc_first = False
         assert rc == 0
         M = M.value
         self.last_M = M

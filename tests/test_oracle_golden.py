@@ -71,3 +71,34 @@ def test_oracle_live_tape_at_sensor_size(name, oracle_lib):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
     if "moving_dot" in name:
         assert emu.num_events_total == 8435
+
+
+def test_oracle_scidvs_replays_reference_tape(oracle_lib):
+    """scidvs=True (emulator.py:56-80, 719-725, 747; float64 state): the reference's recorded torch draws, incl. the per-pixel
+    time-constant normal and its exp.  Events bit for bit; scidvs_highpass to 1e-12 (torch's vectorised float64 sinh and libm's
+    differ in the last bit on a few percent of the arguments, which never reaches an event)."""
+    import os
+    from fixtures import GOLDEN
+    fx = TapeFixture("tape_scidvs_40x48")
+    emu = oracle_lib.OracleEmulator(seed=0, rng_mode="tape", tape=oracle_lib.RecordedTape(fx.items), **fx.kw)
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        assert events_equal(emu.generate_events(f, float(t)), fx.events[k]), "frame %d differs" % k
+    assert emu.tape.pos == len(fx.items), "tape not fully consumed"
+    z = np.load(os.path.join(GOLDEN, "tape_scidvs_40x48.npz"))
+    assert np.array_equal(emu.scidvs_tau_arr, z["scidvs_tau"])
+    assert np.max(np.abs(emu.scidvs_highpass - z["scidvs_highpass_final"])) <= 1e-12 * max(1.0, np.max(np.abs(z["scidvs_highpass_final"])))
+    assert np.array_equal(emu.lp_log_frame, fx.lp_final)
+
+
+def test_oracle_scidvs_philox_matches_reference(oracle_lib):
+    import os
+    from fixtures import GOLDEN
+    fx = PhiloxFixture("philox_scidvs_97x131")
+    emu = oracle_lib.OracleEmulator(seed=fx.seed, rng_mode="philox", **fx.kw)
+    evs = [emu.generate_events(f, float(t)) for f, t in zip(fx.frames, fx.times)]
+    assert [0 if e is None else len(e) for e in evs] == list(fx.n_events)
+    for k, e in enumerate(evs):
+        assert events_equal(e, fx.events[k] if len(fx.events[k]) else None), "frame %d differs" % k
+    z = np.load(os.path.join(GOLDEN, "philox_scidvs_97x131.npz"))
+    assert np.max(np.abs(emu.scidvs_highpass - z["scidvs_highpass_final"])) <= 1e-12 * max(1.0, np.max(np.abs(z["scidvs_highpass_final"])))
+    assert np.max(np.abs(emu.base_log_frame - z["base_final"])) <= 1e-12 * max(1.0, np.max(np.abs(z["base_final"])))
