@@ -7,7 +7,7 @@
 
 constexpr unsigned SPIN_MAX = 400000u;
 
-// V1: one counter per iteration, fetch_add + poll (what emu_fused.h clip_barrier does)
+// V1: one counter per iteration, fetch_add + poll (what clip_barrier in emu_chain.h does)
 __global__ __launch_bounds__(256) void k_counter(unsigned *ctr, int iters, float4 *ev, int dirty, int *fail)
 {
     const int g = blockIdx.x, tid = threadIdx.x;
