@@ -129,6 +129,12 @@ int v2e_emu_init_state(v2e_emu *h, const v2e_emu_params *p, const void *frame, i
  * (emulator.py:720-722).  All NULL switches it off.  Runs on the count / rank / scan / emit kernels. */
 int v2e_emu_set_scidvs(v2e_emu *h, void *highpass, void *previous_photo, float *tau, uint32_t first_frame_idx);
 
+/* Model-state planes the reference keeps as attributes and the kernels otherwise never store: log_new_frame (emulator.py:666),
+ * c_minus_s_frame (:753, zero without CSDVS) and diff_frame (:749-754), float64 [n_clips][npx_pad] each (caller-owned), written
+ * by every v2e_emu_count from then on -- what show_dvs_model_state / record_single_pixel_states (emulator.py:756-764, 985-1006)
+ * read.  All three or none (NULL switches it off).  Frame-at-a-time kernels only. */
+int v2e_emu_set_model_state_planes(v2e_emu *h, double *log_new_frame, double *c_minus_s_frame, double *diff_frame);
+
 int v2e_emu_set_pnoise(v2e_emu *h, void *pn_arr, const float *randn_tape);
 
 /* Centre-surround DVS (cs_lambda_pixels; emulator.py:245-272, 707-716, 753-754, 1061-1124).  The surround plane
@@ -336,6 +342,11 @@ int v2e_slomo_prep(const float *i0, const float *i1, const float *flow, const fl
 /* slomo.py:421-433: refine flows, visibility, two backWarps, fusion -> out [n_t*b][1][h][w] */
 int v2e_slomo_fuse(const float *i0, const float *i1, const float *x12, const float *intrp,
                    const float *tcoef, int n_t, int b, int h, int w, float *out, void *stream);
+
+/* slomo.py:352-368 (auto_upsample): max over the batch and both flow pairs of the SQUARED flow magnitude vx*vx + vy*vy (float32,
+ * each operation rounded) of flow [b][4][h][w] = [F_0_1 x, y, F_1_0 x, y], as float32 bits in *out_bits (device); the host takes
+ * one float32 sqrt of it (sqrt is monotone: the same number as the reference's max of sqrt planes).  0xffffffff: a NaN flow. */
+int v2e_slomo_max_speed2(const float *flow, int b, int h, int w, uint32_t *out_bits, void *stream);
 
 /* ------------------------------------------- SloMo <-> emulator hand-off */
 

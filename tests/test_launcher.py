@@ -64,3 +64,88 @@ def _check_binding(v2e, tmp_path):
             emu.generate_events(np.zeros((260, 346), np.uint8), 0.0)
         with pytest.raises(v2e_amd.V2EAmdError):
             sm.interpolate(str(tmp_path), str(tmp_path), (346, 260))
+
+
+class _FakeCapture:
+    """cv2.VideoCapture over generated grey 346x260 frames (the size the CLI asks for, monochrome: stage 1 then neither
+    resizes nor converts -- v2e.py:713-731)."""
+    N = 6
+
+    def __init__(self, path):
+        self.i = 0
+
+    def get(self, prop):
+        return {"fps": 30.0, "count": self.N, "w": 346, "h": 260, "mono": 1}[prop]
+
+    def read(self):
+        if self.i >= self.N:
+            return False, None
+        self.i += 1
+        yy, xx = np.mgrid[0:260, 0:346]
+        return True, ((xx + 3 * self.i + yy) % 256).astype(np.uint8)
+
+    def release(self):
+        pass
+
+
+def test_v2e_main_with_the_cli_defaults_reaches_the_first_device_call(tmp_path, monkeypatch):
+    """v2e.main() as a user starts it -- video output ON (no --skip_video_output), preview ON (no --no_preview): v2e.py:471-478
+    then passes video_path / vid_orig / vid_slomo / preview to SuperSloMo.  The run must get through both constructors and
+    stage 1 and stop only where the device is first needed (here, without a GPU: V2EAmdError from SuperSloMo.interpolate)."""
+    import torch
+    import v2e_amd
+    from v2e_amd.launcher import bind
+    rh.install_stubs()
+    rh.install_torchvision_stub()
+    if "argcomplete" not in sys.modules:
+        rh._mod("argcomplete", __getattr__=rh._ga)
+    import v2ecore.emulator
+    import v2ecore.slomo
+    saved = (v2ecore.emulator.EventEmulator, v2ecore.slomo.SuperSloMo)
+    video = tmp_path / "in.avi"
+    video.write_bytes(b"not a real video: the capture below is a fake")
+    out = tmp_path / "out"
+    built = {}
+    try:
+        v2e = bind(rh.REF_ROOT)
+        cv2 = sys.modules["cv2"]
+        for k, v in dict(VideoCapture=_FakeCapture, CAP_PROP_FPS="fps", CAP_PROP_FRAME_COUNT="count", CAP_PROP_FRAME_WIDTH="w",
+                         CAP_PROP_FRAME_HEIGHT="h", CAP_PROP_MONOCHROME="mono").items():
+            monkeypatch.setattr(cv2, k, v, raising=False)
+        real_slomo = v2e.SuperSloMo
+
+        def spy(*a, **k):
+            built["slomo_kwargs"] = dict(k)
+            built["slomo"] = real_slomo(*a, **k)
+            return built["slomo"]
+        monkeypatch.setattr(v2e, "SuperSloMo", spy)
+        monkeypatch.setattr(v2e, "v2e_quit", lambda *a: (_ for _ in ()).throw(SystemExit(a[0] if a else 0)), raising=False)
+        monkeypatch.setattr(sys, "argv", ["v2e.py", "-i", str(video), "--output_folder", str(out), "--overwrite", "--dvs346",
+                                          "--ignore-gooey"])
+        if torch.cuda.is_available():
+            with pytest.raises(FileNotFoundError):  # the default checkpoint input/SuperSloMo39.ckpt is not here
+                v2e.main()
+        else:
+            with pytest.raises(v2e_amd.V2EAmdError, match="ROCm GPU"):
+                v2e.main()
+    finally:
+        v2ecore.emulator.EventEmulator, v2ecore.slomo.SuperSloMo = saved
+        v2e = sys.modules.get("v2e")
+        if v2e is not None:
+            v2e.EventEmulator, v2e.SuperSloMo = saved
+    kw = built["slomo_kwargs"]
+    assert kw["video_path"] == str(out) and kw["vid_orig"] and kw["vid_slomo"] and kw["preview"] is True  # the CLI defaults
+    sm = built["slomo"]
+    assert sm.video_path == str(out) and sm.preview is True
+    sm.cleanup()
+
+
+def test_slomo_constructor_accepts_the_video_keywords():
+    """slomo.py:44-54: every keyword of the reference constructor; none of them raises (the AVI writers are host work that is
+    skipped with a warning when OpenCV is absent)."""
+    import v2e_amd
+    sm = v2e_amd.SuperSloMo(model="x.pth", auto_upsample=True, upsampling_factor=2, batch_size=4, video_path="/tmp",
+                            vid_orig="original.avi", vid_slomo="slomo.avi", preview=True, avi_frame_rate=30)
+    assert (sm.video_path, sm.vid_orig, sm.vid_slomo, sm.preview, sm.avi_frame_rate) == ("/tmp", "original.avi", "slomo.avi", True, 30)
+    sm._open_writers((346, 260))  # no cv2 here: one warning, no writers, no exception
+    sm.cleanup()

@@ -81,6 +81,7 @@ SIGNATURES = {
     "v2e_emu_bind_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "v2e_emu_init_state": (_i, [_vp, _PP, _vp, _i, _d, _vp, _vp, _vp, _vp]),
     "v2e_emu_set_pnoise": (_i, [_vp, _vp, _vp]),
+    "v2e_emu_set_model_state_planes": (_i, [_vp, _vp, _vp, _vp]),
     "v2e_emu_set_scidvs": (_i, [_vp, _vp, _vp, _vp, _u32]),
     "v2e_emu_frame_host_rows": (_i, [_vp, _vp, _u64]),
     "v2e_emu_set_csdvs": (_i, [_vp, _vp]),
@@ -127,6 +128,7 @@ SIGNATURES = {
     "v2e_render_area_segments": (_i, [_vp, _i64, _vp, _i, _i, _d, _i, _vp, _i64, _vp, _vp]),
     "v2e_render_packet": (_i, [_vp, _i64, _i, _vp, _i, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _d, _d, _d, _d, _d, _vp]),
     "v2e_slomo_fuse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "v2e_slomo_max_speed2": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

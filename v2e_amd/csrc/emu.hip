@@ -126,6 +126,9 @@ struct KArgs {
     uint32_t sc_first_frame; // frame index at which scidvs_previous_photo is taken from the frame itself
     const void *cs_sur; // CSDVS: the surround plane the frame's photoreceptor output is compared against (emulator.py:753-754)
     int emit_guard; // k_emit: leave everything untouched (flag the record) when the frame's rows do not fit the buffer
+    // model-state planes the reference keeps as attributes but the kernels otherwise never store (emulator.py:666, 749-754;
+    // show_dvs_model_state, record_single_pixel_states): float64 [n_clips][npx_pad] each, written by k_count, nullptr = off
+    double *dbg_lognew, *dbg_cms, *dbg_diff;
 };
 
 __device__ constexpr double SCIDVS_EFOLD = 1 / 0.7; // efold of the sinh conductance (emulator.py:78)
@@ -421,6 +424,11 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
         }
         R diff = (photo + pn) - b; // photoreceptor + photoreceptor_noise_arr - base_log_frame (emulator.py:747-751)
         if (a.cs_sur) diff = ((photo + pn) - ((const R *)a.cs_sur)[sp]) - b; // c_minus_s_frame - base_log_frame (:753-754)
+        if (a.dbg_diff) {
+            a.dbg_lognew[sp] = L;
+            a.dbg_cms[sp] = a.cs_sur ? (double)((photo + pn) - ((const R *)a.cs_sur)[sp]) : 0.0;
+            a.dbg_diff[sp] = (double)diff;
+        }
         R pf = diff > (R)0 ? diff : (R)0;
         R nf = (-diff) > (R)0 ? -diff : (R)0;
         R tpd = a.scalar_thres ? (R)a.pos_div : (R)thp;
@@ -776,6 +784,7 @@ struct v2e_emu {
     const void *cs_sur = nullptr;              // CSDVS surround plane (v2e_emu_set_csdvs)
     float *sc_tau = nullptr;
     uint32_t sc_first_frame = 0;
+    double *dbg_lognew = nullptr, *dbg_cms = nullptr, *dbg_diff = nullptr; // v2e_emu_set_model_state_planes
     int ngroups = 0;
     float *lut_L = nullptr;
     double *lut_I = nullptr;
@@ -892,6 +901,7 @@ static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
     if (p->photoreceptor_noise) { a.pn_arr = h->pn_arr; a.pn_tape = h->pn_tape; a.pn_vrms_f = (float)p->photoreceptor_noise_vrms; }
     a.cs_sur = h->cs_sur;
     if (h->sc_hp) { a.sc_hp = h->sc_hp; a.sc_prev = h->sc_prev; a.sc_tau = h->sc_tau; a.sc_first_frame = h->sc_first_frame; }
+    a.dbg_lognew = h->dbg_lognew; a.dbg_cms = h->dbg_cms; a.dbg_diff = h->dbg_diff;
     return a;
 }
 
@@ -1108,6 +1118,15 @@ int v2e_emu_lp_preview(v2e_emu *h, const v2e_emu_params *p, const void *frame, i
         else k_cs_lp<float, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, (float *)lp_out);
     });
     V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_emu_set_model_state_planes(v2e_emu *h, double *log_new_frame, double *c_minus_s_frame, double *diff_frame)
+{
+    V2E_REQUIRE(h, "null handle");
+    V2E_REQUIRE((log_new_frame && c_minus_s_frame && diff_frame) || (!log_new_frame && !c_minus_s_frame && !diff_frame),
+                "model-state planes: all three or none");
+    h->dbg_lognew = log_new_frame; h->dbg_cms = c_minus_s_frame; h->dbg_diff = diff_frame;
     return 0;
 }
 

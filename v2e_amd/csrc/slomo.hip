@@ -528,6 +528,39 @@ __global__ __launch_bounds__(256) void k_fuse(const float *__restrict__ i0, cons
     out[(size_t)s * hw + p] = (w0 * v0 * g0 + w1 * v1 * g1) / (w0 * v0 + w1 * v1);
 }
 
+__global__ void k_zero_u32(unsigned *__restrict__ p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+// slomo.py:359-368 (auto_upsample): the largest flow magnitude of a batch.  sqrt is monotone, so the kernel reduces the
+// squared speed vx*vx + vy*vy (two products and one sum, each rounded: contraction is off for this file) of both flow pairs
+// and the host takes ONE float32 sqrt of the maximum -- the same number as max(sqrt(...)) over the planes.  Non-negative floats
+// order like their bit patterns: one atomicMax per wave.
+__global__ __launch_bounds__(256) void k_max_speed2(const float *__restrict__ flow, int b, int hw, unsigned *__restrict__ out_bits)
+{
+    float m = 0.f;
+    const long long n = (long long)b * hw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int bi = (int)(i / hw);
+        const int p = (int)(i - (long long)bi * hw);
+        const float *fl = flow + (size_t)bi * 4 * hw + p;
+        const float x0 = fl[0], y0 = fl[hw], x1 = fl[2 * (size_t)hw], y1 = fl[3 * (size_t)hw];
+        const float s0 = x0 * x0 + y0 * y0;
+        const float s1 = x1 * x1 + y1 * y1;
+        // torch.max propagates NaN; a NaN flow makes int(np.ceil(nan)) raise in the reference: report it as NaN too
+        if (s0 != s0 || s1 != s1) m = __int_as_float(0x7fc00000);
+        else if (m == m) m = fmaxf(m, fmaxf(s0, s1));
+    }
+    unsigned bits = (m != m) ? 0xffffffffu : __float_as_uint(m);
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)bits, o, 64);
+        bits = other > bits ? other : bits;
+    }
+    if ((threadIdx.x & 63) == 0 && bits != 0u) atomicMax(out_bits, bits);
+}
+
 // ---------------------------------------------------------------- dispatch
 template <int KS, int CI_T, int CT, int PT, int WP, int TW, int PRE>
 static void launch_conv(const ConvArgs &a0, hipStream_t s)
@@ -899,6 +932,19 @@ int v2e_slomo_fuse(const float *i0, const float *i1, const float *x12, const flo
     V2E_REQUIRE(i0 && i1 && x12 && intrp && t && out && n_t > 0 && b > 0, "bad fuse args");
     dim3 grid(v2e_cdiv((int64_t)h * w, 256), n_t * b);
     k_fuse<<<grid, 256, 0, (hipStream_t)stream>>>(i0, i1, x12, intrp, t, n_t, b, h, w, out);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_slomo_max_speed2(const float *flow, int b, int h, int w, uint32_t *out_bits, void *stream)
+{
+    V2E_REQUIRE(flow && out_bits && b > 0 && h > 0 && w > 0, "bad max_speed args");
+    hipStream_t s = (hipStream_t)stream;
+    k_zero_u32<<<1, 64, 0, s>>>(out_bits, 1);
+    const long long n = (long long)b * h * w;
+    int blocks = v2e_cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    k_max_speed2<<<blocks, 256, 0, s>>>(flow, b, h * w, out_bits);
     V2E_HIP(hipGetLastError());
     return 0;
 }

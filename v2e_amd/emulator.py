@@ -18,7 +18,11 @@ Random numbers come in two modes, selected with the extra key
            per-iteration shuffle computed on device; no host round trip except the final
            copy of the event list.  `generate_events_batch` keeps a whole clip on device.
 
-Not part of the hot path, NotImplementedError here: show_dvs_model_state, record_single_pixel_states.  `hdr=True`
+`show_dvs_model_state` / `save_dvs_model_state` (emulator.py:580-617, 756-764) and `record_single_pixel_states`
+(emulator.py:279-300, 985-1009) are host pass-throughs: the named state planes are read back from the device after every frame
+(three of them -- log_new_frame, c_minus_s_frame, diff_frame -- are left in extra planes by k_count while one of the two options
+is on, v2e_emu_set_model_state_planes) and displayed / saved through cv2 where it is importable, resp. recorded and pickled
+as the reference does; both put generate_events on the step-wise kernels.  `hdr=True`
 (log-encoded input, emulator.py:304, 666), `photoreceptor_noise=True` (emulator.py:694-703), `scidvs=True` (float64 state)
 and the centre-surround pixel (`cs_lambda_pixels`, emulator.py:1061-1124: the diffuser is stepped on the device between
 frames, csrc/csdvs.hip) are supported.
@@ -179,12 +183,32 @@ class EventEmulator(object):
             photoreceptor_noise_vrms: Optional[float] = None,
             tape_host_threads: Optional[int] = 1,
     ):
-        unsupported = []
-        if show_dvs_model_state is not None: unsupported.append("show_dvs_model_state")
-        if record_single_pixel_states is not None: unsupported.append("record_single_pixel_states")
-        if unsupported:
-            raise NotImplementedError(
-                "v2e_amd.EventEmulator implements the v2e hot path only; not available: " + ", ".join(unsupported))
+        # research tooling (host pass-throughs, see the module docstring)
+        self.dont_show_list = []
+        self.show_list = []
+        self.video_writers = {}
+        self._state_planes = None
+        self._cv2 = None
+        self._show_warned = False
+        if show_dvs_model_state is not None and len(show_dvs_model_state) == 1 and show_dvs_model_state[0] == 'all':
+            logger.info(f'will show all model states that exist from {EventEmulator.MODEL_STATES.keys()}')  # emulator.py:365-368
+            show_dvs_model_state = list(EventEmulator.MODEL_STATES.keys())
+        self.record_single_pixel_states = record_single_pixel_states  # emulator.py:279-300
+        self.single_pixel_sample_count = 0
+        if self.record_single_pixel_states is None:
+            self.single_pixel_states = None
+        else:
+            if not (type(self.record_single_pixel_states) is tuple):
+                raise ValueError(f'--record_single_pixel_states {self.record_single_pixel_states} should be a tuple, e.g. (10,20)')
+            if len(self.record_single_pixel_states) != 2:
+                raise ValueError(f'--record_single_pixel_states {self.record_single_pixel_states} should have two pixel addresses (x,y)')
+            for i in self.record_single_pixel_states:
+                if not (type(i) is int):
+                    raise ValueError(f'--record_single_pixel_states {self.record_single_pixel_states} should have two '
+                                     f'integer-value pixel addresses (x,y)')
+            self.single_pixel_states = {k: np.full(self.SINGLE_PIXEL_MAX_SAMPLES, np.nan) for k in (
+                'time', 'new_frame', 'base_log_frame', 'lp_log_frame', 'log_new_frame', 'pos_thres', 'neg_thres', 'diff_frame',
+                'final_neg_evts_frame', 'final_pos_evts_frame')}
 
         self.no_events_warning_count = 0
         logger.info("ON/OFF log_e temporal contrast thresholds: {} / {} +/- {}".format(
@@ -215,7 +239,7 @@ class EventEmulator(object):
         self.output_folder = output_folder
         self.output_width = output_width
         self.output_height = output_height
-        self.show_dvs_model_state = None
+        self.show_dvs_model_state = show_dvs_model_state
         self.save_dvs_model_state = save_dvs_model_state
         self.label_signal_noise = label_signal_noise
         self.log_input = bool(hdr)  # emulator.py:304: frames are log-encoded already
@@ -267,8 +291,8 @@ class EventEmulator(object):
     def _open_writers(self, dvs_h5, dvs_aedat2, dvs_aedat4, dvs_text):
         """Event file sinks (emulator.py:312-346).  AEDAT-2.0 and text: v2e_amd.sinks writers fed from the device-resident
         event buffer (integer conversion on the GPU, byte-identical to the reference writers).  HDF5: the reference's own
-        layout through h5py (rows converted on the GPU).  AEDAT-4: delegated to the reference's AEDat4Output (dv_processing),
-        where importable."""
+        layout through h5py (rows converted on the GPU).  AEDAT-4: v2e_amd.sinks.HostAEDat4Output over the third-party
+        dv_processing package (as the reference's writer is), or any writer object the caller passes as `dvs_aedat4`."""
         if not (dvs_h5 or dvs_aedat2 or dvs_aedat4 or dvs_text):
             return
 
@@ -294,12 +318,11 @@ class EventEmulator(object):
             self.dvs_text = DeviceTextOutput(suffixed(os.path.join(folder, dvs_text), '.txt'),
                                              label_signal_noise=self.label_signal_noise)
         if dvs_aedat4:
-            try:
-                from v2ecore.output.aedat4_output import AEDat4Output
-            except ImportError as e:
-                raise NotImplementedError("dvs_aedat4 is delegated to the reference's AEDat4Output (dv_processing), which "
-                                          "is not importable here: %s" % e)
-            self.dvs_aedat4 = AEDat4Output(suffixed(os.path.join(folder, dvs_aedat4), '.aedat4'))
+            if hasattr(dvs_aedat4, "appendEvents"):  # a caller-supplied writer object
+                self.dvs_aedat4 = dvs_aedat4
+            else:
+                from .sinks import HostAEDat4Output  # over dv_processing; NotImplementedError where that is absent
+                self.dvs_aedat4 = HostAEDat4Output(suffixed(os.path.join(folder, dvs_aedat4), '.aedat4'))
 
     def prepare_storage(self, n_frames, frame_ts):  # emulator.py:374-400
         if self.dvs_h5:
@@ -322,6 +345,17 @@ class EventEmulator(object):
         if getattr(self, "_host_threads_prev", None) is not None:
             torch.set_num_threads(self._host_threads_prev)
             self._host_threads_prev = None
+        for name, vw in list(getattr(self, "video_writers", {}).items()):  # emulator.py:424-426
+            logger.info(f'closing video AVI {name}')
+            try:
+                vw.release()
+            except Exception:
+                pass
+        if getattr(self, "video_writers", None):
+            self.video_writers = {}
+        if getattr(self, "record_single_pixel_states", None) is not None:  # emulator.py:428-429
+            self.save_recorded_single_pixel_states()
+            self.record_single_pixel_states = None
         for w in ("dvs_h5", "dvs_aedat2", "dvs_aedat4", "dvs_text"):
             o = getattr(self, w, None)
             if o is not None:
@@ -464,6 +498,12 @@ class EventEmulator(object):
             self.cs_surround_frame = eng.plane(self._cs_planes[0])
         else:
             eng.set_csdvs(None)
+        if self._wants_states():
+            self._state_planes = [torch.zeros((1, eng.npx_pad), dtype=torch.float64, device=eng.device) for _ in range(3)]
+            eng.set_model_state_planes(self._state_planes)
+        else:
+            self._state_planes = None
+            eng.set_model_state_planes(None)
         # public state attributes, as [H,W] device views
         self.lp_log_frame = eng.plane(eng.lp)
         self.base_log_frame = eng.plane(eng.base)
@@ -502,7 +542,8 @@ class EventEmulator(object):
         eng = self._ensure_engine(H, W)
         # Philox mode after the first frame: the whole frame is ONE C call (v2e_emu_frame), the host frame goes through
         # the handle's pinned staging instead of a torch tensor
-        fast = self._initialized and self.rng_mode == "philox" and not self.photoreceptor_noise and not self.csdvs_enabled
+        fast = self._initialized and self.rng_mode == "philox" and not self.photoreceptor_noise and not self.csdvs_enabled \
+            and not self._wants_states()
         host_frame = None
         if fast and isinstance(new_frame, np.ndarray) and new_frame.dtype in (np.uint8, np.float32, np.float64):
             host_frame = np.ascontiguousarray(new_frame)
@@ -571,6 +612,8 @@ class EventEmulator(object):
             self._update_csdvs(P, frame_dev, t_prev, t_frame, fidx)
         if not counted:
             eng.count(P, frame_dev, [t_prev], [t_frame], fidx, leak_randn=leak)
+        if self._state_planes is not None:
+            self._after_count_states(new_frame, t_frame)
         rec = eng.read_rec(fidx)[0]
         M = int(rec.max_events)
         if M > 100:
@@ -645,8 +688,123 @@ class EventEmulator(object):
             self._write_events(events, n_signal, events_dev=ev[0, :n_events])
         if self.frame_ev_idx_dataset is not None:
             self.frame_ev_idx_dataset[self.frame_counter - 1] = self.dvs_h5_dataset.shape[0]
+        if self.record_single_pixel_states is not None:
+            self._record_single_pixel(new_frame, t_frame, events, n_signal)
         self.t_previous = t_frame
         return events
+
+    # ------------------------------------------------------------- research tooling (host pass-throughs)
+    def _wants_states(self):
+        return self.show_dvs_model_state is not None or self.record_single_pixel_states is not None
+
+    def _after_count_states(self, new_frame, t_frame):
+        """The attributes the reference holds at emulator.py:756 (after the leak, before the events), as device views; then
+        emulator.py:756-767: show / save the requested ones."""
+        eng = self._engine
+        sd = torch.float64 if eng.f64_state else torch.float32
+        self.new_frame = new_frame
+        self.log_new_frame = eng.plane(self._state_planes[0]).to(torch.float32)  # lin_log returns float32 (emulator_utils.py:45)
+        self.c_minus_s_frame = eng.plane(self._state_planes[1]).to(sd) if self.csdvs_enabled else None
+        self.diff_frame = eng.plane(self._state_planes[2]).to(sd)
+        if self.show_dvs_model_state is None:
+            return
+        cv2 = self._host_cv2()
+        for s in self.show_dvs_model_state:
+            if s in self.dont_show_list:
+                continue
+            f = getattr(self, s, None)
+            if f is None:
+                logger.error(f'{s} does not exist so we cannot show it')
+                self.dont_show_list.append(s)
+            elif cv2 is not None:
+                self._show(f, s)
+        if cv2 is not None:
+            try:
+                k = cv2.waitKey(30)
+            except Exception:
+                k = -1
+            if k == 27 or k == ord('x'):
+                raise SystemExit(0)  # v2e_quit()
+
+    def _host_cv2(self):
+        if self._cv2 is None and not self._show_warned:
+            try:
+                import cv2
+                if not callable(getattr(cv2, "imshow", None)):
+                    raise ImportError("cv2 has no imshow")
+                self._cv2 = cv2
+            except Exception as e:
+                logger.warning("v2e_amd.EventEmulator: show_dvs_model_state / save_dvs_model_state need OpenCV on the host (%s): "
+                               "nothing is displayed or saved; the state planes stay readable as attributes (%s)", e,
+                               ", ".join(self.show_dvs_model_state))
+                self._show_warned = True
+        return self._cv2
+
+    def _show(self, inp, name):
+        """emulator.py:580-617: normalise by MODEL_STATES[name], show, and append to <name>.avi with save_dvs_model_state."""
+        cv2 = self._cv2
+        img = np.array(inp.detach().cpu().numpy() if torch.is_tensor(inp) else inp, dtype=np.float64)
+        (lo, hi) = EventEmulator.MODEL_STATES[name]
+        img = (img - lo) / (hi - lo)
+        try:
+            cv2.namedWindow(name, cv2.WINDOW_NORMAL)
+            if name not in self.show_list:
+                self.show_list.append(name)
+                if self.save_dvs_model_state:
+                    fn = os.path.join(self.output_folder or "", name + '.avi')
+                    self.video_writers[name] = cv2.VideoWriter(fn, cv2.VideoWriter_fourcc(*'XVID'), 30,
+                                                               (int(self.output_width or img.shape[1]),
+                                                                int(self.output_height or img.shape[0])))
+            for org, col in (((0, img.shape[0]), (0, 0, 0)), ((1, img.shape[0] - 1), (255, 255, 255))):
+                cv2.putText(img, f'fr:{self.frame_counter} t:{self.t_previous:.4f}s', org=org, fontScale=1.3, color=col,
+                            fontFace=cv2.FONT_HERSHEY_PLAIN, thickness=1)
+            cv2.imshow(name, img)
+            if self.save_dvs_model_state:
+                g = (img * 255).astype(np.uint8)
+                self.video_writers[name].write(np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)))
+        except Exception as e:  # no display
+            logger.warning("v2e_amd.EventEmulator: cannot show %s (%s)", name, e)
+            self.dont_show_list.append(name)
+
+    def _record_single_pixel(self, new_frame, t_frame, events, n_signal):
+        """emulator.py:985-1009.  The index tuple addresses the [H, W] planes as the reference's does (plane[a, b]); the
+        final per-pixel ON / OFF counts are the frame's signal events at that pixel (what final_pos/neg_evts_frame hold)."""
+        ij = self.record_single_pixel_states
+        if self.single_pixel_sample_count < self.SINGLE_PIXEL_MAX_SAMPLES:
+            k = self.single_pixel_sample_count
+            if k % 250 == 0:
+                logger.info(f'recorded {k} single pixel states')
+            st = self.single_pixel_states
+            st['time'][k] = t_frame
+            st['new_frame'][k] = float(new_frame[ij])
+            st['base_log_frame'][k] = float(self.base_log_frame[ij])
+            st['lp_log_frame'][k] = float(self.lp_log_frame[ij])
+            st['log_new_frame'][k] = float(self.log_new_frame[ij])
+            st['pos_thres'][k] = self.pos_thres if type(self.pos_thres) is float else float(self.pos_thres[ij])
+            st['neg_thres'][k] = self.neg_thres if type(self.neg_thres) is float else float(self.neg_thres[ij])
+            st['diff_frame'][k] = float(self.diff_frame[ij])
+            on = off = 0
+            if events is not None and n_signal > 0:
+                sig = events[:n_signal]
+                here = (sig[:, 2] == ij[0]) & (sig[:, 1] == ij[1])  # rows are [t, x = column, y = row, p]
+                on = int(np.count_nonzero(here & (sig[:, 3] > 0)))
+                off = int(np.count_nonzero(here & (sig[:, 3] < 0)))
+            st['final_neg_evts_frame'][k] = off
+            st['final_pos_evts_frame'][k] = on
+            self.single_pixel_sample_count += 1
+        else:
+            self.save_recorded_single_pixel_states()
+            self.record_single_pixel_states = None
+
+    def save_recorded_single_pixel_states(self):  # emulator.py:431-437
+        import pickle
+        try:
+            with open(self.SINGLE_PIXEL_STATES_FILENAME, 'wb') as outfile:
+                pickle.dump(self.single_pixel_states, outfile, protocol=pickle.HIGHEST_PROTOCOL)
+                logger.info(f'saved single pixel states with {self.single_pixel_sample_count} samples to '
+                            f'{self.SINGLE_PIXEL_STATES_FILENAME}')
+        except Exception as e:
+            logger.error(f'could not save pickled pixel states, got {e}')
 
     def _write_events(self, events, n_signal, events_dev=None):
         """emulator.py:953-977: append this frame's events to the open sinks.  The integer conversions of the HDF5 rows
@@ -736,6 +894,9 @@ class EventEmulator(object):
             raise _capi.V2EAmdError("a previous device-resident run failed (%s); call reset()" % self._failed)
         if self.rng_mode != "philox":
             raise ValueError("generate_events_batch needs rng_mode='philox' (tape mode needs the host per frame)")
+        if self._wants_states():
+            raise ValueError("show_dvs_model_state / record_single_pixel_states read the state after every frame: use "
+                             "generate_events per frame")
         if self.csdvs_enabled:
             raise NotImplementedError("generate_events_batch with cs_lambda_pixels: the surround's stepping loop ends on a "
                                       "host-visible maximum per frame (emulator.py:1107); use generate_events per frame")

@@ -210,6 +210,12 @@ class EmuEngine:
         the next count(); None switches the feature off."""
         check(self.lib.v2e_emu_set_pnoise(self._h, _ptr(pn_plane), _ptr(randn_tape)), "v2e_emu_set_pnoise")
 
+    def set_model_state_planes(self, planes):
+        """Three float64 planes [n_clips][npx_pad] (log_new_frame, c_minus_s_frame, diff_frame) every count() fills from
+        now on; None switches it off (v2e_emu_set_model_state_planes)."""
+        a, b, c = planes if planes is not None else (None, None, None)
+        check(self.lib.v2e_emu_set_model_state_planes(self._h, _ptr(a), _ptr(b), _ptr(c)), "v2e_emu_set_model_state_planes")
+
     def shot(self, P, frame_dev, frame_idx, shot_rand):
         check(self.lib.v2e_emu_shot(self._h, C.byref(P), _ptr(frame_dev), _DT[frame_dev.dtype],
                                     int(frame_idx), _ptr(shot_rand), self.stream), "v2e_emu_shot")

@@ -7,8 +7,11 @@ is edited: this module imports `v2e` from a checkout, rebinds the two names (the
     python -m v2e_amd.launcher /path/to/v2e  -i input.mp4 --dvs346 ...   (or V2E_ROOT=/path/to/v2e)
 """
 import importlib
+import logging
 import os
 import sys
+
+logger = logging.getLogger(__name__)
 
 
 def bind(v2e_root=None):
@@ -25,7 +28,26 @@ def bind(v2e_root=None):
         m.EventEmulator = v2e_amd.EventEmulator
     for m in (v2e, slomo_mod):
         m.SuperSloMo = v2e_amd.SuperSloMo
+    log_modes()
     return v2e
+
+
+def log_modes():
+    """Say which random-number mode and convolution math the bound classes will run, and what the choice costs (the defaults
+    reproduce the reference event for event, which is not the fast configuration)."""
+    rng = os.environ.get("V2E_AMD_RNG", "tape").lower()
+    if rng == "philox":
+        logger.warning("v2e_amd: V2E_AMD_RNG=philox -- DVS noise from counter-based Philox streams on the GPU: same pixel model "
+                       "and statistics, NOT the reference's torch MT19937 sequence (events differ from a reference run with the "
+                       "same seed); about 12x the frame rate of tape mode (15 900 vs 1 300 frames/s at 346x260)")
+    else:
+        logger.warning("v2e_amd: rng_mode=tape (default) -- the host replays the reference's torch random draws in the reference's "
+                       "order, so a seeded run gives the reference's events bit for bit; this bounds the emulator at about "
+                       "1 300 frames/s (346x260).  Set V2E_AMD_RNG=philox for in-kernel Philox noise: about 12x faster, "
+                       "statistically equivalent, not sequence-identical")
+    logger.warning("v2e_amd: SuperSloMo conv_math=%s (V2E_AMD_CONV_MATH: auto | bf16x3 | fp16x2 | f32; 'bf16x3' is the exact float32 "
+                   "split at 0.7x the frame rate of 'auto')", os.environ.get("V2E_AMD_CONV_MATH", "auto"))
+    return rng
 
 
 def main(argv=None):

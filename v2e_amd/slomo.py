@@ -9,8 +9,10 @@ in libv2e_amd.so (f32 MFMA implicit-GEMM convolutions); PyTorch only owns the bu
 Differences from the reference, all at the edges of the hot path:
   * all `upsampling_factor` time points of a batch go through the interpolation UNet as one
     batch (n_t * B samples) instead of a Python loop -- same arithmetic per sample;
-  * the AVI/preview writers (slomo.py:288-303, 447-490) are not implemented
-    (`video_path`/`preview` raise NotImplementedError);
+  * the AVI / preview writers (slomo.py:288-303, 447-490) are host work outside the hot path: `video_path`, `vid_orig`,
+    `vid_slomo` and `preview` are accepted as the reference's CLI passes them (v2e.py:471-478); the two AVIs are written on the
+    host through cv2 when cv2 is importable and skipped with ONE warning when it is not -- the constructor never raises for
+    them, and the interpolation itself is unaffected;
   * host-side pre/post-processing (PIL LANCZOS / BILINEAR resize, PNG files) is kept as is.
 """
 import atexit
@@ -30,6 +32,17 @@ logger = logging.getLogger(__name__)
 # forward order of the 23 convolutions of model.UNet (model.py:184-196, 198-226)
 UNET_LAYERS = (["conv1", "conv2"] + ["down%d.conv%d" % (d, c) for d in range(1, 6) for c in (1, 2)] +
                ["up%d.conv%d" % (u, c) for u in range(1, 6) for c in (1, 2)] + ["conv3"])
+
+
+OUTPUT_VIDEO_CODEC_FOURCC = 'XVID'  # v2ecore/v2e_utils.py:22, the codec of video_writer
+
+
+def _all_images(data_path):
+    """slomo.py:500-521: the PNGs of a folder in numerical order."""
+    images = glob.glob(os.path.join(data_path, '*.png'))
+    if len(images) == 0:
+        raise ValueError("Input folder is empty or images are not in 'png' format.")
+    return sorted(images, key=lambda line: int(line.split(os.sep)[-1].split('.')[0]))
 
 
 def _ptr(t):
@@ -166,6 +179,7 @@ class SloMoEngine:
         self.flow_net = HipUNet(flow_state_dict, 2, 4, self.device, conv_math)
         self.interp_net = HipUNet(interp_state_dict, 12, 5, self.device, conv_math)
         self._x2 = None
+        self._speed_bits = None
 
     def _stream(self):
         import ctypes as C
@@ -175,6 +189,19 @@ class SloMoEngine:
         """flowOut = flow_estimator(cat(I0, I1)) (slomo.py:343); I0, I1: [B,1,H,W] float32."""
         x = torch.cat((I0, I1), dim=1).contiguous()  # 2 channels; the large concats are fused in-kernel
         return self.flow_net.forward(x)
+
+    def max_speed(self, flow):
+        """slomo.py:352-368: the largest flow magnitude (pixels per source frame) over the batch and both directions, reduced on
+        the device (k_max_speed2: max of the squared speed; ONE float32 sqrt on the host -- sqrt is monotone)."""
+        b, c, h, w = flow.shape
+        assert c == 4 and flow.dtype == torch.float32 and flow.is_contiguous()
+        if self._speed_bits is None:
+            self._speed_bits = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(self.lib.v2e_slomo_max_speed2(_ptr(flow), b, h, w, _ptr(self._speed_bits), self._stream()), "v2e_slomo_max_speed2")
+        bits = int(self._speed_bits.item()) & 0xFFFFFFFF
+        if bits == 0xFFFFFFFF:
+            return float("nan")
+        return float(np.sqrt(np.array([bits], dtype=np.uint32).view(np.float32)[0]))
 
     def interpolate(self, I0, I1, ts, flow=None):
         """Ft_p for every t in ts and every pair in the batch: returns [len(ts), B, 1, H, W]."""
@@ -213,18 +240,109 @@ class SuperSloMo(object):
                 upsampling_factor))  # slomo.py:91-94
         self.upsampling_factor = upsampling_factor
         self.auto_upsample = auto_upsample
-        if video_path is not None or preview:
-            raise NotImplementedError("v2e_amd.SuperSloMo: AVI output / preview are outside the hot path")
-        self.video_path = None
-        self.preview = False
+        # slomo.py:110-121: kept as given.  The writers are built on first need in interpolate() (the frame size is known there)
+        self.video_path = video_path
+        self.preview = preview
+        self.preview_resized = False
         self.vid_orig, self.vid_slomo, self.avi_frame_rate = vid_orig, vid_slomo, avi_frame_rate
+        self.ori_writer = None
+        self.slomo_writer = None
+        self.numOrigVideoFramesWritten = 0
+        self.numSlomoVideoFramesWritten = 0
+        self._cv2 = None
+        self._host_video_warned = False
         self.model_loaded = False
         self.engine = None
         self.mean = 0.428  # slomo.py:148: Normalize(mean=[0.428], std=[1]) on the GPU path only
         atexit.register(self.cleanup)
 
-    def cleanup(self):
-        pass
+    def cleanup(self):  # slomo.py:126-138
+        for attr, name, n in (("ori_writer", "vid_orig", "numOrigVideoFramesWritten"),
+                              ("slomo_writer", "vid_slomo", "numSlomoVideoFramesWritten")):
+            w = getattr(self, attr, None)
+            if w is not None:
+                logger.info('closing video AVI {} after writing {} frames'.format(getattr(self, name), getattr(self, n)))
+                try:
+                    w.release()
+                except Exception:
+                    pass
+                setattr(self, attr, None)
+        if getattr(self, "preview", False) and getattr(self, "_cv2", None) is not None:
+            try:
+                self._cv2.destroyAllWindows()
+            except Exception:
+                pass
+
+    def _host_video(self):
+        """cv2 for the AVI / preview side outputs (host work, not the hot path), or None with one warning."""
+        if self._cv2 is not None:
+            return self._cv2
+        try:
+            import cv2
+            if not callable(getattr(cv2, "VideoWriter", None)) or not callable(getattr(cv2, "VideoWriter_fourcc", None)):
+                raise ImportError("cv2 has no VideoWriter")
+            self._cv2 = cv2
+        except Exception as e:
+            if not self._host_video_warned:
+                logger.warning("v2e_amd.SuperSloMo: video_path=%r / preview=%r need OpenCV on the host (%s): the AVI / preview "
+                               "side outputs are skipped, the interpolated frames are written as usual",
+                               self.video_path, self.preview, e)
+                self._host_video_warned = True
+        return self._cv2
+
+    def _open_writers(self, ori_dim):
+        """slomo.py:287-301: the AVI writers, now that the frame size is known (v2e_utils.video_writer: codec
+        OUTPUT_VIDEO_CODEC_FOURCC, frame size (width, height))."""
+        if self.video_path is None or (self.vid_orig is None and self.vid_slomo is None):
+            return
+        cv2 = self._host_video()
+        if cv2 is None:
+            return
+        fourcc = cv2.VideoWriter_fourcc(*OUTPUT_VIDEO_CODEC_FOURCC)
+        size = (int(ori_dim[0]), int(ori_dim[1]))  # frame_size is (width, height), as cv2.VideoWriter wants it
+        if self.vid_orig is not None and self.ori_writer is None:
+            self.ori_writer = cv2.VideoWriter(os.path.join(self.video_path, self.vid_orig), fourcc, self.avi_frame_rate, size)
+        if self.vid_slomo is not None and self.slomo_writer is None:
+            self.slomo_writer = cv2.VideoWriter(os.path.join(self.video_path, self.vid_slomo), fourcc, self.avi_frame_rate, size)
+
+    def _write_videos(self, source_frame_path, output_folder):
+        """slomo.py:463-490: the source frames and the interpolated PNGs, grey -> 3 equal channels, into the two AVIs."""
+        from PIL import Image
+        if self.ori_writer is not None:
+            for f in sorted(glob.glob("{}".format(source_frame_path) + "/*.npy")):
+                a = np.load(f)
+                if a.ndim == 2:
+                    a = np.repeat(a[:, :, None], 3, axis=2)  # cv2.COLOR_GRAY2BGR
+                self.ori_writer.write(np.ascontiguousarray(a))
+                self.numOrigVideoFramesWritten += 1
+        if self.slomo_writer is not None:
+            for f in _all_images(output_folder):
+                a = np.asarray(Image.open(f).convert("L"))
+                self.slomo_writer.write(np.ascontiguousarray(np.repeat(a[:, :, None], 3, axis=2)))
+                self.numSlomoVideoFramesWritten += 1
+
+    def _preview_batch(self, output_folder, first, last):
+        """slomo.py:451-468: show the frames just written (needs a display and cv2; off with one warning otherwise)."""
+        cv2 = self._host_video()
+        if cv2 is None or not callable(getattr(cv2, "imshow", None)):
+            return
+        try:
+            name = "v2e_amd.slomo"
+            cv2.namedWindow(name, cv2.WINDOW_NORMAL)
+            for idx in range(first, last):
+                frame = cv2.imread(os.path.join(output_folder, str(idx) + ".png"))
+                cv2.imshow(name, frame)
+                if not self.preview_resized:
+                    cv2.resizeWindow(name, 800, 600)
+                    self.preview_resized = True
+                k = cv2.waitKey(1)
+                if k == 27 or k == ord('x'):
+                    raise SystemExit(0)  # v2e_quit()
+        except SystemExit:
+            raise
+        except Exception as e:  # no display: the side output is dropped
+            logger.warning("v2e_amd.SuperSloMo: preview not available (%s)", e)
+            self.preview = False
 
     def _load_model(self):
         if not os.path.isfile(self.checkpoint):
@@ -273,6 +391,7 @@ class SuperSloMo(object):
                             'size or increase number of input frames'.format(nbatches, source_frame_path))
         if not self.model_loaded:
             self._load_model()
+        self._open_writers(ori_dim)
         outputFrameCounter = 0
         inputFrameCounter = 0
         upsamplingSum = 0
@@ -287,10 +406,7 @@ class SuperSloMo(object):
             num_batch_frames = I0.shape[0]
             flowOut = self.engine.flow(I0, I1)
             if self.auto_upsample:  # slomo.py:352-379
-                v = flowOut.flatten(2, 3)
-                sp0 = torch.sqrt(v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1])
-                sp1 = torch.sqrt(v[:, 2] * v[:, 2] + v[:, 3] * v[:, 3])
-                maxSpeed = float(torch.max(torch.cat((sp0, sp1), 1)).cpu().item())
+                maxSpeed = self.engine.max_speed(flowOut)
                 upsampling_factor = int(np.ceil(maxSpeed))
                 if self.upsampling_factor is not None and self.upsampling_factor > upsampling_factor:
                     upsampling_factor = self.upsampling_factor
@@ -319,8 +435,11 @@ class SuperSloMo(object):
                     img_resize = img.resize(ori_dim, Image.BILINEAR)
                     outputFrameIdx = outputFrameCounter + upsampling_factor * batchIndex + k
                     img_resize.save(os.path.join(output_folder, str(outputFrameIdx) + ".png"))
+            if self.preview:
+                self._preview_batch(output_folder, outputFrameCounter, outputFrameCounter + numOutputFramesThisBatch)
             inputFrameCounter += num_batch_frames
             outputFrameCounter += numOutputFramesThisBatch
+        self._write_videos(source_frame_path, output_folder)
         avgUpsampling = upsamplingSum / nUpsamplingSamples
         return interpTimes, avgUpsampling
 
