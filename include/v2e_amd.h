@@ -387,7 +387,8 @@ int v2e_events_unpack64(const uint64_t *in, float *events, int64_t n, void *stre
 
 /* Lossless 4-byte wire format for sensors up to 2048 x 1024: the rows of a run come in blocks of one time stamp (all events
  * of one (frame, iteration) share it: emulator.py:793-796, 861-870), so t travels once per block.  payload[i] = x | y << 11
- * | (p > 0) << 21; runs[0] = number of blocks R, runs[1 + r] = float32 bits of t << 32 | index of the block's first event
+ * | (p > 0) << 21; runs[0] = number of blocks R in its low 32 bits (never more than cap_runs) and the overflow flags below in
+ * bits 62 (coordinate) and 63 (table too small), so that a receiver of the table sees them too; runs[1 + r] = float32 bits of t << 32 | index of the block's first event
  * (in order).  cap_runs: entries the run table holds besides runs[0] (a bound is sum over frames of max(iterations, 1));
  * scratch: device uint32 [v2e_events_pack32_scratch_words(n)], scratch[0] after the call: bit 0 a coordinate did not fit,
  * bit 1 the run table was too small (the caller then sends pack64).  unpack32 restores the float32 rows bit for bit. */

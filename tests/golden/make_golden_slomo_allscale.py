@@ -9,6 +9,13 @@ would show.  So:
                                   activations run up to O(10) (reported per layer), B = 2 pairs, 3 time points, 64x96
   slomo_trained_scale_64x96.npz   (regenerated) the conv3-heads-scaled case, now with the float64 result too
 
+  slomo_smallact_64x96.npz        (`python make_golden_slomo_allscale.py smallact`) the adversarial case for the ACTIVATION
+                                  side of the two-float16-piece convolutions: conv1's weights and every bias but conv3's times
+                                  s = 2^-17, conv3's weights times 2^17 -- the same function as the unscaled network (leaky-ReLU
+                                  networks are homogeneous; powers of two are exact, so the reference's float32 result is the
+                                  unscaled network's bit for bit), but every trunk activation is 1e-7 ... 1e-4: float16
+                                  subnormals unless the kernel scales its operands (round-3 review, "What's weak" 1)
+
 Each holds the reference's float32 result (`model.UNet` / `backWarp` and the slomo.py:404-433 lines, as make_golden_slomo.py
 drives them) AND the same computation in float64 (the same modules `.double()`; backWarp's `.float()` casts restated in
 float64).  The tests assert, per tensor,  max|HIP - f64| <= 1.5 * max|ref_f32 - f64|  for both conv maths: the HIP path
@@ -79,6 +86,19 @@ def save(name, fr, ts, extra, o32, o64):
     print(name, os.path.getsize(os.path.join(HERE, name)) // 1024, "KB")
 
 
+def smallact_state_dicts(log2s=-17):
+    """Seeds 101 / 102 with the trunk scaled down by 2^log2s and the heads scaled back up (see the module docstring)."""
+    s = np.float32(2.0 ** log2s)
+    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
+    for sd in (sd_f, sd_i):
+        sd["conv1.weight"] = sd["conv1.weight"] * s
+        for k in sd:
+            if k.endswith(".bias") and k != "conv3.bias":
+                sd[k] = sd[k] * s
+        sd["conv3.weight"] = sd["conv3.weight"] / s
+    return sd_f, sd_i
+
+
 def main():
     model = rh.ref_model()
     torch.set_num_threads(8)
@@ -87,6 +107,18 @@ def main():
     I0 = torch.from_numpy(fr[:b].astype(np.float32) / 255.0).unsqueeze(1) - 0.428
     I1 = torch.from_numpy(fr[1:b + 1].astype(np.float32) / 255.0).unsqueeze(1) - 0.428
     ts = [(k + 0.5) / 3 for k in range(3)]
+
+    if len(sys.argv) > 1 and sys.argv[1] == "smallact":
+        sd_f, sd_i = smallact_state_dicts()
+        o32, o64, acts = run(model, sd_f, sd_i, I0, I1, ts, h, w)
+        print("trunk x 2^-17: activation maxima of the interpolation UNet per conv:")
+        print("   " + "  ".join("%s %.2g" % (k, v) for k, v in acts.items()))
+        # the same function as the unscaled network, bit for bit in float32
+        u32, _, _ = run(model, portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102), I0, I1, ts, h, w)
+        for k in ("flow", "intrp", "Ft"):
+            print("   %-6s == unscaled network bit for bit: %s" % (k, bool(torch.equal(o32[k], u32[k]))))
+        save("slomo_smallact_64x96.npz", fr, ts, dict(log2s=np.int32(-17), act_max=np.asarray(list(acts.values()))), o32, o64)
+        return
 
     # ---- every layer scaled: pick the factor that brings the interpolation UNet's activations to O(10)
     gain = float(sys.argv[1]) if len(sys.argv) > 1 else 1.9

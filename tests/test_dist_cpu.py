@@ -90,6 +90,65 @@ def test_event_stream_exchange_gloo_world4_unequal_counts(wire, algo):
     _run_gloo(4, wire, algo)
 
 
+def _worker_flags(rank, world, port, q):
+    """Round-3 advisor finding: a pack32 overflow on ONE rank must be seen by EVERY rank (it used to raise on the sender only,
+    after the exchange, and the peers unpacked against a truncated run table); ranks that disagree about the run bound must
+    not issue different collectives."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from v2e_amd.dist import EventStreamGatherer
+    ok = True
+    # (a) rank 1 under-states its run bound: both ranks raise, with rank 1 named
+    g = EventStreamGatherer("cpu", world, wire="pack32", sensor=(720, 1280))
+    n = 5 if rank == 0 else 40   # the run tables are sized by the largest bound of the step: 5 here, rank 1 has more blocks
+    ev = _rows_runs(n, rank, 0)
+    g.submit(ev, n, run_bound=(5 if rank == 0 else 3))
+    try:
+        g.result()
+        ok = False
+    except ValueError as e:
+        ok &= "rank 1" in str(e) and "run_bound too small" in str(e) and "rank 0" not in str(e)
+    # (b) a coordinate that does not fit on rank 0 (explicit pack32 without a sensor): both ranks raise
+    g = EventStreamGatherer("cpu", world, wire="pack32")
+    ev = _rows_runs(40, rank, 0)
+    if rank == 0:
+        ev[5, 1] = 2050.0
+    g.submit(ev, 40, run_bound=40)
+    try:
+        g.result()
+        ok = False
+    except ValueError as e:
+        ok &= "rank 0" in str(e) and "coordinate" in str(e)
+    # (c) only one rank supplies a bound: every rank sends the 8-byte format for that step, and the data arrive
+    g = EventStreamGatherer("cpu", world, wire="auto", sensor=(720, 1280))
+    ev = _rows_runs(30 + rank, rank, 1)
+    g.submit(ev, 30 + rank, run_bound=(30 if rank == 0 else None))
+    ok &= g.last["wire"] == "pack64"
+    parts = g.result()
+    for r in range(world):
+        exp = _rows_runs(30 + r, r, 1)
+        ok &= torch.equal(parts[r].view(torch.int32), exp.view(torch.int32))
+    # (d) no sensor given: "auto" never assumes the frame fits 2048 x 1024
+    ok &= EventStreamGatherer("cpu", world).wire == "pack64"
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pack32_overflow_and_wire_disagreement_are_seen_by_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flags, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
+
+
 def test_wire_formats_round_trip_and_agree():
     """pack32 (payload + run table) and pack64 restore the same float32 rows bit for bit: blocks of one time stamp, a
     negative time stamp, -0.0 next to +0.0 (different bits: two blocks), coordinates up to 2047 x 1023; a coordinate beyond

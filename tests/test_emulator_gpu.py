@@ -621,3 +621,48 @@ def test_scidvs_matches_oracle_on_seeded_inputs(shape, oracle_lib):
     hp = emu.scidvs_highpass.cpu().numpy()
     assert np.max(np.abs(hp - ora.scidvs_highpass)) <= 1e-12 * max(1.0, np.max(np.abs(ora.scidvs_highpass)))
     assert np.array_equal(emu.scidvs_tau_arr.cpu().numpy(), ora.scidvs_tau_arr)
+
+
+@pytest.mark.parametrize("name", ["tape_defaults_40x48", "tape_refractory_float_33x37"])
+def test_single_pixel_recorder_matches_reference(name, oracle_lib, tmp_path, monkeypatch):
+    """record_single_pixel_states (emulator.py:279-300, 985-1009): the ten series the reference records for one pixel, from
+    the reference itself (tests/golden/make_golden_single_pixel.py: same run as the tape fixture), bit for bit as float64 --
+    log_new_frame and diff_frame come from the planes k_count leaves for this option, the ON / OFF counts from the frame's
+    signal events.  The events of the run are unchanged by the option, and cleanup() pickles the dict as the reference does."""
+    import os
+    import pickle
+    from fixtures import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "single_pixel.npz"))
+    ij = tuple(int(v) for v in g[name + "__pixel"])
+    fx = TapeFixture(name)
+    monkeypatch.chdir(tmp_path)  # SINGLE_PIXEL_STATES_FILENAME is relative, as in the reference
+    emu = _mk(fx, seed=0, rng_mode="tape", tape=oracle_lib.RecordedTape(fx.items), record_single_pixel_states=ij)
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        assert events_equal(emu.generate_events(f, float(t)), fx.events[k]), "frame %d differs from the reference" % k
+    n = emu.single_pixel_sample_count
+    assert n == len(g[name + "__time"]) == len(fx.frames) - 1
+    for key, arr in emu.single_pixel_states.items():
+        ref = g["%s__%s" % (name, key)]
+        assert np.array_equal(arr[:n], ref), (key, arr[:n], ref)
+        assert np.isnan(arr[n:]).all()
+    assert float(np.sum(g[name + "__final_neg_evts_frame"]) + np.sum(g[name + "__final_pos_evts_frame"])) > 0
+    emu.cleanup()
+    with open(str(tmp_path / emu.SINGLE_PIXEL_STATES_FILENAME), "rb") as f:
+        d = pickle.load(f)
+    assert sorted(d) == sorted(emu.single_pixel_states) and np.array_equal(d["diff_frame"][:n], g[name + "__diff_frame"])
+    with pytest.raises(ValueError):
+        _mk(fx, record_single_pixel_states=[1, 2])  # emulator.py:284-285: a tuple
+
+
+def test_model_state_planes_are_readable_without_a_display():
+    """show_dvs_model_state (emulator.py:756-767): without OpenCV / a display nothing is shown, one warning, and the run is the
+    same run; the named states are readable as attributes (diff_frame == lp_log_frame - base_log_frame before the update)."""
+    fx = PhiloxFixture("philox_moving_dot_64x64")
+    emu = _mk(fx, seed=fx.seed, rng_mode="philox", show_dvs_model_state=["all"])
+    for k, (f, t) in enumerate(zip(fx.frames[:30], fx.times[:30])):
+        ev = emu.generate_events(f, float(t))
+        n = 0 if ev is None else len(ev)
+        assert n == fx.n_events[k] and (n == 0 or sha(ev) == fx.ev_sha[k])
+    assert emu.diff_frame is not None and tuple(emu.diff_frame.shape) == tuple(fx.frames[0].shape)
+    assert emu.log_new_frame.dtype == torch.float32 and emu.c_minus_s_frame is None
+    emu.cleanup()

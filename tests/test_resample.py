@@ -60,7 +60,9 @@ def test_device_pipeline_equals_png_pipeline(tmp_path):
               refractory_period_s=0.001)
     dt_src = 1 / 30.0
     ref_emu = EventEmulator(device="cuda", seed=5, rng_mode="philox", **kw)
-    ref_ev = [ref_emu.generate_events(p.astype(np.float32), float(t) * dt_src) for p, t in zip(pngs, times)]  # v2e.py:832-834
+    duration = (n - 1) * dt_src  # v2e.py:786-797: the interpTimes are stretched to span the processed duration
+    vt = (duration / (np.max(times) - np.min(times))) * times
+    ref_ev = [ref_emu.generate_events(p.astype(np.float32), float(t)) for p, t in zip(pngs, vt)]  # v2e.py:832-834
     ref_ev = np.concatenate([e for e in ref_ev if e is not None])
     pipe = VideoToEvents(sm.engine, EventEmulator(device="cuda", seed=5, rng_mode="philox", **kw), U, batch_size=2)
     up = pipe.upsample(torch.from_numpy(fr).cuda())

@@ -144,9 +144,14 @@ __global__ __launch_bounds__(1024) void k_pack32_scan(uint32_t *__restrict__ blk
         if (j < nblk) { const uint32_t c = blk_runs[j]; blk_runs[j] = run; run += c; }
     }
     if (tid == 1023) {
+        // runs[0]: the number of blocks IN THE TABLE (never more than it holds: a receiver searches runs[1 .. 1 + R)), and in
+        // bits 62 / 63 what went wrong -- a coordinate that does not fit, a table that was too small -- so that every rank
+        // that receives the table sees it, not only the sender
         const uint32_t total = s_part[1023];
-        runs[0] = total;
-        if ((int64_t)total > cap_runs) atomicOr(overflow, 2u); // run table too small
+        uint32_t fl = *overflow & 1u; // k_pack32_words ran before this kernel on the same stream
+        if ((int64_t)total > cap_runs) { fl |= 2u; atomicOr(overflow, 2u); }
+        const unsigned long long kept = (int64_t)total > cap_runs ? (unsigned long long)cap_runs : (unsigned long long)total;
+        runs[0] = kept | ((unsigned long long)fl << 62);
     }
 }
 
@@ -174,7 +179,8 @@ __global__ __launch_bounds__(256) void k_unpack32(const uint32_t *__restrict__ p
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int nr = (int)runs[0];
+    const int nr = (int)(runs[0] & 0xFFFFFFFFull); // bits 62 / 63: the sender's overflow flags (the host refuses such a table)
+    if (nr <= 0) return;
     int lo = 0, hi = nr; // last run whose first event index is <= i
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;

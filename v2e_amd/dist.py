@@ -75,7 +75,8 @@ def unpack_events64(words):
 
 def pack_events32(ev, payload=None, runs=None, cap_runs=None, scratch=None):
     """[n,4] float32 rows -> (payload int32 [n], runs int64 [1 + R]) in the 4-byte wire format (include/v2e_amd.h
-    v2e_events_pack32): runs[0] = R, runs[1 + r] = float32 bits of t << 32 | index of the block's first event.  On the
+    v2e_events_pack32): runs[0] = R (low 32 bits; bits 62 / 63 = the overflow flags, so that whoever receives the table sees
+    them), runs[1 + r] = float32 bits of t << 32 | index of the block's first event.  On the
     device the outputs may be preallocated (runs with room for cap_runs blocks); returns (payload, runs, flags) where
     flags is a device int32 [>=1] whose word 0 is non-zero if a coordinate did not fit or the run table was too small."""
     n = int(ev.shape[0])
@@ -108,8 +109,14 @@ def pack_events32(ev, payload=None, runs=None, cap_runs=None, scratch=None):
         tbl = ((tb[idx].to(torch.int64) & 0xFFFFFFFF) << 32) | idx
     else:
         tbl = torch.zeros((0,), dtype=torch.int64)
-    runs_t = torch.cat([torch.tensor([tbl.numel()], dtype=torch.int64), tbl])
-    return pl, runs_t, torch.tensor([1 if bad else 0], dtype=torch.int32)
+    fl = 1 if bad else 0
+    if cap_runs is not None and tbl.numel() > int(cap_runs):  # as the device kernels: the table keeps what it holds, flagged
+        tbl, fl = tbl[:int(cap_runs)], fl | 2
+    head = int(tbl.numel()) | (fl << 62)
+    if head >= 1 << 63:
+        head -= 1 << 64  # bit 63 in a signed word
+    runs_t = torch.cat([torch.tensor([head], dtype=torch.int64), tbl])
+    return pl, runs_t, torch.tensor([fl], dtype=torch.int32)
 
 
 def unpack_events32(payload, runs, n=None):
@@ -123,7 +130,7 @@ def unpack_events32(payload, runs, n=None):
         _capi.check(_capi.lib().v2e_events_unpack32(C.c_void_p(payload.data_ptr()), n, C.c_void_p(runs.data_ptr()),
                                                     C.c_void_p(ev.data_ptr()), _stream_ptr(payload.device)), "v2e_events_unpack32")
         return ev
-    R = int(runs[0])
+    R = int(runs[0]) & 0xFFFFFFFF
     tbl = runs[1:1 + R]
     starts = tbl & 0xFFFFFFFF
     k = torch.bucketize(torch.arange(n, dtype=torch.int64), starts, right=True) - 1
@@ -157,16 +164,23 @@ class EventStreamGatherer:
             raise ValueError("wire must be auto, pack32 or pack64")
         if algo not in ("allgather", "p2p"):
             raise ValueError("algo must be allgather or p2p")
-        fits32 = sensor is None or (int(sensor[0]) <= 1024 and int(sensor[1]) <= 2048)  # (H, W)
-        if wire == "pack32" and not fits32:
+        # pack32 holds x < 2048, y < 1024: it is chosen only for a sensor that is KNOWN to fit (`sensor` = (H, W)); without one
+        # "auto" sends the 8-byte format, and an explicit "pack32" is taken at the caller's word (a coordinate that does not
+        # fit is then flagged inside the run table and result() raises on EVERY rank)
+        fits32 = sensor is not None and int(sensor[0]) <= 1024 and int(sensor[1]) <= 2048
+        if wire == "pack32" and sensor is not None and not fits32:
             raise ValueError("pack32 holds x < 2048, y < 1024")
-        self.wire = "pack64" if (wire == "pack64" or not fits32) else "pack32"
+        self.wire = "pack32" if (wire == "pack32" or (wire == "auto" and fits32)) else "pack64"
         self.algo = algo
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # event counts / run bounds are host integers: they travel over a host-side group, the device is never asked
+        # event counts / run bounds are host integers: they travel over a host-side group of the SAME ranks, the device is
+        # never asked
         self.host_group = group
+        self._global = None  # group-local rank -> global rank (P2POp peers are global ranks)
+        if dist.is_initialized() and group is not None:
+            self._global = list(dist.get_process_group_ranks(group))
         if self.cuda and dist.is_initialized() and dist.get_backend(group) != "gloo":
-            self.host_group = dist.new_group(backend="gloo")
+            self.host_group = dist.new_group(ranks=self._global, backend="gloo")  # (every rank of the job must construct it)
         self.slots = [dict(), dict()]
         self.flip = 0
         self.last = None
@@ -183,7 +197,7 @@ class EventStreamGatherer:
         return b
 
     def _host_counts(self, n, rb):
-        """[world][2] (events, run bound) of all ranks, exchanged on the host."""
+        """[world][2] (events, run bound; -1: this rank has none) of all ranks, exchanged on the host."""
         mine = torch.tensor([int(n), int(rb)], dtype=torch.int64)
         if self.world == 1 or not dist.is_initialized():
             return mine.view(1, 2)
@@ -207,10 +221,11 @@ class EventStreamGatherer:
         for r in range(self.world):
             if r == me:
                 continue
+            peer = r if self._global is None else self._global[r]
             if recv_len[me] > 0:
-                ops.append(dist.P2POp(dist.isend, send[:recv_len[me]], r, group=self.group))
+                ops.append(dist.P2POp(dist.isend, send[:recv_len[me]], peer, group=self.group))
             if recv_len[r] > 0:
-                ops.append(dist.P2POp(dist.irecv, out[r * elem_max: r * elem_max + recv_len[r]], r, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, out[r * elem_max: r * elem_max + recv_len[r]], peer, group=self.group))
         if ops:
             for w in dist.batch_isend_irecv(ops):  # one ncclGroupStart / End: every peer's stream on its own link
                 w.wait()
@@ -221,11 +236,13 @@ class EventStreamGatherer:
         slot = self.flip
         self.flip ^= 1
         n = int(n)
-        wire = self.wire if (run_bound is not None or self.wire == "pack64") else "pack64"
-        rb = int(run_bound) if (wire == "pack32") else 0
+        # the wire format is agreed on by ALL ranks (they must issue the same collectives): the 4-byte format only if this
+        # gatherer is set up for it and EVERY rank supplied a run bound for this step
+        rb = int(run_bound) if (self.wire == "pack32" and run_bound is not None) else -1
         hc = self._host_counts(n, rb)
         counts = [int(v) for v in hc[:, 0].tolist()]
         nmax = max(max(counts), 1)
+        wire = "pack32" if int(hc[:, 1].min()) >= 0 else "pack64"
         rmax = max(int(hc[:, 1].max()), 1)
         st = self.slots[slot]
         if self.cuda:
@@ -267,9 +284,7 @@ class EventStreamGatherer:
             st["packed"] = torch.cuda.Event()
             st["packed"].record(self.side)
         else:
-            pl, rt, fl = pack_events32(ev[:n])
-            if int(fl[0]) or rt.numel() - 1 > rmax:
-                raise ValueError("pack32: a coordinate does not fit or run_bound %d is too small (%d blocks)" % (rmax, rt.numel() - 1))
+            pl, rt, fl = pack_events32(ev[:n], cap_runs=rmax)
             payload = self._buf(slot, "p32", nmax, torch.int32)
             runs = self._buf(slot, "r32", rmax + 1, torch.int64)
             payload[:n] = pl
@@ -293,8 +308,14 @@ class EventStreamGatherer:
         if L["wire"] == "pack64":
             out = st["o64"]
             return [unpack_events64(out[r * nmax: r * nmax + c[r]]) for r in range(self.world)]
-        if self.cuda and int(st["flags"][0].item()):
-            raise ValueError("pack32: a coordinate does not fit 2048 x 1024 or run_bound was too small on this rank")
         outp, outr = st["op32"], st["or32"]
+        # every rank received every rank's table, flags included: all ranks raise together (a rank that raised alone would
+        # leave its peers with events whose time stamps were searched in a truncated table)
+        heads = outr[: self.world * (rmax + 1): rmax + 1].cpu()
+        bad = [(r, (int(h) >> 62) & 3) for r, h in enumerate(heads.tolist()) if (int(h) >> 62) & 3]
+        if bad:
+            raise ValueError("pack32 stream refused on every rank: " + "; ".join(
+                "rank %d: %s" % (r, " and ".join(m for b, m in ((1, "a coordinate beyond 2048 x 1024"), (2, "run_bound too small")) if f & b))
+                for r, f in bad) + " -- construct the gatherer with sensor=(H, W) / wire='pack64', or pass a correct run_bound")
         return [unpack_events32(outp[r * nmax: r * nmax + max(c[r], 1)], outr[r * (rmax + 1): (r + 1) * (rmax + 1)], c[r])
                 for r in range(self.world)]

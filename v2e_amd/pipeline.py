@@ -9,8 +9,9 @@ frame in HBM and produces the same uint8 frames for the emulator:
   points per batch) --(+mean)*255, byte truncation--> uint8 --Pillow-exact BILINEAR--> [P*U,H,W]
   --> emulator (HIP, Philox, one device-resident run)
 
-Frame order and times follow slomo.py:391-400, 441 and v2e.py:794-797: output frame b*U + k of a
-batch, times (pair + k/U) * source frame interval.
+Frame order and times follow slomo.py:391-400, 441 and v2e.py:786-797: output frame b*U + k of a batch has
+interpTime pair + k/U (in source frame intervals), and v2e.py stretches the interpTimes so that they SPAN the processed
+duration of the source clip: t = interpTime * (N_src - 1) * interval / (max(interpTimes) - min(interpTimes)).
 """
 import ctypes as C
 
@@ -52,6 +53,23 @@ class DeviceResampler:
         check(self.lib.v2e_resample_u8(_ptr(x), _ptr(tmp), _ptr(out), n, self.ih, self.iw, self.oh, self.ow, _ptr(self.hb),
                                        _ptr(self.hk), self.hks, _ptr(self.vb), _ptr(self.vk), self.vks, s), "v2e_resample_u8")
         return out
+
+
+def interp_frame_times(n_src, U, src_frame_interval_s, batch_size=None):
+    """Times of the (n_src - 1) * U interpolated frames as v2e.py computes them, operation for operation: interpTimes are built
+    per batch of `batch_size` pairs as inputFrameCounter + k * (1 / U) (slomo.py:391-400; None: one batch), then normalised
+    to the processed duration of the source clip (v2e.py:786-797: f = srcVideoRealProcessedDuration / (max(interpTimes) -
+    min(interpTimes)); interpTimes = f * interpTimes)."""
+    npairs = n_src - 1
+    bs = npairs if not batch_size else int(batch_size)
+    parts = []
+    for b0 in range(0, npairs, bs):
+        nb = min(bs, npairs - b0)
+        parts.append(b0 + np.array(range(U * nb)) * (1 / U))
+    interp = np.concatenate(parts)
+    duration = npairs * float(src_frame_interval_s)
+    f = duration / (np.max(interp) - np.min(interp))
+    return f * interp
 
 
 class VideoToEvents:
@@ -103,7 +121,6 @@ class VideoToEvents:
         """Full pipeline; returns (events, counts_per_interpolated_frame, n_interpolated_frames)."""
         up = self.upsample(frames_u8)
         n = up.shape[0]
-        # interpTimes = pair + k/U in units of the source frame interval (slomo.py:391-400; v2e.py:794-797)
-        times = (np.arange(n) / self.U) * float(src_frame_interval_s)
+        times = interp_frame_times(int(frames_u8.shape[0]), self.U, float(src_frame_interval_s), self.batch_size)
         ev, counts = self.emu.generate_events_batch(up, times, return_device=return_device)
         return ev, counts, n
