@@ -467,10 +467,12 @@ def test_auto_upsample_follows_the_flow_magnitude(tmp_path, oracle_lib):
     assert sorted(os.listdir(str(dst)), key=lambda s: int(s.split(".")[0])) == ["%d.png" % i for i in range(nout)]
 
 
-def test_range_guard_redoes_a_pass_that_leaves_float16():
-    """conv_math 'auto': an activation beyond 65 504 would become inf in the two-float16-piece split; the convolutions report
-    it and the forward pass is redone with the exact three-bf16-piece split -- bit-identical to conv_math 'bf16x3' -- while
-    a pass that stays in range is the two-piece result and costs no second pass."""
+def test_operand_scaling_and_range_guard_of_the_two_piece_math():
+    """conv_math 'auto' / 'fp16x2': every convolution stages its activations times the power of two that puts the largest one
+    (tracked by the producing convolution's epilogue) in [2^13, 2^14), so neither a network whose activations are 3e5 times
+    larger nor one whose activations are 1e-5 times smaller leaves float16's normal range: same accuracy, no second pass.
+    What is left for the guard is an activation that is inf or NaN: such a pass is redone with the exact three-bf16-piece
+    split -- bit-identical to conv_math 'bf16x3' -- and the guard does not stick."""
     from v2e_amd.slomo import HipUNet
     from v2e_amd.synth import portable_unet_state_dict
     sd = {k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}
@@ -480,11 +482,18 @@ def test_range_guard_redoes_a_pass_that_leaves_float16():
     auto, exact, fast = (HipUNet(sd, 12, 5, dev, m) for m in ("auto", "bf16x3", "fp16x2"))
     y = auto.forward(x)
     assert auto.fallbacks == 0 and torch.equal(y, fast.forward(x))
-    xb = x * 3.0e5                      # the first layers' activations now exceed float16's 65 504
+    ye = exact.forward(x)
+    for scale in (3.0e5, 2.0 ** -17, 1.0e-5):   # beyond 65 504 in the first layers / float16 subnormals throughout
+        ys = auto.forward(x * scale)
+        assert auto.fallbacks == 0 and torch.isfinite(ys).all()
+        es = exact.forward(x * scale)
+        tol = 1e-5 * max(1.0, float(es.abs().max()))
+        assert float((ys - es).abs().max()) <= tol, (scale, float((ys - es).abs().max()), tol)
+    assert float((y - ye).abs().max()) <= 1e-5 * max(1.0, float(ye.abs().max()))
+    xb = x.clone()
+    xb[0, 3, 10, 10] = float("inf")
     yb = auto.forward(xb)
     assert auto.fallbacks == 1
-    ye = exact.forward(xb)
-    assert torch.isfinite(ye).all() and torch.equal(yb, ye)
-    assert not torch.isfinite(fast.forward(xb)).all()   # what the unguarded two-piece math makes of it
+    assert torch.equal(torch.nan_to_num(yb, nan=7.0), torch.nan_to_num(exact.forward(xb), nan=7.0))
     y2 = auto.forward(x)                # and the guard does not stick
     assert auto.fallbacks == 1 and torch.equal(y2, y)

@@ -39,7 +39,51 @@ struct ConvArgs {
     int np;             // pieces the split weights ws3 hold: 3 (bf16) or 2 (float16)
     float out_scale;    // np == 2: 2^-s, the inverse of the power of two the weights were packed times
     int *ovf;           // np == 2: device flag set when an activation is beyond float16's range (or NaN), or nullptr
+    // Activation range tracking (v2e_unet_forward): every convolution leaves the largest |output| it wrote in *am_out (float32
+    // bits: non-negative floats, inf and NaN order like their bit patterns; atomicMax per wave), and a two-float16-piece
+    // convolution reads the maxima of its input's producer(s) and stages its activations times the power of two that puts that
+    // maximum in [2^13, 2^14): no piece of an activation that matters falls into float16's subnormals however small the
+    // layer's activations are, nothing overflows however large; the epilogue divides the power out again (exact).
+    const uint32_t *am_in0, *am_in1;
+    uint32_t *am_out;
 };
+
+// |v| as ordered bits, folded into a running maximum (NaN > inf > finite)
+__device__ __forceinline__ void amax_fold(uint32_t &m, float v)
+{
+    const uint32_t b = __float_as_uint(v) & 0x7FFFFFFFu;
+    m = b > m ? b : m;
+}
+// one atomicMax per wave
+__device__ __forceinline__ void amax_commit(uint32_t *slot, uint32_t m)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(slot, m);
+}
+// the power of two a two-float16-piece convolution stages its activations times: in_scale = 2^k with amax * 2^k in [2^13, 2^14),
+// inv = 2^-k (both normal float32 numbers: |k| <= 126); bad = the producer wrote an inf or a NaN
+__device__ __forceinline__ void act_scale(const ConvArgs &a, float &in_scale, float &inv, bool &bad)
+{
+    in_scale = 1.0f; inv = 1.0f; bad = false;
+    if (!a.am_in0) return;
+    uint32_t m = *a.am_in0;
+    if (a.am_in1) { const uint32_t m1 = *a.am_in1; m = m1 > m ? m1 : m; }
+    const int e = (int)(m >> 23); // biased exponent of the maximum (sign bit is clear)
+    if (e == 255) { bad = true; return; }
+    if (m == 0u) return; // an all-zero input
+    int k = 140 - e;     // amax in [2^(e-127), 2^(e-126)) -> [2^13, 2^14)
+    k = k > 126 ? 126 : (k < -126 ? -126 : k);
+    in_scale = __uint_as_float((uint32_t)(127 + k) << 23);
+    inv = __uint_as_float((uint32_t)(127 - k) << 23);
+}
+
+// where v2e_unet_forward hands the next convolution its range slots (per host thread; all null outside a forward pass)
+static thread_local const uint32_t *g_am_in0 = nullptr, *g_am_in1 = nullptr;
+static thread_local uint32_t *g_am_out = nullptr;
 
 // where the two-float16-piece convolutions report an activation beyond float16's range (v2e_conv_set_range_flag), or nullptr
 static thread_local int *g_conv_range_flag = nullptr;
@@ -245,6 +289,7 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
         }
     }
     // epilogue: bias + leaky_relu(0.1); register r of lane: channel (r&3)+8(r>>2)+4*hsel, pixel l31
+    uint32_t omax = 0u;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = (wave * PT + pt) * 32 + l31;
@@ -259,11 +304,13 @@ __global__ __launch_bounds__(WP * 64) void k_conv(ConvArgs a)
                 if (pok && ch < a.cout) {
                     float v = acc[ct][pt][r] + a.bias[ch];
                     v = v > 0.f ? v : v * 0.1f;
+                    amax_fold(omax, v);
                     a.y[(((size_t)(n + sidx) * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
                 }
             }
         }
     }
+    if (a.am_out) amax_commit(a.am_out, omax);
 }
 
 #include "slomo_s3.h"
@@ -528,6 +575,20 @@ __global__ __launch_bounds__(256) void k_fuse(const float *__restrict__ i0, cons
     out[(size_t)s * hw + p] = (w0 * v0 * g0 + w1 * v1 * g1) / (w0 * v0 + w1 * v1);
 }
 
+// largest |x| of a tensor into a range slot (the network input of v2e_unet_forward)
+__global__ __launch_bounds__(256) void k_amax(const float *__restrict__ x, long long n, uint32_t *__restrict__ slot)
+{
+    uint32_t m = 0u;
+    const long long n4 = n >> 2;
+    const float4 *x4 = (const float4 *)x;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = x4[i];
+        amax_fold(m, v.x); amax_fold(m, v.y); amax_fold(m, v.z); amax_fold(m, v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) amax_fold(m, x[(n4 << 2) + threadIdx.x]);
+    amax_commit(slot, m);
+}
+
 __global__ void k_zero_u32(unsigned *__restrict__ p, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -782,6 +843,7 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
         a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout; a.tiles_x = a.tiles_y = 0;
         V2E_REQUIRE((conv->split_kind & 0xFF) != 2, "pre-split input is three bf16 pieces");
         a.ws3 = conv->weight_s3; a.xs_plane = (long long)n * (c0 / 8) * h * w; a.np = 3; a.tl_on = 0; a.out_scale = 1.0f; a.ovf = nullptr;
+        a.am_in0 = a.am_in1 = nullptr; a.am_out = g_am_out;
         const int r3 = conv_dispatch_s3_presplit(a, conv->ksize, (hipStream_t)stream);
         V2E_REQUIRE(r3 == 0, "no pre-split tile for this layer shape");
         V2E_HIP(hipGetLastError());
@@ -806,6 +868,7 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     a.out_scale = ldexpf(1.0f, -(conv->split_kind >> 8));
     a.ovf = g_conv_range_flag;
     a.tl_on = 0;
+    a.am_in0 = g_am_in0; a.am_in1 = g_am_in1; a.am_out = g_am_out;
     if (conv->ksize == 3 && pre == 0 && c1 == 0 && (conv->cout == 4 || conv->cout == 5)) {
         const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;
         dim3 grid((unsigned)(n * tiles_x * tiles_y));
@@ -836,7 +899,8 @@ int64_t v2e_unet_workspace_bytes(int n, int h, int w, int cin)
     const int64_t hw = (int64_t)h * w;
     // s1 32hw, s2 16hw, s3 8hw, s4 4hw, s5 2hw, two temporaries of 32hw, one of 64hw for the
     // pooled / upsampled input of the first conv of each down / up block
-    return (int64_t)n * hw * (32 + 16 + 8 + 4 + 2 + 32 + 32 + 64) * (int64_t)sizeof(float);
+    // + the range slots of the forward pass (32 words: the input's and every convolution's largest |output|)
+    return (int64_t)n * hw * (32 + 16 + 8 + 4 + 2 + 32 + 32 + 64) * (int64_t)sizeof(float) + 256;
 }
 
 int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout, float *y, int n, int h, int w,
@@ -851,11 +915,27 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     float *s5 = s4 + n * hw * 4; float *tA = s5 + n * hw * 2; float *tB = tA + n * hw * 32; float *tU = tB + n * hw * 32;
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    // range slots: am[0] = the input, am[1 + i] = the output of convolution i.  Tracked only when some layer runs on two
+    // float16 pieces (it is what their operand scaling reads); avg_pool2d / bilinear x2 cannot exceed their input's maximum, so
+    // a convolution behind one of them reads the slot of the convolution before it.
+    uint32_t *am = (uint32_t *)(tU + n * hw * 64);
+    bool track = false;
+    for (int i = 0; i < 23; ++i) track = track || ((cv[i].split_kind & 0xFF) == 2 && cv[i].weight_s3);
+    struct AmReset { ~AmReset() { g_am_in0 = g_am_in1 = nullptr; g_am_out = nullptr; } } am_reset;
+    if (track) {
+        k_zero_u32<<<1, 64, 0, st>>>(am, 32);
+        const long long nx = (long long)n * cin * hw;
+        long long nb = (nx / 4 + 255) / 256;
+        k_amax<<<(unsigned)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb)), 256, 0, st>>>(x, nx, am);
+    }
 #define CONV(X0, C0, X1, C1, PRE, IDX, Y, HH, WW)                                              \
     do {                                                                                        \
+        if (track) { g_am_in0 = am + am_src0; g_am_in1 = (X1) ? am + am_src1 : nullptr; g_am_out = am + 1 + (IDX); } \
         rc = v2e_conv2d_lrelu((X0), (C0), (X1), (C1), (PRE), &cv[(IDX)], (Y), n, (HH), (WW), stream); \
         if (rc) return rc;                                                                      \
+        am_src0 = 1 + (IDX);                                                                    \
     } while (0)
+    int am_src0 = 0, am_src1 = 0; // slots of the producers of the next convolution's x0 / x1
     // producer ops as their own streaming passes: measured faster than fusing them into the conv
     // loader (the fused bilinear fetch costs 4 gathers + address math per staged element)
 #define POOL(X, C, HH, WW) /* (HH,WW) = output size */                                              \
@@ -896,14 +976,19 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
         else { UPS((X), (C), (HH), (WW)); CONV(tU, (C), nullptr, 0, 0, (IDX), (Y), (HH), (WW)); } \
     } while (0)
     UPCONV(1, tB, 512, 12, tA, h / 16, w / 16);
+    am_src1 = 1 + 9;  // s5 = the output of convolution 9 (down4.conv2)
     CONV(tA, 512, s5, 512, 0, 13, tB, h / 16, w / 16);
     UPCONV(2, tB, 512, 14, tA, h / 8, w / 8);
+    am_src1 = 1 + 7;  // s4
     CONV(tA, 256, s4, 256, 0, 15, tB, h / 8, w / 8);
     UPCONV(3, tB, 256, 16, tA, h / 4, w / 4);
+    am_src1 = 1 + 5;  // s3
     CONV(tA, 128, s3, 128, 0, 17, tB, h / 4, w / 4);
     UPCONV(4, tB, 128, 18, tA, h / 2, w / 2);
+    am_src1 = 1 + 3;  // s2
     CONV(tA, 64, s2, 64, 0, 19, tB, h / 2, w / 2);
     UPCONV(5, tB, 64, 20, tA, h, w);
+    am_src1 = 1 + 1;  // s1
     CONV(tA, 32, s1, 32, 0, 21, tB, h, w);
     // conv3 (+ leaky relu, model.py:225)
     CONV(tB, 32, nullptr, 0, 0, 22, y, h, w);

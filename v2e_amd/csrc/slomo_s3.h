@@ -259,6 +259,11 @@ void k_conv_s3(ConvArgs a)
 #pragma unroll
         for (int j = 0; j < NWU; ++j) wv[set][j] = wb[woff[j]];
     };
+    // NP == 2: activations are staged times in_scale (a power of two from the producers' range slots: ConvArgs) and the
+    // epilogue multiplies the sums by inv_scale again; without slots (a convolution outside v2e_unet_forward) both are 1
+    float in_scale = 1.0f, inv_scale = 1.0f;
+    bool in_bad = false;
+    if constexpr (NP == 2) act_scale(a, in_scale, inv_scale, in_bad);
     float amax = 0.f; // NP == 2: the largest |activation| this thread staged (float16 holds up to 65 504: see the range flag)
     auto stage_patch = [&](int set, int cbs = 0) { // split and store this thread's patch items (cbs: the chunk, PADC only)
 #pragma unroll
@@ -277,8 +282,11 @@ void k_conv_s3(ConvArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     uint32_t qe[NP];
-                    const float xa = ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, xb = ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f;
-                    if constexpr (NP == 2) amax = fmaxf(amax, fmaxf(fabsf(xa), fabsf(xb)));
+                    float xa = ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, xb = ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f;
+                    if constexpr (NP == 2) {
+                        xa *= in_scale; xb *= in_scale; // exact (a power of two; the products stay far inside float32)
+                        amax = fmaxf(amax, fmaxf(fabsf(xa), fabsf(xb)));
+                    }
                     split_pair<NP>(xa, xb, qe);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) q[p][e] = qe[p];
@@ -387,8 +395,9 @@ void k_conv_s3(ConvArgs a)
     // NP == 2: an activation beyond float16's range (it became +-inf in the split) -- or a NaN -- is reported, so that the caller
     // can redo the layer stack with the exact three-piece split (v2e_conv_set_range_flag)
     if constexpr (NP == 2) {
-        if (a.ovf && __ballot(!(amax <= 65504.f)) != 0ull && lane == 0) atomicOr(a.ovf, 1);
+        if (a.ovf && __ballot(!(amax <= 65504.f) || in_bad) != 0ull && lane == 0) atomicOr(a.ovf, 1);
     }
+    uint32_t omax = 0u;
     // epilogue as k_conv: register r of a lane is channel (r&3)+8(r>>2)+4*hsel of pixel l31
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -402,14 +411,16 @@ void k_conv_s3(ConvArgs a)
                 const int ch = cobase + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
                 if (pok) {
                     float s = acc[ct][pt][r];
-                    if constexpr (NP == 2) s *= a.out_scale; // the weights were packed times an exact power of two
+                    if constexpr (NP == 2) s = (s * a.out_scale) * inv_scale; // the powers of two the weights / activations were staged times
                     float v = s + a.bias[ch];
                     v = v > 0.f ? v : v * 0.1f;
+                    amax_fold(omax, v);
                     a.y[(((size_t)n * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
                 }
             }
         }
     }
+    if (a.am_out) amax_commit(a.am_out, omax);
 }
 
 template <int KS, int CT, int PT, int WP, int TW, int NB = 1, int MODE = 0, int RG = 0, int NP = 3>

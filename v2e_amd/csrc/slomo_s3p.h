@@ -306,6 +306,7 @@ void k_conv_s3p(ConvArgs a)
     }
 
     // epilogue as k_conv_s3: register r of a lane is channel (r&3)+8(r>>2)+4*hsel of pixel l31
+    uint32_t omax = 0u;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = (wave * PT + pt) * 32 + l31;
@@ -319,11 +320,13 @@ void k_conv_s3p(ConvArgs a)
                 if (pok) {
                     float v = acc[ct][pt][r] + a.bias[ch];
                     v = v > 0.f ? v : v * 0.1f;
+                    amax_fold(omax, v);
                     a.y[(((size_t)n * a.cout + ch) * a.h + oy) * a.w_ + ox] = v;
                 }
             }
         }
     }
+    if (a.am_out) amax_commit(a.am_out, omax);
 }
 
 template <int TW, int DBG = 0>

@@ -57,8 +57,9 @@ class HipUNet:
         import ctypes as C
         if conv_math not in ("auto", "bf16x3", "f32", "fp16x2"):
             raise ValueError("conv_math must be 'auto' (two float16 pieces and three products per multiply -- half the "
-                             "matrix-core work, products good to ~2^-21 -- with a range guard: a forward pass in which an activation "
-                             "leaves float16's range is redone with the exact split), 'bf16x3' (f32 operands split exactly into three "
+                             "matrix-core work, products good to ~2^-21; operands are staged times powers of two that keep them in "
+                             "float16's normal range, and a forward pass that meets an inf / NaN activation is redone with the exact "
+                             "split), 'bf16x3' (f32 operands split exactly into three "
                              "bf16 pieces, six piece products on the bf16 matrix cores, f32 accumulation), 'fp16x2' (the two-piece "
                              "math without the guard) or 'f32' (f32 matrix-core instructions)")
         self.conv_math = conv_math
@@ -130,8 +131,9 @@ class HipUNet:
             check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
                   "v2e_unet_forward")
             return out
-        # conv_math 'auto': the two-float16-piece convolutions report an activation beyond float16's range; such a pass is
-        # redone with the exact three-bf16-piece weights (one 4-byte read-back per forward pass)
+        # conv_math 'auto': the two-float16-piece convolutions report an inf / NaN activation (finite ones are scaled into
+        # float16's range inside the kernels); such a pass is redone with the exact three-bf16-piece weights (one 4-byte
+        # read-back per forward pass)
         self._flag.zero_()
         check(self.lib.v2e_conv_set_range_flag(_ptr(self._flag)), "v2e_conv_set_range_flag")
         try:
@@ -162,10 +164,15 @@ class SloMoEngine:
     def __init__(self, flow_state_dict, interp_state_dict, device="cuda", conv_math=None):
         """conv_math: 'auto' (default) -- every f32 operand split into two float16 pieces, three piece products on the f16 matrix
         cores, f32 accumulation: operands good to 2^-22 and, measured on every fixture, as close to the reference and to float64
-        as the other maths (profiles/r03_slomo_precision.txt); float16's range is guarded: weights are packed times an exact
-        power of two, and a forward pass in which an activation exceeds 65 504 is redone with the exact split (HipUNet.forward);
+        as the other maths (profiles/r03_slomo_precision.txt).  float16's narrow exponent is taken out of the picture on both
+        sides: weights are packed times an exact power of two per layer, and activations are staged times the power of two that
+        puts the layer's largest input (tracked on the device by the producing convolution's epilogue) in [2^13, 2^14) -- so a
+        piece is a float16 subnormal only where the activation is below 2^-27 of the layer's largest one (an absolute operand
+        error of 2^-39 of that maximum), whatever the network's scale (tests: inputs x 3e5 and x 2^-17,
+        tests/golden/slomo_smallact_64x96.npz).  A forward pass that meets an inf or NaN activation is redone with the exact
+        split (HipUNet.forward);
         'bf16x3' -- three bf16 pieces, six products: the exact split (v2e_amd/csrc/slomo_s3.h), 0.7x the frames per second;
-        'fp16x2' -- the two-piece math without the guard; 'f32' -- f32 matrix-core instructions.  The environment variable
+        'fp16x2' -- the two-piece math without the redo; 'f32' -- f32 matrix-core instructions.  The environment variable
         V2E_AMD_CONV_MATH sets the default."""
         if conv_math is None:
             conv_math = os.environ.get("V2E_AMD_CONV_MATH", "auto")
