@@ -1809,6 +1809,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     dim3 grid(h->ngroups, gy);
     static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
     static const int chain_prio = getenv("V2E_AMD_CHAIN_PRIO") ? atoi(getenv("V2E_AMD_CHAIN_PRIO")) : 3; // dev: 0 = no raised wave priority
+    static const int bar_light = getenv("V2E_AMD_BAR_LIGHT") ? atoi(getenv("V2E_AMD_BAR_LIGHT")) : 1;    // dev: 0 = fenced rendezvous (round 3)
     // Under stream capture only edges between the origin stream and a forked stream are safe (edges between two forked
     // streams crash hipStreamEndCapture on this runtime): tables and rows then share the side stream.
     static const int tab_env = getenv("V2E_AMD_TABLES_ON_SIDE") ? ST_SIDE : (getenv("V2E_AMD_TABLES_ON_AHEAD") ? ST_AHEAD : ST_TAB); // dev
@@ -1940,6 +1941,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.recs = recs;
         ca.store_out = tail && in != 0;
         ca.prio = chain_prio;
+        ca.bar_light = bar_light;
         ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
         if (pl.wait_join >= 0 && sc.wait(ST_MAIN, EV_JOIN, pl.wait_join)) return V2E_EHIP; // ring slots: read by k_cemit of that batch
         if (pl.wait_ahead >= 0 && sc.wait(ST_MAIN, EV_AHEAD, pl.wait_ahead)) return V2E_EHIP;

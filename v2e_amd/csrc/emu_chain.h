@@ -54,22 +54,28 @@ template <typename R> __device__ __forceinline__ R floor_div_pos(R a, R b)
 // in its counter form): every wave drains its stores, one lane does the agent-scope release, the
 // relaxed arrive, a relaxed bounded poll, and the agent-scope acquire; __syncthreads() extends it
 // to the workgroup.  Requires every workgroup of the grid to be resident (checked by the host).
-__device__ __forceinline__ bool clip_barrier(unsigned *ctr, unsigned target)
+// light: no release / acquire FENCES around it (an agent-scope release writes this XCD's dirty L2 lines back, an acquire
+// invalidates its L2).  Correct where everything the workgroups exchange across the rendezvous is itself written and read
+// with agent-scope atomics -- the chain's rule-on maxima are (atomicMax / __hip_atomic_load): each wave has waited for its own
+// atomics (s_waitcnt vmcnt(0): they are acknowledged where they are performed) before its workgroup arrives.
+__device__ __forceinline__ bool clip_barrier(unsigned *ctr, unsigned target, bool light = false)
 {
     __shared__ int s_ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!light) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         int ok = 1;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(light ? 1 : 4);
             if (++spins > 2000000u) { ok = 0; break; } // bounded: never hang the GPU
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         s_ok = ok;
     }
     __syncthreads();
@@ -146,6 +152,7 @@ struct ChainArgs {
     v2e_frame_rec *recs;              // [n_frames][n_clips]
     int store_out;                    // tail launch: state must be copied to *_out even without a redo
     int prio;                         // wave priority of the chain (3: it outranks the emission waves sharing its SIMDs)
+    int bar_light;                    // the redo rendezvous without release / acquire fences (the maxima rows are atomics)
     unsigned long long *dbg;          // dev tool: [ngroups][16] wall-clock stamps of one launch, or nullptr
 };
 
@@ -399,7 +406,8 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 // first frame after last_exact on which some wave reached the rule threshold: lane k = frame k
                 if (round > 0) {
                     gM_v = 0u;
-                    if (lane < ca.pnf) gM_v = ca.gM_prev[((size_t)round * ca.n_clips + clip) * ca.K + lane];
+                    // (an agent-scope load: other workgroups' atomicMax of this launch, with no acquire fence behind the rendezvous)
+                    if (lane < ca.pnf) gM_v = __hip_atomic_load(ca.gM_prev + ((size_t)round * ca.n_clips + clip) * ca.K + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 // The pass that wrote this row ran frame k > last_exact under the PREDICTION pred_v[k] (0 = rule off; the own
                 // pass predicts 0 everywhere).  Where row and prediction agree the frame was computed exactly; the first
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             // (not at raised priority: a spinning wave that outranks the other kernels' waves on its SIMD keeps them from
             // finishing, and the workgroups this one waits for may need their slots)
             __builtin_amdgcn_s_setprio(0);
-            const bool ok = clip_barrier(ca.bar_prev + (size_t)(round - 1) * ca.n_clips + clip, (unsigned)ca.ngroups);
+            const bool ok = clip_barrier(ca.bar_prev + (size_t)(round - 1) * ca.n_clips + clip, (unsigned)ca.ngroups, ca.bar_light != 0);
             if (ca.prio) __builtin_amdgcn_s_setprio(3);
             if (!ok && tid == 0) atomicOr(&ca.recs[(size_t)ca.pf0 * ca.n_clips + clip].flags, V2E_FLAG_SYNC_TIMEOUT);
         }
@@ -692,6 +700,7 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
         const uint32_t rM = (uint32_t)__builtin_amdgcn_readfirstlane((int)rMq[q]);
         int magv[GPX];
         bool neg[GPX];
+        unsigned long long negb[GPX]; // the sub-group's OFF lanes (a lane without events is neither)
         int mmax = 0;
         uint32_t son = 0, soff = 0;
 #pragma unroll
@@ -699,6 +708,7 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
             const uint32_t cw = cwq[q][j];
             magv[j] = (int)(cw & CNT_MASK);
             neg[j] = (cw & CNT_NEG) != 0;
+            negb[j] = __ballot(neg[j]);
             mmax = max(mmax, magv[j]);
             son += (uint32_t)__popcll(__ballot((cw & CNT_SHOT_ON) != 0));
             soff += (uint32_t)__popcll(__ballot((cw & CNT_SHOT_OFF) != 0));
@@ -729,17 +739,26 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
             const int i_hi = min((kb + WAVE - 2) / 2, wmc);
             for (int i = i_lo; i < i_hi; ++i) {
                 uint32_t on = 0, off = 0;
+                if (!ruled) { // the common case: one compare per sub-group, the polarity split on the scalar unit
 #pragma unroll
-                for (int j = 0; j < GPX; ++j) {
-                    bool pass = magv[j] > i;
-                    if (ruled && pass) {
-                        const float t = tg(i);
-                        const float pt = 1.0f * t - tsm[j];
-                        pass = pt > a.refr_f;
-                        if (pass) tsm[j] = t;
+                    for (int j = 0; j < GPX; ++j) {
+                        const unsigned long long cb = __ballot(magv[j] > i);
+                        on += (uint32_t)__popcll(cb & ~negb[j]);
+                        off += (uint32_t)__popcll(cb & negb[j]);
                     }
-                    on += (uint32_t)__popcll(__ballot(pass && !neg[j]));
-                    off += (uint32_t)__popcll(__ballot(pass && neg[j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < GPX; ++j) {
+                        bool pass = magv[j] > i;
+                        if (pass) {
+                            const float t = tg(i);
+                            const float pt = 1.0f * t - tsm[j];
+                            pass = pt > a.refr_f;
+                            if (pass) tsm[j] = t;
+                        }
+                        on += (uint32_t)__popcll(__ballot(pass && !neg[j]));
+                        off += (uint32_t)__popcll(__ballot(pass && neg[j]));
+                    }
                 }
                 const int kl = 2 + 2 * i - kb;
                 if (lane == kl) mine = on;
@@ -1096,11 +1115,13 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
     const TsGen tg = frame_tsgen(a, c, ftb, n, use_refr);
     int mag[GPX];
     bool neg[GPX];
+    unsigned long long negb[GPX]; // the sub-group's OFF lanes
     float tsm[GPX];
 #pragma unroll
     for (int j = 0; j < GPX; ++j) {
         mag[j] = (int)(cw[j] & CNT_MASK);
         neg[j] = (cw[j] & CNT_NEG) != 0;
+        negb[j] = __ballot(neg[j]);
         tsm[j] = 0.f;
     }
     if (use_refr && ea.tsold) { // ts_mem as it was before the frame (rule-on frames only)
@@ -1151,23 +1172,31 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
         uint32_t nrec = 0;
         bool alive = true;
         for (int i = i0; i < i1; ++i) {
-            unsigned long long cand_any = 0ull;
+            unsigned long long cb[GPX], cand_any = 0ull;
 #pragma unroll
-            for (int j = 0; j < GPX; ++j) cand_any |= __ballot(mag[j] > i);
+            for (int j = 0; j < GPX; ++j) { cb[j] = __ballot(mag[j] > i); cand_any |= cb[j]; }
             if (cand_any == 0ull) { alive = false; break; }
             uint32_t run_on = 0, run_off = 0;
 #pragma unroll
             for (int j = 0; j < GPX; ++j) {
+                // a sub-group without a candidate at this iteration (most of them beyond the first two: a frame's large counts
+                // sit on a few pixels) takes one scalar test; with the rule on a non-candidate is still put to the test below,
+                // as the reference's `pos_cord * ts - timestamp_mem > refractory_period_s` does
+                if (!use_refr && cb[j] == 0ull) continue;
                 const bool cand = mag[j] > i;
                 bool pass = cand;
+                unsigned long long bo, bf;
                 if (use_refr) {
                     const float t = tg(i);
                     const float pt = (cand ? 1.0f : 0.0f) * t - tsm[j];
                     pass = pt > a.refr_f;
                     if (pass) tsm[j] = t;
+                    bo = __ballot(pass && !neg[j]);
+                    bf = __ballot(pass && neg[j]);
+                } else { // the polarity split of the candidates on the scalar unit
+                    bf = cb[j] & negb[j];
+                    bo = cb[j] & ~negb[j];
                 }
-                const unsigned long long bo = __ballot(pass && !neg[j]);
-                const unsigned long long bf = __ballot(pass && neg[j]);
                 if (pass) {
                     const uint32_t rank = neg[j] ? run_off + (uint32_t)__popcll(bf & lt) : run_on + (uint32_t)__popcll(bo & lt);
                     const uint32_t pos = nrec + (uint32_t)__popcll((bo | bf) & lt);
