@@ -72,7 +72,7 @@ __device__ __forceinline__ bool clip_barrier(unsigned *ctr, unsigned target, boo
         unsigned spins = 0;
         int ok = 1;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(light ? 1 : 4);
+            if (light) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
             if (++spins > 2000000u) { ok = 0; break; } // bounded: never hang the GPU
         }
         if (!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
