@@ -4,7 +4,7 @@ The HIP kernel is pinned event for event by the GPU fixture tests; what those ca
 rule-on patterns at the CONTROL FLOW.  This file restates that control flow -- K frames per launch speculated "rule off",
 the rule-on maxima a launch publishes, the next launch's check of that row, redo passes that take the first disagreeing
 frame exactly and run the later frames under the row's values as predictions, mid-launch checkpoints every CHAIN_SUB
-frames, ping-pong state planes, the tail launch -- around a toy pixel whose update depends on the frame's global max
+frames, ping-pong state planes, the tail launch, the lock-step frames of a redo pass (round 4) -- around a toy pixel whose update depends on the frame's global max
 count M exactly when the rule is on, and compares it with plain frame-by-frame processing.
 """
 import numpy as np
@@ -56,7 +56,7 @@ def sequential(toy, frames):
     return base, ts, out
 
 
-def chain(toy, frames, K, n_groups=4, checkpoints=True, predict=True):
+def chain(toy, frames, K, n_groups=4, checkpoints=True, predict=True, lockstep=True):
     """The launch sequence of enqueue_run_chain + the pass loop of k_chain, all 'workgroups' of a launch in lock step."""
     F = len(frames)
     nB = (F + K - 1) // K
@@ -68,8 +68,11 @@ def chain(toy, frames, K, n_groups=4, checkpoints=True, predict=True):
     out = [None] * F                              # per frame: (wave maxima -> M, passed counts) as the last pass left them
     passes_total = 0
 
-    def run_pass(f0, nf, c0, base, ts, exact, row_dst, last_exact, ck_set):
-        """Frames f0+c0 .. f0+nf-1 with exact[k] (0: rule off) as the M they are finalised under; publishes into row_dst."""
+    def run_pass(f0, nf, c0, base, ts, exact, row_dst, last_exact, ck_set, lock_k=-1, pred=None):
+        """Frames f0+c0 .. f0+nf-1 with exact[k] (0: rule off) as the M they are finalised under; publishes into row_dst.
+        lock_k: the frame taken in lock-step (a redo pass, the frame behind one it finalised by the rule): its published
+        maximum is read back after a rendezvous and IS its M; the lock-step goes on while the frames keep being rule-on.
+        Returns (base, ts, last_exact)."""
         nonlocal passes_total
         passes_total += 1
         for k in range(c0, nf):
@@ -81,9 +84,15 @@ def chain(toy, frames, K, n_groups=4, checkpoints=True, predict=True):
                 wm = int(c[g].max()) if g.size else 0
                 if k > last_exact and wm >= toy.mon:
                     row_dst[k] = max(row_dst[k], wm)
+            if k == lock_k:                       # rendezvous, then every workgroup reads the row entry
+                mk = int(row_dst[k])
+                exact[k] = mk
+                pred[k] = mk
+                last_exact = k
+                lock_k = k + 1 if (mk != 0 and k + 1 < nf) else -1
             base, ts, passed = toy.finalise(base, ts, c, f, int(exact[k]))
             out[f] = (int(c.max()), passed.copy())
-        return base, ts
+        return base, ts, last_exact
 
     for L in range(nL):
         tail = L >= nB
@@ -116,12 +125,13 @@ def chain(toy, frames, K, n_groups=4, checkpoints=True, predict=True):
                 else:
                     b, t = ck[(L + 1) % 2][c0 // CHAIN_SUB - 1]
                     b, t = b.copy(), t.copy()
-                base, ts = run_pass(pf0, pnf, c0, b, t, exact, gM[L - 1][rnd], last_exact, ck[(L + 1) % 2])
+                lock_k = j + 1 if (lockstep and row[j] != 0 and j + 1 < pnf) else -1
+                base, ts, last_exact = run_pass(pf0, pnf, c0, b, t, exact, gM[L - 1][rnd], last_exact, ck[(L + 1) % 2], lock_k, pred)
                 assert rnd <= K
             if redone:
                 planes[L % 2] = (base.copy(), ts.copy())  # *_fix: the corrected input state of this launch
         if nf > 0:
-            base, ts = run_pass(f0, nf, 0, base, ts, np.zeros(K, np.int64), gM[L][0], -1, ck[L % 2])
+            base, ts, _ = run_pass(f0, nf, 0, base, ts, np.zeros(K, np.int64), gM[L][0], -1, ck[L % 2])
             planes[(L + 1) % 2] = (base.copy(), ts.copy())
         else:
             planes[(L + 1) % 2] = (base.copy(), ts.copy())
@@ -141,10 +151,11 @@ def test_chain_protocol_equals_sequential(K, mon):
         b_ref, t_ref, out_ref = sequential(toy, frames)
         for ckp in (True, False):
             for pr in (True, False):
-                b, t, out, _ = chain(toy, frames, K, checkpoints=ckp, predict=pr)
-                assert np.array_equal(b, b_ref) and np.array_equal(t, t_ref), (K, mon, seed, ckp, pr)
-                for f in range(F):
-                    assert out[f][0] == out_ref[f][0] and np.array_equal(out[f][1], out_ref[f][1]), (K, mon, seed, f)
+                for ls in (True, False):
+                    b, t, out, _ = chain(toy, frames, K, checkpoints=ckp, predict=pr, lockstep=ls)
+                    assert np.array_equal(b, b_ref) and np.array_equal(t, t_ref), (K, mon, seed, ckp, pr, ls)
+                    for f in range(F):
+                        assert out[f][0] == out_ref[f][0] and np.array_equal(out[f][1], out_ref[f][1]), (K, mon, seed, f, ls)
 
 
 def test_prediction_and_checkpoints_save_passes():
@@ -155,9 +166,11 @@ def test_prediction_and_checkpoints_save_passes():
     toy = Toy(npx, 4, 3)
     drift = np.cumsum(rng.integers(4, 14, (F, 1)), axis=0)
     frames = (drift + rng.integers(0, 40, (F, npx))).astype(np.int64)
-    _, _, ref, _ = chain(toy, frames, K, checkpoints=False, predict=False)
-    n_plain = chain(toy, frames, K, checkpoints=False, predict=False)[3]
-    n_pred = chain(toy, frames, K, checkpoints=True, predict=True)[3]
+    _, _, ref, _ = chain(toy, frames, K, checkpoints=False, predict=False, lockstep=False)
+    n_plain = chain(toy, frames, K, checkpoints=False, predict=False, lockstep=False)[3]
+    n_pred = chain(toy, frames, K, checkpoints=True, predict=True, lockstep=False)[3]
+    n_lock = chain(toy, frames, K, checkpoints=True, predict=True, lockstep=True)[3]
+    assert n_lock <= n_pred  # runs of rule-on frames: a rendezvous per frame of the run instead of a pass
     rule_on = sum(1 for m, _ in ref if m >= toy.mon)
     assert rule_on > 10
     assert n_pred < n_plain

@@ -851,7 +851,7 @@ struct v2e_emu {
     int ch_E = 0;                   // frames per k_ahead launch / emission batch (a multiple of ch_K)
     int last_kind = -1, last_fpl = 0, last_fpb = 0; // v2e_emu_last_pipeline
     uint32_t *ch_gM = nullptr;      // [ch_launch_cap][ch_K + 1][n_clips][ch_K]
-    unsigned *ch_bar = nullptr;     // [ch_launch_cap][ch_K][n_clips]
+    unsigned *ch_bar = nullptr;     // [ch_launch_cap][2 ch_K][n_clips]: one counter per rendezvous of a launch (passes + lock-step frames)
     void *ch_base2 = nullptr, *ch_lp2 = nullptr; // second set of state planes (ping-pong between launches)
     float *ch_ts2 = nullptr;
     CFrame *ch_cf = nullptr;        // [2][ch_E][n_clips]
@@ -1741,7 +1741,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
             hipFree(h->ch_gM); hipFree(h->ch_bar);
             h->ch_launch_cap = n_launch;
             V2E_HIP(hipMalloc(&h->ch_gM, sizeof(uint32_t) * (size_t)n_launch * (K + 1) * h->n_clips * K));
-            V2E_HIP(hipMalloc(&h->ch_bar, sizeof(unsigned) * (size_t)n_launch * K * h->n_clips));
+            V2E_HIP(hipMalloc(&h->ch_bar, sizeof(unsigned) * (size_t)n_launch * 2 * K * h->n_clips));
             h->drop_graphs();
         }
     }
@@ -1792,7 +1792,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     if (sc.zero(ST_MAIN, h->run_off, sizeof(unsigned long long) * NC)) return V2E_EHIP; // batch 0 starts at row 0
     if (has_refr) {
         if (sc.zero(ST_MAIN, h->ch_gM, sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K)) return V2E_EHIP;
-        if (sc.zero(ST_MAIN, h->ch_bar, sizeof(unsigned) * (size_t)nL * K * NC)) return V2E_EHIP;
+        if (sc.zero(ST_MAIN, h->ch_bar, sizeof(unsigned) * (size_t)nL * 2 * K * NC)) return V2E_EHIP;
     }
     auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t stq) -> int { // instrumented runs (never graphs)
         if (!v || graph) return 0;
@@ -1810,6 +1810,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
     static const int chain_prio = getenv("V2E_AMD_CHAIN_PRIO") ? atoi(getenv("V2E_AMD_CHAIN_PRIO")) : 3; // dev: 0 = no raised wave priority
     static const int bar_light = getenv("V2E_AMD_BAR_LIGHT") ? atoi(getenv("V2E_AMD_BAR_LIGHT")) : 1;    // dev: 0 = fenced rendezvous (round 3)
+    static const int lockstep = getenv("V2E_AMD_LOCKSTEP") ? atoi(getenv("V2E_AMD_LOCKSTEP")) : 1;       // dev: 0 = no lock-step frames in redo passes
     // Under stream capture only edges between the origin stream and a forked stream are safe (edges between two forked
     // streams crash hipStreamEndCapture on this runtime): tables and rows then share the side stream.
     static const int tab_env = getenv("V2E_AMD_TABLES_ON_SIDE") ? ST_SIDE : (getenv("V2E_AMD_TABLES_ON_AHEAD") ? ST_AHEAD : ST_TAB); // dev
@@ -1918,7 +1919,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (has_refr) {
             ca.gM_cur = h->ch_gM + (size_t)L * (K + 1) * NC * K;
             ca.gM_prev = h->ch_gM + (size_t)(L > 0 ? L - 1 : 0) * (K + 1) * NC * K;
-            ca.bar_prev = h->ch_bar + (size_t)(L > 0 ? L - 1 : 0) * K * NC;
+            ca.bar_prev = h->ch_bar + (size_t)(L > 0 ? L - 1 : 0) * 2 * K * NC;
         }
         const int in = L % 2, out = tail ? 0 : (L + 1) % 2, pin = (L + 1) % 2;
         ca.base_in = xb[in]; ca.lp_in = xl[in]; ca.ts_in = xt[in];
@@ -1942,6 +1943,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.store_out = tail && in != 0;
         ca.prio = chain_prio;
         ca.bar_light = bar_light;
+        ca.lockstep = lockstep;
         ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
         if (pl.wait_join >= 0 && sc.wait(ST_MAIN, EV_JOIN, pl.wait_join)) return V2E_EHIP; // ring slots: read by k_cemit of that batch
         if (pl.wait_ahead >= 0 && sc.wait(ST_MAIN, EV_AHEAD, pl.wait_ahead)) return V2E_EHIP;

@@ -153,6 +153,7 @@ struct ChainArgs {
     int store_out;                    // tail launch: state must be copied to *_out even without a redo
     int prio;                         // wave priority of the chain (3: it outranks the emission waves sharing its SIMDs)
     int bar_light;                    // the redo rendezvous without release / acquire fences (the maxima rows are atomics)
+    int lockstep;                     // redo passes take the frame(s) right behind a rule-on frame in lock-step (see k_chain)
     unsigned long long *dbg;          // dev tool: [ngroups][16] wall-clock stamps of one launch, or nullptr
 };
 
@@ -399,6 +400,13 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
         uint32_t pred_v = 0u;  // lane k: the M frame k was run under in the pass whose row is being checked
         uint32_t exact_v = 0u; // lane k: M of the previous launch's frame k in the coming redo pass (0: speculate)
         int c0 = 0;            // first frame of the pass (a redo pass may restart at a checkpoint)
+        int bar_idx = 0;       // rendezvous of this launch so far (each has its own counter; the same sequence in every workgroup)
+        // Lock-step frame of a redo pass.  Fixing a rule-on frame j leaves the pixels whose events the rule filtered with their
+        // brightness difference, so frame j + 1 fires more and turns out rule-on itself in about half the cases -- a surprise no
+        // prediction covers, which used to cost one more whole pass.  A redo pass therefore takes the frame right behind a frame
+        // it finalised by the rule in LOCK-STEP: counts, publish, one (fence-free, ~5 us) rendezvous, the frame's exact M read
+        // back, finalise -- and goes on like that while the frames keep being rule-on.
+        int lock_k = -1;
         for (;;) {
             int fs, fn;
             uint32_t *gM_dst;
@@ -424,6 +432,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     last_exact = j;
                     ++round;
                     redone = true;
+                    lock_k = (ca.lockstep && __builtin_amdgcn_readlane((int)gM_v, j) != 0 && j + 1 < ca.pnf) ? j + 1 : -1;
                     // restart point: every frame before j is exact, so is the checkpoint at or below j (written by the
                     // own pass, or by the redo pass before this one, in which the frames up to j were exact already)
                     c0 = ca.ckp_base ? (j / CHAIN_SUB) * CHAIN_SUB : 0;
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             auto frame_body = [&](const int k, const uint4 rc_in) __attribute__((always_inline)) {
                 const int f = fs + k;
                 const uint32_t Mon = (uint32_t)__builtin_amdgcn_readlane((int)mon_v, k);
-                const uint32_t exM = own ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)exact_v, k);
+                uint32_t exM = own ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)exact_v, k);
                 // the frame's record: eps (+ shot decisions in its two free bits), lin-log value, leak step
                 uint4 rc = rc_in;
                 if (FUSED) {
@@ -502,6 +511,20 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 if (a.has_refr && k > (own ? -1 : last_exact) && __ballot((uint32_t)magv >= Mon) != 0ull) {
                     const int wm = wave_max_i32(magv);
                     if (lane == 0) atomicMax(gM_dst + k, (uint32_t)wm);
+                }
+                if (!own && k == lock_k) { // lock-step: every frame before this one is exact, so the published maximum is M(k)
+                    __builtin_amdgcn_s_setprio(0);
+                    const bool okb = clip_barrier(ca.bar_prev + (size_t)bar_idx * ca.n_clips + clip, (unsigned)ca.ngroups, ca.bar_light != 0);
+                    ++bar_idx;
+                    if (ca.prio) __builtin_amdgcn_s_setprio(3);
+                    if (!okb && tid == 0) atomicOr(&ca.recs[(size_t)ca.pf0 * ca.n_clips + clip].flags, V2E_FLAG_SYNC_TIMEOUT);
+                    uint32_t mk = 0u;
+                    if (lane == 0) mk = __hip_atomic_load(gM_dst + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mk = (uint32_t)__builtin_amdgcn_readfirstlane((int)mk);
+                    exM = mk; // >= the rule threshold, or 0: nobody reached it
+                    if (lane == k) { exact_v = mk; pred_v = mk; }
+                    last_exact = k;
+                    lock_k = (mk != 0u && k + 1 < fn) ? k + 1 : -1;
                 }
                 // ---- finalise (emulator.py:830-842, 936-942) -- by the refractory rule where M is known to switch it on.
                 // The rule-on walk is its own branch: nothing it loads (timestamp tables) may be live in the common path,
@@ -603,7 +626,8 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
             // (not at raised priority: a spinning wave that outranks the other kernels' waves on its SIMD keeps them from
             // finishing, and the workgroups this one waits for may need their slots)
             __builtin_amdgcn_s_setprio(0);
-            const bool ok = clip_barrier(ca.bar_prev + (size_t)(round - 1) * ca.n_clips + clip, (unsigned)ca.ngroups, ca.bar_light != 0);
+            const bool ok = clip_barrier(ca.bar_prev + (size_t)bar_idx * ca.n_clips + clip, (unsigned)ca.ngroups, ca.bar_light != 0);
+            ++bar_idx;
             if (ca.prio) __builtin_amdgcn_s_setprio(3);
             if (!ok && tid == 0) atomicOr(&ca.recs[(size_t)ca.pf0 * ca.n_clips + clip].flags, V2E_FLAG_SYNC_TIMEOUT);
         }
