@@ -1810,7 +1810,11 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
     static const int chain_prio = getenv("V2E_AMD_CHAIN_PRIO") ? atoi(getenv("V2E_AMD_CHAIN_PRIO")) : 3; // dev: 0 = no raised wave priority
     static const int bar_light = getenv("V2E_AMD_BAR_LIGHT") ? atoi(getenv("V2E_AMD_BAR_LIGHT")) : 1;    // dev: 0 = fenced rendezvous (round 3)
-    static const int lockstep = getenv("V2E_AMD_LOCKSTEP") ? atoi(getenv("V2E_AMD_LOCKSTEP")) : 1;       // dev: 0 = no lock-step frames in redo passes
+    // lock-step frames in redo passes (emu_chain.h): measured round 4 with the fence-free rendezvous, A/B in one process each:
+    // a launch whose rule-on frames come in a run 109-112 -> 89-92 us, a launch with a single rule-on frame 54-60 -> 68-71 us
+    // (the extra rendezvous is ~10 us inside the frame loop: it also drains the record prefetch), 10.4-10.6 against 10.8-11.0
+    // Gev/s on the benchmark clip: off by default, kept behind V2E_AMD_LOCKSTEP=1 (GPU parity suite green with it on)
+    static const int lockstep = getenv("V2E_AMD_LOCKSTEP") ? atoi(getenv("V2E_AMD_LOCKSTEP")) : 0;
     // Under stream capture only edges between the origin stream and a forked stream are safe (edges between two forked
     // streams crash hipStreamEndCapture on this runtime): tables and rows then share the side stream.
     static const int tab_env = getenv("V2E_AMD_TABLES_ON_SIDE") ? ST_SIDE : (getenv("V2E_AMD_TABLES_ON_AHEAD") ? ST_AHEAD : ST_TAB); // dev
