@@ -42,6 +42,11 @@ FRAMES_PER_STEP = 300
 DEFAULT_KW = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak_rate_hz=.01,
                   shot_noise_rate_hz=.001, refractory_period_s=.0005)
 HBM_PEAK = 8.0e12        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_RATE = 256 * 4 * 2.4e9 / 2  # wave64 VALU instructions per second: a SIMD-32 takes one in 2 cycles (MI355X_MICROARCH.md)
+SALU_RATE = 256 * 2.4e9          # one scalar unit per CU
+PMC_FILES = ("r04_emulator_pmc_hbm.txt", "r03_emulator_pmc_hbm.txt")
+TRACE_FILES = ("r04_emulator_chain_kernel_trace.txt", "r03_emulator_chain_kernel_trace.txt")
+SQ_FILES = ("r04_emulator_sq.txt",)
 F32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: f32-input MFMA peak
 CLIP_STEPS = 24           # distinct seconds of synthetic video generated; longer runs cycle through them
 
@@ -80,27 +85,56 @@ def pmc_traffic_per_launch(kernel):
     """HBM bytes per chain-kernel launch from the committed rocprofv3 PMC passes of this same command
     (profiles/r03_emulator_pmc_hbm.txt: FETCH_SIZE and WRITE_SIZE in separate runs).  Counters cannot
     be read from inside this process, so the value is the recorded one or null."""
-    for name in ("r03_emulator_pmc_hbm.txt", "r02_emulator_pmc_hbm.txt"):
+    for name in PMC_FILES:
         try:
             for line in open(os.path.join(ROOT, "profiles", name)):
                 if line.startswith("# " + kernel + "<") or line.startswith("# " + kernel + " "):
                     parts = line.split()
-                    return int((float(parts[-2]) + float(parts[-1])) * 1024)
+                    return int((float(parts[-2]) + float(parts[-1])) * 1024), "profiles/" + name
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def rocprof_kernel_us(kernel):
     """Average duration (us) of the chain kernel in the committed rocprofv3 kernel trace of this same command
     (profiles/r03_emulator_chain_kernel_trace.txt), or None: bench.py's own figure is measured live with HIP events."""
-    try:
-        for line in open(os.path.join(ROOT, "profiles", "r03_emulator_chain_kernel_trace.txt")):
-            parts = line.split()
-            if len(parts) > 4 and parts[0].isdigit() and (kernel + "<") in line:
-                return float(parts[2])
-    except Exception:
-        pass
+    for name in TRACE_FILES:
+        try:
+            for line in open(os.path.join(ROOT, "profiles", name)):
+                parts = line.split()
+                if len(parts) > 4 and parts[0].isdigit() and (kernel + "<") in line:
+                    return float(parts[2]), "profiles/" + name
+        except Exception:
+            pass
+    return None, None
+
+
+def instruction_issue(ms_per_frame):
+    """The resource that binds this pipeline (round-3 review): vector and scalar instructions issued per frame over ALL its
+    kernels, from the committed SQ-counter pass of the headline workload (profiles/r04_emulator_sq.txt, line
+    '# headline_instr_per_frame <VALU> <SALU> <wave-frames>': SQ_INSTS_VALU / SQ_INSTS_SALU summed over k_ahead, k_chain, k_ctot,
+    k_cframe1, k_cemit, divided by the frames run), against the chip's issue rates (MI355X_MICROARCH.md: a wave64 VALU
+    instruction occupies its SIMD-32 for 2 cycles -> 256 CUs x 4 SIMDs x 2.4 GHz / 2; one scalar unit per CU, one
+    instruction per cycle).  frac = the time the busier of the two pipes needs / the time a frame takes."""
+    for name in SQ_FILES:
+        try:
+            for line in open(os.path.join(ROOT, "profiles", name)):
+                if line.startswith("# headline_instr_per_frame"):
+                    parts = line.split()
+                    valu, salu = float(parts[2]), float(parts[3])
+                    t_v, t_s = valu / VALU_RATE, salu / SALU_RATE
+                    out = {"valu_per_frame": int(valu), "salu_per_frame": int(salu),
+                           "per_64px_wave_frame": round((valu + salu) / (H * W / 64.0), 1),
+                           "valu_rate_per_s": VALU_RATE, "salu_rate_per_s": SALU_RATE,
+                           "bound_us_per_frame": round(max(t_v, t_s) * 1e6, 4), "measured_us_per_frame": round(ms_per_frame * 1e3, 4),
+                           "frac": round(max(t_v, t_s) / (ms_per_frame * 1e-3), 4), "source": "profiles/" + name,
+                           "note": "instructions of all kernels of the pipeline per frame (rocprofv3 SQ counters, recorded) over the "
+                                   "chip's vector / scalar issue rates against this run's time per frame: the fraction of the "
+                                   "BINDING resource; the rest is dependency latency that one wave per SIMD cannot hide"}
+                    return out
+        except Exception:
+            pass
     return None
 
 
@@ -113,10 +147,9 @@ def recorded_reference():
         return None
 
 
-def cpu_baseline(frames_host, budget_s=15.0):
-    """CPU oracle (C restatement of the reference, 1 thread) on a bounded sample of the same clip."""
+def _oracle_run(frames_host, budget_s, out, idx):
     from oracle import oracle as orc
-    o = orc.OracleEmulator(seed=1, rng_mode="philox", **DEFAULT_KW)
+    o = orc.OracleEmulator(seed=1 + idx, rng_mode="philox", **DEFAULT_KW)
     o.generate_events(frames_host[0], 0.0)
     n_ev, n_fr = 0, 0
     t0 = time.perf_counter()
@@ -126,10 +159,36 @@ def cpu_baseline(frames_host, budget_s=15.0):
         n_fr += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
+    out[idx] = (n_ev, n_fr, time.perf_counter() - t0)
+
+
+def cpu_baseline(frames_host, budget_s=8.0):
+    """CPU oracle (C restatement of the reference) on a bounded sample of the same clip, on THIS host: one thread (`value`), and
+    every core (`all_cores`: one independent oracle instance per thread over the same frames -- clips are independent, this is
+    how a CPU would be filled; the C calls and numpy release the GIL)."""
+    import threading
+    res = {}
+    _oracle_run(frames_host, budget_s, res, 0)
+    n_ev, n_fr, dt = res[0]
     out = {"value": round(n_ev / dt / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
            "frames_per_s": round(n_fr / dt, 1),
            "sample": "first %d frames of the same 346x260 clip, C oracle (oracle/emu_oracle.c), Philox RNG, %.1f s" % (n_fr, dt)}
+    try:
+        nthr = max(1, min(len(os.sched_getaffinity(0)), 64))
+        res = {}
+        th = [threading.Thread(target=_oracle_run, args=(frames_host, budget_s, res, i)) for i in range(nthr)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(sum(v[0] for v in res.values()) / wall / 1e6, 3), "unit": "Mevents/s", "cores": nthr,
+                            "kind": "port", "frames_per_s": round(sum(v[1] for v in res.values()) / wall, 1),
+                            "sample": "%d independent oracle instances (one per thread, of %d hardware threads) over the first %d "
+                                      "frames of the same clip, %.1f s" % (nthr, os.cpu_count() or 0, max(v[1] for v in res.values()), wall)}
+    except Exception as e:
+        out["all_cores"] = {"error": repr(e)[:200]}
     ref = recorded_reference()
     if ref:
         runs = ref["emulator"]["runs"]
@@ -138,6 +197,24 @@ def cpu_baseline(frames_host, budget_s=15.0):
                             "runs": [{"cores": r["threads"], "value": r["Mevents_per_s"], "unit": "Mevents/s",
                                       "frames_per_s": r["frames_per_s"]} for r in runs]}
     return out
+
+
+def slomo_cpu_baseline():
+    """The SloMo stage's CPU port on THIS host: oracle/slomo_oracle.c (OpenMP over output channels x rows) on one pair at
+    320x256, two time points -- 51.45 + 2 x 54.07 GFLOP of scalar float32 fma chains."""
+    from oracle import oracle as orc
+    from v2e_amd.synth import portable_unet_state_dict
+    rng = np.random.default_rng(2)
+    I0 = (rng.random((1, 1, 256, 320), dtype=np.float32) - np.float32(0.428))
+    I1 = (rng.random((1, 1, 256, 320), dtype=np.float32) - np.float32(0.428))
+    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
+    ts = [0.25, 0.75]
+    t0 = time.perf_counter()
+    orc.slomo_interpolate(I0, I1, ts, sd_f, sd_i)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(ts) / dt, 3), "unit": "frames/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": "one pair at 320x256, U = 2 (flow UNet + 2 x interpolation UNet + warps), oracle/slomo_oracle.c with OpenMP "
+                      "(scalar float32 fma chains, no SIMD intrinsics), %.1f s" % dt}
 
 
 def frame_api_bench(frames_all, budget_frames=600):
@@ -207,6 +284,40 @@ def delivered_to_host_bench(device, frames_all, steps=6):
     return {"value": round(n_ev / sec / 1e6, 1), "unit": "Mevents/s", "GB_per_s_over_pcie": round(n_ev * 16 / sec / 1e9, 2),
             "note": "same device-resident run, event rows (16 B each) copied to pinned host memory on a side stream while the "
                     "next step executes"}
+
+
+def self_allgather_bench(device, frames_all, steps=30, warmup=3):
+    """N = 1 self-test of the exchange path (round-3 review): the headline loop with the event-stream all-gather switched on
+    over a one-rank RCCL group -- the pack32 kernels, the host-side count exchange and the ncclAllGather enqueue are
+    executed and timed on the driver's box, beside the same loop without them.  Says nothing about links (there is no
+    peer); it pins that the path runs and what it costs the producing GPU."""
+    import torch.distributed as dist
+    from v2e_amd import EventEmulator
+    from v2e_amd.benchutil import run_steps
+    from v2e_amd.dist import EventStreamGatherer
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        res = {}
+        for tag, wire in (("compute_only", None), ("pack32", "pack32"), ("pack64", "pack64")):
+            emu = EventEmulator(device=device, seed=1, rng_mode="philox", **DEFAULT_KW)
+            emu.generate_events(frames_all[0], 0.0)
+            g = EventStreamGatherer(device, 1, wire=wire, algo="allgather", sensor=(H, W)) if wire else None
+            el, ne = run_steps(emu, frames_all, FRAMES_PER_STEP, DT, steps, warmup, g, dist, device)
+            res[tag] = {"value": round(ne / el / 1e6, 1), "unit": "Mevents/s", "ms_per_step": round(el / steps * 1e3, 4)}
+            if g is not None:
+                res[tag]["bytes_gathered_per_step"] = int(g.bytes_gathered / (steps + warmup))
+                parts = g.result()
+                res[tag]["last_step_rows_back"] = int(parts[0].shape[0])
+        res["note"] = ("world size 1 over RCCL: pack kernels + host count exchange + ncclAllGather enqueue on a side stream, "
+                       "overlapped with the next step; no link is exercised")
+        return res
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
 
 
 def main():
@@ -354,13 +465,14 @@ def main():
         full = sorted(per_launch[:F // fpl])       # the launches that advance fpl frames (the partial and the tail one excluded)
         p50 = full[len(full) // 2] if full else None
         whole = (bpp * npx + 16 * ev_per_frame)
-        prof_file = "profiles/r03_emulator_pmc_hbm.txt"
+        traffic, prof_file = pmc_traffic_per_launch(kname.split("(")[0])
+        rp_us, rp_file = rocprof_kernel_us(kname.split("(")[0])
         out["roofline"] = {
             "bound": "hbm", "kernel": kname.split("(")[0],
             "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK, 5),
-            "traffic": pmc_traffic_per_launch(kname.split("(")[0]),
-            "traffic_source": prof_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; counters cannot be read "
+            "traffic": traffic,
+            "traffic_source": str(prof_file) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; counters cannot be read "
                                           "from inside the process)",
             "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
             "frames_per_launch_avg": round(F / n_step, 2),
@@ -376,9 +488,9 @@ def main():
                              "frac": round(step_bytes / (period_us * 1e-6) / HBM_PEAK, 5),
                              "note": "the same bytes against the timed region's time per chain launch (ms_per_step / launches per step: "
                                      "everything the step does -- k_ahead, the emission kernels, gaps, redo passes -- included)"},
-            "rocprof_recorded": (lambda us: None if us is None else {
-                "avg_kernel_us": us, "source": "profiles/r03_emulator_chain_kernel_trace.txt",
-                "frac": round(step_bytes / (us * 1e-6) / HBM_PEAK, 5)})(rocprof_kernel_us(kname.split("(")[0])),
+            "rocprof_recorded": None if rp_us is None else {
+                "avg_kernel_us": rp_us, "source": rp_file, "frac": round(step_bytes / (rp_us * 1e-6) / HBM_PEAK, 5)},
+            "instruction_issue": instruction_issue(elapsed / (K * F) * 1e3),
             "event_writer_us_per_batch": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3),
             "emission": {"frames_per_batch": fpb, "algorithmic_bytes_per_frame": int(emit_bytes)},
             "whole_step": {"algorithmic_bytes_per_frame": int(whole),
@@ -388,6 +500,7 @@ def main():
                     "on average) / the launches' average duration, HIP events before and after every launch of an instrumented re-run "
                     "of the last step's frames with all kernels of the run on ONE stream, i.e. each running alone (in the timed runs "
                     "the three streams overlap and every kernel is stretched: profiles/r03_graph_scheduling.txt); "
+                    "instruction_issue states the fraction of the resource that actually binds this pipeline; "
                     "the per-pixel state (2.9 MB at 346x260) stays in registers for the launch's frames and one frame is only "
                     "1408 waves, so the chain is bounded by instruction latency, not HBM (DESIGN.md section 3); whole_step prices "
                     "the complete frame (state traffic + event rows) against the driver-timed region",
@@ -404,6 +517,8 @@ def main():
                 out["slomo"] = slomo_bench(device)
                 out["slomo_f32"] = slomo_bench(device, conv_math="f32")
                 out["slomo_bf16x3"] = slomo_bench(device, conv_math="bf16x3")  # the exact three-piece split (what the range guard falls back to)
+                if not args.no_cpu_baseline:
+                    out["slomo"]["cpu_baseline_this_host"] = slomo_cpu_baseline()
                 ref = recorded_reference()
                 if ref:
                     out["slomo"]["cpu_baseline"] = {
@@ -413,6 +528,11 @@ def main():
                 out["end_to_end"] = e2e_bench(device)
             except Exception as e:  # side measurements must never hide the headline number
                 out["extras_error"] = repr(e)[:300]
+            if dist is None:
+                try:
+                    out["self_allgather"] = self_allgather_bench(device, frames_all)
+                except Exception as e:
+                    out["self_allgather"] = {"error": repr(e)[:300]}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -131,7 +131,9 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     roof = {"bound": "mfma", "kernel": ("k_conv_s3 / k_conv_s3p" if s3 else "k_conv") + " (23 launches of the interpolation UNet)",
             "achieved": round(ach * npr / 1e12, 2), "peak": (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK) / 1e12,
             "unit": "TFLOP/s", "frac": round(ach * npr / (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK), 4),
-            "traffic": slomo_pmc_traffic(), "f32_equivalent_TFLOPs": round(ach / 1e12, 2),
+            "traffic": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W))[0],
+            "traffic_detail": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W))[1],
+            "f32_equivalent_TFLOPs": round(ach / 1e12, 2),
             "f32_equivalent_vs_f32_mfma_peak": round(ach / F32_MFMA_PEAK, 4),
             "whole_step_TFLOPs": round(flops / sec / 1e12, 2),
             "note": ("achieved = algorithmic f32 FLOPs of the UNet x 6 (bf16 piece products executed per f32 multiply: x = p0+p1+p2 "
@@ -155,19 +157,44 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     }
 
 
-def slomo_pmc_traffic():
-    """HBM bytes per interpolation-UNet forward (80 samples) from the committed rocprofv3 PMC passes
-    (profiles/r02_slomo_counters.txt, line '# unet_forward_bytes <fetch> <write>'), or None."""
+def slomo_pmc_traffic(conv_math, algorithmic=None):
+    """HBM bytes per interpolation-UNet forward (80 samples) of the conv math that ran, from the committed rocprofv3 PMC
+    passes of THIS round's kernels (profiles/r04_slomo_counters.txt, lines '# unet_forward_bytes <conv_math> <fetch> <write>',
+    made by scripts/gpu_r04_profiles.sh + scripts/make_profiles_r04.py).  Returns (bytes or None, detail dict)."""
     import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "r04_slomo_counters.txt"
     try:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for line in open(os.path.join(root, "profiles", "r02_slomo_counters.txt")):
+        for line in open(os.path.join(root, "profiles", name)):
             if line.startswith("# unet_forward_bytes"):
                 parts = line.split()
-                return int(float(parts[2]) + float(parts[3]))
+                if parts[2] == conv_math:
+                    fetch, write = float(parts[3]), float(parts[4])
+                    d = {"source": "profiles/" + name, "fetch_bytes": int(fetch), "write_bytes": int(write)}
+                    if algorithmic:
+                        d["algorithmic_bytes"] = int(algorithmic)
+                        d["traffic_over_algorithmic"] = round((fetch + write) / algorithmic, 3)
+                    return int(fetch + write), d
     except Exception:
         pass
-    return None
+    return None, {"source": None, "note": "no PMC pass of this conv math committed for this round"}
+
+
+def unet_algorithmic_bytes(n, cin, cout, h, w):
+    """Bytes one UNet forward has to move if every activation is written once and read once by its consumer(s) (skip
+    connections twice), plus the weights once: the 'algorithmic' side of the traffic ratio."""
+    from .synth import unet_layer_shapes
+    res = {"conv1": 0, "conv2": 0, "conv3": 0}
+    for d in range(1, 6):
+        res["down%d" % d] = d
+    for u in range(1, 6):
+        res["up%d" % u] = 5 - u
+    byts = 0
+    for name, co, ci, k in unet_layer_shapes(cin, cout):
+        lvl = res[name.split(".")[0]]
+        hw = (h >> lvl) * (w >> lvl)
+        byts += 4 * n * hw * (ci + co) + 4 * co * ci * k * k  # read the input, write the output, the weights
+    return byts
 
 
 def batched_emulator_bench(device, n_clips=64, frames=60, H=260, W=346):
