@@ -155,6 +155,14 @@ int v2e_emu_lp_preview(v2e_emu *h, const v2e_emu_params *p, const void *frame, i
  * of 200 x 200 and more (DAVIS346 included; on small planes its backend sums in another order, see csdvs.hip).  h_scratch: a
  * second plane of the same size.  steps_taken: the reference's `steps`; last_max_change (may be NULL): its `max_change`.
  * Synchronises the stream once per 32 steps. */
+/* CSDVS inside a device-resident run (v2e_emu_run; one clip): per frame of the COMING run the Euler parameters the host
+ * computes as emulator.py:1066-1096 does (alpha_p, alpha_h, num_steps), a scratch surround plane and a plane for the frame's
+ * lp_log_frame (state dtype, [npx_pad] each, caller-owned), and steps_taken_dev (device int32 [n_frames]: the reference's `steps`
+ * per frame, readable after the run).  The run then steps the diffuser on the stream before every frame: every one of the frame's
+ * num_steps launches is enqueued and the ones after the step that settles (max |change| <= max_change_to_stop, evaluated on the
+ * device) return at once -- no host step, capturable in the run's hipGraph.  n_frames = 0 clears it. */
+int v2e_emu_set_csdvs_run(v2e_emu *h, void *h_scratch, void *lp_scratch, const double *alpha_p, const double *alpha_h,
+                          const int *num_steps, int n_frames, double max_change_to_stop, int *steps_taken_dev);
 int v2e_csdvs_update(const void *p_plane, void *h_plane, void *h_scratch, int H, int W, int f64, double alpha_p, double alpha_h,
                      int num_steps, double max_change_to_stop, int *steps_taken, double *last_max_change, void *stream);
 

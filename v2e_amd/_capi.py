@@ -85,6 +85,7 @@ SIGNATURES = {
     "v2e_emu_set_scidvs": (_i, [_vp, _vp, _vp, _vp, _u32]),
     "v2e_emu_frame_host_rows": (_i, [_vp, _vp, _u64]),
     "v2e_emu_set_csdvs": (_i, [_vp, _vp]),
+    "v2e_emu_set_csdvs_run": (_i, [_vp, _vp, _vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i), _i, _d, _vp]),
     "v2e_emu_lp_preview": (_i, [_vp, _PP, _vp, _i, C.POINTER(_d), C.POINTER(_d), _u32, _vp, _vp]),
     "v2e_csdvs_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _d, _i, _d, C.POINTER(_i), C.POINTER(_d), _vp]),
     "v2e_emu_count": (_i, [_vp, _PP, _vp, _i, C.POINTER(_d), C.POINTER(_d), _u32, _vp, _vp, _vp]),

@@ -26,3 +26,7 @@ void v2e_set_error(const char *fmt, ...);
     } while (0)
 
 static inline int v2e_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// csdvs.hip: one frame's surround (diffuser) update enqueued on `s` without a host step (emu.hip's per-frame run loop)
+int v2e_csdvs_enqueue_frame(const void *p_plane, void *h_plane, void *h_scratch, int H, int W, int f64, double alpha_p, double alpha_h,
+                            int num_steps, double thr, unsigned long long *slots, int *steps_taken_dev, hipStream_t s);

@@ -78,6 +78,35 @@ __global__ __launch_bounds__(256) void k_cs_step(const R *__restrict__ p, const 
     }
 }
 
+// ---- device-resident variant (v2e_emu_run with a surround: no host step between the diffuser's steps).  Slot 0 = +inf, slot
+// i + 1 = step i's max |change| (k_cs_step runs step i only if slot i is above the threshold, so every step after the first
+// one that settles is a no-op launch); the steps that ran = the slots 0 .. n - 1 above the threshold.
+__global__ void k_cs_begin(unsigned long long *slots, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) slots[i] = i == 0 ? 0x7FF0000000000000ull : 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_cs_count(const unsigned long long *__restrict__ slots, int n, double thr, int *__restrict__ steps_out)
+{
+    __shared__ int s_part[4];
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) c += !(__longlong_as_double((long long)slots[i]) <= thr) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) *steps_out = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// an odd number of steps leaves the result in the scratch plane
+template <typename R>
+__global__ __launch_bounds__(256) void k_cs_settle(const R *__restrict__ scratch, R *__restrict__ plane, int n, const int *__restrict__ steps)
+{
+    if (!(*steps & 1)) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) plane[i] = scratch[i];
+}
+
 struct CsScratch {
     unsigned long long *dev = nullptr;  // [CHUNK + 1]: entry 0 carries the previous chunk's last maximum
     unsigned long long *host = nullptr; // pinned [CHUNK + 1]
@@ -86,6 +115,28 @@ struct CsScratch {
 thread_local CsScratch g_cs;
 
 } // namespace
+
+// One frame's surround update, all on the stream (declared in common.h; called by emu.hip's per-frame run loop)
+int v2e_csdvs_enqueue_frame(const void *p_plane, void *h_plane, void *h_scratch, int H, int W, int f64, double alpha_p, double alpha_h,
+                            int num_steps, double thr, unsigned long long *slots, int *steps_taken_dev, hipStream_t s)
+{
+    const int blocks = (int)v2e_cdiv((int64_t)H * W, 256);
+    k_cs_begin<<<v2e_cdiv((int64_t)num_steps + 1, 256), 256, 0, s>>>(slots, num_steps);
+    void *buf[2] = {h_plane, h_scratch};
+    for (int i = 0; i < num_steps; ++i) {
+        const void *hin = buf[i & 1];
+        void *hout = buf[(i + 1) & 1];
+        if (f64) k_cs_step<double><<<blocks, 256, 0, s>>>((const double *)p_plane, (const double *)hin, (double *)hout, H, W, alpha_p,
+                                                         (float)alpha_h, thr, slots + i, slots + i + 1);
+        else k_cs_step<float><<<blocks, 256, 0, s>>>((const float *)p_plane, (const float *)hin, (float *)hout, H, W, (float)alpha_p,
+                                                     (float)alpha_h, thr, slots + i, slots + i + 1);
+    }
+    k_cs_count<<<1, 256, 0, s>>>(slots, num_steps, thr, steps_taken_dev);
+    if (f64) k_cs_settle<double><<<blocks, 256, 0, s>>>((const double *)h_scratch, (double *)h_plane, H * W, steps_taken_dev);
+    else k_cs_settle<float><<<blocks, 256, 0, s>>>((const float *)h_scratch, (float *)h_plane, H * W, steps_taken_dev);
+    V2E_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" {
 
@@ -96,7 +147,12 @@ int v2e_csdvs_update(const void *p_plane, void *h_plane, void *h_scratch, int H,
     V2E_REQUIRE(H > 0 && W > 0 && num_steps >= 0, "bad size");
     hipStream_t s = (hipStream_t)stream;
     int dev = 0;
-    V2E_HIP(hipGetDevice(&dev));
+    {   // the device the planes live on, not whatever device is current on this thread
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, h_plane) == hipSuccess) dev = at.device;
+        else { (void)hipGetLastError(); V2E_HIP(hipGetDevice(&dev)); }
+        V2E_HIP(hipSetDevice(dev));
+    }
     if (g_cs.device != dev) {
         if (g_cs.dev) { hipFree(g_cs.dev); hipHostFree(g_cs.host); g_cs.dev = nullptr; g_cs.host = nullptr; }
         V2E_HIP(hipMalloc((void **)&g_cs.dev, sizeof(unsigned long long) * (CHUNK + 1)));

@@ -782,6 +782,14 @@ struct v2e_emu {
     const float *pn_tape = nullptr;
     void *sc_hp = nullptr, *sc_prev = nullptr; // SCIDVS planes (v2e_emu_set_scidvs)
     const void *cs_sur = nullptr;              // CSDVS surround plane (v2e_emu_set_csdvs)
+    // CSDVS in a device-resident run (v2e_emu_set_csdvs_run): per-frame Euler parameters, scratch planes, step slots
+    void *csr_scratch = nullptr, *csr_lp = nullptr;
+    std::vector<double> csr_ap, csr_ah;
+    std::vector<int> csr_steps;
+    double csr_thr = 0.0;
+    int *csr_steps_dev = nullptr;
+    unsigned long long *csr_slots = nullptr;
+    int csr_slots_cap = 0;
     float *sc_tau = nullptr;
     uint32_t sc_first_frame = 0;
     double *dbg_lognew = nullptr, *dbg_cms = nullptr, *dbg_diff = nullptr; // v2e_emu_set_model_state_planes
@@ -995,7 +1003,7 @@ int v2e_emu_destroy(v2e_emu *h)
     for (hipEvent_t e : h->ev_join) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
     hipFree(h->ch_cnt); hipFree(h->ch_ruleM); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck);
-    hipFree(h->ch_gM); hipFree(h->ch_bar); hipFree(h->ch_rec);
+    hipFree(h->ch_gM); hipFree(h->ch_bar); hipFree(h->ch_rec); hipFree(h->csr_slots);
     for (hipEvent_t e : h->ev_ahead) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_chain) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_tab) hipEventDestroy(e);
@@ -1118,6 +1126,31 @@ int v2e_emu_lp_preview(v2e_emu *h, const v2e_emu_params *p, const void *frame, i
         else k_cs_lp<float, FT><<<grid, BLOCK, 0, s>>>(a, (const FT *)frame, ctl, (float *)lp_out);
     });
     V2E_HIP(hipGetLastError());
+    return 0;
+}
+
+int v2e_emu_set_csdvs_run(v2e_emu *h, void *h_scratch, void *lp_scratch, const double *alpha_p, const double *alpha_h,
+                          const int *num_steps, int n_frames, double max_change_to_stop, int *steps_taken_dev)
+{
+    V2E_REQUIRE(h, "null handle");
+    h->csr_ap.clear(); h->csr_ah.clear(); h->csr_steps.clear();
+    if (n_frames <= 0) return 0;
+    V2E_REQUIRE(h_scratch && lp_scratch && alpha_p && alpha_h && num_steps && steps_taken_dev, "null");
+    int mx = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        V2E_REQUIRE(num_steps[f] >= 0 && num_steps[f] <= 65536, "CSDVS steps per frame out of range for a device-resident run");
+        mx = num_steps[f] > mx ? num_steps[f] : mx;
+    }
+    V2E_HIP(hipSetDevice(h->device));
+    if (mx + 1 > h->csr_slots_cap) {
+        V2E_HIP(hipDeviceSynchronize());
+        if (h->csr_slots) V2E_HIP(hipFree(h->csr_slots));
+        h->csr_slots_cap = mx + 1;
+        V2E_HIP(hipMalloc((void **)&h->csr_slots, sizeof(unsigned long long) * (size_t)h->csr_slots_cap));
+    }
+    h->csr_scratch = h_scratch; h->csr_lp = lp_scratch; h->csr_thr = max_change_to_stop; h->csr_steps_dev = steps_taken_dev;
+    h->csr_ap.assign(alpha_p, alpha_p + n_frames); h->csr_ah.assign(alpha_h, alpha_h + n_frames);
+    h->csr_steps.assign(num_steps, num_steps + n_frames);
     return 0;
 }
 
@@ -1474,6 +1507,16 @@ static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, cons
         v2e_frame_rec *rec = recs + (size_t)f * h->n_clips;
         const v2e_frame_rec *rec_prev = f > 0 ? rec - h->n_clips : nullptr;
         V2E_MARK(4 * f + 0);
+        if (h->cs_sur) { // emulator.py:707-708: the surround is stepped against the coming frame's lp_log_frame, on the stream
+            dim3 gridp(v2e_cdiv(h->npx, BLOCK), h->n_clips);
+            DISPATCH_FT(dtype, {
+                if (p->f64_state) k_cs_lp<double, FT><<<gridp, BLOCK, 0, s>>>(a, (const FT *)fr, ctl, (double *)h->csr_lp);
+                else k_cs_lp<float, FT><<<gridp, BLOCK, 0, s>>>(a, (const FT *)fr, ctl, (float *)h->csr_lp);
+            });
+            int rcs = v2e_csdvs_enqueue_frame(h->csr_lp, const_cast<void *>(h->cs_sur), h->csr_scratch, h->H, h->W, p->f64_state,
+                                              h->csr_ap[f], h->csr_ah[f], h->csr_steps[f], h->csr_thr, h->csr_slots, h->csr_steps_dev + f, s);
+            if (rcs) return rcs;
+        }
         int rc = launch_count(h, a, p->f64_state, fr, dtype, ctl, h->run_fidx, (uint32_t)f, nullptr, nullptr, rec, s);
         if (rc) return rc;
         V2E_MARK(4 * f + 1);
@@ -1986,6 +2029,8 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     V2E_REQUIRE(p->rng_mode == V2E_RNG_PHILOX, "v2e_emu_run is the device-resident Philox path");
     V2E_REQUIRE(frames && t_prev && t_frame && events && recs_dev && n_frames > 0, "bad run args");
     V2E_REQUIRE(dtype == V2E_DT_U8 || dtype == V2E_DT_F32 || dtype == V2E_DT_F64, "bad frame dtype");
+    V2E_REQUIRE(!h->cs_sur || ((int)h->csr_steps.size() == n_frames && h->n_clips == 1),
+                "a run with a CSDVS surround needs v2e_emu_set_csdvs_run for exactly these frames (one clip)");
     V2E_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (n_frames > h->run_cap) {
@@ -2085,6 +2130,12 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
     int lg = legacy ? 1 : 3; push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
+    if (h->cs_sur) { // everything the diffuser's launches bake in
+        push(&h->cs_sur, sizeof(h->cs_sur)); push(&h->csr_scratch, sizeof(void *)); push(&h->csr_lp, sizeof(void *));
+        push(&h->csr_steps_dev, sizeof(void *)); push(&h->csr_slots, sizeof(void *)); push(&h->csr_thr, sizeof(double));
+        push(h->csr_ap.data(), sizeof(double) * h->csr_ap.size()); push(h->csr_ah.data(), sizeof(double) * h->csr_ah.size());
+        push(h->csr_steps.data(), sizeof(int) * h->csr_steps.size());
+    }
     if (chain) {
         push(&h->ch_K, sizeof(h->ch_K)); push(&h->ch_E, sizeof(h->ch_E)); push(&h->ch_fused, sizeof(h->ch_fused)); push(&h->ch_nD, sizeof(h->ch_nD));
         push(&h->ch_max_blocks, sizeof(h->ch_max_blocks));

@@ -25,7 +25,8 @@ is on, v2e_emu_set_model_state_planes) and displayed / saved through cv2 where i
 as the reference does; both put generate_events on the step-wise kernels.  `hdr=True`
 (log-encoded input, emulator.py:304, 666), `photoreceptor_noise=True` (emulator.py:694-703), `scidvs=True` (float64 state)
 and the centre-surround pixel (`cs_lambda_pixels`, emulator.py:1061-1124: the diffuser is stepped on the device between
-frames, csrc/csdvs.hip) are supported.
+frames, csrc/csdvs.hip; in generate_events_batch too: the stepping loop is enqueued whole with its stop rule on the device)
+are supported.
 """
 import atexit
 import logging
@@ -832,13 +833,11 @@ class EventEmulator(object):
 
     # ------------------------------------------------------------- centre-surround
     MAX_CHANGE_TO_TERMINATE_EULER_SURROUND_STEPPING = 1e-5  # emulator.py:52
+    CSDVS_RUN_MAX_STEPS = 8192  # Euler steps per frame a device-resident run enqueues up front
 
-    def _update_csdvs(self, P, frame_dev, t_prev, t_frame, fidx):
-        """emulator.py:1061-1124.  The host part (step count, IIR coefficients, warnings, the refusal of a diverging
-        diffuser) as the reference writes it; the stepping loop is v2e_csdvs_update on the device planes, driven by the
-        coming frame's lp_log_frame (v2e_emu_lp_preview: the low-pass applied to the state as it is)."""
-        eng = self._engine
-        delta_time = t_frame - t_prev
+    def _csdvs_step_params(self, delta_time):
+        """emulator.py:1066-1096: (num_steps, alpha_p, alpha_h) of one frame interval, with the reference's warnings and its
+        refusal of a diverging diffuser."""
         abs_min_tau_p = 1e-9
         tau_p = abs_min_tau_p if (self.cs_tau_p_ms is None or self.cs_tau_p_ms == 0) else self.cs_tau_p_ms * 1e-3
         tau_h = abs_min_tau_p / (self.cs_lambda_pixels ** 2) if (self.cs_tau_h_ms is None or self.cs_tau_h_ms == 0) \
@@ -865,6 +864,14 @@ class EventEmulator(object):
             logger.warning(f'CSDVS update alpha (of IIR update) is too large; simulation will be inaccurate: '
                            f'alpha_p={alpha_p:.3f} alpha_h={alpha_h:.3f}')
             self.cs_alpha_warning_printed = True
+        return num_steps, alpha_p, alpha_h
+
+    def _update_csdvs(self, P, frame_dev, t_prev, t_frame, fidx):
+        """emulator.py:1061-1124.  The host part (step count, IIR coefficients, warnings, the refusal of a diverging
+        diffuser) as the reference writes it; the stepping loop is v2e_csdvs_update on the device planes, driven by the
+        coming frame's lp_log_frame (v2e_emu_lp_preview: the low-pass applied to the state as it is)."""
+        eng = self._engine
+        num_steps, alpha_p, alpha_h = self._csdvs_step_params(t_frame - t_prev)
         sur, scratch, lp_new = self._cs_planes
         eng.lp_preview(P, frame_dev, [t_prev], [t_frame], fidx, lp_new)
         steps = eng.csdvs_update(lp_new, sur, scratch, alpha_p, alpha_h, num_steps, self.MAX_CHANGE_TO_TERMINATE_EULER_SURROUND_STEPPING)
@@ -897,9 +904,6 @@ class EventEmulator(object):
         if self._wants_states():
             raise ValueError("show_dvs_model_state / record_single_pixel_states read the state after every frame: use "
                              "generate_events per frame")
-        if self.csdvs_enabled:
-            raise NotImplementedError("generate_events_batch with cs_lambda_pixels: the surround's stepping loop ends on a "
-                                      "host-visible maximum per frame (emulator.py:1107); use generate_events per frame")
         if isinstance(frames, np.ndarray):
             if frames.dtype not in (np.uint8, np.float32, np.float64):
                 frames = frames.astype(np.float64)
@@ -954,6 +958,26 @@ class EventEmulator(object):
                 use_graph = int(use_graph) | 16  # the pipeline that carries the noise plane
         if self.scidvs and (isinstance(use_graph, bool) or use_graph in (0, 1)):
             use_graph = int(use_graph) | 16  # the kernels that carry the SCIDVS planes
+        cs_steps_dev = None
+        if self.csdvs_enabled:
+            # emulator.py:1061-1124 inside the run: per frame the host part (step count, coefficients) as the reference computes
+            # it; the stepping loop is enqueued whole, its stop rule evaluated on the device (v2e_emu_set_csdvs_run)
+            pars = [self._csdvs_step_params(t_frames[f] - t_prev[f - start]) for f in range(start, F)]
+            if max(q[0] for q in pars) > self.CSDVS_RUN_MAX_STEPS:
+                raise ValueError("generate_events_batch with cs_lambda_pixels: %d Euler steps per frame (cs_tau_p_ms / cs_lambda_pixels) "
+                                 "would all be enqueued up front; beyond %d use generate_events per frame (its loop ends as soon as "
+                                 "the diffuser has settled)" % (max(q[0] for q in pars), self.CSDVS_RUN_MAX_STEPS))
+            cs_steps_dev = torch.zeros(nrun, dtype=torch.int32, device=eng.device)
+            import ctypes as C
+            ns = (C.c_int * nrun)(*[q[0] for q in pars])
+            ap = (C.c_double * nrun)(*[q[1] for q in pars])
+            ah = (C.c_double * nrun)(*[q[2] for q in pars])
+            sur, scratch, lp_new = self._cs_planes
+            _capi.check(eng.lib.v2e_emu_set_csdvs_run(eng._h, scratch.data_ptr(), lp_new.data_ptr(), ap, ah, ns, nrun,
+                                                      float(self.MAX_CHANGE_TO_TERMINATE_EULER_SURROUND_STEPPING),
+                                                      cs_steps_dev.data_ptr()), "v2e_emu_set_csdvs_run")
+            if isinstance(use_graph, bool) or use_graph in (0, 1):
+                use_graph = int(use_graph) | 16  # the per-frame kernels carry the surround
         P = self._params()
         if cap is None:
             # 4 events per pixel and frame (the reference never drops events; a clip that exceeds this raises below and
@@ -976,7 +1000,9 @@ class EventEmulator(object):
         self.frame_counter += nrun
         self.t_previous = t_frames[-1]
         dts = np.asarray(t_frames[start:]) - np.asarray(t_prev)
-        return _PendingRun(self, ev, recs, done, counts, start, return_device, None, dts)
+        pend = _PendingRun(self, ev, recs, done, counts, start, return_device, None, dts)
+        pend.cs_steps_dev = cs_steps_dev
+        return pend
 
     def _finish_run(self, pend):
         eng = self._engine
@@ -1003,6 +1029,8 @@ class EventEmulator(object):
             raise _capi.V2EAmdError(err + " -- the pixel state is past this run: call reset() before feeding more frames")
         pend.counts[pend.start:] = r["n_events"]
         pend.rec_host = r
+        if getattr(pend, "cs_steps_dev", None) is not None:
+            self.cs_steps_taken.extend(int(v) for v in pend.cs_steps_dev.cpu().tolist())  # emulator.py:1124
         total = int(r["n_events"].sum())
         self.num_events_total += total
         self.num_events_on += int(r["n_on"].sum())
