@@ -375,6 +375,19 @@ int v2e_u8_to_f32_norm(const uint8_t *in, float *out, int64_t n, float mean, voi
  * in is [U][B][hw] (interpolation batch order), out is [B][U][hw] (time order, slomo.py:441) */
 int v2e_f32_to_u8_trunc(const float *in, uint8_t *out, int U, int B, int hw, float mean, int reorder, void *stream);
 
+/* ------------------------------------------- stage-1 pre-processing (v2e.py:687-738) -- PARITY UNPINNED:
+ * OpenCV 4.x's published INTER_AREA / BGR2GRAY 8-bit algorithms restated (see v2e_amd/csrc/preproc.hip); cv2 is in neither
+ * tree nor this image, so the restatement has not been compared with cv2 itself. */
+
+/* cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) of n uint8 images [sh][sw][cn] (cn = 1 or 3, interleaved), shrinking
+ * only.  Integer scale factors: pass xofs = NULL (box sums).  Otherwise the tables of computeResizeAreaTab, grouped per
+ * destination index (v2e_amd/preproc.py area_tab): entries [xofs[dx], xofs[dx + 1]) of (xsi, xalpha) feed column dx, in order;
+ * the same for rows. */
+int v2e_resize_area_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int dh, int dw, int cn, const int32_t *xofs,
+                       const int32_t *xsi, const float *xalpha, const int32_t *yofs, const int32_t *ysi, const float *yalpha, void *stream);
+/* cv2.cvtColor(src, cv2.COLOR_BGR2GRAY) of npx interleaved BGR uint8 pixels */
+int v2e_bgr2gray_u8(const uint8_t *src_bgr, uint8_t *dst, int64_t npx, void *stream);
+
 /* ----------------------------------------------------- event sinks */
 
 /* AEDAT-2.0 records of aedat2_output.py:155-173: out_bytes gets n x 8 bytes (big-endian int32 address,

@@ -63,10 +63,15 @@ def test_emulator_errors_like_reference():
     with pytest.raises(ValueError):  # emulator.py:650-653
         e.generate_events(np.zeros((4, 4), np.uint8), 0.5)
     EventEmulator(cs_lambda_pixels=2.0, cs_tau_p_ms=2.0)  # CSDVS: built (tests/test_csdvs.py)
-    for kw in (dict(scidvs=True), dict(show_dvs_model_state=["all"]),  # SCIDVS with float32 state (no cutoff): refused
-               dict(record_single_pixel_states=(1, 2))):
-        with pytest.raises(NotImplementedError):
-            EventEmulator(**kw)
+    with pytest.raises(NotImplementedError):  # SCIDVS with float32 state (no cutoff): refused
+        EventEmulator(scidvs=True)
+    # research tooling: accepted as host pass-throughs (emulator.py:279-300, 365-368), validated as the reference does
+    e2 = EventEmulator(show_dvs_model_state=["all"], record_single_pixel_states=(1, 2), rng_mode="philox")
+    assert list(e2.show_dvs_model_state) == list(EventEmulator.MODEL_STATES) and e2.single_pixel_states["time"].shape == (10000,)
+    e2.record_single_pixel_states = None  # nothing recorded: no pickle file from cleanup()
+    for bad in ([1, 2], (1, 2, 3), (1.0, 2)):
+        with pytest.raises(ValueError):
+            EventEmulator(record_single_pixel_states=bad)
     with pytest.raises(SystemExit):  # emulator.py:196-204: v2e_quit when the rate or the cutoff is zero
         EventEmulator(photoreceptor_noise=True, shot_noise_rate_hz=0.0, cutoff_hz=10)
     e = EventEmulator(photoreceptor_noise=True, shot_noise_rate_hz=1.0, cutoff_hz=10, rng_mode="tape")

@@ -1,0 +1,89 @@
+"""Stage 1 of v2e.py (:687-738): INTER_AREA resize + BGR2GRAY on device.  PARITY UNPINNED against OpenCV
+itself (not in this image, un-pinned in the reference, no vectors in its tests): what is pinned here is (CPU) the restatement's
+own invariants -- the properties OpenCV's area filter has by construction -- and (GPU) the HIP kernels == the restatement
+(oracle/preproc_oracle.py), bit for bit."""
+import numpy as np
+import pytest
+
+
+def _oracle():
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import preproc_oracle
+    return preproc_oracle
+
+
+@pytest.mark.parametrize("ssize,dsize", [(1280, 346), (720, 260), (640, 346), (480, 260), (347, 346), (1000, 7), (10, 10)])
+def test_area_tables_cover_every_source_sample_once(ssize, dsize):
+    """computeResizeAreaTab: the weights of a destination sample sum to 1, every source sample's weights over all destinations
+    sum to its share dsize / ssize of a cell, indices are in range and ascending."""
+    from v2e_amd.preproc import area_tab
+    ofs, si, al = area_tab(ssize, dsize)
+    assert ofs[0] == 0 and ofs[-1] == len(si) and (np.diff(ofs) >= 1).all()
+    assert si.min() >= 0 and si.max() <= ssize - 1
+    for d in range(dsize):
+        k = slice(ofs[d], ofs[d + 1])
+        assert abs(float(al[k].astype(np.float64).sum()) - 1.0) < 1e-5
+        assert (np.diff(si[k]) == 1).all()
+    cover = np.zeros(ssize)
+    np.add.at(cover, si, al.astype(np.float64))
+    assert np.allclose(cover, dsize / ssize, atol=2e-3)
+
+
+def test_restatement_invariants():
+    po = _oracle()
+    from v2e_amd.preproc import area_tab, is_area_fast
+    rng = np.random.Generator(np.random.PCG64(3))
+    flat = np.full((720, 1280), 93, np.uint8)
+    assert (po.resize_area(flat, (346, 260), area_tab, is_area_fast) == 93).all()        # a constant image stays constant
+    img = rng.integers(0, 256, size=(96, 128), dtype=np.uint8)
+    half = po.resize_area(img, (64, 48), area_tab, is_area_fast)                          # 2 x 2 boxes: (sum + 2) >> 2
+    assert np.array_equal(half, ((img.reshape(48, 2, 64, 2).astype(int).sum(axis=(1, 3)) + 2) >> 2).astype(np.uint8))
+    third = po.resize_area(img[:, :126], (42, 32), area_tab, is_area_fast)               # 3 x 3 boxes: rounded mean
+    m = img[:, :126].reshape(32, 3, 42, 3).astype(np.float64).mean(axis=(1, 3))
+    assert np.abs(third.astype(np.float64) - m).max() <= 0.5 + 1e-6
+    out = po.resize_area(img, (50, 37), area_tab, is_area_fast)                           # general path: close to the exact area mean
+    assert out.shape == (37, 50) and abs(float(out.mean()) - float(img.mean())) < 1.0
+    assert is_area_fast((1280, 720), (640, 360)) and not is_area_fast((1280, 720), (346, 260))
+    bgr = np.zeros((2, 2, 3), np.uint8)
+    bgr[0, 0] = (255, 255, 255); bgr[0, 1] = (255, 0, 0); bgr[1, 0] = (0, 255, 0); bgr[1, 1] = (0, 0, 255)
+    assert po.bgr2gray(bgr).tolist() == [[255, 29], [150, 76]]                           # 0.114 / 0.587 / 0.299 of 255
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # (in_h, in_w, channels, out_w, out_h, crop)
+    (720, 1280, 3, 346, 260, None),      # a 720p colour video to DAVIS346: the general path, both axes
+    (720, 1280, 1, 346, 260, None),
+    (480, 640, 3, 320, 240, None),       # 2 x 2 boxes
+    (780, 1038, 1, 346, 260, None),      # 3 x 3 boxes
+    (521, 693, 3, 346, 260, (3, 1, 0, 1)),  # cropped, then resized: near-unity scale factors
+    (260, 346, 3, 346, 260, None),       # no resize: grey conversion only
+    (97, 131, 1, 17, 5, (0, 0, 2, 0)),
+])
+def test_hip_stage1_equals_the_restatement(case):
+    import torch
+    po = _oracle()
+    from v2e_amd.preproc import Stage1, area_tab, is_area_fast
+    ih, iw, cn, ow, oh, crop = case
+    rng = np.random.Generator(np.random.PCG64(ih * 3 + ow))
+    shape = (3, ih, iw) + ((3,) if cn == 3 else ())
+    fr = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    fr[0, : ih // 2] = 255  # saturated and black regions: ties and the clamp
+    fr[1, :, : iw // 3] = 0
+    st = Stage1((ih, iw), (ow, oh), channels=cn, crop=crop, device="cuda")
+    got = st(torch.from_numpy(fr).cuda()).cpu().numpy()
+    assert got.shape == (3, oh, ow) or (not st.resize and got.shape[0] == 3)
+    for i in range(3):
+        ref = po.stage1(fr[i], (ow, oh), area_tab, is_area_fast, crop=crop)
+        assert np.array_equal(got[i], ref), (case, i, int(np.abs(got[i].astype(int) - ref.astype(int)).max()))
+
+
+@pytest.mark.gpu
+def test_stage1_refuses_upscaling():
+    from v2e_amd.preproc import Stage1
+    with pytest.raises(NotImplementedError):
+        Stage1((100, 100), (346, 260), device="cuda")

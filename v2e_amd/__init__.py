@@ -8,6 +8,7 @@ kernels for gfx950 (v2e_amd/csrc, C ABI in include/v2e_amd.h); there is no CPU p
 from .emulator import EventEmulator  # noqa: F401
 from .slomo import SuperSloMo  # noqa: F401
 from .renderer import EventRenderer, ExposureMode  # noqa: F401
+from .preproc import Stage1  # noqa: F401  (v2e.py stage 1: INTER_AREA resize + BGR2GRAY on device; parity unpinned)
 from ._capi import V2EAmdError  # noqa: F401
 
-__all__ = ["EventEmulator", "SuperSloMo", "EventRenderer", "ExposureMode", "V2EAmdError"]
+__all__ = ["EventEmulator", "SuperSloMo", "EventRenderer", "ExposureMode", "Stage1", "V2EAmdError"]
