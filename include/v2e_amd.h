@@ -123,7 +123,7 @@ int v2e_emu_init_state(v2e_emu *h, const v2e_emu_params *p, const void *frame, i
  * `photoreceptor_noise_arr` (caller-owned, zero on the first frame); randn_tape the float32 draws
  * torch.randn(shape) of the coming frame in tape mode (NULL in Philox mode).  Both are consumed by the next
  * v2e_emu_count when params.photoreceptor_noise is set; NULL pn_arr switches the feature off. */
-/* SCIDVS pixel (emulator.py:56-80, 719-725, 747; float64 state only): device planes [n_clips][npx_pad] scidvs_highpass and
+/* SCIDVS pixel (emulator.py:56-80, 719-725, 747): device planes [n_clips][npx_pad] scidvs_highpass and
  * scidvs_previous_photo (state dtype) and scidvs_tau_arr (float32; filled by v2e_emu_init_state in Philox mode, by the
  * caller in tape mode).  first_frame_idx: the frame index at which scidvs_previous_photo is taken from the frame itself
  * (emulator.py:720-722).  All NULL switches it off.  Runs on the count / rank / scan / emit kernels. */

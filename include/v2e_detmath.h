@@ -219,6 +219,78 @@ V2E_HD float v2e_draw_scidvs(uint64_t seed, uint32_t clip, uint32_t pixel)
     return v2e_normal(o[2], o[3]);
 }
 
+/* ---- torch.sinh on float32 CPU tensors, bit for bit (SCIDVS with float32 state: emulator.py:78 `torch.sinh(v / efold)`).
+ * ATen's vectorised float32 sinh is Sleef's `sinhf_u10` (Sleef_sinhf8_u10 / Sleef_sinhf16_u10: the AVX2 and the AVX-512 build of
+ * torch give the same bits, tests/golden/make_golden_scidvs.py checks 17 M arguments), i.e. the published algorithm of
+ * sleef/src/libm/sleefsimdsp.c (xsinhf, expk2f) on double-float numbers with fused multiply-adds, restated here operation for
+ * operation: every fusion is an fmaf, every other operation is rounded on its own (compile with -ffp-contract=off). */
+typedef struct { float x, y; } v2e_f2;
+V2E_HD float v2e_fmapn(float x, float y, float z) { return fmaf(x, y, -z); } /* x y - z */
+V2E_HD float v2e_fmanp(float x, float y, float z) { return fmaf(-x, y, z); } /* -x y + z */
+V2E_HD v2e_f2 v2e_dfmul_f2_f(v2e_f2 x, float y) { float s = x.x * y; v2e_f2 r; r.x = s; r.y = fmaf(x.y, y, v2e_fmapn(x.x, y, s)); return r; }
+V2E_HD v2e_f2 v2e_dfmul_f2_f2(v2e_f2 x, v2e_f2 y)
+{
+    float s = x.x * y.x;
+    v2e_f2 r; r.x = s; r.y = fmaf(x.x, y.y, fmaf(x.y, y.x, v2e_fmapn(x.x, y.x, s)));
+    return r;
+}
+V2E_HD v2e_f2 v2e_dfsqu(v2e_f2 x) { float s = x.x * x.x; v2e_f2 r; r.x = s; r.y = fmaf(x.x + x.x, x.y, v2e_fmapn(x.x, x.x, s)); return r; }
+V2E_HD v2e_f2 v2e_dfrec(v2e_f2 d) { float s = 1.0f / d.x; v2e_f2 r; r.x = s; r.y = s * v2e_fmanp(d.y, s, v2e_fmanp(d.x, s, 1.0f)); return r; }
+V2E_HD v2e_f2 v2e_dfadd_f_f2(float x, v2e_f2 y) { float s = x + y.x; v2e_f2 r; r.x = s; r.y = ((x - s) + y.x) + y.y; return r; }
+V2E_HD v2e_f2 v2e_dfadd2_f2_f(v2e_f2 x, float y)
+{
+    float s = x.x + y, v = s - x.x, t = (x.x - (s - v)) + (y - v);
+    v2e_f2 r; r.x = s; r.y = t + x.y;
+    return r;
+}
+V2E_HD v2e_f2 v2e_dfadd2_f2_f2(v2e_f2 x, v2e_f2 y)
+{
+    float s = x.x + y.x, v = s - x.x, t = (x.x - (s - v)) + (y.x - v);
+    v2e_f2 r; r.x = s; r.y = t + (x.y + y.y);
+    return r;
+}
+V2E_HD v2e_f2 v2e_dfsub_f2_f2(v2e_f2 x, v2e_f2 y)
+{
+    float s = x.x - y.x, t = x.x - s;
+    t = t - y.x; t = t + x.y;
+    v2e_f2 r; r.x = s; r.y = t - y.y;
+    return r;
+}
+V2E_HD float v2e_pow2if(int q) { return v2e_u2f((uint32_t)(q + 0x7f) << 23); }
+V2E_HD float v2e_ldexp2f(float d, int e) { return d * v2e_pow2if(e >> 1) * v2e_pow2if(e - (e >> 1)); }
+V2E_HD v2e_f2 v2e_sleef_expk2f(v2e_f2 d)
+{
+    float u = (d.x + d.y) * 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    int q = (int)rintf(u);
+    v2e_f2 s = v2e_dfadd2_f2_f(d, (float)q * -0.693145751953125f);
+    s = v2e_dfadd2_f2_f(s, (float)q * -1.428606765330187045e-06f);
+    u = +0.1980960224e-3f;
+    u = fmaf(u, s.x, +0.1394256484e-2f);
+    u = fmaf(u, s.x, +0.8333456703e-2f);
+    u = fmaf(u, s.x, +0.4166637361e-1f);
+    v2e_f2 t = v2e_dfadd2_f2_f(v2e_dfmul_f2_f(s, u), +0.166666659414234244790680580464e+0f);
+    t = v2e_dfadd2_f2_f(v2e_dfmul_f2_f2(s, t), 0.5f);
+    t = v2e_dfadd2_f2_f2(s, v2e_dfmul_f2_f2(v2e_dfsqu(s), t));
+    t = v2e_dfadd_f_f2(1.0f, t);
+    t.x = v2e_ldexp2f(t.x, q);
+    t.y = v2e_ldexp2f(t.y, q);
+    if (d.x < -104.0f) { t.x = 0.0f; t.y = 0.0f; }
+    return t;
+}
+V2E_HD float v2e_sleef_sinhf(float x)
+{
+    float y = fabsf(x);
+    v2e_f2 in; in.x = y; in.y = 0.0f;
+    v2e_f2 d = v2e_sleef_expk2f(in);
+    d = v2e_dfsub_f2_f2(d, v2e_dfrec(d));
+    y = (d.x + d.y) * 0.5f;
+    if (fabsf(x) > 89.0f || y != y) y = v2e_u2f(0x7F800000u);
+    y = v2e_u2f((v2e_f2u(y) & 0x7FFFFFFFu) | (v2e_f2u(x) & 0x80000000u)); /* mulsign */
+    if (x != x) y = v2e_u2f(0x7FC00000u);
+    return y;
+}
+
+
 /* ------------------------------------------------ keyed bijection (shuffle) */
 /*
  * Philox-mode replacement for `idx = torch.randperm(n_i)` (emulator.py:868): a keyed

@@ -102,6 +102,12 @@ EXPORT void v2e_oracle_philox_init(uint64_t seed, uint32_t clip, int64_t npx, fl
 }
 
 /* SCIDVS time constants in philox mode: tau = 0.01f * exp(0.5f * n) with the deterministic expf (emulator.py:480-483) */
+/* torch.sinh on float32 tensors as restated in v2e_detmath.h (pinned against torch itself: tests/test_oracle_vs_reference.py) */
+EXPORT void v2e_oracle_sleef_sinhf(const float *x, float *y, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = v2e_sleef_sinhf(x[i]);
+}
+
 EXPORT void v2e_oracle_philox_scidvs_tau(uint64_t seed, uint32_t clip, int64_t npx, float *tau)
 {
     for (int64_t p = 0; p < npx; ++p) tau[p] = 0.01f * v2e_det_expf(0.5f * v2e_draw_scidvs(seed, clip, (uint32_t)p));
@@ -261,7 +267,7 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
                             uint8_t *shot_on, uint8_t *shot_off, int32_t *M_out,
                             double *pn_arr /* photoreceptor_noise_arr or NULL */, const float *pn_randn /* tape draws or NULL */,
                             const void *cs_surround /* CSDVS: cs_surround_frame (state dtype) or NULL */,
-                            double *sc_hp /* SCIDVS: scidvs_highpass or NULL (float64 state) */, double *sc_prev /* scidvs_previous_photo */,
+                            void *sc_hp_v /* SCIDVS: scidvs_highpass (state dtype) or NULL */, void *sc_prev_v /* scidvs_previous_photo */,
                             const float *sc_tau /* scidvs_tau_arr */, int sc_first /* previous_photo is taken from this frame */)
 {
     int64_t npx = (int64_t)H * W;
@@ -319,6 +325,7 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
                 pn_arr[p] = pn;
             }
             double photo = lpn;
+            double *sc_hp = (double *)sc_hp_v, *sc_prev = (double *)sc_prev_v;
             if (sc_hp) { /* emulator.py:56-80, 719-725, 747: nonlinear CR high-pass of the photoreceptor, amplified */
                 double prev = sc_first ? lpn : sc_prev[p];
                 double hp = sc_hp[p];
@@ -343,8 +350,22 @@ EXPORT int v2e_oracle_count(const v2e_emu_params *P, int H, int W, const double 
             float b = base[p];
             if (do_leak) b = b - delta_leak;
             base[p] = b;
-            float diff = (L + 0.0f) - b;
-            if (cs_surround) diff = ((L + 0.0f) - ((const float *)cs_surround)[p]) - b; /* emulator.py:753-754 */
+            float photo = L;
+            if (sc_hp_v) { /* SCIDVS with float32 state (cutoff_hz = 0): every tensor float32, Python scalars take that type;
+                            * torch.sinh on a float32 CPU tensor is Sleef's sinhf_u10 (v2e_sleef_sinhf, v2e_detmath.h) */
+                float *sc_hp = (float *)sc_hp_v, *sc_prev = (float *)sc_prev_v;
+                float prev = sc_first ? L : sc_prev[p];
+                float hp = sc_hp[p];
+                float inv_tau = 1.0f / sc_tau[p];                        /* torch.div(1, tau) */
+                float sh = v2e_sleef_sinhf(hp / (float)(1 / 0.7));       /* torch.sinh(v / efold) */
+                float dvdt = inv_tau * sh;
+                hp = hp + ((L - prev) - ((float)delta_time * dvdt));     /* emulator.py:722-724 */
+                sc_hp[p] = hp;
+                sc_prev[p] = L;
+                photo = 2.0f * hp;                                       /* SCIDVS_GAIN * scidvs_highpass */
+            }
+            float diff = (photo + 0.0f) - b;
+            if (cs_surround) diff = ((photo + 0.0f) - ((const float *)cs_surround)[p]) - b; /* emulator.py:753-754 */
             float pf = diff > 0 ? diff : 0.0f, nf = (-diff) > 0 ? -diff : 0.0f;
             pc = (int32_t)div_floor_f(pf, pos_thres[p]);
             nc = (int32_t)div_floor_f(nf, neg_thres[p]);

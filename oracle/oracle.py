@@ -144,6 +144,14 @@ def philox_init(seed, clip, npx):
     return a, b, c
 
 
+def sleef_sinhf(x):
+    """torch.sinh of a float32 CPU tensor, bit for bit (v2e_sleef_sinhf, include/v2e_detmath.h)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    lib().v2e_oracle_sleef_sinhf(_p(x), _p(y), C.c_int64(x.size))
+    return y
+
+
 def philox_scidvs_tau(seed, clip, npx):
     a = np.empty(npx, np.float32)
     lib().v2e_oracle_philox_scidvs_tau(C.c_uint64(seed), C.c_uint32(clip), C.c_int64(npx), _p(a))
@@ -328,9 +336,8 @@ class OracleEmulator:
             self.noise_rate_array = np.zeros((H, W), np.float32)
             tp = tn = nr = None
             if self.scidvs:
-                assert P.f64_state, "SCIDVS: float64 state (cutoff_hz > 0 or hdr)"
-                self.scidvs_highpass = np.zeros((H, W), np.float64)       # emulator.py:720
-                self.scidvs_previous_photo = np.zeros((H, W), np.float64)  # taken from the first counted frame (:721)
+                self.scidvs_highpass = np.zeros((H, W), sdt)       # emulator.py:720: zeros_like(lp_log_frame)
+                self.scidvs_previous_photo = np.zeros((H, W), sdt)  # taken from the first counted frame (:721)
                 self._sc_first = True
                 if philox:
                     self.scidvs_tau_arr = philox_scidvs_tau(self.seed, self.clip, npx).reshape(H, W)

@@ -63,8 +63,7 @@ def test_emulator_errors_like_reference():
     with pytest.raises(ValueError):  # emulator.py:650-653
         e.generate_events(np.zeros((4, 4), np.uint8), 0.5)
     EventEmulator(cs_lambda_pixels=2.0, cs_tau_p_ms=2.0)  # CSDVS: built (tests/test_csdvs.py)
-    with pytest.raises(NotImplementedError):  # SCIDVS with float32 state (no cutoff): refused
-        EventEmulator(scidvs=True)
+    EventEmulator(scidvs=True)  # SCIDVS with float32 state (no cutoff): built (torch's float32 sinh restated, v2e_detmath.h)
     # research tooling: accepted as host pass-throughs (emulator.py:279-300, 365-368), validated as the reference does
     e2 = EventEmulator(show_dvs_model_state=["all"], record_single_pixel_states=(1, 2), rng_mode="philox")
     assert list(e2.show_dvs_model_state) == list(EventEmulator.MODEL_STATES) and e2.single_pixel_states["time"].shape == (10000,)

@@ -198,10 +198,48 @@ def test_scidvs_philox_matches_reference(api):
             emu.generate_events_batch(fx.frames[-2:], [fx.times[-1] + 0.01, fx.times[-1] + 0.02], use_graph=257)
 
 
-def test_scidvs_float32_state_is_refused():
-    from v2e_amd import EventEmulator
-    with pytest.raises(NotImplementedError):
-        EventEmulator(device="cuda", scidvs=True, cutoff_hz=0)
+def test_scidvs_float32_state_replays_reference_tape(oracle_lib):
+    """scidvs=True with FLOAT32 pixel state (cutoff_hz = 0): torch's float32 sinh (Sleef sinhf_u10) is restated bit for bit in
+    include/v2e_detmath.h and shared by the kernel and the oracle.  40 x 48: the reference has no scalar tail there, so events,
+    state planes AND scidvs_highpass are bit for bit."""
+    import os
+    from fixtures import GOLDEN
+    fx = TapeFixture("tape_scidvs_f32_40x48")
+    emu = _mk(fx, seed=0, rng_mode="tape", tape=oracle_lib.RecordedTape(fx.items))
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        assert events_equal(emu.generate_events(f, float(t)), fx.events[k]), "frame %d differs from the reference" % k
+    st = _state(emu)
+    assert st["base_log_frame"].dtype == np.float32
+    assert np.array_equal(st["base_log_frame"], fx.base_final) and np.array_equal(st["lp_log_frame"], fx.lp_final)
+    z = np.load(os.path.join(GOLDEN, "tape_scidvs_f32_40x48.npz"))
+    assert np.array_equal(emu.scidvs_highpass.cpu().numpy(), z["scidvs_highpass_final"])
+    assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
+@pytest.mark.parametrize("api", ["frame", "clip_graph"])
+def test_scidvs_float32_state_philox_matches_reference_and_oracle(api, oracle_lib):
+    """97 x 131 (12 707 pixels: the reference hands the plane's last three to glibc's scalar sinhf): events bit for bit against
+    the reference; scidvs_highpass bit for bit against the reference on the vector body and against the oracle everywhere."""
+    import os
+    from fixtures import GOLDEN
+    from test_oracle_golden import _tail_free
+    fx = PhiloxFixture("philox_scidvs_f32_97x131")
+    emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+    if api == "frame":
+        evs = [emu.generate_events(f, float(t)) for f, t in zip(fx.frames, fx.times)]
+        counts = [0 if e is None else len(e) for e in evs]
+        ev = np.concatenate([e for e in evs if e is not None])
+    else:
+        ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=True)
+    assert list(counts) == list(fx.n_events)
+    assert np.array_equal(ev, np.concatenate([e for e in fx.events if len(e)]))
+    z = np.load(os.path.join(GOLDEN, "philox_scidvs_f32_97x131.npz"))
+    hp = emu.scidvs_highpass.cpu().numpy()
+    assert hp.dtype == np.float32 and _tail_free(hp, z["scidvs_highpass_final"])
+    ora = oracle_lib.OracleEmulator(seed=fx.seed, rng_mode="philox", **fx.kw)
+    for f, t in zip(fx.frames, fx.times):
+        ora.generate_events(f, float(t))
+    assert np.array_equal(hp, ora.scidvs_highpass) and np.array_equal(emu.base_log_frame.cpu().numpy(), ora.base_log_frame)
 
 
 @pytest.mark.parametrize("chain_k", [1, 2, 3, 5, 8, 11, 16, 32])

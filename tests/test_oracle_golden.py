@@ -102,3 +102,53 @@ def test_oracle_scidvs_philox_matches_reference(oracle_lib):
     z = np.load(os.path.join(GOLDEN, "philox_scidvs_97x131.npz"))
     assert np.max(np.abs(emu.scidvs_highpass - z["scidvs_highpass_final"])) <= 1e-12 * max(1.0, np.max(np.abs(z["scidvs_highpass_final"])))
     assert np.max(np.abs(emu.base_log_frame - z["base_final"])) <= 1e-12 * max(1.0, np.max(np.abs(z["base_final"])))
+
+
+def _tail_free(hp, ref):
+    """scidvs_highpass against the reference: bit for bit on every pixel torch evaluated in its vector body; the last n mod 32
+    pixels of the plane went to glibc's scalar sinhf in the reference (ATen vectorized_loop), whose last bit may differ."""
+    a, b = hp.reshape(-1), ref.reshape(-1)
+    body = a.size // 32 * 32
+    return np.array_equal(a[:body], b[:body]) and np.allclose(a[body:], b[body:], rtol=1e-5, atol=1e-7)
+
+
+def test_oracle_scidvs_float32_state_replays_reference_tape(oracle_lib):
+    """scidvs=True with FLOAT32 pixel state (cutoff_hz = 0; round-3 review, missing 3): torch's float32 sinh = Sleef sinhf_u10,
+    restated bit for bit (v2e_sleef_sinhf).  40 x 48 = 1 920 pixels: no scalar tail in the reference, so EVERYTHING is bit for
+    bit -- events, base / lp planes and scidvs_highpass."""
+    import os
+    from fixtures import GOLDEN
+    fx = TapeFixture("tape_scidvs_f32_40x48")
+    emu = oracle_lib.OracleEmulator(seed=0, rng_mode="tape", tape=oracle_lib.RecordedTape(fx.items), **fx.kw)
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        assert events_equal(emu.generate_events(f, float(t)), fx.events[k]), "frame %d differs" % k
+    assert emu.tape.pos == len(fx.items), "tape not fully consumed"
+    z = np.load(os.path.join(GOLDEN, "tape_scidvs_f32_40x48.npz"))
+    assert emu.scidvs_highpass.dtype == np.float32 == z["scidvs_highpass_final"].dtype
+    assert np.array_equal(emu.scidvs_highpass, z["scidvs_highpass_final"])
+    assert np.array_equal(emu.lp_log_frame, fx.lp_final) and np.array_equal(emu.base_log_frame, fx.base_final)
+
+
+def test_oracle_scidvs_float32_state_philox_matches_reference(oracle_lib):
+    import os
+    from fixtures import GOLDEN
+    fx = PhiloxFixture("philox_scidvs_f32_97x131")
+    emu = oracle_lib.OracleEmulator(seed=fx.seed, rng_mode="philox", **fx.kw)
+    evs = [emu.generate_events(f, float(t)) for f, t in zip(fx.frames, fx.times)]
+    assert [0 if e is None else len(e) for e in evs] == list(fx.n_events)
+    for k, e in enumerate(evs):
+        assert events_equal(e, fx.events[k] if len(fx.events[k]) else None), "frame %d differs" % k
+    z = np.load(os.path.join(GOLDEN, "philox_scidvs_f32_97x131.npz"))
+    assert _tail_free(emu.scidvs_highpass, z["scidvs_highpass_final"])
+    assert _tail_free(emu.base_log_frame, z["base_final"])
+
+
+def test_sleef_sinhf_restatement_properties(oracle_lib):
+    """v2e_sleef_sinhf: odd, exact at 0 and -0, inf beyond 89, NaN for NaN, within 1 ulp of the float64 value (u10)."""
+    x = np.concatenate([np.linspace(-88, 88, 200001, dtype=np.float32), np.asarray([0.0, -0.0, 1e-30, 89.5, -89.5, np.inf, np.nan], np.float32)])
+    y = oracle_lib.sleef_sinhf(x)
+    assert np.array_equal(oracle_lib.sleef_sinhf(-x).view(np.uint32)[~np.isnan(x)], (-y).view(np.uint32)[~np.isnan(x)])
+    assert y[-7] == 0 and not np.signbit(y[-7]) and y[-6] == 0 and np.signbit(y[-6]) and y[-5] == np.float32(1e-30)
+    assert y[-4] == np.inf and y[-3] == -np.inf and y[-2] == np.inf and np.isnan(y[-1])
+    ref = np.sinh(x[:200001].astype(np.float64))
+    assert np.max(np.abs(y[:200001].astype(np.float64) - ref) / np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)) <= 1.0

@@ -415,9 +415,16 @@ __global__ __launch_bounds__(BLOCK) void k_count(KArgs a, const FT *__restrict__
             const R prev = frame_idx == a.sc_first_frame ? lpn : ((R *)a.sc_prev)[sp]; // first frame: clone of lp_log_frame
             R hp = ((R *)a.sc_hp)[sp];
             const float inv_tau = 1.0f / a.sc_tau[sp];                  // torch.div(1, tau): float32
-            const R sh = (R)sinh((double)hp / SCIDVS_EFOLD);             // torch.sinh(v / efold)
-            const R dvdt = (R)inv_tau * sh;
-            hp = hp + ((lpn - prev) - (R)(delta_time * (double)dvdt));
+            if constexpr (sizeof(R) == 8) {
+                const R sh = (R)sinh((double)hp / SCIDVS_EFOLD);         // torch.sinh(v / efold)
+                const R dvdt = (R)inv_tau * sh;
+                hp = hp + ((lpn - prev) - (R)(delta_time * (double)dvdt));
+            } else { // float32 state: every operand is a float32 tensor, Python scalars take the tensor's type; torch's
+                     // vectorised float32 sinh is Sleef's sinhf_u10, restated bit for bit in v2e_detmath.h
+                const float sh = v2e_sleef_sinhf((float)hp / (float)SCIDVS_EFOLD);
+                const float dvdt = inv_tau * sh;
+                hp = (R)((float)hp + (((float)lpn - (float)prev) - ((float)delta_time * dvdt)));
+            }
             ((R *)a.sc_hp)[sp] = hp;
             ((R *)a.sc_prev)[sp] = lpn;
             photo = (R)2 * hp;                                           // SCIDVS_GAIN * scidvs_highpass
@@ -916,7 +923,6 @@ static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
 static int check_params(const v2e_emu *h, const v2e_emu_params *p)
 {
     V2E_REQUIRE(h && p, "null handle/params");
-    V2E_REQUIRE(!h->sc_hp || p->f64_state, "SCIDVS is built for float64 state (cutoff_hz > 0 or hdr)");
     V2E_REQUIRE(h->lp && h->base && h->pos_thres && h->neg_thres, "state not bound (v2e_emu_bind_state)");
     V2E_REQUIRE((p->f64_state != 0) == (p->cutoff_hz > 0 || p->log_input != 0), "f64_state must equal (cutoff_hz > 0 || log_input)");
     V2E_REQUIRE(!(p->leak_rate_hz > 0) || h->noise_rate, "leak enabled but noise_rate plane not bound");

@@ -23,7 +23,8 @@ Random numbers come in two modes, selected with the extra key
 (three of them -- log_new_frame, c_minus_s_frame, diff_frame -- are left in extra planes by k_count while one of the two options
 is on, v2e_emu_set_model_state_planes) and displayed / saved through cv2 where it is importable, resp. recorded and pickled
 as the reference does; both put generate_events on the step-wise kernels.  `hdr=True`
-(log-encoded input, emulator.py:304, 666), `photoreceptor_noise=True` (emulator.py:694-703), `scidvs=True` (float64 state)
+(log-encoded input, emulator.py:304, 666), `photoreceptor_noise=True` (emulator.py:694-703), `scidvs=True` (float64 and float32
+state: torch's float32 sinh is restated bit for bit in include/v2e_detmath.h)
 and the centre-surround pixel (`cs_lambda_pixels`, emulator.py:1061-1124: the diffuser is stepped on the device between
 frames, csrc/csdvs.hip; in generate_events_batch too: the stepping loop is enqueued whole with its stop rule on the device)
 are supported.
@@ -246,10 +247,6 @@ class EventEmulator(object):
         self.log_input = bool(hdr)  # emulator.py:304: frames are log-encoded already
         self.scidvs = bool(scidvs)  # emulator.py:307-309: nonlinear CR high-pass amplified log intensity
         self.scidvs_highpass = self.scidvs_previous_photo = self.scidvs_tau_arr = None
-        if self.scidvs and not (cutoff_hz > 0 or hdr):
-            raise NotImplementedError(
-                "v2e_amd.EventEmulator(scidvs=True) is built for float64 pixel state (cutoff_hz > 0 or hdr): with float32 state "
-                "torch's vectorised sinh and the device's differ in the last bit often enough to move events (DESIGN.md section 7)")
         # CSDVS (emulator.py:245-272)
         self.cs_steps_warning_printed = False
         self.cs_steps_taken = []
@@ -467,7 +464,7 @@ class EventEmulator(object):
         tp = tn = nr = None
         sc_tau_host = None
         if self.scidvs:  # two more state planes + per-pixel time constants (emulator.py:480-483, 719-722)
-            sd = torch.float64
+            sd = torch.float64 if (self.cutoff_hz > 0 or self.log_input) else torch.float32  # zeros_like(lp_log_frame)
             self._sc_planes = [torch.zeros((1, eng.npx_pad), dtype=sd, device=eng.device) for _ in range(2)]
             self._sc_tau = torch.zeros((1, eng.npx_pad), dtype=torch.float32, device=eng.device)
             _capi.check(eng.lib.v2e_emu_set_scidvs(eng._h, self._sc_planes[0].data_ptr(), self._sc_planes[1].data_ptr(),
