@@ -93,6 +93,19 @@ def photoreceptor_noise_vrms(shot_noise_rate_hz, f3db, sample_rate_hz, pos_thr, 
     return float(np.std(rin) / np.std(rout) * vn)
 
 
+_THREAD_OVERRIDE = {"users": 0, "prev": None}  # tape-mode emulators alive that rely on the one-thread setting
+
+
+def _release_host_threads():
+    """cleanup() of a tape-mode emulator: the previous thread count comes back when the LAST one that relies on it is gone."""
+    o = _THREAD_OVERRIDE
+    if o["users"] > 0:
+        o["users"] -= 1
+        if o["users"] == 0 and o["prev"] is not None:
+            torch.set_num_threads(o["prev"])
+            o["prev"] = None
+
+
 def _limit_host_threads(n):
     """Tape mode issues a handful of small torch CPU ops per frame (randn / rand of one frame, a randperm per
     iteration).  Their values do not depend on the intra-op thread count, but on a many-core host fanning each of
@@ -100,9 +113,14 @@ def _limit_host_threads(n):
     The setting is process-global in torch, so it is applied once, when a tape-mode emulator is constructed
     (`tape_host_threads`, default 1; None leaves torch alone), said so in the log, and put back by cleanup().
     Returns the previous value (None if nothing was changed)."""
-    if n is None or torch.get_num_threads() == int(n):
+    if n is None:
         return None
+    o = _THREAD_OVERRIDE
+    if o["users"] > 0 or torch.get_num_threads() == int(n):  # already in force (or nothing to change): just count this user
+        o["users"] += 1
+        return True
     prev = torch.get_num_threads()
+    o["users"], o["prev"] = 1, prev
     logger.warning("v2e_amd.EventEmulator (tape mode): torch.set_num_threads(%d) for this process (was %d; restored by "
                    "cleanup(); pass tape_host_threads=None to leave torch alone)", int(n), prev)
     torch.set_num_threads(int(n))
@@ -341,7 +359,7 @@ class EventEmulator(object):
             logger.info(f'CSDVS steps statistics: mean+std= {np.mean(self.cs_steps_taken):.0f} + {np.std(self.cs_steps_taken):.0f} '
                         f'(median= {np.median(self.cs_steps_taken):.0f})')
         if getattr(self, "_host_threads_prev", None) is not None:
-            torch.set_num_threads(self._host_threads_prev)
+            _release_host_threads()
             self._host_threads_prev = None
         for name, vw in list(getattr(self, "video_writers", {}).items()):  # emulator.py:424-426
             logger.info(f'closing video AVI {name}')

@@ -42,7 +42,8 @@ class _RowsPool:
     it).  A caller that keeps its arrays makes the pool grow to MAX_BUFS buffers; beyond that, and for frames larger than a
     buffer, the rows are copied into an ordinary array as before."""
     MAX_BUFS = 64
-    MIN_ROWS = 1 << 16  # 1 MB
+    MAX_BYTES = 1 << 30  # page-locked memory the pool may hold in all (a caller that keeps every array gets copies beyond it)
+    MIN_ROWS = 1 << 16   # 1 MB
 
     def __init__(self):
         self.bufs = []
@@ -53,8 +54,16 @@ class _RowsPool:
             if b.free and b.cap >= want // 2:
                 b.free = False
                 return b
-        if len(self.bufs) >= self.MAX_BUFS:
-            return None
+        held = sum(b.cap for b in self.bufs) * 16
+        if len(self.bufs) >= self.MAX_BUFS or held + want * 16 > self.MAX_BYTES:
+            # make room by dropping a free buffer that is too small (frames grew), else hand out nothing: the frame's rows
+            # are then copied into an ordinary array
+            small = [b for b in self.bufs if b.free]
+            if not small:
+                return None
+            self.bufs.remove(small[0])
+            if held - small[0].cap * 16 + want * 16 > self.MAX_BYTES:
+                return None
         b = _RowsBuf(want)
         b.free = False
         self.bufs.append(b)
@@ -288,29 +297,29 @@ class EmuEngine:
         # the rows land in a pinned buffer of ours that becomes the result array itself (no host copy); see _RowsPool
         pool = self._rows_pool
         buf = pool.acquire(self._rows_est)
-        if buf is not None:
-            check(self.lib.v2e_emu_frame_host_rows(self._h, C.c_void_p(buf.ptr), buf.cap), "v2e_emu_frame_host_rows")
-        rc = self.lib.v2e_emu_frame(self._h, C.byref(P), fp, on_host, dt, float(t_prev), float(t_frame), int(frame_idx),
-                                    _ptr(events), int(events.shape[1]), out8, C.byref(rows), self.stream)
-        if rc < 0:
+        try:  # whatever raises below, the buffer goes back to the pool unless it has become the result array
+            if buf is not None:
+                check(self.lib.v2e_emu_frame_host_rows(self._h, C.c_void_p(buf.ptr), buf.cap), "v2e_emu_frame_host_rows")
+            rc = self.lib.v2e_emu_frame(self._h, C.byref(P), fp, on_host, dt, float(t_prev), float(t_frame), int(frame_idx),
+                                        _ptr(events), int(events.shape[1]), out8, C.byref(rows), self.stream)
+            if rc < 0:
+                check(rc, "v2e_emu_frame")
+            ev = None
+            n = int(out8[0])
+            if rc == 0 and n > 0:
+                self._rows_est = n + n // 4 + 256
+                if buf is not None and C.cast(rows, C.c_void_p).value == buf.ptr:
+                    ev = pool.hand_out(buf, n)
+                    buf = None
+                else:
+                    # the handle's own pinned rows are reused by the next call (memmove, not ctypeslib.as_array: that builds a
+                    # ctypes array type per distinct row count, ~100 us a frame)
+                    ev = np.empty((n, 4), dtype=np.float32)
+                    C.memmove(ev.ctypes.data, rows, 16 * n)
+            return rc, out8, ev
+        finally:
             if buf is not None:
                 pool.release(buf)
-            check(rc, "v2e_emu_frame")
-        ev = None
-        n = int(out8[0])
-        if rc == 0 and n > 0:
-            self._rows_est = n + n // 4 + 256
-            if buf is not None and C.cast(rows, C.c_void_p).value == buf.ptr:
-                ev = pool.hand_out(buf, n)
-                buf = None
-            else:
-                # the handle's own pinned rows are reused by the next call (memmove, not ctypeslib.as_array: that builds a
-                # ctypes array type per distinct row count, ~100 us a frame)
-                ev = np.empty((n, 4), dtype=np.float32)
-                C.memmove(ev.ctypes.data, rows, 16 * n)
-        if buf is not None:
-            pool.release(buf)
-        return rc, out8, ev
 
     def run(self, P, frames_dev, t_prev, t_frame, frame_idx0, events, recs_dev, use_graph=True):
         """Device-resident Philox run over frames_dev [F][n_clips][H*W]; no host sync."""
