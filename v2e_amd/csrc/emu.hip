@@ -1627,8 +1627,12 @@ static bool chain_fused_records(const v2e_emu *h, int dtype)
 
 static size_t chain_dyn_lds(bool fused) { return fused ? 0 : (size_t)CHAIN_SUB * BLOCK * (sizeof(uint4) + sizeof(uint32_t)); }
 
-static const void *chain_fn(bool f64, int dtype, bool fused)
+// allon: every run-time feature switch of the frame loop is on (cutoff, leak, shot noise, refractory period: the v2e CLI
+// defaults) -> the instantiation without those tests; built for float64 state and uint8 frames (what that configuration has)
+static const void *chain_fn(bool f64, int dtype, bool fused, bool allon = false)
 {
+    if (allon && f64 && dtype == V2E_DT_U8)
+        return fused ? (const void *)k_chain<double, uint8_t, true, true> : (const void *)k_chain<double, uint8_t, false, true>;
     if (!fused) return f64 ? (const void *)k_chain<double, uint8_t, false> : (const void *)k_chain<float, uint8_t, false>;
     switch (dtype) {
     case V2E_DT_U8: return f64 ? (const void *)k_chain<double, uint8_t, true> : (const void *)k_chain<float, uint8_t, true>;
@@ -1957,7 +1961,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     if (!capturing && (sc.wait(ST_TAB, EV_FORK, nL) || sc.wait(ST_SIDE2, EV_FORK, nL))) return V2E_EHIP;
     for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b)
         if (launch_ahead(b)) return V2E_EHIP;
-    const void *kfn = chain_fn(p->f64_state != 0, dtype, fused_rec);
+    static const int allon_env = getenv("V2E_AMD_CHAIN_ALLON") ? atoi(getenv("V2E_AMD_CHAIN_ALLON")) : 1; // dev: 0 = the generic instantiation
+    const bool allon = allon_env && a_in.has_cutoff && a_in.do_leak && a_in.do_shot && a_in.has_refr;
+    const void *kfn = chain_fn(p->f64_state != 0, dtype, fused_rec, allon);
     for (int L = 0; L < nL; ++L) {
         const ChainLaunch &pl = plan[L];
         const bool tail = pl.nf == 0;

@@ -32,6 +32,16 @@
 //   Clips (independent pixel arrays) beyond what is co-resident are walked by a loop inside the workgroup.
 #pragma once
 
+// lock-step frames in redo passes (see k_chain): measured round 4, break-even at best; compiled out by default (the per-frame
+// test costs the common path), -DV2E_CHAIN_LOCKSTEP=1 + V2E_AMD_LOCKSTEP=1 bring it back
+#ifndef V2E_CHAIN_LOCKSTEP
+#define V2E_CHAIN_LOCKSTEP 0
+#endif
+// dev tool: wall-clock stamps of one launch (ChainArgs::dbg); compiled out unless -DV2E_CHAIN_STAMPS
+#ifndef V2E_CHAIN_STAMPS
+#define V2E_CHAIN_STAMPS 0
+#endif
+
 constexpr int CHAIN_K_MAX = 32;
 constexpr int CFRAME_THREADS = 1024;
 constexpr int CHAIN_SUB = 8; // frames whose records are in LDS at a time (4 KB per frame and workgroup)
@@ -161,7 +171,7 @@ struct ChainArgs {
 // release at the end of the launch, on the critical path between two dependent launches.
 #define WT_STORE(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
-#define V2E_STAMP_C(i) do { if (ca.dbg && tid == 0) ca.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
+#define V2E_STAMP_C(i) do { if (V2E_CHAIN_STAMPS && ca.dbg && tid == 0) ca.dbg[(size_t)g * 16 + (i)] = wall_clock64(); } while (0)
 
 // One frame's state-independent quantities of a pixel as a 16-byte record (layout: see k_ahead):
 // lin-log / eps (emulator_utils.py:18-45, 80-96), leak step (:126-129, float32 left to right), shot decisions (:326-349).
@@ -270,12 +280,15 @@ __global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
 // floor_div_pos, which equals c10::div_floor_floating for these operands).  Anything unusual takes floor_div_pos.
 template <typename R> __device__ __forceinline__ R floor_div_rcp(R a, R b, R rb)
 {
-    if (a < b) return (R)0;
+    // branch-free on the path every lane takes (the frame loop of k_chain is one dependency chain per wave: a divergent
+    // branch around two instructions costs more than the instructions): quotient estimate, exact remainder, one-step fix-up
+    // by selects; a < b gives q = 0 through the same arithmetic (floor(a rb) is 0 or 1, fixed by the remainder's sign)
     R q = floor(a * rb);
     R r = fma(-q, b, a);
-    if (r < (R)0) { q -= (R)1; r += b; }
-    else if (r >= b) { q += (R)1; r -= b; }
-    if (!(r >= (R)0 && r < b)) return floor_div_pos<R>(a, b);
+    const bool lo = r < (R)0, hi = r >= b;
+    q = lo ? q - (R)1 : (hi ? q + (R)1 : q);
+    r = lo ? r + b : (hi ? r - b : r);
+    if (__builtin_expect(!(r >= (R)0 && r < b), 0)) return floor_div_pos<R>(a, b); // anything unusual (NaN, b <= 0, a huge)
     return q;
 }
 
@@ -283,9 +296,14 @@ template <typename R> __device__ __forceinline__ R floor_div_rcp(R a, R b, R rb)
 // instruction in it is latency).  FUSED = true: the chain builds each record itself (large grids: the occupancy hides
 // latencies, and the records' 32 B per pixel and frame of extra HBM traffic would be what bounds the run).
 // Dynamic LDS (FUSED = false): [CHAIN_SUB][BLOCK] uint4 records + [CHAIN_SUB][BLOCK] count words.
-template <typename R, typename FT, bool FUSED>
-__global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
+// ALLON: instantiation for runs with a photoreceptor cutoff, leak, shot noise AND a refractory period (the v2e CLI defaults,
+// i.e. the benchmark): the per-frame tests of those run-time switches -- a scalar compare and a branch each, in a loop whose
+// every instruction is exposed latency -- are compiled out.  ALLON = false reads the switches from KArgs.
+template <typename R, typename FT, bool FUSED, bool ALLON = false>
+__global__ __launch_bounds__(BLOCK) void k_chain(KArgs a_in, ChainArgs ca)
 {
+    KArgs a = a_in;
+    if (ALLON) { a.has_cutoff = 1; a.do_leak = 1; a.do_shot = 1; a.has_refr = 1; a.use_inten = 1; }
     extern __shared__ uint4 s_arec[];         // [CHAIN_SUB][BLOCK] k_ahead's records of the frames in flight, then s_cw
     __shared__ float s_lutL[FUSED ? 256 : 1]; // FUSED: lin-log tables and the pass's frame scalars
     __shared__ double s_lutI[FUSED ? 256 : 1];
@@ -432,7 +450,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     last_exact = j;
                     ++round;
                     redone = true;
-                    lock_k = (ca.lockstep && __builtin_amdgcn_readlane((int)gM_v, j) != 0 && j + 1 < ca.pnf) ? j + 1 : -1;
+                    lock_k = (V2E_CHAIN_LOCKSTEP && ca.lockstep && __builtin_amdgcn_readlane((int)gM_v, j) != 0 && j + 1 < ca.pnf) ? j + 1 : -1;
                     // restart point: every frame before j is exact, so is the checkpoint at or below j (written by the
                     // own pass, or by the redo pass before this one, in which the frames up to j were exact already)
                     c0 = ca.ckp_base ? (j / CHAIN_SUB) * CHAIN_SUB : 0;
@@ -504,7 +522,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 if (FUSED) {
                     if (valid) WT_STORE(&ca.cnt[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p], cw);
                 } else {
-                    s_cw[(size_t)(k % CHAIN_SUB) * BLOCK + tid] = cw;
+                    s_cw[(size_t)((unsigned)k % CHAIN_SUB) * BLOCK + tid] = cw;
                 }
                 const int magv = valid ? mag : 0;
                 // speculation check: only a wave with a lane that reaches the rule threshold says so
@@ -512,7 +530,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     const int wm = wave_max_i32(magv);
                     if (lane == 0) atomicMax(gM_dst + k, (uint32_t)wm);
                 }
-                if (!own && k == lock_k) { // lock-step: every frame before this one is exact, so the published maximum is M(k)
+                if (V2E_CHAIN_LOCKSTEP && !own && k == lock_k) { // lock-step: every frame before this one is exact, so the published maximum is M(k)
                     __builtin_amdgcn_s_setprio(0);
                     const bool okb = clip_barrier(ca.bar_prev + (size_t)bar_idx * ca.n_clips + clip, (unsigned)ca.ngroups, ca.bar_light != 0);
                     ++bar_idx;
@@ -560,7 +578,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 }
                 lp = lpn;
                 if (++slot == ca.D) slot = 0;
-                if (own && k < 12) V2E_STAMP_C(3 + k);
+                if (V2E_CHAIN_STAMPS && own && k < 12) V2E_STAMP_C(3 + k);
             };
             // records of the pass's frames [kn, kn + CHAIN_SUB) into registers (in flight while the frames before them compute)
             uint4 nx[CHAIN_SUB];
@@ -588,10 +606,10 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                 slot = slot0;
                 // the record of frame k + 1 is read from LDS while frame k computes
                 uint4 rc_cur = make_uint4(0u, 0u, 0u, 0u);
-                if (!FUSED) rc_cur = s_arec[(size_t)(k0 % CHAIN_SUB) * BLOCK + tid];
+                if (!FUSED) rc_cur = s_arec[(size_t)((unsigned)k0 % CHAIN_SUB) * BLOCK + tid];
                 for (int k = k0; k < kend; ++k) {
                     uint4 rc_nxt = make_uint4(0u, 0u, 0u, 0u);
-                    if (!FUSED && k + 1 < kend) rc_nxt = s_arec[(size_t)((k + 1) % CHAIN_SUB) * BLOCK + tid];
+                    if (!FUSED && k + 1 < kend) rc_nxt = s_arec[(size_t)((unsigned)(k + 1) % CHAIN_SUB) * BLOCK + tid];
                     frame_body(k, rc_cur);
                     rc_cur = rc_nxt;
                 }
@@ -608,7 +626,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(KArgs a, ChainArgs ca)
                     if (valid) {
                         int sl = slot0;
                         for (int k = k0; k < kend; ++k) { // the sub-pass's count words
-                            WT_STORE(&ca.cnt[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p], s_cw[(size_t)(k % CHAIN_SUB) * BLOCK + tid]);
+                            WT_STORE(&ca.cnt[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p], s_cw[(size_t)((unsigned)k % CHAIN_SUB) * BLOCK + tid]);
                             if (++sl == ca.D) sl = 0;
                         }
                     }
