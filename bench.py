@@ -296,6 +296,10 @@ def self_allgather_bench(device, frames_all, steps=30, warmup=3):
     from v2e_amd.benchutil import run_steps
     from v2e_amd.dist import EventStreamGatherer
     own_pg = not dist.is_initialized()
+    # RCCL and gloo print banners through C stdio on fd 1: the JSON line must stay the only thing on stdout
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
     if own_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29519")
@@ -318,6 +322,13 @@ def self_allgather_bench(device, frames_all, steps=30, warmup=3):
     finally:
         if own_pg:
             dist.destroy_process_group()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
 
 
 def main():
