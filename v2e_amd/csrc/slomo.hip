@@ -54,7 +54,10 @@ __device__ __forceinline__ void amax_fold(uint32_t &m, float v)
     const uint32_t b = __float_as_uint(v) & 0x7FFFFFFFu;
     m = b > m ? b : m;
 }
-// one atomicMax per wave
+// one atomicMax per wave AT MOST: a layer is tens of thousands of workgroups and an atomic to one address is serialised where
+// it is performed (measured: +1.3 ms per forward pass, 8 %, with an unconditional atomic per wave), so the wave first reads
+// the slot -- a plain load; a stale (smaller) value only costs an atomic that was not needed, never a wrong maximum -- and
+// only a wave that would raise it goes to the atomic unit: a few hundred per layer instead of 100 000
 __device__ __forceinline__ void amax_commit(uint32_t *slot, uint32_t m)
 {
 #pragma unroll
@@ -62,7 +65,9 @@ __device__ __forceinline__ void amax_commit(uint32_t *slot, uint32_t m)
         const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
         m = other > m ? other : m;
     }
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(slot, m);
+    if ((threadIdx.x & 63) == 0 && m != 0u) {
+        if (m > *(volatile uint32_t *)slot) atomicMax(slot, m);
+    }
 }
 // the power of two a two-float16-piece convolution stages its activations times: in_scale = 2^k with amax * 2^k in [2^13, 2^14),
 // inv = 2^-k (both normal float32 numbers: |k| <= 126); bad = the producer wrote an inf or a NaN
