@@ -471,7 +471,7 @@ def test_operand_scaling_and_range_guard_of_the_two_piece_math():
     """conv_math 'auto' / 'fp16x2': every convolution stages its activations times the power of two that puts the largest one
     (tracked by the producing convolution's epilogue) in [2^13, 2^14), so neither a network whose activations are 3e5 times
     larger nor one whose activations are 1e-5 times smaller leaves float16's normal range: same accuracy, no second pass.
-    What is left for the guard is an activation that is inf or NaN: such a pass is redone with the exact three-bf16-piece
+    What is left for the guard is an activation that is inf: such a pass is redone with the exact three-bf16-piece
     split -- bit-identical to conv_math 'bf16x3' -- and the guard does not stick."""
     from v2e_amd.slomo import HipUNet
     from v2e_amd.synth import portable_unet_state_dict

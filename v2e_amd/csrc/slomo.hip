@@ -48,11 +48,13 @@ struct ConvArgs {
     uint32_t *am_out;
 };
 
-// |v| as ordered bits, folded into a running maximum (NaN > inf > finite)
+// |v| folded into a running maximum kept as float32 bits: one v_max_f32 with the |.| source modifier.  Non-negative floats and
+// +inf order like their bit patterns, so the per-wave / per-slot reductions are integer maxima.  A NaN is ignored by the
+// maximum: a NaN activation gives a NaN result in every conv math alike (as in the reference); what the range guard needs to
+// see is inf, and it does.
 __device__ __forceinline__ void amax_fold(uint32_t &m, float v)
 {
-    const uint32_t b = __float_as_uint(v) & 0x7FFFFFFFu;
-    m = b > m ? b : m;
+    m = __float_as_uint(fmaxf(__uint_as_float(m), fabsf(v)));
 }
 // one atomicMax per wave AT MOST: a layer is tens of thousands of workgroups and an atomic to one address is serialised where
 // it is performed (measured: +1.3 ms per forward pass, 8 %, with an unconditional atomic per wave), so the wave first reads

@@ -264,6 +264,7 @@ void k_conv_s3(ConvArgs a)
     float in_scale = 1.0f, inv_scale = 1.0f;
     bool in_bad = false;
     if constexpr (NP == 2) act_scale(a, in_scale, inv_scale, in_bad);
+    const bool scaled = NP == 2 && a.am_in0 != nullptr; // block-uniform
     float amax = 0.f; // NP == 2: the largest |activation| this thread staged (float16 holds up to 65 504: see the range flag)
     auto stage_patch = [&](int set, int cbs = 0) { // split and store this thread's patch items (cbs: the chunk, PADC only)
 #pragma unroll
@@ -284,8 +285,12 @@ void k_conv_s3(ConvArgs a)
                     uint32_t qe[NP];
                     float xa = ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, xb = ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f;
                     if constexpr (NP == 2) {
-                        xa *= in_scale; xb *= in_scale; // exact (a power of two; the products stay far inside float32)
-                        amax = fmaxf(amax, fmaxf(fabsf(xa), fabsf(xb)));
+                        // ONE extra instruction per element, whichever way the range is kept (these kernels are at the chip's
+                        // power limit: a second one cost 8 % per forward pass): with range slots the scaling (exact: a power of
+                        // two) -- the scaled maximum is below 2^14 by construction, nothing to watch; without them (a
+                        // convolution outside v2e_unet_forward) the running maximum the range flag is raised from
+                        if (scaled) { xa *= in_scale; xb *= in_scale; }
+                        else amax = fmaxf(amax, fmaxf(fabsf(xa), fabsf(xb)));
                     }
                     split_pair<NP>(xa, xb, qe);
 #pragma unroll
