@@ -312,10 +312,13 @@ int v2e_pack_conv_weight_s3(const float *w_oihw, void *w_s3, int cout, int cin, 
  * |w| 2^scale_log2 is below 2^14: nothing overflows float16 and no weight piece falls into its subnormal range); the
  * convolution divides it out again exactly.  Set v2e_conv_desc.split_kind = 2 | (scale_log2 << 8) with it. */
 int v2e_pack_conv_weight_h2(const float *w_oihw, void *w_h2, int cout, int cin, int k, int scale_log2, void *stream);
-/* Range guard of the two-float16-piece convolutions: while a device flag is set here (per host thread; NULL switches it off),
- * every such convolution launched ORs 1 into it if an input activation is beyond float16's range (|x| > 65 504: it became
- * +-inf in the split) or NaN.  The caller zeroes the flag, runs its layers, reads it back, and on 1 redoes them with the exact
- * three-piece weights -- what SloMoEngine's default conv math "auto" does. */
+/* Range guard of the two-float16-piece convolutions inside v2e_unet_forward: while a device flag is set here (per host thread;
+ * NULL switches it off), a forward pass ORs 1 into it if a convolution's input holds an inf or a NaN (seen in the range slot its
+ * producer left: the largest |output| of every convolution is tracked on the device, and a two-piece convolution stages its
+ * activations times the power of two that puts that maximum in [2^13, 2^14) -- finite activations of any magnitude stay in
+ * float16's normal range).  The caller zeroes the flag, runs the pass, reads it back, and on 1 redoes it with the exact three-piece
+ * weights -- what SloMoEngine's default conv math "auto" does.  A two-piece v2e_conv2d_lrelu called on its own stages unscaled and
+ * is not watched. */
 int v2e_conv_set_range_flag(int *device_flag);
 
 /* activations in the same split form: x [n][c][h][w] f32 -> xs [3 pieces][n][c/8][h][w][8 bf16] (6 bytes per element;

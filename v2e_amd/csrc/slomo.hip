@@ -62,13 +62,17 @@ __device__ __forceinline__ void amax_fold(uint32_t &m, float v)
 // only a wave that would raise it goes to the atomic unit: a few hundred per layer instead of 100 000
 __device__ __forceinline__ void amax_commit(uint32_t *slot, uint32_t m)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)m, o, 64);
-        m = other > m ? other : m;
-    }
-    if ((threadIdx.x & 63) == 0 && m != 0u) {
-        if (m > *(volatile uint32_t *)slot) atomicMax(slot, m);
+    // wave maximum on the VALU data-parallel-primitive path (no LDS crossbar round trips at the tail of every wave)
+#define V2E_S_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, true)
+    m = max(m, (uint32_t)V2E_S_DPP(m, 0xB1));  // quad_perm [1,0,3,2]   (bit patterns of non-negative floats: all below 2^31)
+    m = max(m, (uint32_t)V2E_S_DPP(m, 0x4E));  // quad_perm [2,3,0,1]
+    m = max(m, (uint32_t)V2E_S_DPP(m, 0x141)); // row_half_mirror
+    m = max(m, (uint32_t)V2E_S_DPP(m, 0x140)); // row_mirror
+#undef V2E_S_DPP
+    const uint32_t w = max(max((uint32_t)__builtin_amdgcn_readlane((int)m, 0), (uint32_t)__builtin_amdgcn_readlane((int)m, 16)),
+                           max((uint32_t)__builtin_amdgcn_readlane((int)m, 32), (uint32_t)__builtin_amdgcn_readlane((int)m, 48)));
+    if ((threadIdx.x & 63) == 0 && w != 0u) {
+        if (w > *(volatile uint32_t *)slot) atomicMax(slot, w);
     }
 }
 // the power of two a two-float16-piece convolution stages its activations times: in_scale = 2^k with amax * 2^k in [2^13, 2^14),

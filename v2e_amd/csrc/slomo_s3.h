@@ -264,8 +264,8 @@ void k_conv_s3(ConvArgs a)
     float in_scale = 1.0f, inv_scale = 1.0f;
     bool in_bad = false;
     if constexpr (NP == 2) act_scale(a, in_scale, inv_scale, in_bad);
-    const bool scaled = NP == 2 && a.am_in0 != nullptr; // block-uniform
-    float amax = 0.f; // NP == 2: the largest |activation| this thread staged (float16 holds up to 65 504: see the range flag)
+    // (the range flag is raised from the producers' slots: an inf / NaN there; the scaled operands cannot leave float16's range.
+    //  A two-piece convolution launched WITHOUT slots -- outside v2e_unet_forward -- stages unscaled and is not watched.)
     auto stage_patch = [&](int set, int cbs = 0) { // split and store this thread's patch items (cbs: the chunk, PADC only)
 #pragma unroll
         for (int j = 0; j < NPI; ++j) {
@@ -284,14 +284,8 @@ void k_conv_s3(ConvArgs a)
                 for (int e = 0; e < 4; ++e) {
                     uint32_t qe[NP];
                     float xa = ok && 2 * e < nv ? pv[set][j][2 * e] : 0.f, xb = ok && 2 * e + 1 < nv ? pv[set][j][2 * e + 1] : 0.f;
-                    if constexpr (NP == 2) {
-                        // ONE extra instruction per element, whichever way the range is kept (these kernels are at the chip's
-                        // power limit: a second one cost 8 % per forward pass): with range slots the scaling (exact: a power of
-                        // two) -- the scaled maximum is below 2^14 by construction, nothing to watch; without them (a
-                        // convolution outside v2e_unet_forward) the running maximum the range flag is raised from
-                        if (scaled) { xa *= in_scale; xb *= in_scale; }
-                        else amax = fmaxf(amax, fmaxf(fabsf(xa), fabsf(xb)));
-                    }
+                    if constexpr (NP == 2) { xa *= in_scale; xb *= in_scale; } // exact (a power of two); replaces round 3's running
+                                                                               // maximum one for one: these kernels are power-bound
                     split_pair<NP>(xa, xb, qe);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) q[p][e] = qe[p];
@@ -400,7 +394,7 @@ void k_conv_s3(ConvArgs a)
     // NP == 2: an activation beyond float16's range (it became +-inf in the split) -- or a NaN -- is reported, so that the caller
     // can redo the layer stack with the exact three-piece split (v2e_conv_set_range_flag)
     if constexpr (NP == 2) {
-        if (a.ovf && __ballot(!(amax <= 65504.f) || in_bad) != 0ull && lane == 0) atomicOr(a.ovf, 1);
+        if (a.ovf && in_bad && tid == 0) atomicOr(a.ovf, 1);
     }
     uint32_t omax = 0u;
     // epilogue as k_conv: register r of a lane is channel (r&3)+8(r>>2)+4*hsel of pixel l31
