@@ -87,7 +87,11 @@ __device__ __forceinline__ void act_scale(const ConvArgs &a, float &in_scale, fl
     if (e == 255) { bad = true; return; }
     if (m == 0u) return; // an all-zero input
     int k = 140 - e;     // amax in [2^(e-127), 2^(e-126)) -> [2^13, 2^14)
-    k = k > 126 ? 126 : (k < -126 ? -126 : k);
+    // ... as far as 2^-k times the weights' 2^-s (a.out_scale) stays a normal float32, so that the epilogue divides both out
+    // with ONE exact multiply: s <= 40, i.e. maxima down to 2^-73 are scaled all the way
+    const int sl2 = 127 - (int)((__float_as_uint(a.out_scale) >> 23) & 0xFF);
+    const int kmax = 126 - (sl2 > 0 ? sl2 : 0);
+    k = k > kmax ? kmax : (k < -126 ? -126 : k);
     in_scale = __uint_as_float((uint32_t)(127 + k) << 23);
     inv = __uint_as_float((uint32_t)(127 - k) << 23);
 }

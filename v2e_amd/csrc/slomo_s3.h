@@ -397,14 +397,8 @@ void k_conv_s3(ConvArgs a)
         if (a.ovf && in_bad && tid == 0) atomicOr(a.ovf, 1);
     }
     uint32_t omax = 0u;
-    // the two scale factors as ONE multiply where their product is a normal float32 (always, short of activations below 2^-80)
-    float os1 = a.out_scale;
-    bool os_two = false;
-    if constexpr (NP == 2) {
-        const int e = (int)((__float_as_uint(a.out_scale) >> 23) & 0xFF) + (int)((__float_as_uint(inv_scale) >> 23) & 0xFF) - 127;
-        if (e >= 1 && e <= 254) os1 = a.out_scale * inv_scale; // exact: both are powers of two
-        else os_two = true;
-    }
+    // the two scale factors as ONE multiply: act_scale keeps 2^-(k + s) a normal float32, so the product is exact
+    const float os1 = NP == 2 ? a.out_scale * inv_scale : 1.0f;
     // epilogue as k_conv: register r of a lane is channel (r&3)+8(r>>2)+4*hsel of pixel l31
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -418,7 +412,7 @@ void k_conv_s3(ConvArgs a)
                 const int ch = cobase + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
                 if (pok) {
                     float s = acc[ct][pt][r];
-                    if constexpr (NP == 2) { s *= os1; if (os_two) s *= inv_scale; } // the powers of two the operands were staged times
+                    if constexpr (NP == 2) s *= os1; // the powers of two the operands were staged times, divided out (exact)
                     float v = s + a.bias[ch];
                     v = v > 0.f ? v : v * 0.1f;
                     amax_fold(omax, v);
