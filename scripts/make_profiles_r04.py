@@ -64,12 +64,12 @@ def emulator():
 """ + kt + "\n# k_chain launch timeline (same trace)\n" + tl + "\n# a window of the same trace (scripts/trace_window.py)\n" + window)
     f, w = rd("p4_FETCH_SIZE.txt"), rd("p4_WRITE_SIZE.txt")
     rows = []
-    for k in ("k_chain<double, unsigned char, false>", "k_ahead<unsigned char>", "k_cemit", "k_ctot", "k_cframe1"):
+    for k in ("k_chain<double, unsigned char, false", "k_ahead<unsigned char>", "k_cemit", "k_ctot", "k_cframe1"):
         n, fa = pmc_avg(f, k)
         n2, wa = pmc_avg(w, k)
         if n is None and n2 is None:
             continue
-        rows.append("# %-38s %4d  %9.1f  %9.1f" % (k, n or n2, fa or 0.0, wa or 0.0))
+        rows.append("# %-38s %4d  %9.1f  %9.1f" % (k + (", true>" if k.startswith("k_chain") else ""), n or n2, fa or 0.0, wa or 0.0))
     wr("r04_emulator_pmc_hbm.txt", """# HBM traffic of the emulator kernels, round 4
 # commands (separate passes, as the MI355X guide prescribes; summary by profiles/summarize_rocprof_pmc.py):
 #   rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 4 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline

@@ -20,6 +20,12 @@ def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device, first
     Works on any object with EventEmulator's generate_events_batch_async (the CPU tests pass a stub)."""
     device = torch.device(device)
     cuda = device.type == "cuda"
+    # Python's cyclic collector: a full (generation-2) collection over everything torch imported is a 50-70 ms pause that lands
+    # in whichever 20-step block is running when the allocation counter trips (measured: scripts/step_times.py).  What exists
+    # now is moved to the permanent generation once, so collections during the loop only look at what the loop allocated.
+    import gc
+    gc.collect()
+    gc.freeze()
     buf = torch.empty((F,) + tuple(frames_all.shape[1:]), dtype=frames_all.dtype, device=device)
     nclip = max((int(frames_all.shape[0]) - 1) // F, 1)
 
