@@ -299,8 +299,12 @@ template <typename R> __device__ __forceinline__ R floor_div_rcp(R a, R b, R rb)
 // ALLON: instantiation for runs with a photoreceptor cutoff, leak, shot noise AND a refractory period (the v2e CLI defaults,
 // i.e. the benchmark): the per-frame tests of those run-time switches -- a scalar compare and a branch each, in a loop whose
 // every instruction is exposed latency -- are compiled out.  ALLON = false reads the switches from KArgs.
+// Five waves per SIMD for the fused instantiations on float64 state and uint8 frames (1280x720, multi-clip runs: throughput-bound,
+// 96 VGPRs without a spill; measured 1280x720 noisy 10.25 -> 10.5 Gev/s); the other fused ones would spill a few registers.
 template <typename R, typename FT, bool FUSED, bool ALLON = false>
-__global__ __launch_bounds__(BLOCK) void k_chain(KArgs a_in, ChainArgs ca)
+__global__ __launch_bounds__(BLOCK)
+__attribute__((amdgpu_waves_per_eu((FUSED && sizeof(R) == 8 && sizeof(FT) == 1) ? 5 : 1, 8)))
+void k_chain(KArgs a_in, ChainArgs ca)
 {
     KArgs a = a_in;
     if (ALLON) { a.has_cutoff = 1; a.do_leak = 1; a.do_shot = 1; a.has_refr = 1; a.use_inten = 1; }
