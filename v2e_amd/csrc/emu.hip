@@ -768,6 +768,18 @@ __global__ void k_zero_words(uint32_t *p, size_t n)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
+// up to four ranges zeroed by ONE launch (the start of a run: four dependent 4-us launches were 17 us of every 300-frame step)
+struct ZeroRanges { uint32_t *p[4]; unsigned long long n[4]; };
+__global__ __launch_bounds__(256) void k_zero_ranges(ZeroRanges z)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long base = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (i >= base && i < base + z.n[r]) z.p[r][i - base] = 0u;
+        base += z.n[r];
+    }
+}
 } // namespace
 static inline hipError_t zero_async(void *p, size_t bytes, hipStream_t s)
 {
@@ -1598,6 +1610,15 @@ struct Sched {
         void *args[] = {(void *)&p32, (void *)&n};
         return kernel(s, (const void *)k_zero_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, args);
     }
+    int zero4(int s, void *const ptr[4], const size_t bytes[4])
+    {
+        ZeroRanges z;
+        unsigned long long tot = 0;
+        for (int r = 0; r < 4; ++r) { z.p[r] = (uint32_t *)ptr[r]; z.n[r] = ptr[r] ? (bytes[r] + 3) / 4 : 0; tot += z.n[r]; }
+        if (tot == 0) return 0;
+        void *args[] = {(void *)&z};
+        return kernel(s, (const void *)k_zero_ranges, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, args);
+    }
     int record(int kind, int idx, int s)
     {
         if (!graph) { V2E_HIP(hipEventRecord(real_event(kind, idx), st[s])); return 0; }
@@ -1841,11 +1862,11 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         sc.ev_cap = nL + 2;
         sc.evdeps.assign((size_t)EV_KINDS * sc.ev_cap, std::vector<hipGraphNode_t>());
     }
-    if (sc.zero(ST_MAIN, recs, sizeof(v2e_frame_rec) * (size_t)n_frames * NC)) return V2E_EHIP;
-    if (sc.zero(ST_MAIN, h->run_off, sizeof(unsigned long long) * NC)) return V2E_EHIP; // batch 0 starts at row 0
-    if (has_refr) {
-        if (sc.zero(ST_MAIN, h->ch_gM, sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K)) return V2E_EHIP;
-        if (sc.zero(ST_MAIN, h->ch_bar, sizeof(unsigned) * (size_t)nL * 2 * K * NC)) return V2E_EHIP;
+    {   // one launch: the run's records, batch 0's event offset, and (refractory runs) the rule-on maxima and rendezvous counters
+        void *const zp[4] = {recs, h->run_off, has_refr ? (void *)h->ch_gM : nullptr, has_refr ? (void *)h->ch_bar : nullptr};
+        const size_t zb[4] = {sizeof(v2e_frame_rec) * (size_t)n_frames * NC, sizeof(unsigned long long) * NC,
+                              sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K, sizeof(unsigned) * (size_t)nL * 2 * K * NC};
+        if (sc.zero4(ST_MAIN, zp, zb)) return V2E_EHIP;
     }
     auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t stq) -> int { // instrumented runs (never graphs)
         if (!v || graph) return 0;
@@ -1861,7 +1882,11 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     if (has_refr && K > 1) gy = std::max(1, std::min(NC, h->ch_max_blocks / std::max(h->ngroups, 1)));
     dim3 grid(h->ngroups, gy);
     static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
+    const bool no_emit_run = false;
     static const int chain_prio = getenv("V2E_AMD_CHAIN_PRIO") ? atoi(getenv("V2E_AMD_CHAIN_PRIO")) : 3; // dev: 0 = no raised wave priority
+    // occupancy cap of the kernels that run BESIDE the chain (k_ahead, k_ctot, k_cemit): dynamic LDS they do not use, so that a
+    // CU holds at most floor(160 KB / pad) of their workgroups (0: no cap)
+    static const int side_pad = (getenv("V2E_AMD_SIDE_LDS_KB") ? atoi(getenv("V2E_AMD_SIDE_LDS_KB")) : 0) * 1024;
     static const int bar_light = getenv("V2E_AMD_BAR_LIGHT") ? atoi(getenv("V2E_AMD_BAR_LIGHT")) : 1;    // dev: 0 = fenced rendezvous (round 3)
     // lock-step frames in redo passes (emu_chain.h): measured round 4 with the fence-free rendezvous, A/B in one process each:
     // a launch whose rule-on frames come in a run 109-112 -> 89-92 us, a launch with a single rule-on frame 54-60 -> 68-71 us
@@ -1875,11 +1900,13 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     const int tab_stream = capturing ? (tabs_on_main ? ST_MAIN : ST_SIDE) : tab_env;
     constexpr int NSET = 3; // emission table sets (chain_alloc sizes them)
     static const bool one_row_stream = getenv("V2E_AMD_ONE_ROW_STREAM") != nullptr; // dev
-    auto launch_emission = [&](int b) -> int { // EV_FORK[b] has been recorded on the chain stream
+    // b: the emission's slot (event indices, table set b % NSET, event offsets run_off[b] -> run_off[b + 1]); frames [ef0, ef0 + enE).
+    // A batch is normally slot b = frames [b E, (b + 1) E); the run's LAST batch may be emitted in two pieces (slots nEB - 1, nEB).
+    auto launch_emission = [&](int b, int ef0, int enE) -> int { // EV_FORK[b] has been recorded on the chain stream
         CEmitArgs ea;
         memset(&ea, 0, sizeof(ea));
         ea.ctl = h->run_ctl; ea.recs = recs; ea.fidx_base = h->run_fidx;
-        ea.f0 = b * E; ea.nE = std::min((b + 1) * E, n_frames) - ea.f0; ea.D = D; ea.n_clips = NC;
+        ea.f0 = ef0; ea.nE = enE; ea.D = D; ea.n_clips = NC;
         ea.nwp = h->ch_nwp; ea.nwaves = chain_egroups(h); ea.E = E; // emission groups (GROUP_PX pixels, one wave each)
         ea.cnt = h->ch_cnt; ea.tsold = has_refr ? h->ch_tsold : nullptr; ea.ruleM = has_refr ? h->ch_ruleM : nullptr;
         const size_t set = (size_t)(b % NSET) * E * NC; // table set of this batch
@@ -1911,7 +1938,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (tab_stream != ST_MAIN && sc.wait(tab_stream, EV_FORK, b)) return V2E_EHIP;
         if (b >= NSET && tab_stream != ST_SIDE && sc.wait(tab_stream, EV_JOIN, b - NSET)) return V2E_EHIP;
         if (!no_emit) {
-            if (sc.kernel(tab_stream, (const void *)k_ctot, dim3(egx, NC, (ea.nE + CTOT_ZF - 1) / CTOT_ZF), dim3(BLOCK), 0, args)) return V2E_EHIP;
+            if (sc.kernel(tab_stream, (const void *)k_ctot, dim3(egx, NC, (ea.nE + CTOT_ZF - 1) / CTOT_ZF), dim3(BLOCK), (size_t)side_pad, args)) return V2E_EHIP;
             // a key row of a small grid is a couple of steps of one wave: one workgroup per frame; of a large grid (1280x720:
             // 14 400 waves) a segmented scan by a workgroup of its own
             if (h->ch_nwp <= 4096) {
@@ -1930,25 +1957,37 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (sc.record(EV_TAB, b, tab_stream)) return V2E_EHIP;
         if (row_stream != tab_stream && sc.wait(row_stream, EV_TAB, b)) return V2E_EHIP;
         if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
-        if (!no_emit && sc.kernel(row_stream, (const void *)k_cemit, dim3(egx, NC, ea.nE), dim3(BLOCK), REC_LDS, args)) return V2E_EHIP;
+        if (!no_emit && sc.kernel(row_stream, (const void *)k_cemit, dim3(egx, NC, ea.nE), dim3(BLOCK), (size_t)std::max(REC_LDS, side_pad), args)) return V2E_EHIP;
         if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
         return sc.record(EV_JOIN, b, row_stream);
     };
+    // Batch 0 of a run is split at the first chain launch's frames: the chain starts after the records of K frames, not of E
+    // (its first launch idled through the whole first k_ahead: ~15 us of every 300-frame step); the rest of the batch follows on
+    // the same stream and is waited for by the batch's other launches (event slot nL of EV_AHEAD: the batches use 0 .. nEB - 1).
+    static const bool split_first_ahead = getenv("V2E_AMD_NO_AHEAD_SPLIT") == nullptr;
+    const bool split0 = split_first_ahead && m > 1 && n_frames > K;
     auto launch_ahead = [&](int b) -> int {
-        AheadArgs aa;
-        memset(&aa, 0, sizeof(aa));
-        aa.frames = frames; aa.frame_stride = (unsigned long long)NC * h->npx * esz;
-        aa.ctl = h->run_ctl; aa.fidx_base = h->run_fidx;
-        aa.f0 = b * E; aa.nf = std::min((b + 1) * E, n_frames) - b * E; aa.D = D; aa.n_clips = NC;
-        aa.rec = h->ch_rec;
         if (b >= nD && sc.wait(ST_AHEAD, EV_CHAIN, (b - nD + 1) * m)) return V2E_EHIP; // records of batch b - nD: last read by that launch's redo
-        // frame pairs touched by the batch: at most nf / 2 + 1 (the device knows the run's first frame index, the host
-        // does not when it builds a graph: one extra pair covers either alignment; threads of a pair outside the batch return)
+        // frame pairs touched by a launch: at most nf / 2 + 1 (the device knows the run's first frame index, the host
+        // does not when it builds a graph: one extra pair covers either alignment; threads of a pair outside the range return)
         static const int ppt_env = getenv("V2E_AMD_AHEAD_PPT") ? atoi(getenv("V2E_AMD_AHEAD_PPT")) : 0;
-        aa.ppt = ppt_env > 0 ? ppt_env : 1;
-        void *args[] = {(void *)&a, (void *)&aa};
-        if (sc.kernel(ST_AHEAD, (const void *)k_ahead<uint8_t>, dim3(h->ngroups, NC, (aa.nf / 2 + 1 + aa.ppt - 1) / aa.ppt), dim3(BLOCK), 0, args)) return V2E_EHIP;
-        return sc.record(EV_AHEAD, b, ST_AHEAD);
+        const int b0 = b * E, b1 = std::min((b + 1) * E, n_frames);
+        const int cut = (b == 0 && split0) ? std::min(K, b1) : b1;
+        for (int part = 0; part < 2; ++part) {
+            const int f0 = part == 0 ? b0 : cut, f1 = part == 0 ? cut : b1;
+            if (f1 <= f0) continue;
+            AheadArgs aa;
+            memset(&aa, 0, sizeof(aa));
+            aa.frames = frames; aa.frame_stride = (unsigned long long)NC * h->npx * esz;
+            aa.ctl = h->run_ctl; aa.fidx_base = h->run_fidx;
+            aa.f0 = f0; aa.nf = f1 - f0; aa.D = D; aa.n_clips = NC;
+            aa.rec = h->ch_rec;
+            aa.ppt = ppt_env > 0 ? ppt_env : 1;
+            void *args[] = {(void *)&a, (void *)&aa};
+            if (sc.kernel(ST_AHEAD, (const void *)k_ahead<uint8_t>, dim3(h->ngroups, NC, (aa.nf / 2 + 1 + aa.ppt - 1) / aa.ppt), dim3(BLOCK), (size_t)side_pad, args)) return V2E_EHIP;
+            if (sc.record(EV_AHEAD, part == 0 ? b : nL, ST_AHEAD)) return V2E_EHIP;
+        }
+        return 0;
     };
     // state planes: X[0] the caller's (bound) planes, X[1] the engine's second set; launch L reads X[L % 2], writes X[(L + 1) % 2]
     void *xb[2] = {h->base, has_refr ? h->ch_base2 : h->base}, *xl[2] = {h->lp, has_refr ? h->ch_lp2 : h->lp};
@@ -1961,6 +2000,11 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     if (!capturing && (sc.wait(ST_TAB, EV_FORK, nL) || sc.wait(ST_SIDE2, EV_FORK, nL))) return V2E_EHIP;
     for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b)
         if (launch_ahead(b)) return V2E_EHIP;
+    // last batch in two pieces: only where the last launch is not the first of its batch (else there is nothing to emit early)
+    static const bool split_tail_env = getenv("V2E_AMD_NO_TAIL_SPLIT") == nullptr;
+    const int tail_f0 = (nB - 1) * K;                          // first frame of the last chain launch with frames
+    const bool split_tail = split_tail_env && has_refr && m > 1 && nB >= 2 && (nB - 1) % m != 0 && !no_emit_run;
+    const int last_slot = (split_tail && tail_f0 > (nEB - 1) * E) ? nEB : nEB - 1;
     static const int allon_env = getenv("V2E_AMD_CHAIN_ALLON") ? atoi(getenv("V2E_AMD_CHAIN_ALLON")) : 1; // dev: 0 = the generic instantiation
     const bool allon = allon_env && a_in.has_cutoff && a_in.do_leak && a_in.do_shot && a_in.has_refr;
     const void *kfn = chain_fn(p->f64_state != 0, dtype, fused_rec, allon);
@@ -2006,6 +2050,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
         if (pl.wait_join >= 0 && sc.wait(ST_MAIN, EV_JOIN, pl.wait_join)) return V2E_EHIP; // ring slots: read by k_cemit of that batch
         if (pl.wait_ahead >= 0 && sc.wait(ST_MAIN, EV_AHEAD, pl.wait_ahead)) return V2E_EHIP;
+        if (split0 && !fused_rec && !tail && L >= 1 && L < m && sc.wait(ST_MAIN, EV_AHEAD, nL)) return V2E_EHIP; // the rest of batch 0
         if (mark(ev_main, s)) return V2E_EHIP; // instrumented runs: an event before and after every chain launch
         void *args[] = {(void *)&a, (void *)&ca};
         if (sc.kernel(ST_MAIN, kfn, grid, dim3(BLOCK), chain_dyn_lds(fused_rec), args)) return V2E_EHIP;
@@ -2016,16 +2061,26 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         // r03_graph_scheduling.txt), with k_ahead first it runs beside them.
         static const bool ahead_first = getenv("V2E_AMD_ORDER_EMISSION_FIRST") == nullptr;
         if (ahead_first && pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
-        if (pl.emit_batch >= 0) {
+        // The run's last batch in two pieces (refractory runs, several launches per batch): the frames of its launches before
+        // the last one are final one launch earlier -- emitted then, beside the chain, instead of behind the tail launch with the
+        // rest (the chain idled ~50 us at the end of every 300-frame step while 44 frames were emitted; now 12).
+        if (split_tail && L == nB - 1 && tail_f0 > (nEB - 1) * E) {
+            if (sc.record(EV_FORK, nEB - 1, ST_MAIN)) return V2E_EHIP;
+            if (launch_emission(nEB - 1, (nEB - 1) * E, tail_f0 - (nEB - 1) * E)) return V2E_EHIP;
+        }
+        if (pl.emit_batch >= 0 && split_tail && pl.emit_batch == nEB - 1 && tail_f0 > (nEB - 1) * E) {
+            if (sc.record(EV_FORK, nEB, ST_MAIN)) return V2E_EHIP;
+            if (launch_emission(nEB, tail_f0, n_frames - tail_f0)) return V2E_EHIP;
+        } else if (pl.emit_batch >= 0) {
             if (sc.record(EV_FORK, pl.emit_batch, ST_MAIN)) return V2E_EHIP;
-            if (launch_emission(pl.emit_batch)) return V2E_EHIP;
+            if (launch_emission(pl.emit_batch, pl.emit_batch * E, std::min((pl.emit_batch + 1) * E, n_frames) - pl.emit_batch * E)) return V2E_EHIP;
         }
         if (!ahead_first && pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
     }
     if (!graph) { // join: the run is complete on `s` (a graph is complete when all its nodes are)
-        if (sc.wait(ST_MAIN, EV_JOIN, nEB - 1)) return V2E_EHIP;
-        if (!capturing && sc.wait(ST_MAIN, EV_TAB, nEB - 1)) return V2E_EHIP;
-        if (!capturing && nEB >= 2 && sc.wait(ST_MAIN, EV_JOIN, nEB - 2)) return V2E_EHIP;
+        if (sc.wait(ST_MAIN, EV_JOIN, last_slot)) return V2E_EHIP;
+        if (!capturing && sc.wait(ST_MAIN, EV_TAB, last_slot)) return V2E_EHIP;
+        if (!capturing && last_slot >= 1 && sc.wait(ST_MAIN, EV_JOIN, last_slot - 1)) return V2E_EHIP;
         if (!fused_rec && sc.wait(ST_MAIN, EV_AHEAD, nEB - 1)) return V2E_EHIP;
     }
     V2E_HIP(hipGetLastError());
