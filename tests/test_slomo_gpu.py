@@ -497,3 +497,39 @@ def test_operand_scaling_and_range_guard_of_the_two_piece_math():
     assert torch.equal(torch.nan_to_num(yb, nan=7.0), torch.nan_to_num(exact.forward(xb), nan=7.0))
     y2 = auto.forward(x)                # and the guard does not stick
     assert auto.fallbacks == 1 and torch.equal(y2, y)
+
+
+@pytest.mark.gpu
+def test_flow_started_ahead_on_the_side_stream_changes_nothing():
+    """SloMoEngine.interpolate(..., next_pair=): the next batch's flow UNet runs on the engine's side stream beside this batch's
+    interpolation UNet, and the range flags are read once per batch behind the fusion -- same kernels on the same inputs, so the
+    frames are bit-identical to the one-stream order; an unclaimed look-ahead is dropped; an inf in a batch whose flow was
+    started ahead still takes the exact split (both networks), as it does in line."""
+    from v2e_amd.slomo import SloMoEngine
+    from v2e_amd.synth import portable_unet_state_dict
+    sd_f = {k: torch.from_numpy(v) for k, v in portable_unet_state_dict(2, 4, 101).items()}
+    sd_i = {k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}
+    dev = torch.device("cuda")
+    eng = SloMoEngine(sd_f, sd_i, dev)
+    g = torch.Generator().manual_seed(21)
+    batches = [((torch.rand((2, 1, 64, 96), generator=g) - 0.428).to(dev), (torch.rand((2, 1, 64, 96), generator=g) - 0.428).to(dev))
+               for _ in range(3)]
+    ts = [0.25, 0.75]
+    ref = [eng.interpolate(a, b, ts).clone() for a, b in batches]
+    for i, (a, b) in enumerate(batches):
+        out = eng.interpolate(a, b, ts, next_pair=batches[i + 1] if i + 1 < len(batches) else None)
+        assert torch.equal(out, ref[i]), i
+    assert eng._ahead is None
+    eng.flow_ahead(*batches[0])                      # never claimed: the next call is for other tensors
+    assert torch.equal(eng.interpolate(*batches[1], ts), ref[1]) and eng._ahead is None
+    assert eng.flow_net.fallbacks == 0 and eng.interp_net.fallbacks == 0
+    bad = (batches[2][0].clone(), batches[2][1])
+    bad[0][1, 0, 5, 7] = float("inf")
+    want = eng.interpolate(bad[0], bad[1], ts).clone()
+    f0, i0 = eng.flow_net.fallbacks, eng.interp_net.fallbacks
+    assert f0 >= 1
+    eng.interpolate(*batches[0], ts, next_pair=bad)
+    got = eng.interpolate(bad[0], bad[1], ts)
+    assert eng.flow_net.fallbacks == 2 * f0 and eng.interp_net.fallbacks == 2 * i0
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(want, nan=7.0))
+    assert torch.equal(eng.interpolate(*batches[1], ts), ref[1])   # and nothing sticks

@@ -106,12 +106,14 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     I0 = torch.rand((B, 1, H, W), device=device, generator=g) - 0.428
     I1 = torch.rand((B, 1, H, W), device=device, generator=g) - 0.428
     ts = [(k + 0.5) / U for k in range(U)]
-    eng.interpolate(I0, I1, ts)  # warm-up (allocations)
+    # as SuperSloMo.interpolate runs its batches: the flow UNet of the NEXT batch is started (side stream) before this batch's
+    # interpolation UNet is enqueued -- every iteration still executes one flow pass and one interpolation pass
+    eng.interpolate(I0, I1, ts, next_pair=(I0, I1))  # warm-up (allocations)
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        eng.interpolate(I0, I1, ts)
+        eng.interpolate(I0, I1, ts, next_pair=(I0, I1))
     e1.record()
     torch.cuda.synchronize(device)
     sec = e0.elapsed_time(e1) * 1e-3 / iters

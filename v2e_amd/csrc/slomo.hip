@@ -738,6 +738,8 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
         // fewer LDS operand bytes per multiply than the 32 x 64 tile, bit-identical output, 4 % per forward (variant 18: off).
         // With half the multiplies of the three-piece math the matrix pipe is far from the rate at which four accumulator
         // chains x two waves per SIMD are slow (slomo_s3p.h), so the tile can keep two workgroups per CU.
+        // (64 x 128 register tiles -- CT 2, PT 4: half the LDS operand bytes per multiply again -- measured slower in round 4, at two
+        //  waves per SIMD (15 spilled registers) and at one with two operand sets: 128x160 803 -> 950 us, forward 17.7 -> 18.2 / 18.5 ms)
         if (ks == 3 && a.cout % 64 == 0 && variant != 18) {
             if (a.w_ % 32 == 0) return launch_conv_s3<3, 2, 2, 4, 32, 1, 0, 1, 2>(a, s);
             if (a.w_ % 16 == 0) return launch_conv_s3<3, 2, 2, 4, 16, 1, 0, 1, 2>(a, s);

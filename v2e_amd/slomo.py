@@ -116,8 +116,12 @@ class HipUNet:
             self.descs, self.descs_exact = descs_exact, None
         self._flag = torch.zeros(1, dtype=torch.int32, device=self.device) if self.descs_exact is not None else None
         self._ws = None
+        self._pending = None
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, defer_check=False):
+        """One forward pass on the current stream.  defer_check (conv_math 'auto'): do not read the range flag back now -- the
+        caller enqueues whatever follows and calls `redo_if_flagged()` afterwards (one host synchronisation per batch instead of
+        one per network; the flow UNet of a later batch can run on another stream meanwhile)."""
         import ctypes as C
         n, c, h, w = x.shape
         assert c == self.cin and x.dtype == torch.float32 and x.is_contiguous()
@@ -127,6 +131,7 @@ class HipUNet:
         if out is None:
             out = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._pending = None
         if self._flag is None:
             check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
                   "v2e_unet_forward")
@@ -141,11 +146,27 @@ class HipUNet:
                   "v2e_unet_forward")
         finally:
             self.lib.v2e_conv_set_range_flag(None)
-        if int(self._flag.item()) != 0:
-            self.fallbacks += 1
-            check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs_exact, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
-                  "v2e_unet_forward")
+        self._pending = (x, out)
+        if not defer_check:
+            self.redo_if_flagged()
         return out
+
+    def redo_if_flagged(self):
+        """Read the range flag of the last forward pass (on the CURRENT stream, which must be ordered behind that pass) and redo
+        the pass with the exact split if it was raised.  Returns True when it was redone (what consumed `out` must be redone too)."""
+        if self._pending is None:
+            return False
+        import ctypes as C
+        x, out = self._pending
+        self._pending = None
+        if int(self._flag.item()) == 0:
+            return False
+        self.fallbacks += 1
+        n, c, h, w = x.shape
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.v2e_unet_forward(_ptr(x), c, self.descs_exact, self.cout, _ptr(out), n, h, w, _ptr(self._ws), stream),
+              "v2e_unet_forward")
+        return True
 
 
 def time_coefficients(ts):
@@ -187,15 +208,52 @@ class SloMoEngine:
         self.interp_net = HipUNet(interp_state_dict, 12, 5, self.device, conv_math)
         self._x2 = None
         self._speed_bits = None
+        self._fstream = None
+        self._ahead = None  # (I0, I1, x, flow) of a flow pass started ahead on the side stream
 
     def _stream(self):
         import ctypes as C
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def flow(self, I0, I1):
-        """flowOut = flow_estimator(cat(I0, I1)) (slomo.py:343); I0, I1: [B,1,H,W] float32."""
+        """flowOut = flow_estimator(cat(I0, I1)) (slomo.py:343); I0, I1: [B,1,H,W] float32.  If `flow_ahead` was started for
+        exactly these two tensors, its result is taken (the current stream is ordered behind the side stream first)."""
+        la = self._ahead
+        if la is not None and la[0] is I0 and la[1] is I1:
+            self._ahead = None
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self._fstream)
+            la[3].record_stream(cur)
+            la[2].record_stream(cur)
+            self.flow_net.redo_if_flagged()  # (the pass ended long ago: no stall)
+            return la[3]
+        self._drop_ahead()
         x = torch.cat((I0, I1), dim=1).contiguous()  # 2 channels; the large concats are fused in-kernel
         return self.flow_net.forward(x)
+
+    def _drop_ahead(self):
+        """An unclaimed look-ahead pass: the flow UNet's workspace is its, so it finishes before the network runs again."""
+        if self._ahead is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._fstream)
+            self.flow_net._pending = None
+            self._ahead = None
+
+    def flow_ahead(self, I0, I1):
+        """Start the flow UNet of a LATER batch on the engine's side stream, behind what the current stream holds NOW (so: call it
+        before enqueuing the current batch's interpolation).  At the v2e batch size (8 pairs) the flow UNet is a chain of small
+        launches that leaves most of the chip idle -- 3 ms of a 21 ms batch; beside the previous batch's interpolation UNet it is
+        nearly free.  `flow(I0, I1)` with the same two tensors collects the result."""
+        self._drop_ahead()
+        if self._fstream is None:
+            # (a high-priority stream: its own hardware queue whatever else the process has created -- streams of one priority
+            #  share a few queues round-robin, and on the queue of the current stream the pass would simply run in line)
+            self._fstream = torch.cuda.Stream(self.device, priority=-1)
+        cur = torch.cuda.current_stream(self.device)
+        self._fstream.wait_stream(cur)
+        with torch.cuda.stream(self._fstream):
+            x = torch.cat((I0, I1), dim=1).contiguous()
+            f = self.flow_net.forward(x, defer_check=True)
+        self._ahead = (I0, I1, x, f)
 
     def max_speed(self, flow):
         """slomo.py:352-368: the largest flow magnitude (pixels per source frame) over the batch and both directions, reduced on
@@ -210,22 +268,29 @@ class SloMoEngine:
             return float("nan")
         return float(np.sqrt(np.array([bits], dtype=np.uint32).view(np.float32)[0]))
 
-    def interpolate(self, I0, I1, ts, flow=None):
-        """Ft_p for every t in ts and every pair in the batch: returns [len(ts), B, 1, H, W]."""
+    def interpolate(self, I0, I1, ts, flow=None, next_pair=None):
+        """Ft_p for every t in ts and every pair in the batch: returns [len(ts), B, 1, H, W].
+        next_pair = (I0, I1) of the batch the caller will pass NEXT (the same tensor objects): its flow UNet is started on the
+        side stream now and runs beside this batch's interpolation UNet (`flow_ahead`)."""
         B, _, H, W = I0.shape
-        I0 = I0.contiguous()
-        I1 = I1.contiguous()
+        I0 = I0 if I0.is_contiguous() else I0.contiguous()
+        I1 = I1 if I1.is_contiguous() else I1.contiguous()
         if flow is None:
             flow = self.flow(I0, I1)
+        if next_pair is not None:
+            self.flow_ahead(next_pair[0], next_pair[1])
         nt = len(ts)
         coef = torch.from_numpy(time_coefficients(ts)).to(self.device)
         x12 = torch.empty((nt * B, 12, H, W), dtype=torch.float32, device=self.device)
         check(self.lib.v2e_slomo_prep(_ptr(I0), _ptr(I1), _ptr(flow), _ptr(coef), nt, B, H, W, _ptr(x12), self._stream()),
               "v2e_slomo_prep")
-        intrp = self.interp_net.forward(x12)
         out = torch.empty((nt * B, 1, H, W), dtype=torch.float32, device=self.device)
-        check(self.lib.v2e_slomo_fuse(_ptr(I0), _ptr(I1), _ptr(x12), _ptr(intrp), _ptr(coef), nt, B, H, W, _ptr(out),
-                                      self._stream()), "v2e_slomo_fuse")
+        intrp = self.interp_net.forward(x12, defer_check=True)
+        for _ in range(2):  # the range flag is read behind the fusion: one host synchronisation per batch
+            check(self.lib.v2e_slomo_fuse(_ptr(I0), _ptr(I1), _ptr(x12), _ptr(intrp), _ptr(coef), nt, B, H, W, _ptr(out),
+                                          self._stream()), "v2e_slomo_fuse")
+            if not self.interp_net.redo_if_flagged():
+                break
         self.last = dict(flow=flow, x12=x12, intrp=intrp)
         return out.view(nt, B, 1, H, W)
 
@@ -405,11 +470,17 @@ class SuperSloMo(object):
         nUpsamplingSamples = 0
         interpTimes = None
         dev = self.engine.device
-        for b0 in range(0, npairs, self.batch_size):
+        def load_batch(b0):
             idxs = list(range(b0, min(b0 + self.batch_size, npairs)))
             pairs = [self._load_pair_tensor(files, i, dim) for i in idxs]
-            I0 = (torch.stack([p[0] for p in pairs]) - self.mean).to(dev)
-            I1 = (torch.stack([p[1] for p in pairs]) - self.mean).to(dev)
+            return ((torch.stack([p[0] for p in pairs]) - self.mean).to(dev).contiguous(),
+                    (torch.stack([p[1] for p in pairs]) - self.mean).to(dev).contiguous())
+        starts = list(range(0, npairs, self.batch_size))
+        nxt = load_batch(starts[0])
+        for bi, b0 in enumerate(starts):
+            # the next batch is loaded first: its flow UNet runs beside this batch's interpolation UNet (SloMoEngine.flow_ahead)
+            I0, I1 = nxt
+            nxt = load_batch(starts[bi + 1]) if bi + 1 < len(starts) else None
             num_batch_frames = I0.shape[0]
             flowOut = self.engine.flow(I0, I1)
             if self.auto_upsample:  # slomo.py:352-379
@@ -427,7 +498,7 @@ class SuperSloMo(object):
             interframeTimes = inputFrameCounter + np.array(range(numOutputFramesThisBatch)) * (1 / upsampling_factor)
             interpTimes = interframeTimes if interpTimes is None else np.concatenate((interpTimes, interframeTimes))
             ts = [(k + 0.5) / upsampling_factor for k in range(upsampling_factor)]  # slomo.py:405
-            Ft = self.engine.interpolate(I0, I1, ts, flow=flowOut)  # [U,B,1,H,W]
+            Ft = self.engine.interpolate(I0, I1, ts, flow=flowOut, next_pair=nxt)  # [U,B,1,H,W]
             # ToPILImage after revNormalize (slomo.py:153-161, 437): (x + mean) * 255 -> byte, the CPU conversion the
             # reference performs (truncation, low byte): same kernel as the PNG-free pipeline uses
             import ctypes as C
