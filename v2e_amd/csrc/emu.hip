@@ -1906,7 +1906,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         CEmitArgs ea;
         memset(&ea, 0, sizeof(ea));
         ea.ctl = h->run_ctl; ea.recs = recs; ea.fidx_base = h->run_fidx;
-        ea.f0 = ef0; ea.nE = enE; ea.D = D; ea.n_clips = NC;
+        ea.f0 = ef0; ea.nE = enE; ea.D = D; ea.n_clips = NC; ea.slot0 = ef0 % D;
         ea.nwp = h->ch_nwp; ea.nwaves = chain_egroups(h); ea.E = E; // emission groups (GROUP_PX pixels, one wave each)
         ea.cnt = h->ch_cnt; ea.tsold = has_refr ? h->ch_tsold : nullptr; ea.ruleM = has_refr ? h->ch_ruleM : nullptr;
         const size_t set = (size_t)(b % NSET) * E * NC; // table set of this batch
@@ -1980,7 +1980,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
             memset(&aa, 0, sizeof(aa));
             aa.frames = frames; aa.frame_stride = (unsigned long long)NC * h->npx * esz;
             aa.ctl = h->run_ctl; aa.fidx_base = h->run_fidx;
-            aa.f0 = f0; aa.nf = f1 - f0; aa.D = D; aa.n_clips = NC;
+            aa.f0 = f0; aa.nf = f1 - f0; aa.D = D; aa.n_clips = NC; aa.slot0 = f0 % D;
             aa.rec = h->ch_rec;
             aa.ppt = ppt_env > 0 ? ppt_env : 1;
             void *args[] = {(void *)&a, (void *)&aa};
@@ -2017,6 +2017,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.ctl = h->run_ctl;
         ca.f0 = pl.f0; ca.nf = pl.nf; ca.pf0 = pl.pf0; ca.pnf = pl.pnf;
         ca.D = D; ca.n_clips = NC; ca.K = K; ca.ngroups = h->ngroups;
+        ca.slot_f0 = pl.f0 % D; ca.slot_pf0 = pl.pf0 % D;
         ca.cnt = h->ch_cnt; ca.ruleM = h->ch_ruleM; ca.tsold = has_refr ? h->ch_tsold : nullptr;
         ca.rec = h->ch_rec;
         if (has_refr) {

@@ -139,6 +139,7 @@ struct ChainArgs {
     int f0, nf;                       // this launch advances frames [f0, f0 + nf) of the run (nf = 0: tail launch)
     int pf0, pnf;                     // the previous launch's frames, to be validated (pnf = 0: nothing to validate)
     int D, n_clips, K, ngroups;
+    int slot_f0, slot_pf0;            // f0 % D, pf0 % D from the host (the ring slot of frame fs + k is slot(fs) + k, wrapped: K <= D)
     uint32_t *cnt;                    // [D][n_clips][npx_pad] count words, slot = frame % D
     uint32_t *ruleM;                  // [D][n_clips] M of a frame finalised by the refractory rule, 0 otherwise
     float *tsold;                     // [D][n_clips][npx_pad] ts_mem before a rule-on frame's update, or nullptr
@@ -229,6 +230,7 @@ struct AheadArgs {
     const FrameCtl *ctl;
     const uint32_t *fidx_base;
     int f0, nf, D, n_clips;
+    int slot0;  // f0 % D, from the host (a 64-bit remainder per frame and thread is ~60 instructions of a kernel that has 240)
     int ppt;    // frame pairs per thread (grid z = ceil(pairs / ppt))
     uint4 *rec; // [D][n_clips][npx_pad]
 };
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
     for (int zz = 0; zz < aa.ppt; ++zz) {
         // pair z of the launch: global frames 2q-1 (odd) and 2q (even), q = pair of the launch's first frame + z
         const uint32_t q = v2e_frame_pair(fbase + (uint32_t)aa.f0) + blockIdx.z * (uint32_t)aa.ppt + (uint32_t)zz;
-        const long long f_odd = 2ll * q - 1 - (long long)fbase; // run-relative
+        const int f_odd = (int)(2u * q - 1u - fbase); // run-relative (frame f0 - 1 at the earliest: the pair that holds frame f0)
         const bool in0 = f_odd >= aa.f0 && f_odd < aa.f0 + aa.nf, in1 = f_odd + 1 >= aa.f0 && f_odd + 1 < aa.f0 + aa.nf;
         if (!in0 && !in1) continue;
         float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f;
@@ -265,12 +267,14 @@ __global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (!(half ? in1 : in0)) continue;
-            const long long f = f_odd + half;
+            const int f = f_odd + half;
+            int sl = aa.slot0 + (f - aa.f0); // ring slot f % D (nf <= D)
+            if (sl >= aa.D) sl -= aa.D;
             const FrameCtl *c = aa.ctl + (size_t)f * aa.n_clips + clip;
             const FT px = ((const FT *)((const char *)aa.frames + (size_t)f * aa.frame_stride))[(size_t)clip * a.npx + p];
             const uint4 r = make_frame_record<FT>(a, px, s_lutL, s_lutI, c->dt_over_tau, c->shot_base, (float)(c->t_frame - c->t_prev), lk, thp,
                                                   ppre, npre, half ? r_even : r_odd, half ? u_even : u_odd);
-            aa.rec[((size_t)(f % aa.D) * aa.n_clips + clip) * a.npx_pad + p] = r;
+            aa.rec[((size_t)sl * aa.n_clips + clip) * a.npx_pad + p] = r;
         }
     }
 }
@@ -340,10 +344,12 @@ void k_chain(KArgs a_in, ChainArgs ca)
         // A pass's records go through LDS, CHAIN_SUB frames at a time, their loads in flight at once.  The next CHAIN_SUB
         // frames' records are fetched into registers BEFORE the current ones are processed and moved to LDS after them.
         // Every thread reads back only what it wrote: no barrier.
-        auto stage = [&](const int fs, const int fn) __attribute__((always_inline)) { // the first CHAIN_SUB frames of a pass
+        // ring slot of a pass's frame k: the slot of its first frame (from the host: no division in the kernel) + k, wrapped (K <= D)
+        auto wrap_slot = [&](const int sl) __attribute__((always_inline)) -> int { return sl >= ca.D ? sl - ca.D : sl; };
+        auto stage = [&](const int sl0, const int fn) __attribute__((always_inline)) { // the first CHAIN_SUB frames of a pass (sl0: the first one's slot)
             if (FUSED || !valid) return;
             uint4 t[CHAIN_SUB];
-            int sl = fs % ca.D;
+            int sl = sl0;
 #pragma unroll
             for (int j = 0; j < CHAIN_SUB; ++j) {
                 t[j] = make_uint4(0u, 0u, 0u, 0u);
@@ -397,7 +403,7 @@ void k_chain(KArgs a_in, ChainArgs ca)
             dtime_r = (float)(c->t_frame - c->t_prev);
         }
         if (FUSED && valid && a.do_leak) nr = a.noise_rate[sp];
-        stage(ca.f0, ca.nf); // this launch's own frames (almost always the only pass)
+        stage(ca.slot_f0, ca.nf); // this launch's own frames (almost always the only pass)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(b), "+v"(lp), "+v"(tsm), "+v"(thp), "+v"(thn), "+v"(gM_v), "+v"(mon_own), "+v"(mon_prev) : : "memory");
         if (FUSED) {
             if (tid < CHAIN_K_MAX) {
@@ -475,9 +481,10 @@ void k_chain(KArgs a_in, ChainArgs ca)
             }
             if (own) { fs = ca.f0; fn = ca.nf; gM_dst = ca.gM_cur + (size_t)clip * ca.K; c0 = 0; }
             else { fs = ca.pf0; fn = ca.pnf; gM_dst = ca.gM_prev + ((size_t)round * ca.n_clips + clip) * ca.K; }
+            const int fs_slot = own ? ca.slot_f0 : ca.slot_pf0;
             if (redone) { // a redo pass, or the own pass after one: its inputs replace what the prologue staged
                 fill_scalars(fs, fn);
-                stage(fs + c0, fn - c0);
+                stage(wrap_slot(fs_slot + c0), fn - c0);
             }
             const uint32_t mon_v = own ? mon_own : mon_prev;
             // checkpoints of this pass go to the set of the launch whose frames it runs
@@ -588,7 +595,7 @@ void k_chain(KArgs a_in, ChainArgs ca)
             uint4 nx[CHAIN_SUB];
             auto fetch_next = [&](const int kn) __attribute__((always_inline)) {
                 const int cn = min(CHAIN_SUB, fn - kn); // <= 0: none
-                int sl = cn > 0 ? (fs + kn) % ca.D : 0;
+                int sl = cn > 0 ? wrap_slot(fs_slot + kn) : 0;
 #pragma unroll
                 for (int j = 0; j < CHAIN_SUB; ++j) {
                     nx[j] = make_uint4(0u, 0u, 0u, 0u);
@@ -606,7 +613,7 @@ void k_chain(KArgs a_in, ChainArgs ca)
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const int kend = min(k0 + CHAIN_SUB, fn);
-                const int slot0 = (fs + k0) % ca.D;
+                const int slot0 = wrap_slot(fs_slot + k0);
                 slot = slot0;
                 // the record of frame k + 1 is read from LDS while frame k computes
                 uint4 rc_cur = make_uint4(0u, 0u, 0u, 0u);
@@ -673,6 +680,7 @@ struct CEmitArgs {
     v2e_frame_rec *recs;
     const uint32_t *fidx_base;
     int f0, nE, D, n_clips, nwp, nwaves, E;
+    int slot0;           // f0 % D, from the host
     const uint32_t *cnt;
     const uint32_t *ruleM; // [D][n_clips] (refractory runs) or nullptr
     uint16_t *wmax;      // [E][n_clips][nwp] per-group max count (k_ctot); nwaves = groups of 256 pixels, nwp = that padded to 16
@@ -724,7 +732,8 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
     uint32_t cwq[CTOT_ZF][GPX], rMq[CTOT_ZF];
     int slotq[CTOT_ZF];
     {
-        int sl = (ea.f0 + zb) % ea.D;
+        int sl = ea.slot0 + zb; // nE <= D
+        if (sl >= ea.D) sl -= ea.D;
 #pragma unroll
         for (int q = 0; q < CTOT_ZF; ++q) {
             slotq[q] = sl;
@@ -1097,7 +1106,8 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
 {
     extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw]
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z, slot = fe % ea.D;
+    const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z;
+    const int slot = ea.slot0 + z >= ea.D ? ea.slot0 + z - ea.D : ea.slot0 + z; // nE <= D
     const int grp = blockIdx.x * (BLOCK / WAVE) + wave;
     if (grp >= ea.nwaves) return;
     const size_t zc = (size_t)z * ea.n_clips + clip;
