@@ -16,7 +16,8 @@ for m in maths:
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5): net.forward(x)
+    IT = int(os.environ.get('ITERS', '5'))
+    for _ in range(IT): net.forward(x)
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
+    ms = e0.elapsed_time(e1) / IT
     print("%s %s n=%d: %.3f ms, %.1f TF f32-equivalent" % (os.environ.get("TAG", ""), m, n, ms, n * unet_flops(12, 5, 256, 320) / ms / 1e9))

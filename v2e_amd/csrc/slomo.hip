@@ -750,6 +750,10 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
             if (a.w_ % 32 == 0) return launch_conv_s3<3, 1, 2, 4, 32, 1, 0, 0, 2>(a, s);
             if (a.w_ % 16 == 0) return launch_conv_s3<3, 1, 2, 4, 16, 1, 0, 0, 2>(a, s);
             if (a.w_ % 8 == 0) return launch_conv_s3<3, 1, 2, 4, 8, 1, 0, 0, 2>(a, s);
+            // 20-wide levels of 16 rows (the 16 x 20 level of a 320 x 256 input): one whole sample per five-wave workgroup, two pixel
+            // tiles per wave -- a weight operand read from LDS feeds two multiplies instead of one (forward 18.33 -> 18.09 ms, A/B x 3; variant 24:
+            // the 8 x 20 tiles of round 3; 64 output channels per workgroup on top of it measured slower, 18.46)
+            if (a.w_ % 20 == 0 && a.h % 16 == 0 && variant != 24) return launch_conv_s3<3, 1, 2, 5, 20, 1, 0, 0, 2>(a, s);
             if (a.w_ % 20 == 0 && a.h % 8 == 0) return launch_conv_s3<3, 1, 1, 5, 20, 1, 0, 0, 2>(a, s);
             if (a.w_ == 10 && a.h <= 16) return launch_conv_s3<3, 1, 1, 5, 10, 1, 0, 0, 2>(a, s); // the 8 x 10 level: half of a 16-row tile masked
             return 1;
@@ -776,6 +780,7 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
         }
         if (a.w_ % 16 == 0) return c64 ? launch_conv_s3<3, 2, 2, 4, 16>(a, s) : (variant == 7 ? launch_conv_s3<3, 1, 2, 4, 16, 2>(a, s) : launch_conv_s3<3, 1, 2, 4, 16>(a, s));
         if (a.w_ % 8 == 0) return c64 ? launch_conv_s3<3, 2, 2, 4, 8>(a, s) : (variant == 7 ? launch_conv_s3<3, 1, 2, 4, 8, 2>(a, s) : launch_conv_s3<3, 1, 2, 4, 8>(a, s));
+        // (the 16 x 20 tile of the two-piece math measured slower here: 26.4 -> 27.0 ms per forward)
         if (a.w_ % 20 == 0 && a.h % 8 == 0) return c64 ? launch_conv_s3<3, 2, 1, 5, 20>(a, s) : launch_conv_s3<3, 1, 1, 5, 20>(a, s);
         // the 8 x 10 level: a 16 x 10 tile with its lower half masked is still 1.5x the f32 matrix-core kernel's two stacked samples
         if (a.w_ == 10 && a.h <= 16 && variant != 13) return launch_conv_s3<3, 1, 1, 5, 10>(a, s);
