@@ -533,3 +533,27 @@ def test_flow_started_ahead_on_the_side_stream_changes_nothing():
     assert eng.flow_net.fallbacks == 2 * f0 and eng.interp_net.fallbacks == 2 * i0
     assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(want, nan=7.0))
     assert torch.equal(eng.interpolate(*batches[1], ts), ref[1])   # and nothing sticks
+
+
+@pytest.mark.gpu
+def test_pooled_copy_from_the_convolution_epilogue_equals_the_pooling_pass(tmp_path):
+    """conv2 and down1.conv2 leave avg_pool2d(2) of their output beside it (slomo_s3.h epilogue: the window is two registers of a
+    lane and of its neighbour lane, added in k_avgpool2's order); V2E_AMD_FUSE_POOL=0 restores the separate pooling passes.  Same
+    numbers either way, in every conv math that has the tiles (and trivially in f32, which never takes the request)."""
+    import subprocess, sys, os
+    code = (
+        "import sys, numpy as np, torch\n"
+        "from v2e_amd.slomo import HipUNet\n"
+        "from v2e_amd.synth import portable_unet_state_dict\n"
+        "sd = {k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "x = (torch.rand((3, 12, 64, 96), generator=g) - 0.4).cuda()\n"
+        "np.savez(sys.argv[1], **{m: HipUNet(sd, 12, 5, torch.device('cuda'), m).forward(x).cpu().numpy() for m in ('auto', 'bf16x3', 'f32')})\n")
+    outs = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, V2E_AMD_FUSE_POOL=flag, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        path = str(tmp_path / ("pool%s.npz" % flag))
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+        outs[flag] = np.load(path)
+    for m in ("auto", "bf16x3", "f32"):
+        assert np.array_equal(outs["1"][m], outs["0"][m]), m

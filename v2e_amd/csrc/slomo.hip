@@ -46,6 +46,9 @@ struct ConvArgs {
     // layer's activations are, nothing overflows however large; the epilogue divides the power out again (exact).
     const uint32_t *am_in0, *am_in1;
     uint32_t *am_out;
+    // avg_pool2d(2) of the output, written beside it by the epilogue ([n][cout][h/2][w/2]; k_conv_s3 tiles of 32-pixel rows, two
+    // rows per wave: the 2 x 2 window is two registers of a lane and its neighbour lane), or nullptr
+    float *ypool;
 };
 
 // |v| folded into a running maximum kept as float32 bits: one v_max_f32 with the |.| source modifier.  Non-negative floats and
@@ -99,6 +102,8 @@ __device__ __forceinline__ void act_scale(const ConvArgs &a, float &in_scale, fl
 // where v2e_unet_forward hands the next convolution its range slots (per host thread; all null outside a forward pass)
 static thread_local const uint32_t *g_am_in0 = nullptr, *g_am_in1 = nullptr;
 static thread_local uint32_t *g_am_out = nullptr;
+// v2e_unet_forward asks the next convolution to write its avg_pool2d(2) too; the launcher that can do it clears the request
+static thread_local float *g_pool_out = nullptr;
 
 // where the two-float16-piece convolutions report an activation beyond float16's range (v2e_conv_set_range_flag), or nullptr
 static thread_local int *g_conv_range_flag = nullptr;
@@ -865,7 +870,7 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
         a.n = n; a.h = h; a.w_ = w; a.cin = conv->cin; a.cout = conv->cout; a.tiles_x = a.tiles_y = 0;
         V2E_REQUIRE((conv->split_kind & 0xFF) != 2, "pre-split input is three bf16 pieces");
         a.ws3 = conv->weight_s3; a.xs_plane = (long long)n * (c0 / 8) * h * w; a.np = 3; a.tl_on = 0; a.out_scale = 1.0f; a.ovf = nullptr;
-        a.am_in0 = a.am_in1 = nullptr; a.am_out = g_am_out;
+        a.am_in0 = a.am_in1 = nullptr; a.am_out = g_am_out; a.ypool = nullptr;
         const int r3 = conv_dispatch_s3_presplit(a, conv->ksize, (hipStream_t)stream);
         V2E_REQUIRE(r3 == 0, "no pre-split tile for this layer shape");
         V2E_HIP(hipGetLastError());
@@ -890,7 +895,7 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     a.out_scale = ldexpf(1.0f, -(conv->split_kind >> 8));
     a.ovf = g_conv_range_flag;
     a.tl_on = 0;
-    a.am_in0 = g_am_in0; a.am_in1 = g_am_in1; a.am_out = g_am_out;
+    a.am_in0 = g_am_in0; a.am_in1 = g_am_in1; a.am_out = g_am_out; a.ypool = nullptr;
     if (conv->ksize == 3 && pre == 0 && c1 == 0 && (conv->cout == 4 || conv->cout == 5)) {
         const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;
         dim3 grid((unsigned)(n * tiles_x * tiles_y));
@@ -943,7 +948,7 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     uint32_t *am = (uint32_t *)(tU + n * hw * 64);
     bool track = false;
     for (int i = 0; i < 23; ++i) track = track || ((cv[i].split_kind & 0xFF) == 2 && cv[i].weight_s3);
-    struct AmReset { ~AmReset() { g_am_in0 = g_am_in1 = nullptr; g_am_out = nullptr; } } am_reset;
+    struct AmReset { ~AmReset() { g_am_in0 = g_am_in1 = nullptr; g_am_out = nullptr; g_pool_out = nullptr; } } am_reset;
     if (track) {
         k_zero_u32<<<1, 64, 0, st>>>(am, 32);
         const long long nx = (long long)n * cin * hw;
@@ -957,6 +962,7 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
         if (rc) return rc;                                                                      \
         am_src0 = 1 + (IDX);                                                                    \
     } while (0)
+    static const int fuse_pool = getenv("V2E_AMD_FUSE_POOL") ? atoi(getenv("V2E_AMD_FUSE_POOL")) : 0;
     int am_src0 = 0, am_src1 = 0; // slots of the producers of the next convolution's x0 / x1
     // producer ops as their own streaming passes: measured faster than fusing them into the conv
     // loader (the fused bilinear fetch costs 4 gathers + address math per staged element)
@@ -972,12 +978,21 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     } while (0)
     // conv1, conv2
     CONV(x, cin, nullptr, 0, 0, 0, tA, h, w);
-    CONV(tA, 32, nullptr, 0, 0, 1, s1, h, w);
+    // V2E_AMD_FUSE_POOL=1: the pooled copy of a skip tensor comes out of the producing convolution's epilogue where its tile allows
+    // (the two largest of the five poolings: 0.28 of the 0.33 ms the pooling passes take at 80 samples).  Built and bit-identical
+    // (tests/test_slomo_gpu.py), measured round 4, A/B x 3 at 80 samples: 17.83 ms fused against 17.80 ms with the separate
+    // passes (bf16x3: 26.30 both) -- the convolutions are at the chip's power limit, and what the epilogue adds costs what the
+    // streaming pass did.  Off by default.
+#define CONV_POOLED(X0, C0, IDX, Y, CO, HH, WW) /* Y = conv(X0) at (HH, WW); tU = avg_pool2d(Y, 2) */ \
+    do {                                                                                             \
+        g_pool_out = fuse_pool ? tU : nullptr;                                                       \
+        CONV((X0), (C0), nullptr, 0, 0, (IDX), (Y), (HH), (WW));                                     \
+        if (g_pool_out || !fuse_pool) { g_pool_out = nullptr; POOL((Y), (CO), (HH) / 2, (WW) / 2); } /* not taken: its own pass */ \
+    } while (0)
+    CONV_POOLED(tA, 32, 1, s1, 32, h, w);
     // down1..down5
-    POOL(s1, 32, h / 2, w / 2);
     CONV(tU, 32, nullptr, 0, 0, 2, tA, h / 2, w / 2);
-    CONV(tA, 64, nullptr, 0, 0, 3, s2, h / 2, w / 2);
-    POOL(s2, 64, h / 4, w / 4);
+    CONV_POOLED(tA, 64, 3, s2, 64, h / 2, w / 2);
     CONV(tU, 64, nullptr, 0, 0, 4, tA, h / 4, w / 4);
     CONV(tA, 128, nullptr, 0, 0, 5, s3, h / 4, w / 4);
     POOL(s3, 128, h / 8, w / 8);
@@ -991,7 +1006,6 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     CONV(tA, 512, nullptr, 0, 0, 11, tB, h / 32, w / 32);
     // up1..up5: skip concat fused into conv2 (x first, skip second)
     static const int fuse_up = getenv("V2E_AMD_FUSE_UP") ? atoi(getenv("V2E_AMD_FUSE_UP")) : 0; // dev: bit u-1 = fuse the bilinear x2 of up<u> into its conv loader
-    static const int fuse_pool = getenv("V2E_AMD_FUSE_POOL") ? atoi(getenv("V2E_AMD_FUSE_POOL")) : 0;
 #define UPCONV(U, X, C, IDX, Y, HH, WW)                                                    \
     do {                                                                                    \
         if (fuse_up & (1 << ((U) - 1))) CONV((X), (C), nullptr, 0, 2, (IDX), (Y), (HH), (WW)); \
@@ -1015,6 +1029,7 @@ int v2e_unet_forward(const float *x, int cin, const v2e_conv_desc *cv, int cout,
     // conv3 (+ leaky relu, model.py:225)
     CONV(tB, 32, nullptr, 0, 0, 22, y, h, w);
 #undef UPCONV
+#undef CONV_POOLED
 #undef POOL
 #undef UPS
 #undef CONV

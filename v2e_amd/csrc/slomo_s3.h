@@ -422,6 +422,34 @@ void k_conv_s3(ConvArgs a)
         }
     }
     if (a.am_out) amax_commit(a.am_out, omax);
+    // avg_pool2d(2) of what was just written (model.py:96: the next block's input), in k_avgpool2's order of additions:
+    // ((row0[x] + row0[x + 1]) + row1[x]) + row1[x + 1], times 0.25.  A wave of these tiles holds rows 2 wave, 2 wave + 1 of the
+    // tile (pt 0 / 1), a lane one pixel of each: the window is the lane's two registers and its odd neighbour's.
+    if constexpr (TW == 32 && PT == 2 && (WP * PT) % 2 == 0) {
+        if (a.ypool) {
+            const int oy = oy0 + wave * 2, ox = ox0 + l31; // row of pt 0 (even), this lane's column
+            const int ph = a.h >> 1, pw = a.w_ >> 1;
+            const bool st = (l31 & 1) == 0 && oy + 1 < a.h && ox + 1 < a.w_;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = cobase + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                    float v[2];
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) { // the stored value, recomputed from the accumulator (same operations)
+                        float sacc = acc[ct][pt][r];
+                        if constexpr (NP == 2) sacc *= os1;
+                        float t = sacc + a.bias[ch];
+                        v[pt] = t > 0.f ? t : t * 0.1f;
+                    }
+                    const float n0 = __shfl_xor(v[0], 1), n1 = __shfl_xor(v[1], 1);
+                    const float o = (((v[0] + n0) + v[1]) + n1) * 0.25f;
+                    if (st) a.ypool[(((size_t)n * a.cout + ch) * ph + (oy >> 1)) * pw + (ox >> 1)] = o;
+                }
+            }
+        }
+    }
 }
 
 template <int KS, int CT, int PT, int WP, int TW, int NB = 1, int MODE = 0, int RG = 0, int NP = 3>
@@ -432,6 +460,8 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     constexpr int PP = (TH + KS - 1) * (TW + KS - 1);
     constexpr int G = (KS == 3 && !RG) ? 9 : KS;
     constexpr size_t lds = (size_t)(2 * NP * PP + G * 2 * NP * CT * 32) * 16;
+    a.ypool = nullptr;
+    if (TW == 32 && PT == 2 && g_pool_out && a.h % 2 == 0 && a.w_ % 2 == 0) { a.ypool = g_pool_out; g_pool_out = nullptr; } // taken
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set = false; // one per instantiation
     if (!attr_set) {
