@@ -48,6 +48,7 @@ PMC_FILES = ("r04_emulator_pmc_hbm.txt", "r03_emulator_pmc_hbm.txt")
 TRACE_FILES = ("r04_emulator_chain_kernel_trace.txt", "r03_emulator_chain_kernel_trace.txt")
 SQ_FILES = ("r04_emulator_sq.txt",)
 F32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: f32-input MFMA peak
+INSTR_STEPS = 6           # steps re-run instrumented for the live per-launch kernel times of the roofline object
 CLIP_STEPS = 24           # distinct seconds of synthetic video generated; longer runs cycle through them
 
 
@@ -447,33 +448,50 @@ def main():
         eng = emu._engine
         P = emu._params()
         buf = torch.empty((F, H, W), dtype=torch.uint8, device=device)
-        lo = 1 + ((Wm + K - 1) % CLIP_STEPS) * F
-        buf.copy_(frames_all[lo:lo + F])
-        # re-run one step's frames instrumented (state keeps advancing; timing only)
-        t_prev = [emu.t_previous + i * DT for i in range(F)]
-        t_frame = [emu.t_previous + (i + 1) * DT for i in range(F)]
+        # re-run the frames of INSTR_STEPS steps instrumented (state keeps advancing; timing only).  Several steps, because the
+        # launches that first redo their predecessor are few and uneven (one step of the clip holds a 245 us launch, others
+        # none above 70): the average over one step says little
         ev = eng.event_buffer(1)
         recs = eng.alloc_recs(F)
-        eng.run(P, buf, t_prev, t_frame, emu.frame_counter, ev, recs, use_graph=2)
-        prof = eng.last_profile()
+        prof, per_launch_all, evs = None, [], []
+        for si in range(INSTR_STEPS):
+            lo = 1 + ((Wm + K - 1 + si) % CLIP_STEPS) * F
+            buf.copy_(frames_all[lo:lo + F])
+            t0s = emu.t_previous + si * F * DT
+            t_prev = [t0s + i * DT for i in range(F)]
+            t_frame = [t0s + (i + 1) * DT for i in range(F)]
+            eng.run(P, buf, t_prev, t_frame, emu.frame_counter + si * F, ev, recs, use_graph=2)
+            pr = eng.last_profile()
+            per_launch_all += list(pr.get("chain_launch_us", []))
+            evs.append(float(eng.recs_to_numpy(recs)[:, 0]["n_events"].mean()))
+            if prof is None:
+                prof = dict(pr)
+            else:
+                for key in ("rank", "emit"):
+                    prof[key] += pr[key]
+                for key in ("step_launches", "emit_batches"):
+                    if key in pr:
+                        prof[key] = prof.get(key, 0) + pr[key]
+        prof["chain_launch_us"] = per_launch_all
         kname, fpl, fpb = eng.last_pipeline()
-        r = eng.recs_to_numpy(recs)[:, 0]
-        ev_per_frame = float(r["n_events"].mean())
+        ev_per_frame = float(np.mean(evs))
         npx = H * W
         # The dependency chain owns the per-pixel state traffic: SURVEY 8(d) prices a frame at 53 B/pixel (frame 1 + lp 16 +
         # base 16 + thresholds 8 + noise rate 4 + ts_mem 8) + 16 B/event; the chain kernel also writes the 4-byte count word the
         # event writer reads.  A launch covers `fpl` frames.
-        n_step = max(prof.get("step_launches", 0), 1)
-        period_us = elapsed / K / n_step * 1e6     # the driver-timed region: one step = n_step chain launches
+        n_step = max(prof.get("step_launches", 0), 1)   # chain launches of the instrumented steps
+        n_per_step = n_step / INSTR_STEPS
+        period_us = elapsed / K / n_per_step * 1e6  # the driver-timed region: one step = n_per_step chain launches
         kernel_us = prof["rank"] / n_step * 1e3    # HIP events before and after every chain launch, on its stream: the kernels alone
         # 53 B per pixel and frame x the frames a launch advances ON AVERAGE: a step's launches are full ones (fpl
         # frames), one partial one and the tail launch that only validates, and all of them are in the average duration
-        step_bytes = bpp * npx * F / n_step
+        step_bytes = bpp * npx * F / n_per_step
         full_bytes = bpp * npx * fpl
         emit_bytes = 16 * ev_per_frame + 4 * npx
         ach = step_bytes / (kernel_us * 1e-6)
         per_launch = prof.get("chain_launch_us", [])
-        full = sorted(per_launch[:F // fpl])       # the launches that advance fpl frames (the partial and the tail one excluded)
+        nps = int(round(n_per_step))
+        full = sorted(u for i, u in enumerate(per_launch) if i % nps < F // fpl)  # the launches that advance fpl frames (the partial and the tail one excluded)
         p50 = full[len(full) // 2] if full else None
         whole = (bpp * npx + 16 * ev_per_frame)
         traffic, prof_file = pmc_traffic_per_launch(kname.split("(")[0])
@@ -486,7 +504,7 @@ def main():
             "traffic_source": str(prof_file) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; counters cannot be read "
                                           "from inside the process)",
             "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
-            "frames_per_launch_avg": round(F / n_step, 2),
+            "frames_per_launch_avg": round(F / n_per_step, 2),
             "avg_kernel_us": round(kernel_us, 3), "launches_timed": n_step,
             "launch_us": [round(u, 1) for u in per_launch],
             "median_full_launch": None if p50 is None else {
@@ -509,12 +527,12 @@ def main():
                            "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
             "note": "achieved = algorithmic bytes (53 B x pixels x the step's frames / the step's chain launches: what a launch advances "
                     "on average) / the launches' average duration, HIP events before and after every launch of an instrumented re-run "
-                    "of the last step's frames with all kernels of the run on ONE stream, i.e. each running alone (in the timed runs "
+                    "of %d steps' frames with all kernels of the run on ONE stream, i.e. each running alone (in the timed runs "
                     "the three streams overlap and every kernel is stretched: profiles/r03_graph_scheduling.txt); "
                     "instruction_issue states the fraction of the resource that actually binds this pipeline; "
                     "the per-pixel state (2.9 MB at 346x260) stays in registers for the launch's frames and one frame is only "
                     "1408 waves, so the chain is bounded by instruction latency, not HBM (DESIGN.md section 3); whole_step prices "
-                    "the complete frame (state traffic + event rows) against the driver-timed region",
+                    "the complete frame (state traffic + event rows) against the driver-timed region" % INSTR_STEPS,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())
