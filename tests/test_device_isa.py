@@ -1,0 +1,45 @@
+"""The device code of libv2e_amd.so holds no packed-float32 VALU instruction.
+
+Round 4 (scripts/concurrency_repro.py): on the MI355X a kernel doing packed-float32 math (v_pk_mul_f32 /
+v_pk_add_f32 / v_pk_fma_f32 -- what the compiler's SLP vectoriser makes of adjacent scalar float32 operations) returned values rounded
+to about bf16 / float16 precision while a bf16 / f16 MFMA kernel of another stream shared its CUs.  The library is built with
+-fno-slp-vectorize (v2e_amd/csrc/Makefile); this test disassembles what was built, so that the flag cannot be lost silently."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _device_disassembly(tmp_path):
+    so = os.path.join(ROOT, "v2e_amd", "csrc", "libv2e_amd.so")
+    objcopy, bundler, objdump = (os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"))
+    if not (os.path.isfile(so) and all(os.path.isfile(t) for t in (objcopy, bundler, objdump))):
+        pytest.skip("libv2e_amd.so or the LLVM binary tools are not here")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([objcopy, "-O", "binary", "--only-section=.hip_fatbin", so, fat], check=True)
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    assert starts, "no offload bundle in .hip_fatbin"
+    text = []
+    for i, a in enumerate(starts):  # one bundle per translation unit
+        part = str(tmp_path / ("bundle%d.bin" % i))
+        with open(part, "wb") as f:
+            f.write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        elf = str(tmp_path / ("co%d.elf" % i))
+        subprocess.run([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part,
+                        "--output=" + elf], check=True)
+        text.append(subprocess.run([objdump, "-d", elf], check=True, capture_output=True, text=True).stdout)
+    return "\n".join(text)
+
+
+def test_no_packed_float32_instructions_in_the_device_code(tmp_path):
+    dis = _device_disassembly(tmp_path)
+    assert len(re.findall(r"\bv_mfma_f32_32x32x16_(bf16|f16)\b", dis)) > 100 and "k_chain" in dis  # it IS the library's device code
+    packed = re.findall(r"\bv_pk_(?:mul|add|fma)_f32\b", dis)
+    assert not packed, "%d packed-float32 instructions: built without -fno-slp-vectorize?" % len(packed)
