@@ -1,9 +1,9 @@
 """The device code of libv2e_amd.so holds no packed-float32 VALU instruction.
 
-Round 4 (scripts/concurrency_repro.py): on the MI355X a kernel doing packed-float32 math (v_pk_mul_f32 /
-v_pk_add_f32 / v_pk_fma_f32 -- what the compiler's SLP vectoriser makes of adjacent scalar float32 operations) returned values rounded
-to about bf16 / float16 precision while a bf16 / f16 MFMA kernel of another stream shared its CUs.  The library is built with
--fno-slp-vectorize (v2e_amd/csrc/Makefile); this test disassembles what was built, so that the flag cannot be lost silently."""
+Round 4 (scripts/concurrency_repro.py): built WITH the compiler's SLP vectoriser (which turns adjacent scalar
+float32 operations into v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32), a UNet pass running beside bf16 / f16 MFMA kernels of another
+stream came out wrong in 10 runs of 10 on the MI355X; built with -fno-slp-vectorize (v2e_amd/csrc/Makefile) never.  This test
+disassembles what was built, so that the flag cannot be lost silently."""
 import os
 import re
 import shutil

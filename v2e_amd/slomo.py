@@ -50,6 +50,11 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# V2E_AMD_SLOMO_LOOKAHEAD=0: every UNet pass on the caller's stream, one after the other (SloMoEngine.flow_ahead is then never used by
+# interpolate): the serial order of rounds 1-3, for whoever does not want two UNet passes in flight
+_LOOKAHEAD = os.environ.get("V2E_AMD_SLOMO_LOOKAHEAD", "1") != "0"
+
+
 class HipUNet:
     """One UNet's weights, repacked [Cin][k][k][Cout] in HBM, and its forward pass."""
 
@@ -277,7 +282,7 @@ class SloMoEngine:
         I1 = I1 if I1.is_contiguous() else I1.contiguous()
         if flow is None:
             flow = self.flow(I0, I1)
-        if next_pair is not None:
+        if next_pair is not None and _LOOKAHEAD:
             self.flow_ahead(next_pair[0], next_pair[1])
         nt = len(ts)
         coef = torch.from_numpy(time_coefficients(ts)).to(self.device)
