@@ -1930,7 +1930,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         (void)zpw_env;
         ea.zpw_tot = CTOT_ZF;
         ea.zpw_emit = 1; // (k_cemit: one frame per workgroup; several per workgroup measured slower and cost 25 % more instructions)
-        const int REC_LDS = ea.capw * 4 * (BLOCK / WAVE);
+        const int REC_LDS = (ea.capw + WAVE) * 4 * (BLOCK / WAVE);
         const int egx = (chain_egroups(h) + BLOCK / WAVE - 1) / (BLOCK / WAVE); // workgroups of four emission groups
         void *args[] = {(void *)&a, (void *)&ea};
         // tables on a stream of their own (NSET table sets rotate: tables(b + 1) are built while k_cemit(b) reads those of b;

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(WAVE) void k_coff(CEmitArgs ea)
 // lane: row = frame offset + iteration base + shuffle(ON/OFF block offset + prefix over earlier groups + rank in group).
 __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
 {
-    extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw]
+    extern __shared__ uint32_t s_crec[]; // [BLOCK / WAVE][capw + WAVE]
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int clip = blockIdx.y, z = blockIdx.z, fe = ea.f0 + z;
     const int slot = ea.slot0 + z >= ea.D ? ea.slot0 + z - ea.D : ea.slot0 + z; // nE <= D
@@ -1154,6 +1154,8 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
     if (grp == 0 && lane == 0) {
         rec[clip].ev_offset = ev0;
         if (ea.coff_in_cemit && z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events; // else k_coff's
+        // rows beyond the capacity are dropped by the stores' bounds check (below): the frame says so here, once
+        if (ev0 + n_events > ea.cap || n_events > 0x7FFFFFFu) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
     }
     if (__builtin_amdgcn_readfirstlane((int)disc_v)) return;
     const int wmw = __builtin_amdgcn_readfirstlane(wm_v);
@@ -1185,7 +1187,20 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
         for (int j = 0; j < GPX; ++j)
             if (p0 + j * WAVE < a.npx) tsm[j] = ea.tsold[sp0 + j * WAVE];
     }
-    float4 *ev = ea.events + (size_t)clip * ea.cap;
+    // The frame's rows through a buffer resource over exactly the rows it may write -- base = the frame's first row, size = its
+    // rows that fit below the capacity: a row beyond the capacity is dropped by the bounds check of the store itself (no compare,
+    // no exec-mask branch per store site; k_cemit is bound by its scalar instructions at 1280x720), offsets are frame-relative
+    // 32-bit numbers, and "events dropped" is one comparison per frame (group 0).
+    const uint32_t ev0_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ev0), ev0_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ev0 >> 32));
+    const unsigned long long ev0u = ((unsigned long long)ev0_hi << 32) | ev0_lo;
+    const unsigned long long room = ev0u < ea.cap ? ea.cap - ev0u : 0ull;
+    const unsigned long long frows = room < (unsigned long long)n_events ? room : (unsigned long long)n_events;
+    const uint32_t fbytes = frows > 0x7FFFFFFull ? 0x7FFFFFF0u : (uint32_t)frows * 16u;
+    const __amdgpu_buffer_rsrc_t ev_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(ea.events + (size_t)clip * ea.cap + ev0u), 0, (int)fbytes, 0x00020000);
+    auto store_row = [&](const uint32_t rel, const float t, const float x, const float y, const float pol) __attribute__((always_inline)) {
+        const v2e_f4 v = {t, x, y, pol};
+        __builtin_amdgcn_raw_buffer_store_b128(v, ev_rsrc, (int)(rel * 16u), 0, 17); // sc0 sc1: written through (see store_event_wt)
+    };
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float rcpW = 1.0f / (float)a.W;
     auto pixel_xy = [&](const uint32_t p, float &x, float &y) __attribute__((always_inline)) { // y = p / W, x = p % W, exactly
@@ -1200,8 +1215,7 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
         y = (float)q;
         x = (float)(p - q * (uint32_t)a.W);
     };
-    uint32_t *rec_w = s_crec + (size_t)wave * ea.capw;
-    bool dropped = false;
+    uint32_t *rec_w = s_crec + (size_t)wave * (ea.capw + WAVE); // capw records + one dump word per lane
     const int iters = min(wmw, M);
     for (int i0 = 0; i0 < iters; i0 += ICH) {
         const int i1 = min(i0 + ICH, iters);
@@ -1253,9 +1267,9 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
                     bf = cb[j] & negb[j];
                     bo = cb[j] & ~negb[j];
                 }
-                if (pass) {
+                {   // every lane writes: a lane without an event to its own dump word behind the records (no exec-mask branch)
                     const uint32_t rank = neg[j] ? run_off + (uint32_t)__popcll(bf & lt) : run_on + (uint32_t)__popcll(bo & lt);
-                    const uint32_t pos = nrec + (uint32_t)__popcll((bo | bf) & lt);
+                    const uint32_t pos = pass ? nrec + (uint32_t)__popcll((bo | bf) & lt) : (uint32_t)(ea.capw + lane);
                     rec_w[pos] = (uint32_t)(j * WAVE + lane) | ((uint32_t)(i - i0) << GROUP_SRC_BITS) | ((neg[j] ? 1u : 0u) << (GROUP_SRC_BITS + 5)) |
                                  (rank << (GROUP_SRC_BITS + 6));
                 }
@@ -1288,36 +1302,26 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
                 pm.rmask = (1u << pm.sh) - 1u;
                 if (has) cidx = v2e_perm_apply(&pm, cidx);
             }
-            if (has) {
-                const unsigned long long row = ev0 + it_base + cidx;
-                if (row < ea.cap) store_event_wt(ev, row, tg(i0 + il), ex, ey, eneg ? -1.0f : 1.0f);
-                else dropped = true;
-            }
+            if (has) store_row(it_base + cidx, tg(i0 + il), ex, ey, eneg ? -1.0f : 1.0f);
         }
         if (!alive) break;
     }
-    // shot-noise events after all signal events (ON block, OFF block), ts[-1], unshuffled
+    // shot-noise events after all signal events (ON block, OFF block), ts[-1], unshuffled; a sub-group without one (most: a frame
+    // has a couple per 256 pixels) costs one scalar test
     if (a.do_shot && any_shot) {
         const uint32_t son_tot = cT[0];
-        uint32_t son_off = pre[0], soff_off = pre[(size_t)ea.nwp];
+        uint32_t son_off = n_signal + pre[0], soff_off = n_signal + son_tot + pre[(size_t)ea.nwp];
         const float tl = tg(n - 1);
 #pragma unroll
         for (int j = 0; j < GPX; ++j) {
-            float fx, fy;
-            pixel_xy((uint32_t)(p0 + j * WAVE), fx, fy);
-            if (cw[j] & CNT_SHOT_ON) {
-                const unsigned long long row = ev0 + n_signal + son_off + (uint32_t)__popcll(so[j] & lt);
-                if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, 1.0f);
-                else dropped = true;
+            if ((so[j] | sf[j]) != 0ull) {
+                float fx, fy;
+                pixel_xy((uint32_t)(p0 + j * WAVE), fx, fy);
+                if (cw[j] & CNT_SHOT_ON) store_row(son_off + (uint32_t)__popcll(so[j] & lt), tl, fx, fy, 1.0f);
+                if (cw[j] & CNT_SHOT_OFF) store_row(soff_off + (uint32_t)__popcll(sf[j] & lt), tl, fx, fy, -1.0f);
+                son_off += (uint32_t)__popcll(so[j]);
+                soff_off += (uint32_t)__popcll(sf[j]);
             }
-            if (cw[j] & CNT_SHOT_OFF) {
-                const unsigned long long row = ev0 + n_signal + son_tot + soff_off + (uint32_t)__popcll(sf[j] & lt);
-                if (row < ea.cap) store_event_wt(ev, row, tl, fx, fy, -1.0f);
-                else dropped = true;
-            }
-            son_off += (uint32_t)__popcll(so[j]);
-            soff_off += (uint32_t)__popcll(sf[j]);
         }
     }
-    if (__ballot(dropped) != 0ull && lane == 0) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
 }
