@@ -18,6 +18,14 @@ DEFAULTS = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak
     dict(kw=DEFAULTS, preset="noisy", H=48, W=64),
     dict(kw=dict(DEFAULTS, cutoff_hz=0, shot_noise_rate_hz=8.0, leak_rate_hz=0.4), preset=None, H=37, W=53),
     dict(kw=dict(DEFAULTS, sigma_thres=0.0, refractory_period_s=0.003), preset=None, H=40, W=40),
+    # round 4: corners the fixtures reach only in combination
+    dict(kw=DEFAULTS, preset="clean", H=33, W=47),
+    dict(kw=dict(DEFAULTS, refractory_period_s=0.02), preset=None, H=35, W=41),             # the rule is on in EVERY frame (dt = 4 ms)
+    dict(kw=dict(DEFAULTS, cutoff_hz=0, leak_rate_hz=0, shot_noise_rate_hz=5.0), preset=None, H=31, W=29),   # shot noise alone
+    dict(kw=dict(DEFAULTS, cutoff_hz=0, leak_rate_hz=0.5, shot_noise_rate_hz=0), preset=None, H=30, W=50),   # leak alone, no low-pass
+    dict(kw=dict(DEFAULTS, hdr=True), preset=None, H=36, W=44),
+    dict(kw=dict(DEFAULTS, photoreceptor_noise=True, shot_noise_rate_hz=2.0), preset=None, H=32, W=40),
+    dict(kw=dict(DEFAULTS, pos_thres=0.05, neg_thres=0.35, sigma_thres=0.01), preset=None, H=28, W=60),      # many events per pixel / asymmetric
 ])
 def test_oracle_equals_live_reference(case, oracle_lib):
     import logging
