@@ -3,7 +3,6 @@
 Instrumented runs (every kernel alone on one stream); prints the per-launch times of a 300-frame step for several sensor sizes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 import bench as B
 from v2e_amd import EventEmulator

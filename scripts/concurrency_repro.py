@@ -11,7 +11,7 @@ with AMD_SERIALIZE_KERNEL=3, with GPU_MAX_HW_QUEUES=1, or with a float32-MFMA co
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from v2e_amd.slomo import HipUNet, UNET_LAYERS
+from v2e_amd.slomo import HipUNet
 from v2e_amd.synth import portable_unet_state_dict
 dev = torch.device("cuda")
 sd_i = {k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}

@@ -6,7 +6,6 @@ stream came out wrong in 10 runs of 10 on the MI355X; built with -fno-slp-vector
 disassembles what was built, so that the flag cannot be lost silently."""
 import os
 import re
-import shutil
 import subprocess
 
 import pytest
