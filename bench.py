@@ -557,6 +557,10 @@ def main():
                 out["end_to_end"] = e2e_bench(device)
             except Exception as e:  # side measurements must never hide the headline number
                 out["extras_error"] = repr(e)[:300]
+            try:  # SURVEY 8(a)'s other size (round-3 review): one pair of a 1280x720 source, U = 2, as the 1280x704 parity fixture runs it
+                out["slomo_hd"] = slomo_bench(device, B=1, U=2, H=704, W=1280, iters=3)
+            except Exception as e:
+                out["slomo_hd"] = {"error": repr(e)[:300]}
             if dist is None:
                 try:
                     out["self_allgather"] = self_allgather_bench(device, frames_all)

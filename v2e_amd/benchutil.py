@@ -139,8 +139,9 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     roof = {"bound": "mfma", "kernel": ("k_conv_s3 / k_conv_s3p" if s3 else "k_conv") + " (23 launches of the interpolation UNet)",
             "achieved": round(ach * npr / 1e12, 2), "peak": (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK) / 1e12,
             "unit": "TFLOP/s", "frac": round(ach * npr / (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK), 4),
-            "traffic": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W))[0],
-            "traffic_detail": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W))[1],
+            # (the committed PMC passes are of the 80-sample 320x256 forward: no traffic figure for another shape)
+            "traffic": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W))[0] if (U * B, H, W) == (80, 256, 320) else None,
+            "traffic_detail": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W))[1] if (U * B, H, W) == (80, 256, 320) else None,
             "f32_equivalent_TFLOPs": round(ach / 1e12, 2),
             "f32_equivalent_vs_f32_mfma_peak": round(ach / F32_MFMA_PEAK, 4),
             "whole_step_TFLOPs": round(flops / sec / 1e12, 2),
@@ -153,8 +154,10 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     return {
         "metric": "interpolated frames/s (SuperSloMo flow UNet + per-t warps + interpolation UNet + fusion)",
         "value": round(U * B / sec, 2), "unit": "frames/s",
-        "config": {"workload": "BASELINE configs[2] SloMo stage: 320x256 (346x260 source), U=%d, batch of %d pairs, "
-                               "seeded random-init weights (checkpoint not available offline)" % (U, B)},
+        "config": {"workload": ("BASELINE configs[2] SloMo stage: 320x256 (346x260 source), U=%d, batch of %d pairs, "
+                                "seeded random-init weights (checkpoint not available offline)" % (U, B)) if (H, W) == (256, 320) else
+                               ("SloMo stage at %dx%d (SURVEY 8(a): a 1280x720 source is interpolated at 1280x704), U=%d, batch of %d "
+                                "pair(s), seeded random-init weights" % (W, H, U, B))},
         "dtype": "f32" + ({"bf16x3": " (operands split exactly into 3 bf16 pieces, 6 products on the bf16 matrix cores, f32 accumulation)",
                            "fp16x2": " (operands split into 2 float16 pieces, residual <= 2^-22; 3 products on the f16 matrix cores, f32 accumulation)"}
                           .get(math_run, "")),
