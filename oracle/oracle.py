@@ -82,6 +82,10 @@ class TorchTape:
         import torch
         return torch.exp(math.log(10) * cov * torch.from_numpy(randn)).numpy()
 
+    def exp_scidvs(self, draw):  # emulator.py:480-483: torch.exp of the float32 normal draw
+        import torch
+        return torch.exp(torch.from_numpy(draw)).numpy()
+
 
 class RecordedTape:
     """Replays a list of (kind, array) draws recorded from a reference run."""

@@ -26,6 +26,7 @@ DEFAULTS = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak
     dict(kw=dict(DEFAULTS, hdr=True), preset=None, H=36, W=44),
     dict(kw=dict(DEFAULTS, photoreceptor_noise=True, shot_noise_rate_hz=2.0), preset=None, H=32, W=40),
     dict(kw=dict(DEFAULTS, pos_thres=0.05, neg_thres=0.35, sigma_thres=0.01), preset=None, H=28, W=60),      # many events per pixel / asymmetric
+    dict(kw=dict(DEFAULTS, scidvs=True), preset=None, H=32, W=64),                                         # float64 state: no sinh tail issue
 ])
 def test_oracle_equals_live_reference(case, oracle_lib):
     import logging
