@@ -84,3 +84,24 @@ def test_oracle_philox_mode_equals_live_reference_with_the_philox_source(case, o
             assert a.shape == ev.shape and np.array_equal(a, ev), "frame %d" % k
             n += len(a)
     assert n > 0 and np.array_equal(ref.base_log_frame.numpy(), ora.base_log_frame)
+
+
+@pytest.mark.parametrize("shape", [(1, 12, 5, 32, 64), (2, 2, 4, 96, 32)])
+def test_slomo_oracle_unet_equals_live_reference_model(shape, oracle_lib):
+    """oracle/slomo_oracle.c's UNet against the reference's own model.UNet (v2ecore/model.py:198-226), live, at sizes and weights
+    that are in no fixture: within the north-star tolerance 1e-5 max(1, |reference|)."""
+    from v2e_amd.synth import portable_unet_state_dict
+    n, cin, cout, h, w = shape
+    model = rh.ref_model()
+    torch.set_num_threads(1)
+    sd = portable_unet_state_dict(cin, cout, 977 + h)
+    net = model.UNet(cin, cout)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    g = torch.Generator().manual_seed(h * w)
+    x = torch.rand((n, cin, h, w), generator=g) - 0.4
+    with torch.no_grad():
+        want = net(x).numpy()
+    got = oracle_lib.unet_forward(x.numpy(), sd)
+    err = float(np.max(np.abs(got.astype(np.float64) - want) / np.maximum(1.0, np.abs(want))))
+    assert got.shape == want.shape and err < 1e-5, err
