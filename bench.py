@@ -332,6 +332,45 @@ def self_allgather_bench(device, frames_all, steps=30, warmup=3):
         os.close(saved_fd)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """Bare `python bench.py --gpus N` (no WORLD_SIZE in the environment): start one rank per GPU under
+    torch.distributed.run on this node and relay rank 0's JSON line as the only line on stdout; the exit code is the
+    launcher's.  (The driver's documented N > 1 command already runs under torch.distributed.run and never comes here.)"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in p.stdout.decode("utf-8", "replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr)  # banners of the ranks: never on stdout
+    if line is None:
+        raise SystemExit(p.returncode or 1)
+    print(line, flush=True)
+    raise SystemExit(p.returncode)
+
+
+STUB = os.environ.get("V2E_AMD_BENCH_STUB") == "1"
+"""V2E_AMD_BENCH_STUB=1: the launcher / process-group / step-loop / reduction / JSON plumbing of this file on CPU tensors with
+gloo and a stub engine (tests/bench_stub.py) -- no kernel runs and the line says so (`data: "stub"`, metric prefixed STUB):
+it exists so that the N > 1 start-up path is exercised every round in a container without GPUs (tests/test_bench_launch.py)."""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,33 +386,50 @@ def main():
     ap.add_argument("--gather-wire", choices=["auto", "pack32", "pack64"], default="auto")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus, sys.argv[1:])  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d" % (args.gpus, world))
+    if STUB:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
+    ranks_seen = None
     if world > 1 or args.force_allgather:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if STUB:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        one = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(one)  # the ranks that took part in a collective of this job (RCCL on the GPU box), not the number asked for
+        ranks_seen = int(one.item())
 
-    from v2e_amd import EventEmulator
     from v2e_amd.benchutil import run_steps
     from v2e_amd.dist import EventStreamGatherer
+    if STUB:
+        from tests.bench_stub import StubEmulator
+    else:
+        from v2e_amd import EventEmulator
 
     K, Wm = args.steps, args.warmup
-    F = FRAMES_PER_STEP
+    F = FRAMES_PER_STEP if not STUB else 4
+    H, W = (260, 346) if not STUB else (4, 6)
     # one independent clip per rank (configs[4]: seeds 10..17); rank 0 at N=1 uses seed 1 (configs[1])
     clip_seed = 1 if world == 1 else 10 + rank
-    frames_all = gen_frames_device(min(K + Wm, CLIP_STEPS) * F + 1, clip_seed, device)
+    frames_all = gen_frames_device(min(K + Wm, CLIP_STEPS) * F + 1, clip_seed, device, h=H, w=W)
 
     def make_emu():
+        if STUB:
+            return StubEmulator(rank)
         emu = EventEmulator(device=device, seed=clip_seed, rng_mode="philox", **DEFAULT_KW)
         emu.generate_events(frames_all[0], 0.0)  # first frame: state init, no events
         return emu
@@ -402,7 +458,10 @@ def main():
         return res[order[len(order) // 2]]
 
     emu = make_emu()
-    gather = EventStreamGatherer(device, world, wire=args.gather_wire, algo=args.gather_algo, sensor=(H, W)) if use_gather else None
+    gather = None
+    if use_gather:
+        gather = (EventStreamGatherer("cpu", world) if STUB else
+                  EventStreamGatherer(device, world, wire=args.gather_wire, algo=args.gather_algo, sensor=(H, W)))
     blocks = timed_blocks(emu, gather)
     elapsed, tot_events = median_block(blocks)
     compute_only = None
@@ -414,7 +473,7 @@ def main():
     if rank == 0:
         bpp = emulator_bytes_per_pixel(DEFAULT_KW)
         out = {
-            "metric": "Mevents/s (EventEmulator.generate_events, 346x260, 10x slowdown)",
+            "metric": ("STUB (no kernel ran) " if STUB else "") + "Mevents/s (EventEmulator.generate_events, 346x260, 10x slowdown)",
             "value": round(tot_events / elapsed / 1e6, 3),
             "unit": "Mevents/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
@@ -424,7 +483,9 @@ def main():
                              "spread_rel": round((max(ne / el for el, ne in blocks) - min(ne / el for el, ne in blocks)) /
                                                  (tot_events / elapsed), 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "stub" if STUB else "synthetic",
+            "ranks_seen": ranks_seen if ranks_seen is not None else 1,
+            "collective_backend": None if dist is None else ("gloo (stub)" if STUB else "nccl (RCCL)"),
             "config": {"workload": "BASELINE configs[1]: 346x260 random-gradient video (SURVEY 8(d) config 2), "
                                    "dt=1/300 s, emulator-only, v2e CLI default DVS params, Philox RNG, "
                                    "%d frames/step device-resident, one clip per GPU" % F,
@@ -444,7 +505,7 @@ def main():
                                                      if gather.wire == "pack32" else "8 B per event (v2e_events_pack64)")}
 
     # ---------------- roofline of the dominant emulator kernel (rank 0, HIP events, same workload)
-    if rank == 0:
+    if rank == 0 and not STUB:
         eng = emu._engine
         P = emu._params()
         buf = torch.empty((F, H, W), dtype=torch.uint8, device=device)

@@ -17,10 +17,7 @@ def _free_port():
     return p
 
 
-def _rows(n, rank, step):
-    """n event rows (t, x, y, p) that differ per rank and step; t includes a negative value (sign bit on the wire)."""
-    k = torch.arange(n, dtype=torch.float32)
-    return torch.stack([k * 1e-3 - 0.002 + rank + 0.1 * step, (k + 13 * rank) % 346, (k * 7 + step) % 260, (k % 2) * 2 - 1], dim=1).contiguous()
+from tests.bench_stub import StubEmulator as _StubEmulator, rows as _rows  # noqa: E402
 
 
 def _rows_runs(n, rank, step):
@@ -228,31 +225,6 @@ def test_event_stream_allgather_nccl_world2_unequal_counts(wire, algo):
     for p in procs:
         p.join(timeout=60)
     assert res == {0: True, 1: True}
-
-
-class _StubPending:
-    def __init__(self, ev, counts):
-        self.ev, self.counts = ev, counts
-
-    def result(self):
-        return self.ev, self.counts
-
-
-class _StubEmulator:
-    """Stands in for v2e_amd.EventEmulator in bench.py's step loop: `generate_events_batch_async(frames, times)` returns
-    a handle whose result() is (event rows, per-frame counts); here a deterministic function of (rank, step)."""
-
-    def __init__(self, rank):
-        self.rank, self.step, self.calls = rank, 0, []
-
-    def generate_events_batch_async(self, frames, times, return_device=True, use_graph=True):
-        F = len(times)
-        counts = np.asarray([(3 + self.rank + (self.step + f) % 5) for f in range(F)], dtype=np.int64)
-        counts[0] += int(frames[0, 0, 0])            # depends on the frames the loop copied into its buffer
-        ev = _rows(int(counts.sum()), self.rank, self.step)
-        self.calls.append((float(times[0]), float(times[-1]), int(frames[0, 0, 0])))
-        self.step += 1
-        return _StubPending(ev, counts)
 
 
 def _bench_worker(rank, world, port, q):
