@@ -201,3 +201,7 @@ extern "C" int slp_launch_victim_dump(const float *x, int blocks, int iters, flo
     k_victim_dump<<<blocks, 256, 0, st>>>(x, iters, dump, mism);
     return (int)hipGetLastError();
 }
+
+// ---- dev tool for scripts/step_stamps.py: a device time stamp (100 MHz constant clock) from a kernel of its own on the caller's stream
+__global__ void k_stamp(unsigned long long *out, int idx) { out[idx] = wall_clock64(); }
+extern "C" int slp_stamp(unsigned long long *out, int idx, hipStream_t st) { k_stamp<<<1, 1, 0, st>>>(out, idx); return (int)hipGetLastError(); }

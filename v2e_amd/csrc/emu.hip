@@ -842,6 +842,8 @@ struct v2e_emu {
     int run_cap = 0;
     uint32_t *run_fidx = nullptr;      // device: frame_idx0 of the current run
     uint32_t *run_fidx_host = nullptr; // pinned
+    const void **run_frames = nullptr;      // device: the current run's frames (k_ahead / k_chain read the pointer from here)
+    const void **run_frames_host = nullptr; // pinned, two slots
     // captured runs, keyed by everything baked into them (buffers, sizes, parameters): a caller that alternates between two
     // sets of frame / event / record buffers (the asynchronous API) replays two graphs
     struct CachedGraph { std::vector<unsigned char> key; hipGraphExec_t exec; unsigned long long used; };
@@ -896,6 +898,15 @@ void v2e_set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// pinned host staging -> device (v2e_emu_run): frame scalars of a run and its first frame index
+static __global__ __launch_bounds__(BLOCK) void k_upload_ctl(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                      const uint32_t *__restrict__ fsrc, uint32_t *__restrict__ fdst,
+                                                      const void *const *__restrict__ psrc, const void **__restrict__ pdst)
+{
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *fdst = *fsrc; *pdst = *psrc; }
 }
 
 static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
@@ -1006,6 +1017,8 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
     V2E_HIP(hipHostMalloc(&h->off_host, sizeof(unsigned long long) * n_clips));
     V2E_HIP(hipMalloc(&h->run_fidx, sizeof(uint32_t)));
     V2E_HIP(hipHostMalloc(&h->run_fidx_host, 2 * sizeof(uint32_t)));
+    V2E_HIP(hipMalloc(&h->run_frames, sizeof(void *)));
+    V2E_HIP(hipHostMalloc(&h->run_frames_host, 2 * sizeof(void *)));
     *out = h;
     return 0;
 }
@@ -1037,6 +1050,8 @@ int v2e_emu_destroy(v2e_emu *h)
     for (int q = 0; q < 2; ++q) { if (h->run_ctl_host2[q]) hipHostFree(h->run_ctl_host2[q]); if (h->ev_stage[q]) hipEventDestroy(h->ev_stage[q]); }
     hipFree(h->run_fidx);
     if (h->run_fidx_host) hipHostFree(h->run_fidx_host);
+    hipFree(h->run_frames);
+    if (h->run_frames_host) hipHostFree(h->run_frames_host);
     hipFree(h->fr_dev); hipFree(h->off_zero);
     if (h->fr_stage) hipHostFree(h->fr_stage);
     if (h->fr_par) hipHostFree(h->fr_par);
@@ -1862,12 +1877,6 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         sc.ev_cap = nL + 2;
         sc.evdeps.assign((size_t)EV_KINDS * sc.ev_cap, std::vector<hipGraphNode_t>());
     }
-    {   // one launch: the run's records, batch 0's event offset, and (refractory runs) the rule-on maxima and rendezvous counters
-        void *const zp[4] = {recs, h->run_off, has_refr ? (void *)h->ch_gM : nullptr, has_refr ? (void *)h->ch_bar : nullptr};
-        const size_t zb[4] = {sizeof(v2e_frame_rec) * (size_t)n_frames * NC, sizeof(unsigned long long) * NC,
-                              sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K, sizeof(unsigned) * (size_t)nL * 2 * K * NC};
-        if (sc.zero4(ST_MAIN, zp, zb)) return V2E_EHIP;
-    }
     auto mark = [&](std::vector<hipEvent_t> *v, hipStream_t stq) -> int { // instrumented runs (never graphs)
         if (!v || graph) return 0;
         hipEvent_t e;
@@ -1902,6 +1911,8 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     static const bool one_row_stream = getenv("V2E_AMD_ONE_ROW_STREAM") != nullptr; // dev
     // b: the emission's slot (event indices, table set b % NSET, event offsets run_off[b] -> run_off[b + 1]); frames [ef0, ef0 + enE).
     // A batch is normally slot b = frames [b E, (b + 1) E); the run's LAST batch may be emitted in two pieces (slots nEB - 1, nEB).
+    // (Round 5 measured the tables of the run's LAST pieces on the chain's stream, beside the rows of the batch before on the side
+    // stream: 12.0 -> 11.5 Gev/s -- they delay the tail launch, which the last rows wait for.  Not kept.)
     auto launch_emission = [&](int b, int ef0, int enE) -> int { // EV_FORK[b] has been recorded on the chain stream
         CEmitArgs ea;
         memset(&ea, 0, sizeof(ea));
@@ -1978,7 +1989,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
             if (f1 <= f0) continue;
             AheadArgs aa;
             memset(&aa, 0, sizeof(aa));
-            aa.frames = frames; aa.frame_stride = (unsigned long long)NC * h->npx * esz;
+            aa.frames_pp = h->run_frames; aa.frame_stride = (unsigned long long)NC * h->npx * esz;
             aa.ctl = h->run_ctl; aa.fidx_base = h->run_fidx;
             aa.f0 = f0; aa.nf = f1 - f0; aa.D = D; aa.n_clips = NC; aa.slot0 = f0 % D;
             aa.rec = h->ch_rec;
@@ -1994,6 +2005,15 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     float *xt[2] = {h->ts_mem, has_refr ? h->ch_ts2 : h->ts_mem};
     // the run's uploads (frame times, first frame index) and the zero fills precede everything
     static const bool no_side_fork = getenv("V2E_AMD_INITIAL_SIDE_FORK") == nullptr; // under capture the side stream joins at its first batch
+    // The zero fill precedes the fork.  (Round 5 tried the fork first -- k_ahead touches nothing the fill clears -- and lost 10 %:
+    // 12.0 -> 10.8 Gev/s, A/B x 3 in one session; the enqueue order of a capture decides which branches this runtime overlaps,
+    // profiles/r03_graph_scheduling.txt.)
+    {   // one launch: the run's records, batch 0's event offset, and (refractory runs) the rule-on maxima and rendezvous counters
+        void *const zp[4] = {recs, h->run_off, has_refr ? (void *)h->ch_gM : nullptr, has_refr ? (void *)h->ch_bar : nullptr};
+        const size_t zb[4] = {sizeof(v2e_frame_rec) * (size_t)n_frames * NC, sizeof(unsigned long long) * NC,
+                              sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K, sizeof(unsigned) * (size_t)nL * 2 * K * NC};
+        if (sc.zero4(ST_MAIN, zp, zb)) return V2E_EHIP;
+    }
     if (sc.record(EV_FORK, nL, ST_MAIN)) return V2E_EHIP;
     if (!(capturing && no_side_fork) && sc.wait(ST_SIDE, EV_FORK, nL)) return V2E_EHIP;
     if (!fused_rec && sc.wait(ST_AHEAD, EV_FORK, nL)) return V2E_EHIP;
@@ -2013,7 +2033,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         const bool tail = pl.nf == 0;
         ChainArgs ca;
         memset(&ca, 0, sizeof(ca));
-        ca.frames = frames; ca.frame_stride = (unsigned long long)NC * h->npx * esz; ca.fidx_base = h->run_fidx;
+        ca.frames_pp = h->run_frames; ca.frame_stride = (unsigned long long)NC * h->npx * esz; ca.fidx_base = h->run_fidx;
         ca.ctl = h->run_ctl;
         ca.f0 = pl.f0; ca.nf = pl.nf; ca.pf0 = pl.pf0; ca.pnf = pl.pnf;
         ca.D = D; ca.n_clips = NC; ca.K = K; ca.ngroups = h->ngroups;
@@ -2120,8 +2140,18 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     const size_t nct = (size_t)n_frames * h->n_clips;
     for (size_t i = 0; i < nct; ++i) ctl_host[i] = make_ctl(t_prev[i], t_frame[i], p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
     *fidx_host = frame_idx0;
-    V2E_HIP(hipMemcpyAsync(h->run_ctl, ctl_host, sizeof(FrameCtl) * nct, hipMemcpyHostToDevice, s));
-    V2E_HIP(hipMemcpyAsync(h->run_fidx, fidx_host, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    const void **frames_host = h->run_frames_host + sq; // the chain pipeline reads the frames' address from a device variable:
+    *frames_host = frames;                              // runs over different frame buffers replay the same captured graph
+    // The run's frame scalars, first frame index and frames' address go up through a kernel that reads the pinned staging set
+    // (round 5; before: three hipMemcpyAsync).  A/B x 3 in one session on the benchmark loop: 11.9 -> 12.15 Gev/s -- in the rocprofv3
+    // timeline the copy-engine upload started 40-90 us behind the command before it, the kernel 10 us.
+    {
+        static_assert(sizeof(FrameCtl) % 16 == 0, "FrameCtl is copied in 16-byte pieces");
+        const size_t n16 = sizeof(FrameCtl) * nct / 16;
+        k_upload_ctl<<<(unsigned)std::min<size_t>((n16 + BLOCK - 1) / BLOCK, 1024), BLOCK, 0, s>>>((const uint4 *)ctl_host, (uint4 *)h->run_ctl, n16, fidx_host, h->run_fidx,
+                                                                                                   frames_host, h->run_frames);
+        V2E_HIP(hipGetLastError());
+    }
     V2E_HIP(hipEventRecord(h->ev_stage[sq], s));
     KArgs a = make_kargs(h, p);
     const int mode = use_graph & 3;          // 0 plain launches, 1 hipGraph, 2 instrumented
@@ -2194,7 +2224,8 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     // graph path: everything baked into the graph is part of the cache key
     std::vector<unsigned char> key;
     auto push = [&key](const void *ptr, size_t n) { const unsigned char *b = (const unsigned char *)ptr; key.insert(key.end(), b, b + n); };
-    push(&a, sizeof(a)); push(&frames, sizeof(frames)); push(&dtype, sizeof(dtype)); push(&n_frames, sizeof(n_frames));
+    push(&a, sizeof(a)); push(&dtype, sizeof(dtype)); push(&n_frames, sizeof(n_frames));
+    if (legacy) push(&frames, sizeof(frames)); // the chain pipeline reads the frames' address from h->run_frames
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
     int lg = legacy ? 1 : 3; push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));

@@ -132,7 +132,8 @@ __device__ __forceinline__ void store_event_wt(float4 *ev_clip, unsigned long lo
 }
 
 struct ChainArgs {
-    const void *frames;               // FUSED: frames of the run, frame f at frames + f * frame_stride (bytes)
+    const void *const *frames_pp;     // FUSED: *frames_pp = frames of the run (a device variable the run's upload fills: the pointer is not
+                                      // baked into a captured graph), frame f at *frames_pp + f * frame_stride (bytes)
     unsigned long long frame_stride;
     const uint32_t *fidx_base;        // FUSED: the run's first frame index
     const FrameCtl *ctl;              // [n_frames][n_clips]
@@ -225,7 +226,7 @@ __device__ __forceinline__ uint4 make_frame_record(const KArgs &a, FT px, const 
 //   .z     lin-log value L (float32; the frame itself when it is log-encoded already)
 //   .w     delta_leak (float32)
 struct AheadArgs {
-    const void *frames;
+    const void *const *frames_pp; // *frames_pp = frames of the run (see ChainArgs)
     unsigned long long frame_stride;
     const FrameCtl *ctl;
     const uint32_t *fidx_base;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
     const int clip = blockIdx.y, p = blockIdx.x * BLOCK + tid;
     if (p >= a.npx) return;
     const uint32_t fbase = *aa.fidx_base;
+    const char *const frames = (const char *)*aa.frames_pp;
     const size_t sp = (size_t)clip * a.npx_pad + p;
     const bool need_r = a.do_leak && a.jit_f != 0.f;
     const float thp = a.pos_thres[sp], thn = a.neg_thres[sp];
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
             int sl = aa.slot0 + (f - aa.f0); // ring slot f % D (nf <= D)
             if (sl >= aa.D) sl -= aa.D;
             const FrameCtl *c = aa.ctl + (size_t)f * aa.n_clips + clip;
-            const FT px = ((const FT *)((const char *)aa.frames + (size_t)f * aa.frame_stride))[(size_t)clip * a.npx + p];
+            const FT px = ((const FT *)(frames + (size_t)f * aa.frame_stride))[(size_t)clip * a.npx + p];
             const uint4 r = make_frame_record<FT>(a, px, s_lutL, s_lutI, c->dt_over_tau, c->shot_base, (float)(c->t_frame - c->t_prev), lk, thp,
                                                   ppre, npre, half ? r_even : r_odd, half ? u_even : u_odd);
             aa.rec[((size_t)sl * aa.n_clips + clip) * a.npx_pad + p] = r;
@@ -329,8 +331,10 @@ void k_chain(KArgs a_in, ChainArgs ca)
     if (ca.prio) __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
     V2E_STAMP_C(0);
     uint32_t fbase = 0u;
+    const char *frames = nullptr;
     if (FUSED) {
         fbase = *ca.fidx_base;
+        frames = (const char *)*ca.frames_pp;
         if (U8) {
             s_lutL[tid] = a.lut_L[tid];
             s_lutI[tid] = a.lut_I[tid];
@@ -503,7 +507,7 @@ void k_chain(KArgs a_in, ChainArgs ca)
                 uint4 rc = rc_in;
                 if (FUSED) {
                     FT px = (FT)0;
-                    if (valid) px = ((const FT *)((const char *)ca.frames + (size_t)f * ca.frame_stride))[(size_t)clip * a.npx + p];
+                    if (valid) px = ((const FT *)(frames + (size_t)f * ca.frame_stride))[(size_t)clip * a.npx + p];
                     const uint32_t gf = fbase + (uint32_t)f;
                     if (need_r || a.do_shot) { // one Philox call per pair of frames (v2e_detmath.h)
                         if (!have_pair || v2e_frame_half(gf) == 0u)
