@@ -113,6 +113,35 @@ class LiveTapeFixture(PhiloxFixture):
         return hashlib.sha256(torch.exp(0.23025850929940458 * r).numpy().tobytes()).hexdigest() == self.exp_probe
 
 
+TAPE_PORTABLE_FIXTURES = ["tape_portable_defaults_346x260", "tape_portable_noisy_346x260"]  # tests/golden/make_golden_tape_portable.py
+
+
+class PortableTapeFixture(PhiloxFixture):
+    """Digest-only fixture of the reference run with tests/golden/portable_tape.PortableSource as its random source: pins the
+    tape-mode path at sensor size on ANY torch build (the draws are integer hashing; see portable_tape.py)."""
+
+    def tape(self):
+        from portable_tape import PortableTape
+        return PortableTape(self.seed)
+
+
+def require_same_generator(fx):
+    """The tape_live_* fixtures replay torch's own MT19937 stream: on a torch build that draws differently they cannot be compared.
+    That used to be a silent skip (round-4 review: 'parity evidence that can evaporate silently'); now it is a FAILURE unless
+    V2E_ALLOW_TORCH_DRIFT=1 says the difference is known -- the tape_portable_* fixtures pin the same kernels without torch's
+    generator either way."""
+    import os
+    import pytest
+    import torch
+    if fx.generator_matches():
+        return
+    msg = ("torch %s draws differently from the fixture's torch %s: the default (tape) mode of the drop-in cannot be compared with "
+           "the reference's recorded run on this host" % (torch.__version__, fx.torch_version))
+    if os.environ.get("V2E_ALLOW_TORCH_DRIFT") == "1":
+        pytest.skip(msg + " (V2E_ALLOW_TORCH_DRIFT=1)")
+    pytest.fail(msg + "; set V2E_ALLOW_TORCH_DRIFT=1 to accept (tape_portable_* still pin the kernels)")
+
+
 def events_equal(a, b):
     if a is None:
         a = np.zeros((0, 4), np.float32)

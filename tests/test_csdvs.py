@@ -210,8 +210,7 @@ def test_csdvs_default_tape_mode_matches_reference_at_davis346():
     from fixtures import LiveTapeFixture
     from v2e_amd import EventEmulator
     fx = LiveTapeFixture("tape_live_csdvs_346x260")
-    if not fx.generator_matches():
-        pytest.skip("torch %s draws differently from the fixture's torch %s" % (torch.__version__, fx.torch_version))
+    require_same_generator(fx)
     z = np.load(os.path.join(GOLDEN, "tape_live_csdvs_346x260.npz"))
     emu = EventEmulator(device="cuda", seed=fx.seed, **fx.kw)
     assert emu.rng_mode == "tape" and emu.csdvs_enabled

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from fixtures import (PHILOX_FIXTURES, TAPE_FIXTURES, TAPE_LIVE_FIXTURES, LiveTapeFixture, PhiloxFixture, TapeFixture,
+from fixtures import (PHILOX_FIXTURES, TAPE_FIXTURES, TAPE_LIVE_FIXTURES, TAPE_PORTABLE_FIXTURES, LiveTapeFixture, PhiloxFixture,
+                      PortableTapeFixture, TapeFixture, require_same_generator,
                       events_equal, sha)
 
 pytestmark = pytest.mark.gpu
@@ -43,6 +44,28 @@ def test_hip_replays_reference_tape(name, oracle_lib):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
 
 
+@pytest.mark.parametrize("name", TAPE_PORTABLE_FIXTURES)
+def test_hip_tape_mode_at_sensor_size_with_a_portable_random_source(name):
+    """The tape-mode kernels (count -> rank / scan -> host permutations -> shot -> emit -> permute) at 346x260 against the
+    reference run with the SAME torch-independent random source (tests/golden/portable_tape.py): compared on every host, whatever
+    its torch draws."""
+    fx = PortableTapeFixture(name)
+    emu = _mk(fx, seed=fx.seed, rng_mode="tape", tape=fx.tape())
+    emu.noise_rate_cov_decades = 0.0  # (the 'noisy' preset sets 0.1, emulator.py:535; the fixtures keep exp() out: exp(0 * r) = 1)
+    for k, (f, t) in enumerate(zip(fx.frames, fx.times)):
+        ev = emu.generate_events(f, float(t))
+        n = 0 if ev is None else len(ev)
+        assert n == fx.n_events[k], "frame %d: %d events, reference %d" % (k, n, fx.n_events[k])
+        if n:
+            assert sha(ev) == fx.ev_sha[k], "frame %d event digest differs" % k
+    st = _state(emu)
+    assert sha(st["base_log_frame"]) == fx.base_sha
+    assert sha(st["lp_log_frame"]) == fx.lp_sha
+    if fx.ts_mem_sha:
+        assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
+    assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
 @pytest.mark.parametrize("name", TAPE_LIVE_FIXTURES)
 def test_hip_default_mode_at_sensor_size(name, oracle_lib):
     """The drop-in exactly as v2e.py would construct it (rng_mode default = tape, the reference's seeded MT19937
@@ -51,8 +74,7 @@ def test_hip_default_mode_at_sensor_size(name, oracle_lib):
     frame.  Final state: bit-equal to the oracle run on this host with the same seed, and to the reference's digest
     where this host's torch.exp (noise_rate_array, emulator.py:504) has the fixture host's last bits."""
     fx = LiveTapeFixture(name)
-    if not fx.generator_matches():
-        pytest.skip("torch %s draws differently from the fixture's torch %s" % (torch.__version__, fx.torch_version))
+    require_same_generator(fx)
     emu = _mk(fx, seed=fx.seed)
     assert emu.rng_mode == "tape"
     for k, (f, t) in enumerate(zip(fx.frames, fx.times)):

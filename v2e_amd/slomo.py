@@ -53,6 +53,12 @@ def _ptr(t):
 # V2E_AMD_SLOMO_LOOKAHEAD=0: every UNet pass on the caller's stream, one after the other (SloMoEngine.flow_ahead is then never used by
 # interpolate): the serial order of rounds 1-3, for whoever does not want two UNet passes in flight
 _LOOKAHEAD = os.environ.get("V2E_AMD_SLOMO_LOOKAHEAD", "1") != "0"
+# Two UNet passes in flight went wrong once (round 4) and the cause is known (round 5, profiles/r05_concurrency_rootcause.txt): on
+# gfx950 a packed-float32 instruction whose op_sel routes src1's high half to the low lane reads 0 there while another kernel issues
+# independent 16-K bf16 / f16 MFMAs.  The library is built without any packed-float32 instruction (Makefile, tests/test_device_isa.py),
+# so the look-ahead is safe as built; the canary below makes a differently built library (EXTRA=-fslp-vectorize, another compiler)
+# fall back to one stream instead of corrupting frames silently.  Result per device, decided at the first look-ahead of the process.
+_CANARY = {}
 
 
 class HipUNet:
@@ -260,6 +266,37 @@ class SloMoEngine:
             f = self.flow_net.forward(x, defer_check=True)
         self._ahead = (I0, I1, x, f)
 
+    def lookahead_ok(self):
+        """True iff two UNet passes on two streams reproduce the one-stream result bit for bit on this device with this build of the
+        library: one small interpolation-UNet pass alone, then twice beside three flow-UNet passes on the side stream (the
+        configuration of profiles/r04_concurrency_finding.txt table 1, which failed 4-6 runs of 6 with the faulty build).
+        Run once per process and device (a few ms); a mismatch switches the look-ahead off for the process, with one warning."""
+        key = self.device.index
+        if key not in _CANARY:
+            g = torch.Generator(device=self.device)
+            g.manual_seed(1234)
+            xi = torch.rand((2, 12, 64, 96), device=self.device, generator=g) - 0.4
+            xf = torch.rand((2, 2, 64, 96), device=self.device, generator=g) - 0.4
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(self.device, priority=-1)
+            ref = self.interp_net.forward(xi).clone()
+            ok = True
+            for _ in range(2):
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        self.flow_net.forward(xf)
+                out = self.interp_net.forward(xi)
+                ok = ok and bool(torch.equal(out.view(torch.int32), ref.view(torch.int32)))
+                cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            _CANARY[key] = ok
+            if not ok:
+                logger.warning("v2e_amd.SloMoEngine: a UNet pass beside another stream's pass differs from its stand-alone result on "
+                               "this device with this build of libv2e_amd.so (was it built without -fno-slp-vectorize?): the flow "
+                               "look-ahead is off for this process, every pass runs on the caller's stream")
+        return _CANARY[key]
+
     def max_speed(self, flow):
         """slomo.py:352-368: the largest flow magnitude (pixels per source frame) over the batch and both directions, reduced on
         the device (k_max_speed2: max of the squared speed; ONE float32 sqrt on the host -- sqrt is monotone)."""
@@ -282,7 +319,7 @@ class SloMoEngine:
         I1 = I1 if I1.is_contiguous() else I1.contiguous()
         if flow is None:
             flow = self.flow(I0, I1)
-        if next_pair is not None and _LOOKAHEAD:
+        if next_pair is not None and _LOOKAHEAD and self.lookahead_ok():
             self.flow_ahead(next_pair[0], next_pair[1])
         nt = len(ts)
         coef = torch.from_numpy(time_coefficients(ts)).to(self.device)
