@@ -17,6 +17,12 @@ restates OpenCV 4.x's published source as follows; it has NOT been compared with
       Each product and each sum is rounded on its own (no fused multiply-add: resizeArea_ has no FMA dispatch variant).
   modules/imgproc/src/color_yuv.simd.hpp, RGB2Gray<uchar> (BGR order: blueIdx 0): shift 14, B2Y 1868, G2Y 9617, R2Y 4899,
       D = (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14.
+      (Round-4 advisor, also from memory: 4.x may use the 15-bit set BY15 3735 / GY15 19235 / RY15 9798 with (1 << 14) >> 15 here and
+      the 14-bit set only on the YUV path; the two forms differ by one grey level on ~1 % of random pixels.  Neither of us can open
+      color_rgb.simd.hpp here.  scripts/check_stage1_against_cv2.py prints which of the two equals cv2.cvtColor on a host that has
+      OpenCV -- until someone runs it this stage stays "parity unpinned".)
+  What CAN be checked without OpenCV is checked in tests/test_preproc.py: the integer-factor path equals the exact rational box mean
+  (ties as OpenCV rounds them) and stays within one grey level of Pillow's independent Image.reduce.
 """
 import numpy as np
 

@@ -849,6 +849,7 @@ class EventEmulator(object):
     # ------------------------------------------------------------- centre-surround
     MAX_CHANGE_TO_TERMINATE_EULER_SURROUND_STEPPING = 1e-5  # emulator.py:52
     CSDVS_RUN_MAX_STEPS = 8192  # Euler steps per frame a device-resident run enqueues up front
+    CSDVS_RUN_MAX_TOTAL_STEPS = 65536  # ... and per run: every step is a launch (a graph node), taken or not (round-4 advisor)
 
     def _csdvs_step_params(self, delta_time):
         """emulator.py:1066-1096: (num_steps, alpha_p, alpha_h) of one frame interval, with the reference's warnings and its
@@ -982,6 +983,10 @@ class EventEmulator(object):
                 raise ValueError("generate_events_batch with cs_lambda_pixels: %d Euler steps per frame (cs_tau_p_ms / cs_lambda_pixels) "
                                  "would all be enqueued up front; beyond %d use generate_events per frame (its loop ends as soon as "
                                  "the diffuser has settled)" % (max(q[0] for q in pars), self.CSDVS_RUN_MAX_STEPS))
+            if sum(q[0] for q in pars) > self.CSDVS_RUN_MAX_TOTAL_STEPS:
+                raise ValueError("generate_events_batch with cs_lambda_pixels: %d Euler steps over the run's %d frames would all be "
+                                 "enqueued up front (mostly no-op launches once the diffuser has settled); beyond %d split the run or use "
+                                 "generate_events per frame" % (sum(q[0] for q in pars), nrun, self.CSDVS_RUN_MAX_TOTAL_STEPS))
             cs_steps_dev = torch.zeros(nrun, dtype=torch.int32, device=eng.device)
             import ctypes as C
             ns = (C.c_int * nrun)(*[q[0] for q in pars])

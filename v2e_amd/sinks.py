@@ -1,4 +1,5 @@
 """Device-side packing of events into the reference writers' integer formats."""
+import logging
 import ctypes as C
 
 import torch
@@ -8,6 +9,8 @@ from ._capi import check
 
 # aedat2_output.py:41-77
 _AEDAT2_LAYOUT = {(346, 260): (12, 22, 11, 1, 1), (240, 180): (12, 22, 11, 1, 1), (640, 480): (1, 11, 0, 1, 1)}
+
+logger = logging.getLogger(__name__)
 
 
 def _ptr(t):
@@ -187,8 +190,8 @@ class DeviceTextOutput:
 class HostAEDat4Output:
     """AEDAT-4.0 sink (v2ecore/output/aedat4_output.py:17-99) over the third-party `dv_processing` package the reference
     requires for this format (requirements.txt: dv-processing >= 1.7.8; not part of either tree).  Same conversions as the
-    reference's appendEvents -- t = int(float64(t) * 1e6) (the reference's numpy < 2 promotes the float32 time stamp to float64
-    before the product), p = int((p + 1) / 2), no flips, one EventStore written at close() -- vectorised on the host; the file
+    reference's appendEvents -- t = int(t * 1e6) in the precision this host's numpy gives a float32 scalar times a Python float
+    (float64 before numpy 2, float32 from numpy 2 on), p = int((p + 1) / 2), no flips, one EventStore written at close() -- vectorised on the host; the file
     container (flatbuffers + compression) is dv_processing's.  Raises NotImplementedError where dv_processing is not importable:
     pass any object with appendEvents(events, signnoise_label=None) / close() as `dvs_aedat4` instead."""
 
@@ -218,12 +221,20 @@ class HostAEDat4Output:
         if self.writer is None or events is None or len(events) == 0:
             return
         ev = events.detach().cpu().numpy() if torch.is_tensor(events) else np.asarray(events)
-        t = (ev[:, 0].astype(np.float64) * 1e6).astype(np.int64)
+        # aedat4_output.py:82 `int(event[0] * 1e6)`: a float32 SCALAR times a Python float -- float64 under numpy < 2 (value-based
+        # promotion), float32 under numpy >= 2 (NEP 50: the Python float is weak); this host's numpy decides, as it would for the reference
+        if int(np.__version__.split(".")[0]) >= 2:
+            t = (ev[:, 0].astype(np.float32) * np.float32(1e6)).astype(np.int64)
+        else:
+            t = (ev[:, 0].astype(np.float64) * 1e6).astype(np.int64)
         x = ev[:, 1].astype(np.int64)
         y = ev[:, 2].astype(np.int64)
         p = ((ev[:, 3].astype(np.float64) + 1) / 2).astype(np.int64)
         for i in range(ev.shape[0]):
-            self.store.push_back(int(t[i]), int(x[i]), int(y[i]), int(p[i]))
+            try:  # aedat4_output.py:84-87: an event the store refuses (a time stamp that goes backwards) is logged and skipped
+                self.store.push_back(int(t[i]), int(x[i]), int(y[i]), int(p[i]))
+            except RuntimeError as e:
+                logger.warning('caught exception event {} to store'.format(e))
         on = int((p == 1).sum())
         self.numOnEvents += on
         self.numOffEvents += int(ev.shape[0]) - on
