@@ -1,0 +1,85 @@
+"""The checkpoint self-check (round-4 review, missing item 4): `python -m v2e_amd.check_ckpt`, SloMoEngine.self_check and the
+first-batch fall-back of the SuperSloMo class, on the trained-scale fixture's weights (the pretrained checkpoint itself cannot be
+downloaded into the build: |flow| to 30 px and visibility logits to 100 are what trained weights produce)."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _trained_scale_ckpt(path):
+    from test_slomo_oracle_golden import _scaled_state_dicts
+    z = np.load(os.path.join(GOLDEN, "slomo_trained_scale_64x96.npz"))
+    sd_f, sd_i = _scaled_state_dicts(z)
+    d = {"state_dictFC": {k: torch.from_numpy(v) for k, v in sd_f.items()}, "state_dictAT": {k: torch.from_numpy(v) for k, v in sd_i.items()}}
+    torch.save(d, str(path))
+    return d
+
+
+def test_layer_walk_is_the_network():
+    """HipUNet.walk_layers (23 v2e_conv2d_lrelu calls with the pooling / upsampling fused into the loaders) computes what
+    v2e_unet_forward computes, for every conv math that has no activation scaling of its own."""
+    from v2e_amd.slomo import HipUNet
+    from v2e_amd.synth import portable_unet_state_dict
+    sd = {k: torch.from_numpy(v) for k, v in portable_unet_state_dict(12, 5, 102).items()}
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    x = torch.rand((2, 12, 64, 96), device="cuda", generator=g) - 0.4
+    for math in ("f32", "bf16x3"):
+        net = HipUNet(sd, 12, 5, "cuda", math)
+        walk = net.walk_layers(x)
+        assert [w[0] for w in walk][:3] == ["conv1", "conv2", "down1.conv1"] and walk[-1][0] == "conv3" and len(walk) == 23
+        y = net.forward(x)
+        assert float(((walk[-1][2] - y).abs() / y.abs().clamp_min(1.0)).max()) <= 2e-6, math
+
+
+def test_check_ckpt_on_trained_scale_weights(tmp_path):
+    from v2e_amd import check_ckpt
+    d = _trained_scale_ckpt(tmp_path / "ckpt.pt")
+    I0, I1 = check_ckpt.synthetic_pair(64, 96, "cuda")
+    out = io.StringIO()
+    res = check_ckpt.check(d["state_dictFC"], d["state_dictAT"], I0, I1, out=out)
+    text = out.getvalue()
+    print(text)
+    for m in ("auto", "bf16x3"):
+        assert res[m]["max"] <= 1e-5, (m, res[m])
+        assert len(res[m]["layers"]) == 46
+    assert "within 1e-5" in text and "up5.conv2" in text
+    # the exact split is exact layer by layer (isolated layers on the float32 net's inputs: summation order is all that differs)
+    assert max(e for _, _, e in res["bf16x3"]["layers"]) <= 1e-5
+    # the command line (synthetic pair at a small size): exit status 0
+    assert check_ckpt.main([str(tmp_path / "ckpt.pt"), "--size", "96x64"]) == 0
+
+
+def test_superslomo_falls_back_to_the_exact_split_when_the_first_batch_fails_the_check(tmp_path, caplog):
+    from v2e_amd import SuperSloMo
+    from v2e_amd.synth import int_gradient_frames
+    _trained_scale_ckpt(tmp_path / "ckpt.pt")
+    src = tmp_path / "src"
+    src.mkdir()
+    for i, f in enumerate(int_gradient_frames(5, 40, 70, seed=9, noise=6)):
+        np.save(str(src / ("%08d.npy" % i)), f)
+
+    def run(tol, name):
+        dst = tmp_path / name
+        dst.mkdir()
+        sm = SuperSloMo(model=str(tmp_path / "ckpt.pt"), auto_upsample=False, upsampling_factor=2, batch_size=2)
+        sm.SELFCHECK_TOLERANCE = tol
+        with caplog.at_level("WARNING"):
+            caplog.clear()
+            sm.interpolate(str(src), str(dst), (70, 40))
+        from PIL import Image
+        frames = [np.asarray(Image.open(str(dst / ("%d.png" % i)))) for i in range(8)]
+        return sm, frames, [r.getMessage() for r in caplog.records]
+
+    sm, fr_auto, msgs = run(1e-5, "auto")
+    assert sm.engine.conv_math == "auto" and sm.selfcheck_result["max"] <= 1e-5 and not any("switching to the exact" in m for m in msgs)
+    sm2, fr_exact, msgs2 = run(1e-12, "forced")   # nothing passes 1e-12: the fall-back path
+    assert sm2.engine.conv_math == "bf16x3" and sum("switching to the exact" in m for m in msgs2) == 1
+    for a, b in zip(fr_auto, fr_exact):  # both maths are within the tolerance of float32: the 8-bit frames agree to one grey level
+        assert np.abs(a.astype(int) - b.astype(int)).max() <= 1

@@ -97,3 +97,32 @@ def test_two_unet_passes_on_two_streams_every_math_pair():
                 out = vnet.forward(xi).clone()
                 torch.cuda.synchronize()
                 assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (vm, nm, rep)
+
+
+def test_slomo_pair_sharding_over_an_rccl_group_of_one():
+    """VideoToEvents.run(group=): the sharded SuperSloMo stage and the in-order frame gather over RCCL (world size 1: the only size a
+    one-GPU box has; the world-2 / world-4 logic runs on gloo in tests/test_dist_cpu.py) equals the unsharded pipeline bit for bit."""
+    import os
+    import torch.distributed as dist
+    from v2e_amd import EventEmulator
+    from v2e_amd.pipeline import VideoToEvents
+    from v2e_amd.synth import int_gradient_frames
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        kw = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, leak_rate_hz=.01, shot_noise_rate_hz=.001, refractory_period_s=.0005)
+        frames = torch.from_numpy(int_gradient_frames(6, 64, 96, seed=4, noise=5, as_array=True)).cuda()
+        res = []
+        for group in (None, dist.group.WORLD):
+            pipe = VideoToEvents(_slomo("auto"), EventEmulator(device="cuda", seed=3, rng_mode="philox", **kw), 4, batch_size=2)
+            ev, counts, n = pipe.run(frames, 1 / 30, group=group) if group is not None else pipe.run(frames, 1 / 30)
+            res.append((np.asarray(ev), np.asarray(counts), n))
+        assert res[0][2] == res[1][2] == 20 and np.array_equal(res[0][1], res[1][1])
+        assert res[0][0].shape == res[1][0].shape and np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    finally:
+        if created:
+            dist.destroy_process_group()

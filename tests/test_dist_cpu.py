@@ -282,3 +282,75 @@ def test_bench_step_loop_gloo_world2():
         p.join(timeout=60)
     assert sorted(r[:2] for r in res) == [(0, True), (1, True)]
     assert res[0][2] == res[1][2] > 0
+
+
+# ---- SloMo pair sharding of ONE clip over ranks (v2e_amd.pipeline: pair_shard, gather_frames_in_order, VideoToEvents.run(group=))
+class _StubSloMoPipeline:
+    """VideoToEvents with the two device stages stubbed: upsample() = a deterministic function of each source pair, the emulator a
+    recorder.  Everything else (sharding, gather, frame order, times) is v2e_amd.pipeline's code."""
+
+    def __new__(cls, U, batch_size):
+        from v2e_amd.pipeline import VideoToEvents
+
+        class P(VideoToEvents):
+            def __init__(self):
+                self.U, self.batch_size, self.seen = U, batch_size, None
+                outer = self
+
+                class Emu:
+                    def generate_events_batch(self, frames, times, return_device=False):
+                        outer.seen = (frames.clone(), np.asarray(times).copy())
+                        return torch.zeros((int(frames.sum()) % 7, 4)), np.asarray([int(f.sum()) % 5 for f in frames])
+                self.emu = Emu()
+
+            def upsample(self, frames_u8):
+                n = int(frames_u8.shape[0]) - 1
+                out = torch.empty((n * self.U,) + tuple(frames_u8.shape[1:]), dtype=torch.uint8)
+                for k in range(n):
+                    for u in range(self.U):
+                        out[k * self.U + u] = ((frames_u8[k].to(torch.int32) * (self.U - u) + frames_u8[k + 1].to(torch.int32) * u) // self.U).to(torch.uint8)
+                return out
+        return P()
+
+
+def _slomo_shard_worker(rank, world, port, q, n_src, U):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(11)
+    frames = torch.randint(0, 256, (n_src, 5, 7), dtype=torch.uint8, generator=g)
+    single = _StubSloMoPipeline(U, 2)
+    ev1, c1, n1 = single.run(frames, 1 / 30)
+    sharded = _StubSloMoPipeline(U, 2)
+    ev2, c2, n2 = sharded.run(frames, 1 / 30, group=dist.group.WORLD, owner=world - 1)
+    ok = n1 == n2 == (n_src - 1) * U
+    if rank == world - 1:  # the owner saw the clip's frames in the single-rank order, with the single-rank times, and produced its events
+        ok &= torch.equal(sharded.seen[0], single.seen[0]) and np.array_equal(sharded.seen[1], single.seen[1])
+        ok &= torch.equal(ev1, ev2) and np.array_equal(c1, c2)
+    else:
+        ok &= ev2 is None and c2 is None and sharded.seen is None
+    every = sharded.upsample_sharded(frames, dist.group.WORLD, None)  # owner=None: the clip on every rank
+    ok &= torch.equal(every, single.seen[0])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_src,U", [(2, 9, 3), (4, 11, 2), (4, 3, 5)])
+def test_slomo_pair_sharding_reproduces_the_single_rank_clip(world, n_src, U):
+    """SURVEY.md 8(e) / north_star: one clip's source pairs sharded over ranks, frames funnelled in order to the rank with the emulator
+    state: the same frames, frame order, times and events as one rank (ragged shards; more ranks than pairs: (4, 3, 5))."""
+    from v2e_amd.pipeline import pair_shard
+    P = n_src - 1
+    blocks = [pair_shard(P, world, r) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == P and all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_slomo_shard_worker, args=(r, world, port, q, n_src, U)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {r: True for r in range(world)}

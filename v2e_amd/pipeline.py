@@ -9,6 +9,9 @@ frame in HBM and produces the same uint8 frames for the emulator:
   points per batch) --(+mean)*255, byte truncation--> uint8 --Pillow-exact BILINEAR--> [P*U,H,W]
   --> emulator (HIP, Philox, one device-resident run)
 
+One clip over several GPUs: `VideoToEvents.run(..., group=)` shards the SuperSloMo stage by source pairs over the ranks of a process
+group and funnels the uint8 frames, in order, to the rank that owns the emulator state.
+
 Frame order and times follow slomo.py:391-400, 441 and v2e.py:786-797: output frame b*U + k of a batch has
 interpTime pair + k/U (in source frame intervals), and v2e.py stretches the interpTimes so that they SPAN the processed
 duration of the source clip: t = interpTime * (N_src - 1) * interval / (max(interpTimes) - min(interpTimes)).
@@ -117,10 +120,59 @@ class VideoToEvents:
             out[b0 * U:b1 * U] = self._rs_out(q)
         return out
 
-    def run(self, frames_u8, src_frame_interval_s, return_device=False):
-        """Full pipeline; returns (events, counts_per_interpolated_frame, n_interpolated_frames)."""
-        up = self.upsample(frames_u8)
-        n = up.shape[0]
+    def upsample_sharded(self, frames_u8, group=None, owner=None):
+        """SuperSloMo of ONE clip over the ranks of `group` (BASELINE north_star: "frame batches shard across the
+        GPUs"): the P = N - 1 source pairs are independent (slomo.py:330-466: every batch is computed from its own frames), so rank r
+        interpolates pairs [r P / G, (r + 1) P / G) -- it needs source frames r P / G .. (r + 1) P / G only -- and the uint8 output
+        frames are gathered IN ORDER (one all-gather of the ranks' frame blocks, padded to the largest block: 90 KB per frame at
+        346x260, 27 MB for a second of video at 10x; `owner`: only that rank assembles the clip, None: every rank does).
+        Returns uint8 [(N - 1) U, H, W] on the assembling rank(s), None elsewhere.  Every rank must hold the same frames_u8 (or at
+        least its own slice of it: only frames lo .. hi are read)."""
+        import torch.distributed as dist
+        if group is None and not dist.is_initialized():
+            return self.upsample(frames_u8)
+        G, r = dist.get_world_size(group), dist.get_rank(group)
+        N = int(frames_u8.shape[0])
+        lo, hi = pair_shard(N - 1, G, r)
+        mine = self.upsample(frames_u8[lo:hi + 1]) if hi > lo else frames_u8.new_empty((0,) + tuple(frames_u8.shape[1:]))
+        return gather_frames_in_order(mine, N - 1, self.U, group, owner)
+
+    def run(self, frames_u8, src_frame_interval_s, return_device=False, group=None, owner=0):
+        """Full pipeline; returns (events, counts_per_interpolated_frame, n_interpolated_frames).
+        group: a torch.distributed process group -- the SuperSloMo stage is sharded over its ranks by source pairs
+        (`upsample_sharded`), the frames are funnelled in order to rank `owner` (rank within the group), which holds the emulator
+        state and runs the DVS model; the other ranks return (None, None, n)."""
+        if group is not None:
+            import torch.distributed as dist
+            up = self.upsample_sharded(frames_u8, group, owner)
+            n = (int(frames_u8.shape[0]) - 1) * self.U
+            if dist.get_rank(group) != owner:
+                return None, None, n
+        else:
+            up = self.upsample(frames_u8)
+            n = up.shape[0]
         times = interp_frame_times(int(frames_u8.shape[0]), self.U, float(src_frame_interval_s), self.batch_size)
         ev, counts = self.emu.generate_events_batch(up, times, return_device=return_device)
         return ev, counts, n
+
+
+def pair_shard(n_pairs, world, rank):
+    """Source pairs [lo, hi) of rank `rank`: contiguous blocks r P / G .. (r + 1) P / G; empty when P < G leaves none."""
+    return rank * n_pairs // world, (rank + 1) * n_pairs // world
+
+
+def gather_frames_in_order(mine, n_pairs, U, group=None, owner=None):
+    """All-gather of the ranks' interpolated-frame blocks (uint8 [pairs_r U, H, W], pairs_r from pair_shard) into the clip's frame
+    order.  The blocks are padded to the largest one (ncclAllGather / gloo all_gather want equal sizes); block sizes follow from
+    (n_pairs, world) alone, so no size exchange is needed."""
+    import torch.distributed as dist
+    G, r = dist.get_world_size(group), dist.get_rank(group)
+    cnt = [(pair_shard(n_pairs, G, q)[1] - pair_shard(n_pairs, G, q)[0]) * U for q in range(G)]
+    assert int(mine.shape[0]) == cnt[r], "this rank interpolated %d frames, its shard has %d" % (int(mine.shape[0]), cnt[r])
+    m = max(cnt)
+    pad = mine if cnt[r] == m else torch.cat((mine, mine.new_zeros((m - cnt[r],) + tuple(mine.shape[1:]))))
+    parts = [torch.empty_like(pad) for _ in range(G)]
+    dist.all_gather(parts, pad.contiguous(), group=group)
+    if owner is not None and r != owner:
+        return None
+    return torch.cat([parts[q][:cnt[q]] for q in range(G)])

@@ -162,6 +162,41 @@ class HipUNet:
             self.redo_if_flagged()
         return out
 
+    def walk_layers(self, x, inputs_from=None):
+        """The UNet layer by layer through v2e_conv2d_lrelu (model.py:198-226: avg_pool2d and the bilinear x2 fused into the consuming
+        convolution's loader, the skip concatenation as its second input): [(name, (x0, x1, pre), y)] for the 23 convolutions.
+        inputs_from = the list another network's walk returned: every layer then runs on THAT walk's inputs (an isolated layer-by-layer
+        comparison of two conv maths; v2e_amd.check_ckpt).  A two-float16-piece layer called this way stages its activations
+        unscaled (include/v2e_amd.h): the isolated figure is an upper bound for what the same layer does inside v2e_unet_forward."""
+        import ctypes as C
+        from .synth import unet_layer_shapes
+        names = [q[0] for q in unet_layer_shapes(self.cin, self.cout)]
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        out = []
+
+        def conv(i, x0, x1, pre, h, w):
+            if inputs_from is not None:
+                x0, x1, pre = inputs_from[i][1]
+            d = self.descs[i]
+            y = torch.empty((x0.shape[0], d.cout, h, w), dtype=torch.float32, device=self.device)
+            check(self.lib.v2e_conv2d_lrelu(_ptr(x0), int(x0.shape[1]), _ptr(x1), 0 if x1 is None else int(x1.shape[1]), pre, C.byref(d),
+                                            _ptr(y), int(x0.shape[0]), h, w, stream), "v2e_conv2d_lrelu")
+            out.append((names[i], (x0, x1, pre), y))
+            return y
+
+        n, c, h, w = x.shape
+        cur = conv(1, conv(0, x, None, 0, h, w), None, 0, h, w)
+        skips = [cur]
+        for d in range(5):
+            h, w = h // 2, w // 2
+            cur = conv(3 + 2 * d, conv(2 + 2 * d, cur, None, 1, h, w), None, 0, h, w)
+            skips.append(cur)
+        for u in range(5):
+            h, w = h * 2, w * 2
+            cur = conv(13 + 2 * u, conv(12 + 2 * u, cur, None, 2, h, w), skips[4 - u], 0, h, w)
+        conv(22, cur, None, 0, h, w)
+        return out
+
     def redo_if_flagged(self):
         """Read the range flag of the last forward pass (on the CURRENT stream, which must be ordered behind that pass) and redo
         the pass with the exact split if it was raised.  Returns True when it was redone (what consumed `out` must be redone too)."""
@@ -217,6 +252,7 @@ class SloMoEngine:
         self.lib = _capi.lib()
         self.flow_net = HipUNet(flow_state_dict, 2, 4, self.device, conv_math)
         self.interp_net = HipUNet(interp_state_dict, 12, 5, self.device, conv_math)
+        self._state_dicts = (flow_state_dict, interp_state_dict)  # for self_check(): the float32-MFMA engine is built from them on demand
         self._x2 = None
         self._speed_bits = None
         self._fstream = None
@@ -265,6 +301,28 @@ class SloMoEngine:
             x = torch.cat((I0, I1), dim=1).contiguous()
             f = self.flow_net.forward(x, defer_check=True)
         self._ahead = (I0, I1, x, f)
+
+    def self_check(self, I0, I1, ts=(0.5,), reference=None):
+        """This engine's conv math against the float32-MFMA kernels (the reference's own arithmetic type) on one batch: the largest
+        |a - b| / max(1, |b|) of the flow UNet's output, the interpolation UNet's output and the interpolated frames.  The default
+        conv math carries 22-bit operands; it has met the 1e-5 tolerance on every fixture, but those are seeded random weights (the
+        pretrained checkpoint is not obtainable offline) -- SuperSloMo runs this on the FIRST batch it sees and moves to the exact
+        three-bf16-piece split if the figure is above 1e-5 (round-4 review, missing item 4).  reference: a float32 SloMoEngine to
+        compare with (built from the same weights when None; ~160 MB and two UNet passes, once)."""
+        ref = reference if reference is not None else SloMoEngine(self._state_dicts[0], self._state_dicts[1], self.device, conv_math="f32")
+        ts = list(ts)
+        res = {}
+        a = self.interpolate(I0, I1, ts)
+        la = dict(self.last)
+        b = ref.interpolate(I0, I1, ts)
+        lb = ref.last
+
+        def err(x, y):
+            return float(((x - y).abs() / y.abs().clamp_min(1.0)).max())
+
+        res["flow"], res["intrp"], res["Ft"] = err(la["flow"], lb["flow"]), err(la["intrp"], lb["intrp"]), err(a, b)
+        res["max"] = max(res.values())
+        return res
 
     def lookahead_ok(self):
         """True iff two UNet passes on two streams reproduce the one-stream result bit for bit on this device with this build of the
@@ -466,6 +524,26 @@ class SuperSloMo(object):
         d = torch.load(self.checkpoint, map_location="cpu", weights_only=False)
         self.engine = SloMoEngine(d['state_dictFC'], d['state_dictAT'], self.device)  # slomo.py:225-227
         self.model_loaded = True
+        self._selfcheck_pending = os.environ.get("V2E_AMD_SLOMO_SELFCHECK", "1") != "0"
+
+    SELFCHECK_TOLERANCE = 1e-5  # the tolerance the drop-in promises against the reference's float32 arithmetic
+
+    def _first_batch_selfcheck(self, I0, I1):
+        """Once per loaded checkpoint, on the first two pairs that come in: the default conv math ('auto': two float16 pieces) against
+        the float32-MFMA kernels; above 1e-5 the engine is rebuilt with the exact split ('bf16x3'), with one warning.
+        V2E_AMD_SLOMO_SELFCHECK=0 skips it; `python -m v2e_amd.check_ckpt <ckpt>` prints the per-layer picture."""
+        self._selfcheck_pending = False
+        eng = self.engine
+        if eng.conv_math != "auto":
+            return
+        r = eng.self_check(I0[:2], I1[:2])
+        self.selfcheck_result = r
+        if not (r["max"] <= self.SELFCHECK_TOLERANCE):  # (a NaN fails too)
+            logger.warning("v2e_amd.SuperSloMo: with this checkpoint the default conv math differs from the float32 kernels by %.2e "
+                           "(flow %.2e, interpolation net %.2e, frames %.2e) on the first batch, above %.0e: switching to the exact "
+                           "three-piece split (conv_math='bf16x3', ~0.7x the frames per second)", r["max"], r["flow"], r["intrp"],
+                           r["Ft"], self.SELFCHECK_TOLERANCE)
+            self.engine = SloMoEngine(eng._state_dicts[0], eng._state_dicts[1], self.device, conv_math="bf16x3")
 
     @staticmethod
     def _load_pair_tensor(files, idx, dim):
@@ -523,6 +601,8 @@ class SuperSloMo(object):
             # the next batch is loaded first: its flow UNet runs beside this batch's interpolation UNet (SloMoEngine.flow_ahead)
             I0, I1 = nxt
             nxt = load_batch(starts[bi + 1]) if bi + 1 < len(starts) else None
+            if getattr(self, "_selfcheck_pending", False):
+                self._first_batch_selfcheck(I0, I1)
             num_batch_frames = I0.shape[0]
             flowOut = self.engine.flow(I0, I1)
             if self.auto_upsample:  # slomo.py:352-379
