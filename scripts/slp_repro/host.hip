@@ -205,3 +205,5 @@ extern "C" int slp_launch_victim_dump(const float *x, int blocks, int iters, flo
 // ---- dev tool for scripts/step_stamps.py: a device time stamp (100 MHz constant clock) from a kernel of its own on the caller's stream
 __global__ void k_stamp(unsigned long long *out, int idx) { out[idx] = wall_clock64(); }
 extern "C" int slp_stamp(unsigned long long *out, int idx, hipStream_t st) { k_stamp<<<1, 1, 0, st>>>(out, idx); return (int)hipGetLastError(); }
+__global__ void k_stamp_seq(unsigned long long *buf) { const unsigned long long i = atomicAdd(buf, 1ull); buf[1 + i] = wall_clock64(); }
+extern "C" int slp_stamp_seq(unsigned long long *buf, hipStream_t st) { k_stamp_seq<<<1, 1, 0, st>>>(buf); return (int)hipGetLastError(); }

@@ -1575,6 +1575,13 @@ static int enqueue_run(v2e_emu *h, const v2e_emu_params *p, const KArgs &a, cons
 enum { ST_MAIN = 0, ST_AHEAD = 1, ST_SIDE = 2, ST_TAB = 3, ST_SIDE2 = 4, ST_COUNT = 5 };
 enum { EV_FORK = 0, EV_JOIN = 1, EV_AHEAD = 2, EV_CHAIN = 3, EV_TAB = 4, EV_KINDS = 5 };
 
+// dev tool (scripts/step_stamps.py): sequence-numbered device time stamps from inside a run's graph: buf[0] counts, buf[1 + i] = time
+__global__ void k_dbg_stamp(unsigned long long *buf)
+{
+    const unsigned long long i = atomicAdd(buf, 1ull);
+    buf[1 + i] = wall_clock64();
+}
+
 struct Sched {
     v2e_emu *h;
     hipStream_t st[ST_COUNT];
@@ -2005,6 +2012,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     float *xt[2] = {h->ts_mem, has_refr ? h->ch_ts2 : h->ts_mem};
     // the run's uploads (frame times, first frame index) and the zero fills precede everything
     static const bool no_side_fork = getenv("V2E_AMD_INITIAL_SIDE_FORK") == nullptr; // under capture the side stream joins at its first batch
+    static const char *stamp_env = getenv("V2E_AMD_DBG_STAMP_PTR"); // dev: a device buffer of uint64 (scripts/step_stamps.py)
+    unsigned long long *stamp_buf = stamp_env ? (unsigned long long *)strtoull(stamp_env, nullptr, 0) : nullptr;
+    if (stamp_buf) { void *sargs[] = {(void *)&stamp_buf}; if (sc.kernel(ST_MAIN, (const void *)k_dbg_stamp, dim3(1), dim3(1), 0, sargs)) return V2E_EHIP; }
     // The zero fill precedes the fork.  (Round 5 tried the fork first -- k_ahead touches nothing the fill clears -- and lost 10 %:
     // 12.0 -> 10.8 Gev/s, A/B x 3 in one session; the enqueue order of a capture decides which branches this runtime overlaps,
     // profiles/r03_graph_scheduling.txt.)
@@ -2104,6 +2114,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (!capturing && last_slot >= 1 && sc.wait(ST_MAIN, EV_JOIN, last_slot - 1)) return V2E_EHIP;
         if (!fused_rec && sc.wait(ST_MAIN, EV_AHEAD, nEB - 1)) return V2E_EHIP;
     }
+    if (stamp_buf) { void *sargs[] = {(void *)&stamp_buf}; if (sc.kernel(ST_MAIN, (const void *)k_dbg_stamp, dim3(1), dim3(1), 0, sargs)) return V2E_EHIP; }
     V2E_HIP(hipGetLastError());
     return 0;
 }
