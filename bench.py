@@ -44,9 +44,9 @@ DEFAULT_KW = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, le
 HBM_PEAK = 8.0e12        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_RATE = 256 * 4 * 2.4e9 / 2  # wave64 VALU instructions per second: a SIMD-32 takes one in 2 cycles (MI355X_MICROARCH.md)
 SALU_RATE = 256 * 2.4e9          # one scalar unit per CU
-PMC_FILES = ("r04_emulator_pmc_hbm.txt", "r03_emulator_pmc_hbm.txt")
-TRACE_FILES = ("r04_emulator_chain_kernel_trace.txt", "r03_emulator_chain_kernel_trace.txt")
-SQ_FILES = ("r04_emulator_sq.txt",)
+PMC_FILES = ("r05_emulator_pmc_hbm.txt", "r04_emulator_pmc_hbm.txt")
+TRACE_FILES = ("r05_emulator_chain_kernel_trace.txt", "r04_emulator_chain_kernel_trace.txt")
+SQ_FILES = ("r05_emulator_sq.txt", "r04_emulator_sq.txt")
 F32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: f32-input MFMA peak
 INSTR_STEPS = 6           # steps re-run instrumented for the live per-launch kernel times of the roofline object
 CLIP_STEPS = 24           # distinct seconds of synthetic video generated; longer runs cycle through them
@@ -113,27 +113,45 @@ def rocprof_kernel_us(kernel):
 
 def instruction_issue(ms_per_frame):
     """The resource that binds this pipeline (round-3 review): vector and scalar instructions issued per frame over ALL its
-    kernels, from the committed SQ-counter pass of the headline workload (profiles/r04_emulator_sq.txt, line
-    '# headline_instr_per_frame <VALU> <SALU> <wave-frames>': SQ_INSTS_VALU / SQ_INSTS_SALU summed over k_ahead, k_chain, k_ctot,
-    k_cframe1, k_cemit, divided by the frames run), against the chip's issue rates (MI355X_MICROARCH.md: a wave64 VALU
-    instruction occupies its SIMD-32 for 2 cycles -> 256 CUs x 4 SIMDs x 2.4 GHz / 2; one scalar unit per CU, one
-    instruction per cycle).  frac = the time the busier of the two pipes needs / the time a frame takes."""
+    kernels, from the committed SQ-counter pass of the headline workload (profiles/r05_emulator_sq.txt: SQ_INSTS_VALU / SQ_INSTS_SALU
+    of k_ahead, k_chain, k_ctot, k_cframe1, k_cemit divided by the frames run), against the chip's issue rates
+    (MI355X_MICROARCH.md: a wave64 float32 VALU instruction occupies its SIMD-32 for 2 cycles, a float64 one for 4 -> every
+    kernel's VALU count is priced at 2 + 2 x its float64 share, the share being a static count over the kernel's disassembly
+    ('# kernel_instr_per_frame <kernel> <VALU> <SALU> <f64 share>' lines; round-4 review: "prices every VALU instruction at 2
+    cycles although a large share of k_chain's are f64"); one scalar unit per CU, one instruction per cycle).
+    frac = the time the busier of the two pipes needs / the time a frame takes."""
     for name in SQ_FILES:
         try:
+            valu = salu = None
+            per_kernel = []
             for line in open(os.path.join(ROOT, "profiles", name)):
                 if line.startswith("# headline_instr_per_frame"):
                     parts = line.split()
                     valu, salu = float(parts[2]), float(parts[3])
-                    t_v, t_s = valu / VALU_RATE, salu / SALU_RATE
-                    out = {"valu_per_frame": int(valu), "salu_per_frame": int(salu),
-                           "per_64px_wave_frame": round((valu + salu) / (H * W / 64.0), 1),
-                           "valu_rate_per_s": VALU_RATE, "salu_rate_per_s": SALU_RATE,
-                           "bound_us_per_frame": round(max(t_v, t_s) * 1e6, 4), "measured_us_per_frame": round(ms_per_frame * 1e3, 4),
-                           "frac": round(max(t_v, t_s) / (ms_per_frame * 1e-3), 4), "source": "profiles/" + name,
-                           "note": "instructions of all kernels of the pipeline per frame (rocprofv3 SQ counters, recorded) over the "
-                                   "chip's vector / scalar issue rates against this run's time per frame: the fraction of the "
-                                   "BINDING resource; the rest is dependency latency that one wave per SIMD cannot hide"}
-                    return out
+                elif line.startswith("# kernel_instr_per_frame"):
+                    parts = line.split()
+                    per_kernel.append((parts[2], float(parts[3]), float(parts[4]), float(parts[5])))
+            if valu is None:
+                continue
+            simd_hz = 256 * 4 * 2.4e9
+            if per_kernel:
+                valu_cycles = sum(v * (2.0 + 2.0 * sh) for _, v, _, sh in per_kernel)
+                f64_share = sum(v * sh for _, v, _, sh in per_kernel) / max(sum(v for _, v, _, _ in per_kernel), 1.0)
+            else:  # an older profile without the per-kernel lines: every VALU instruction at 2 cycles (optimistic)
+                valu_cycles, f64_share = valu * 2.0, None
+            t_v, t_s = valu_cycles / simd_hz, salu / SALU_RATE
+            return {"valu_per_frame": int(valu), "salu_per_frame": int(salu),
+                    "per_64px_wave_frame": round((valu + salu) / (H * W / 64.0), 1),
+                    "valu_f64_share_static": None if f64_share is None else round(f64_share, 3),
+                    "per_kernel": [{"kernel": k, "valu": int(v), "salu": int(sa), "f64_share_static": sh} for k, v, sa, sh in per_kernel] or None,
+                    "valu_cycles_per_frame": int(valu_cycles), "simd_cycles_per_s": simd_hz, "salu_rate_per_s": SALU_RATE,
+                    "valu_us_per_frame": round(t_v * 1e6, 4), "salu_us_per_frame": round(t_s * 1e6, 4),
+                    "bound_us_per_frame": round(max(t_v, t_s) * 1e6, 4), "measured_us_per_frame": round(ms_per_frame * 1e3, 4),
+                    "frac": round(max(t_v, t_s) / (ms_per_frame * 1e-3), 4), "source": "profiles/" + name,
+                    "note": "instructions of all kernels of the pipeline per frame (rocprofv3 SQ counters, recorded) priced at the chip's "
+                            "issue costs (float32 VALU 2 cycles, float64 VALU 4 cycles by each kernel's static float64 share, scalar 1 "
+                            "per CU and cycle) against this run's time per frame: the fraction of the BINDING resource; the rest is "
+                            "dependency latency that one wave per SIMD cannot hide"}
         except Exception:
             pass
     return None
@@ -171,7 +189,7 @@ def cpu_baseline(frames_host, budget_s=8.0):
     res = {}
     _oracle_run(frames_host, budget_s, res, 0)
     n_ev, n_fr, dt = res[0]
-    out = {"value": round(n_ev / dt / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port",
+    out = {"value": round(n_ev / dt / 1e6, 3), "unit": "Mevents/s", "cores": 1, "kind": "port", "same_host_reference": False,
            "frames_per_s": round(n_fr / dt, 1),
            "sample": "first %d frames of the same 346x260 clip, C oracle (oracle/emu_oracle.c), Philox RNG, %.1f s" % (n_fr, dt)}
     try:
@@ -193,29 +211,13 @@ def cpu_baseline(frames_host, budget_s=8.0):
     ref = recorded_reference()
     if ref:
         runs = ref["emulator"]["runs"]
+        out["same_host_reference_note"] = ("no same-host reference baseline exists: the reference tree cannot travel to the GPU box; `value` "
+                                            "is the C port on THIS host, `reference` the unmodified reference on the build container")
         out["reference"] = {"kind": "reference, recorded on a DIFFERENT host (the build container: the reference tree does not exist on the GPU box)",
                             "host": ref["host"], "script": "scripts/cpu_reference_baseline.py -> profiles/r02_cpu_reference.json",
                             "runs": [{"cores": r["threads"], "value": r["Mevents_per_s"], "unit": "Mevents/s",
                                       "frames_per_s": r["frames_per_s"]} for r in runs]}
     return out
-
-
-def slomo_cpu_baseline():
-    """The SloMo stage's CPU port on THIS host: oracle/slomo_oracle.c (OpenMP over output channels x rows) on one pair at
-    320x256, two time points -- 51.45 + 2 x 54.07 GFLOP of scalar float32 fma chains."""
-    from oracle import oracle as orc
-    from v2e_amd.synth import portable_unet_state_dict
-    rng = np.random.default_rng(2)
-    I0 = (rng.random((1, 1, 256, 320), dtype=np.float32) - np.float32(0.428))
-    I1 = (rng.random((1, 1, 256, 320), dtype=np.float32) - np.float32(0.428))
-    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
-    ts = [0.25, 0.75]
-    t0 = time.perf_counter()
-    orc.slomo_interpolate(I0, I1, ts, sd_f, sd_i)
-    dt = time.perf_counter() - t0
-    return {"value": round(len(ts) / dt, 3), "unit": "frames/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
-            "sample": "one pair at 320x256, U = 2 (flow UNet + 2 x interpolation UNet + warps), oracle/slomo_oracle.c with OpenMP "
-                      "(scalar float32 fma chains, no SIMD intrinsics), %.1f s" % dt}
 
 
 def frame_api_bench(frames_all, budget_frames=600):
@@ -557,43 +559,53 @@ def main():
         whole = (bpp * npx + 16 * ev_per_frame)
         traffic, prof_file = pmc_traffic_per_launch(kname.split("(")[0])
         rp_us, rp_file = rocprof_kernel_us(kname.split("(")[0])
+        this_round = rp_file is not None and "/r05_" in rp_file
+        live = {"avg_kernel_us": round(kernel_us, 3), "achieved_GBps": round(ach / 1e9, 2), "frac": round(ach / HBM_PEAK, 5),
+                "launches_timed": n_step, "launch_us": [round(u, 1) for u in per_launch],
+                "note": "HIP events before and after every chain launch of an instrumented re-run of %d steps' frames with ALL kernels "
+                        "of the run on ONE stream: each kernel running alone (no contention with k_ahead / the emission kernels)" % INSTR_STEPS}
+        timed = None if rp_us is None else {
+            "avg_kernel_us": rp_us, "source": rp_file, "achieved_GBps": round(step_bytes / (rp_us * 1e-6) / 1e9, 2),
+            "frac": round(step_bytes / (rp_us * 1e-6) / HBM_PEAK, 5),
+            "note": "the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this same command: the "
+                    "TIMED configuration (three streams side by side, every duration under contention, redo passes included)"}
+        # what the line's frac is (round-4 review: "report the roofline that follows from profiles/"): the timed configuration's figure
+        # when this round's trace is committed, else the live one (each kernel alone), and it says which
+        head = timed if (timed and this_round) else live
         out["roofline"] = {
             "bound": "hbm", "kernel": kname.split("(")[0],
-            "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK, 5),
+            "achieved": head["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": head["frac"],
+            "frac_is": ("algorithmic bytes / the kernel's average duration in the TIMED configuration (profiles/, rocprofv3)" if head is timed
+                        else "algorithmic bytes / the kernel's average duration running ALONE (live HIP events): no rocprofv3 trace of this round is committed"),
             "traffic": traffic,
             "traffic_source": str(prof_file) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; counters cannot be read "
                                           "from inside the process)",
+            "traffic_over_algorithmic": None if not traffic else round(traffic / step_bytes, 3),
             "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
             "frames_per_launch_avg": round(F / n_per_step, 2),
-            "avg_kernel_us": round(kernel_us, 3), "launches_timed": n_step,
-            "launch_us": [round(u, 1) for u in per_launch],
+            "timed_configuration": timed,
+            "alone_hip_events": live,
             "median_full_launch": None if p50 is None else {
                 "us": round(p50, 3), "bytes": int(full_bytes), "achieved_GBps": round(full_bytes / (p50 * 1e-6) / 1e9, 2),
                 "frac": round(full_bytes / (p50 * 1e-6) / HBM_PEAK, 5),
-                "note": "the median of the launches that advance %d frames: a launch WITHOUT a redo pass (the average above "
-                        "includes the launches that first redo their predecessor, the partial last launch and the tail launch)" % fpl},
+                "note": "the median of the launches that advance %d frames, each alone: a launch WITHOUT a redo pass" % fpl},
             "launch_period_us": round(period_us, 3),
             "as_delivered": {"achieved_GBps": round(step_bytes / (period_us * 1e-6) / 1e9, 2),
                              "frac": round(step_bytes / (period_us * 1e-6) / HBM_PEAK, 5),
                              "note": "the same bytes against the timed region's time per chain launch (ms_per_step / launches per step: "
                                      "everything the step does -- k_ahead, the emission kernels, gaps, redo passes -- included)"},
-            "rocprof_recorded": None if rp_us is None else {
-                "avg_kernel_us": rp_us, "source": rp_file, "frac": round(step_bytes / (rp_us * 1e-6) / HBM_PEAK, 5)},
             "instruction_issue": instruction_issue(elapsed / (K * F) * 1e3),
             "event_writer_us_per_batch": round(prof["emit"] / max(prof.get("emit_batches", 1), 1) * 1e3, 3),
             "emission": {"frames_per_batch": fpb, "algorithmic_bytes_per_frame": int(emit_bytes)},
             "whole_step": {"algorithmic_bytes_per_frame": int(whole),
                            "achieved_GBps": round(whole * K * F / elapsed / 1e9, 2),
                            "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
-            "note": "achieved = algorithmic bytes (53 B x pixels x the step's frames / the step's chain launches: what a launch advances "
-                    "on average) / the launches' average duration, HIP events before and after every launch of an instrumented re-run "
-                    "of %d steps' frames with all kernels of the run on ONE stream, i.e. each running alone (in the timed runs "
-                    "the three streams overlap and every kernel is stretched: profiles/r03_graph_scheduling.txt); "
-                    "instruction_issue states the fraction of the resource that actually binds this pipeline; "
-                    "the per-pixel state (2.9 MB at 346x260) stays in registers for the launch's frames and one frame is only "
-                    "1408 waves, so the chain is bounded by instruction latency, not HBM (DESIGN.md section 3); whole_step prices "
-                    "the complete frame (state traffic + event rows) against the driver-timed region" % INSTR_STEPS,
+            "note": "algorithmic bytes = 53 B x pixels x the step's frames / the step's chain launches (what a launch advances on average; "
+                    "SURVEY.md 8(d)).  Three durations divide them: timed_configuration (what `frac` is when this round's trace is "
+                    "committed), alone_hip_events (live, each kernel alone), as_delivered (the driver-timed region per launch).  The "
+                    "per-pixel state (2.9 MB at 346x260) stays in registers for a launch's 32 frames and the PMC traffic is below the "
+                    "algorithmic bytes: HBM is not what binds this kernel -- instruction_issue states the fraction of the resource that "
+                    "does, and whole_step prices the complete frame (state + event rows) against the driver-timed region",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())
@@ -607,12 +619,11 @@ def main():
                 out["slomo"] = slomo_bench(device)
                 out["slomo_f32"] = slomo_bench(device, conv_math="f32")
                 out["slomo_bf16x3"] = slomo_bench(device, conv_math="bf16x3")  # the exact three-piece split (what the range guard falls back to)
-                if not args.no_cpu_baseline:
-                    out["slomo"]["cpu_baseline_this_host"] = slomo_cpu_baseline()
                 ref = recorded_reference()
                 if ref:
                     out["slomo"]["cpu_baseline"] = {
                         "kind": "reference, recorded on a DIFFERENT host (scripts/cpu_reference_baseline.py, build container)", "host": ref["host"]["cpu"],
+                        "same_host_reference": False,
                         "runs": [{"cores": q["threads"], "batch_pairs": q["batch_pairs"], "value": q["interpolated_frames_per_s"],
                                   "unit": "frames/s"} for q in ref["slomo"]["runs"]]}
                 out["end_to_end"] = e2e_bench(device)

@@ -141,9 +141,9 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     roof = {"bound": "mfma", "kernel": ("k_conv_s3 / k_conv_s3p" if s3 else "k_conv") + " (23 launches of the interpolation UNet)",
             "achieved": round(ach * npr / 1e12, 2), "peak": (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK) / 1e12,
             "unit": "TFLOP/s", "frac": round(ach * npr / (BF16_MFMA_PEAK if s3 else F32_MFMA_PEAK), 4),
-            # (the committed PMC passes are of the 80-sample 320x256 forward: no traffic figure for another shape)
-            "traffic": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W))[0] if (U * B, H, W) == (80, 256, 320) else None,
-            "traffic_detail": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W))[1] if (U * B, H, W) == (80, 256, 320) else None,
+            # (PMC passes are committed for the 80-sample 320x256 forward in every conv math and for 2 samples at 1280x704)
+            "traffic": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W), "%dx%dx%d" % (U * B, H, W))[0],
+            "traffic_detail": slomo_pmc_traffic(math_run, unet_algorithmic_bytes(U * B, 12, 5, H, W), "%dx%dx%d" % (U * B, H, W))[1],
             "f32_equivalent_TFLOPs": round(ach / 1e12, 2),
             "f32_equivalent_vs_f32_mfma_peak": round(ach / F32_MFMA_PEAK, 4),
             "whole_step_TFLOPs": round(flops / sec / 1e12, 2),
@@ -170,27 +170,28 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
     }
 
 
-def slomo_pmc_traffic(conv_math, algorithmic=None):
-    """HBM bytes per interpolation-UNet forward (80 samples) of the conv math that ran, from the committed rocprofv3 PMC
-    passes of THIS round's kernels (profiles/r04_slomo_counters.txt, lines '# unet_forward_bytes <conv_math> <fetch> <write>',
-    made by scripts/gpu_r04_profiles.sh + scripts/make_profiles_r04.py).  Returns (bytes or None, detail dict)."""
+def slomo_pmc_traffic(conv_math, algorithmic=None, shape="80x256x320"):
+    """HBM bytes per interpolation-UNet forward of the conv math that ran, from the committed rocprofv3 PMC passes of THIS round's
+    kernels (profiles/r05_slomo_counters.txt, lines '# unet_forward_bytes <conv_math> <fetch> <write> <samples>x<H>x<W>', made by
+    scripts/gpu_r05_profiles.sh + scripts/make_profiles_r05.py; the round-4 file, whose lines carry no shape and are 80x256x320, is the
+    fall-back).  Returns (bytes or None, detail dict)."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    name = "r04_slomo_counters.txt"
-    try:
-        for line in open(os.path.join(root, "profiles", name)):
-            if line.startswith("# unet_forward_bytes"):
-                parts = line.split()
-                if parts[2] == conv_math:
-                    fetch, write = float(parts[3]), float(parts[4])
-                    d = {"source": "profiles/" + name, "fetch_bytes": int(fetch), "write_bytes": int(write)}
-                    if algorithmic:
-                        d["algorithmic_bytes"] = int(algorithmic)
-                        d["traffic_over_algorithmic"] = round((fetch + write) / algorithmic, 3)
-                    return int(fetch + write), d
-    except Exception:
-        pass
-    return None, {"source": None, "note": "no PMC pass of this conv math committed for this round"}
+    for name in ("r05_slomo_counters.txt", "r04_slomo_counters.txt"):
+        try:
+            for line in open(os.path.join(root, "profiles", name)):
+                if line.startswith("# unet_forward_bytes"):
+                    parts = line.split()
+                    if parts[2] == conv_math and (parts[5] if len(parts) > 5 else "80x256x320") == shape:
+                        fetch, write = float(parts[3]), float(parts[4])
+                        d = {"source": "profiles/" + name, "shape": shape, "fetch_bytes": int(fetch), "write_bytes": int(write)}
+                        if algorithmic:
+                            d["algorithmic_bytes"] = int(algorithmic)
+                            d["traffic_over_algorithmic"] = round((fetch + write) / algorithmic, 3)
+                        return int(fetch + write), d
+        except Exception:
+            pass
+    return None, {"source": None, "note": "no PMC pass of this conv math and shape is committed"}
 
 
 def unet_algorithmic_bytes(n, cin, cout, h, w):
