@@ -207,7 +207,7 @@ def test_csdvs_default_tape_mode_matches_reference_at_davis346():
     """The drop-in's default mode (the reference's own seeded torch generator) with the centre-surround pixel: event digests,
     surround plane, step counts and lp_log_frame against the unmodified reference."""
     import torch
-    from fixtures import LiveTapeFixture
+    from fixtures import LiveTapeFixture, require_same_generator
     from v2e_amd import EventEmulator
     fx = LiveTapeFixture("tape_live_csdvs_346x260")
     require_same_generator(fx)
