@@ -1,8 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 cd $R
-( time python bench.py --steps 20 --warmup 5 ) > $O/full_bench.json 2> $O/full_bench.log
-tail -c 600 $O/full_bench.json; tail -4 $O/full_bench.log
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/full_pytest.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q > $O/full_pytest.log 2>&1
 tail -5 $O/full_pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3

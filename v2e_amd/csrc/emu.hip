@@ -1432,7 +1432,7 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
                                                  (v2e_frame_rec *)h->fr_rec_host_dev, 0ull, est, rec_next);
     }
     V2E_HIP(hipGetLastError());
-    static const bool timing = getenv("V2E_AMD_FRAME_TIMING") != nullptr; // dev: where a frame's host time goes
+    constexpr bool timing = false; // (round 2-4 dev switch V2E_AMD_FRAME_TIMING: where a frame's host time goes; removed, the block below is dead code the compiler drops)
     static double t_enq = 0, t_sync = 0; static int t_n = 0;
     const auto tp1 = std::chrono::steady_clock::now();
     V2E_HIP(hipStreamSynchronize(s));
@@ -1897,25 +1897,25 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     int gy = NC;
     if (has_refr && K > 1) gy = std::max(1, std::min(NC, h->ch_max_blocks / std::max(h->ngroups, 1)));
     dim3 grid(h->ngroups, gy);
-    static const bool no_emit = getenv("V2E_AMD_CHAIN_NO_EMIT") != nullptr; // dev: time the chain alone (no events)
+    constexpr bool no_emit = false;
     const bool no_emit_run = false;
-    static const int chain_prio = getenv("V2E_AMD_CHAIN_PRIO") ? atoi(getenv("V2E_AMD_CHAIN_PRIO")) : 3; // dev: 0 = no raised wave priority
+    constexpr int chain_prio = 3; // wave priority of the chain (measured against 0 in round 3)
     // occupancy cap of the kernels that run BESIDE the chain (k_ahead, k_ctot, k_cemit): dynamic LDS they do not use, so that a
     // CU holds at most floor(160 KB / pad) of their workgroups (0: no cap)
-    static const int side_pad = (getenv("V2E_AMD_SIDE_LDS_KB") ? atoi(getenv("V2E_AMD_SIDE_LDS_KB")) : 0) * 1024;
-    static const int bar_light = getenv("V2E_AMD_BAR_LIGHT") ? atoi(getenv("V2E_AMD_BAR_LIGHT")) : 1;    // dev: 0 = fenced rendezvous (round 3)
+    constexpr int side_pad = 0; // (an LDS pad capping the side kernels' occupancy was measured in round 3 and bought nothing)
+    constexpr int bar_light = 1; // the fence-free rendezvous (round 4; the fenced one of round 3 is still in clip_barrier)
     // lock-step frames in redo passes (emu_chain.h): measured round 4 with the fence-free rendezvous, A/B in one process each:
     // a launch whose rule-on frames come in a run 109-112 -> 89-92 us, a launch with a single rule-on frame 54-60 -> 68-71 us
     // (the extra rendezvous is ~10 us inside the frame loop: it also drains the record prefetch), 10.4-10.6 against 10.8-11.0
     // Gev/s on the benchmark clip: off by default, kept behind V2E_AMD_LOCKSTEP=1 (GPU parity suite green with it on)
-    static const int lockstep = getenv("V2E_AMD_LOCKSTEP") ? atoi(getenv("V2E_AMD_LOCKSTEP")) : 0;
+    constexpr int lockstep = 0;
     // Under stream capture only edges between the origin stream and a forked stream are safe (edges between two forked
     // streams crash hipStreamEndCapture on this runtime): tables and rows then share the side stream.
-    static const int tab_env = getenv("V2E_AMD_TABLES_ON_SIDE") ? ST_SIDE : (getenv("V2E_AMD_TABLES_ON_AHEAD") ? ST_AHEAD : ST_TAB); // dev
-    static const bool tabs_on_main = getenv("V2E_AMD_TABLES_ON_MAIN") != nullptr; // dev: tables on the chain's stream, rows on the side stream
+    constexpr int tab_env = ST_TAB; // plain streams: tables on a stream of their own
+    constexpr bool tabs_on_main = false;
     const int tab_stream = capturing ? (tabs_on_main ? ST_MAIN : ST_SIDE) : tab_env;
     constexpr int NSET = 3; // emission table sets (chain_alloc sizes them)
-    static const bool one_row_stream = getenv("V2E_AMD_ONE_ROW_STREAM") != nullptr; // dev
+    constexpr bool one_row_stream = false;
     // b: the emission's slot (event indices, table set b % NSET, event offsets run_off[b] -> run_off[b + 1]); frames [ef0, ef0 + enE).
     // A batch is normally slot b = frames [b E, (b + 1) E); the run's LAST batch may be emitted in two pieces (slots nEB - 1, nEB).
     // (Round 5 measured the tables of the run's LAST pieces on the chain's stream, beside the rows of the batch before on the side
@@ -1937,14 +1937,14 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ea.off_out = h->run_off + (size_t)(b + 1) * NC;
         // event records of k_cemit: 256 x ich per group (wave) and pass.  The chain's workgroups need their LDS (5 KB per frame)
         // on every CU: 4 iterations per pass (measured at 346x260: 3 / 6 / 10 per pass 10.47 / 10.30 / 10.31 Gev/s) keep an emission workgroup of four groups at 16 KB
-        static const int ich_env = getenv("V2E_AMD_CEMIT_ICH") ? atoi(getenv("V2E_AMD_CEMIT_ICH")) : 0;
+        constexpr int ich_env = 0;
         ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 4;
         ea.capw = GROUP_PX * ea.ich;
         ea.coff_in_cemit = (tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream) ? 1 : 0;
         // frames per workgroup (measured at 346x260, 32-frame batches: k_ctot 4 frames 13 us, 32 frames 37 us; k_cemit 1 frame
         // 34 us, 8 frames 45 us -- these kernels are bound by the latency of a wave's dependent loads, not by wave dispatch:
         // more, shorter waves win)
-        static const int zpw_env = getenv("V2E_AMD_EMIT_ZPW") ? atoi(getenv("V2E_AMD_EMIT_ZPW")) : 0;
+        constexpr int zpw_env = 0;
         (void)zpw_env;
         ea.zpw_tot = CTOT_ZF;
         ea.zpw_emit = 1; // (k_cemit: one frame per workgroup; several per workgroup measured slower and cost 25 % more instructions)
@@ -1982,13 +1982,13 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // Batch 0 of a run is split at the first chain launch's frames: the chain starts after the records of K frames, not of E
     // (its first launch idled through the whole first k_ahead: ~15 us of every 300-frame step); the rest of the batch follows on
     // the same stream and is waited for by the batch's other launches (event slot nL of EV_AHEAD: the batches use 0 .. nEB - 1).
-    static const bool split_first_ahead = getenv("V2E_AMD_NO_AHEAD_SPLIT") == nullptr;
+    constexpr bool split_first_ahead = true;
     const bool split0 = split_first_ahead && m > 1 && n_frames > K;
     auto launch_ahead = [&](int b) -> int {
         if (b >= nD && sc.wait(ST_AHEAD, EV_CHAIN, (b - nD + 1) * m)) return V2E_EHIP; // records of batch b - nD: last read by that launch's redo
         // frame pairs touched by a launch: at most nf / 2 + 1 (the device knows the run's first frame index, the host
         // does not when it builds a graph: one extra pair covers either alignment; threads of a pair outside the range return)
-        static const int ppt_env = getenv("V2E_AMD_AHEAD_PPT") ? atoi(getenv("V2E_AMD_AHEAD_PPT")) : 0;
+        constexpr int ppt_env = 0;
         const int b0 = b * E, b1 = std::min((b + 1) * E, n_frames);
         const int cut = (b == 0 && split0) ? std::min(K, b1) : b1;
         for (int part = 0; part < 2; ++part) {
@@ -2031,11 +2031,11 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b)
         if (launch_ahead(b)) return V2E_EHIP;
     // last batch in two pieces: only where the last launch is not the first of its batch (else there is nothing to emit early)
-    static const bool split_tail_env = getenv("V2E_AMD_NO_TAIL_SPLIT") == nullptr;
+    constexpr bool split_tail_env = true;
     const int tail_f0 = (nB - 1) * K;                          // first frame of the last chain launch with frames
     const bool split_tail = split_tail_env && has_refr && m > 1 && nB >= 2 && (nB - 1) % m != 0 && !no_emit_run;
     const int last_slot = (split_tail && tail_f0 > (nEB - 1) * E) ? nEB : nEB - 1;
-    static const int allon_env = getenv("V2E_AMD_CHAIN_ALLON") ? atoi(getenv("V2E_AMD_CHAIN_ALLON")) : 1; // dev: 0 = the generic instantiation
+    constexpr int allon_env = 1;
     const bool allon = allon_env && a_in.has_cutoff && a_in.do_leak && a_in.do_shot && a_in.has_refr;
     const void *kfn = chain_fn(p->f64_state != 0, dtype, fused_rec, allon);
     for (int L = 0; L < nL; ++L) {
@@ -2060,7 +2060,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.base_fix = xb[in]; ca.lp_fix = xl[in]; ca.ts_fix = xt[in];
         ca.base_out = xb[out]; ca.lp_out = xl[out]; ca.ts_out = xt[out];
         ca.base_pin = xb[pin]; ca.lp_pin = xl[pin]; ca.ts_pin = xt[pin];
-        static const bool no_ckpt = getenv("V2E_AMD_CHAIN_NO_CKPT") != nullptr; // dev: every redo restarts at the launch's first frame
+        constexpr bool no_ckpt = false;
         if (has_refr && K > CHAIN_SUB && h->ch_ck && !no_ckpt) {
             const size_t plane = (size_t)3 * NC * h->npx_pad; // elements per (parity, quantity)
             auto ck = [&](int par, char *&bp, char *&lpp, float *&tp) {

@@ -904,7 +904,7 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
         V2E_HIP(hipGetLastError());
         return 0;
     }
-    static const bool s3_off = getenv("V2E_AMD_CONV_F32") != nullptr; // dev: force the f32-MFMA kernel
+    constexpr bool s3_off = false;
     // split-bf16 kernel: whole 16-channel chunks -- or the 12-channel 7x7 conv1, whose last chunk is padded with zeros
     // (a third of its multiplies wasted and still 1.4x the f32 kernel; the 2-channel conv1 of the flow UNet is not worth it)
     const bool s3_cin = conv->cin % 16 == 0 || (conv->ksize == 7 && c1 == 0 && conv->cin >= 8);

@@ -470,7 +470,7 @@ static int launch_conv_s3(const ConvArgs &a0, hipStream_t s)
     }
     a.tiles_x = (a.w_ + TW - 1) / TW;
     a.tiles_y = (a.h + TH - 1) / TH;
-    static const int order = getenv("V2E_AMD_S3_ORDER") ? atoi(getenv("V2E_AMD_S3_ORDER")) : 1; // dev: 0 = pixel tiles fastest (2-D grid)
+    constexpr int order = 1; // channel blocks of a pixel tile consecutive (round 2; 0 = pixel tiles fastest measured slower)
     const int ntiles = a.n * a.tiles_x * a.tiles_y, ncb = a.cout / (CT * 32);
     // measured at 40 samples: +6 % where a pixel tile has >= 4 channel blocks (256->128 at 64x80, 512->256 at 32x40), within
     // noise at 2 blocks, -3 % on the five-wave 20-wide tiles (16 blocks: more workgroups than an XCD holds at once)
