@@ -251,6 +251,10 @@ int v2e_emu_frame_host_rows(v2e_emu *h, float *pinned_rows, uint64_t cap_rows);
  * A/B measurements; also what runs photoreceptor noise, float64 log-encoded frames and more than
  * 1024 events per pixel and frame); |256 insists on k_chain (error where it cannot run).  All give
  * identical results.
+ * Round 5: the run's frame scalars, first frame index and the ADDRESS of `frames` reach the device through one small kernel that
+ * reads a pinned staging set (no copy-engine transfer), and the k_chain pipeline's kernels read the frames through that device
+ * variable: with use_graph & 1 a cached graph is replayed over whatever `frames` buffer a call names (events / recs_dev are still
+ * baked in: callers alternate between fixed buffer sets), so a caller need not copy frames into one fixed buffer per run.
  */
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames,
                 const double *t_prev, const double *t_frame, uint32_t frame_idx0, float *events,
