@@ -285,9 +285,11 @@ class SloMoEngine:
             self.flow_net._pending = None
             self._ahead = None
 
-    def flow_ahead(self, I0, I1):
-        """Start the flow UNet of a LATER batch on the engine's side stream, behind what the current stream holds NOW (so: call it
-        before enqueuing the current batch's interpolation).  At the v2e batch size (8 pairs) the flow UNet is a chain of small
+    def flow_ahead(self, I0, I1, after=None):
+        """Start the flow UNet of a LATER batch on the engine's side stream, behind what the current stream holds NOW -- or behind
+        the event `after` recorded on it earlier (interpolate() records one BEFORE it enqueues the batch's interpolation and calls
+        this behind it: the side stream still starts where the event is, but the current stream's work no longer waits for the host
+        to enqueue these 23 launches first).  At the v2e batch size (8 pairs) the flow UNet is a chain of small
         launches that leaves most of the chip idle -- 3 ms of a 21 ms batch; beside the previous batch's interpolation UNet it is
         nearly free.  `flow(I0, I1)` with the same two tensors collects the result."""
         self._drop_ahead()
@@ -296,7 +298,10 @@ class SloMoEngine:
             #  share a few queues round-robin, and on the queue of the current stream the pass would simply run in line)
             self._fstream = torch.cuda.Stream(self.device, priority=-1)
         cur = torch.cuda.current_stream(self.device)
-        self._fstream.wait_stream(cur)
+        if after is not None:
+            self._fstream.wait_event(after)
+        else:
+            self._fstream.wait_stream(cur)
         with torch.cuda.stream(self._fstream):
             x = torch.cat((I0, I1), dim=1).contiguous()
             f = self.flow_net.forward(x, defer_check=True)
@@ -384,10 +389,16 @@ class SloMoEngine:
         I1 = I1 if I1.is_contiguous() else I1.contiguous()
         if flow is None:
             flow = self.flow(I0, I1)
+        # (Round 5 measured the look-ahead enqueued BEHIND this batch's own launches, bound to an event recorded here, so that the
+        # current stream does not idle for the ~1.4 ms of host time the 23 look-ahead launches take: 19.9 ms per batch either way --
+        # the flow UNet does useful work alone in that gap, and beside the interpolation UNet it stretches it by as much.)
         if next_pair is not None and _LOOKAHEAD and self.lookahead_ok():
             self.flow_ahead(next_pair[0], next_pair[1])
         nt = len(ts)
-        coef = torch.from_numpy(time_coefficients(ts)).to(self.device)
+        key = tuple(float(t) for t in ts)
+        if getattr(self, "_coef_key", None) != key:  # (the time points are the same for every batch of a clip: one upload)
+            self._coef, self._coef_key = torch.from_numpy(time_coefficients(ts)).to(self.device), key
+        coef = self._coef
         x12 = torch.empty((nt * B, 12, H, W), dtype=torch.float32, device=self.device)
         check(self.lib.v2e_slomo_prep(_ptr(I0), _ptr(I1), _ptr(flow), _ptr(coef), nt, B, H, W, _ptr(x12), self._stream()),
               "v2e_slomo_prep")
