@@ -255,7 +255,7 @@ def delivered_to_host_bench(device, frames_all, steps=6):
     host = [None, None]
 
     def enqueue(s):
-        lo = 1 + (s % CLIP_STEPS) * F
+        lo = 1 + (s % max((int(frames_all.shape[0]) - 1) // F, 1)) * F   # the steps of video that were generated
         buf.copy_(frames_all[lo:lo + F])
         return emu.generate_events_batch_async(buf, [(1 + s * F + i) * DT for i in range(F)], return_device=True)
 
@@ -518,7 +518,7 @@ def main():
         recs = eng.alloc_recs(F)
         prof, per_launch_all, evs = None, [], []
         for si in range(INSTR_STEPS):
-            lo = 1 + ((Wm + K - 1 + si) % CLIP_STEPS) * F
+            lo = 1 + ((Wm + K - 1 + si) % max((int(frames_all.shape[0]) - 1) // F, 1)) * F
             buf.copy_(frames_all[lo:lo + F])
             t0s = emu.t_previous + si * F * DT
             t_prev = [t0s + i * DT for i in range(F)]
@@ -638,6 +638,16 @@ def main():
                     out["self_allgather"] = self_allgather_bench(device, frames_all)
                 except Exception as e:
                     out["self_allgather"] = {"error": repr(e)[:300]}
+    if dist is not None and not STUB and not args.no_extras:
+        # the SuperSloMo stage of ONE clip sharded over the ranks by source pairs (every rank takes part; rank 0 reports)
+        try:
+            from v2e_amd.benchutil import slomo_sharded_bench
+            r = slomo_sharded_bench(device, dist)
+            if rank == 0:
+                out["slomo_sharded"] = r
+        except Exception as e:
+            if rank == 0:
+                out["slomo_sharded"] = {"error": repr(e)[:300]}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
