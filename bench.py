@@ -114,7 +114,7 @@ def rocprof_kernel_us(kernel):
 def instruction_issue(ms_per_frame):
     """The resource that binds this pipeline (round-3 review): vector and scalar instructions issued per frame over ALL its
     kernels, from the committed SQ-counter pass of the headline workload (profiles/r05_emulator_sq.txt: SQ_INSTS_VALU / SQ_INSTS_SALU
-    of k_ahead, k_chain, k_ctot, k_cframe1, k_cemit divided by the frames run), against the chip's issue rates
+    of k_ahead, k_chain, k_ctot, k_cframe1, k_cpull divided by the frames run), against the chip's issue rates
     (MI355X_MICROARCH.md: a wave64 float32 VALU instruction occupies its SIMD-32 for 2 cycles, a float64 one for 4 -> every
     kernel's VALU count is priced at 2 + 2 x its float64 share, the share being a static count over the kernel's disassembly
     ('# kernel_instr_per_frame <kernel> <VALU> <SALU> <f64 share>' lines; round-4 review: "prices every VALU instruction at 2

@@ -368,6 +368,49 @@ V2E_HD uint32_t v2e_perm_apply(const v2e_perm_t *p, uint32_t c)
     return x;
 }
 
+/* the inverse map: v2e_perm_invert(p, v2e_perm_apply(p, c)) == c for c < n.  The rounds backwards with the additions undone; the
+ * forward map's cycle walk (re-apply while the image lies outside [0, n)) is undone by walking the same cycle backwards.  The event
+ * writer pulls with it: output row j of an iteration holds the event of canonical index v2e_perm_invert(j) (emulator.py:861-870). */
+V2E_HD uint32_t v2e_perm_invert(const v2e_perm_t *p, uint32_t y)
+{
+    uint32_t x = y;
+    do {
+        uint32_t l = x >> p->sh, r = x & p->rmask;
+        for (int round = 3; round >= 0; --round) {
+            if ((round & 1) == 0) {
+                const uint32_t f = (uint32_t)(((uint64_t)v2e_mix32(r + p->k[round]) * p->a) >> 32); /* in [0, a) */
+                l = l >= f ? l - f : l + (p->a - f);
+            } else {
+                r = (r - v2e_mix32(l + p->k[round])) & p->rmask;
+            }
+        }
+        x = (l << p->sh) | r;
+    } while (x >= p->n);
+    return x;
+}
+
+/* position (0 .. 255) of the r-th set bit (r counted from 0, r < the number of set bits) in the 256-bit word m[0] | m[1] << 64 | ...:
+ * which pixel of a 256-pixel emission group is the r-th of its (iteration, polarity) block in pixel order */
+V2E_HD uint32_t v2e_nth_set_bit_256(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, uint32_t r)
+{
+    const uint32_t c0 = (uint32_t)__builtin_popcountll(m0), c1 = c0 + (uint32_t)__builtin_popcountll(m1),
+                   c2 = c1 + (uint32_t)__builtin_popcountll(m2);
+    uint64_t w = m0;
+    uint32_t pos = 0;
+    if (r >= c0) { w = m1; pos = 64; }
+    if (r >= c1) { w = m2; pos = 128; }
+    if (r >= c2) { w = m3; pos = 192; }
+    r -= r >= c2 ? c2 : (r >= c1 ? c1 : (r >= c0 ? c0 : 0u));
+    uint32_t v = (uint32_t)w;
+    const uint32_t cl = (uint32_t)__builtin_popcount(v);
+    if (r >= cl) { r -= cl; v = (uint32_t)(w >> 32); pos += 32; }
+    for (uint32_t s = 16; s >= 1; s >>= 1) {
+        const uint32_t cs = (uint32_t)__builtin_popcount(v & ((1u << s) - 1u));
+        if (r >= cs) { r -= cs; v >>= s; pos += s; }
+    }
+    return pos;
+}
+
 /* ------------------------------------------------------- timestamp formula */
 /*
  * In-kernel stand-in for torch.linspace(start, end, n, dtype=float32)

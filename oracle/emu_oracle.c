@@ -178,6 +178,20 @@ EXPORT void v2e_oracle_perm_idx(uint64_t seed, uint32_t clip, uint32_t frame, ui
     for (uint32_t c = 0; c < n; ++c) idx[v2e_perm_apply(&pm, c)] = (int64_t)c;
 }
 
+/* the same list through the inverse map (what the event writer's pull uses), and the bit select of its group lookup */
+EXPORT void v2e_oracle_perm_inv_idx(uint64_t seed, uint32_t clip, uint32_t frame, uint32_t iter,
+                                    uint32_t n, int64_t *idx)
+{
+    v2e_perm_t pm;
+    v2e_perm_init(&pm, seed, clip, frame, iter, n);
+    for (uint32_t j = 0; j < n; ++j) idx[j] = (int64_t)v2e_perm_invert(&pm, j);
+}
+
+EXPORT uint32_t v2e_oracle_nth_set_bit_256(const uint64_t *m, uint32_t r)
+{
+    return v2e_nth_set_bit_256(m[0], m[1], m[2], m[3], r);
+}
+
 EXPORT void v2e_oracle_ts(double t_prev, double t_frame, int32_t n, float *ts)
 {
     double dt = t_frame - t_prev;

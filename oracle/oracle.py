@@ -183,6 +183,21 @@ def perm_idx(seed, clip, frame, it, n):
     return idx
 
 
+def perm_inv_idx(seed, clip, frame, it, n):
+    """the same list as perm_idx, computed through v2e_perm_invert (the event writer's pull)"""
+    idx = np.empty(n, np.int64)
+    lib().v2e_oracle_perm_inv_idx(C.c_uint64(seed), C.c_uint32(clip), C.c_uint32(frame), C.c_uint32(it),
+                                  C.c_uint32(n), _p(idx))
+    return idx
+
+
+def nth_set_bit_256(words, r):
+    m = np.ascontiguousarray(words, dtype=np.uint64)
+    L = lib()
+    L.v2e_oracle_nth_set_bit_256.restype = C.c_uint32
+    return int(L.v2e_oracle_nth_set_bit_256(_p(m), C.c_uint32(r)))
+
+
 def ts_formula(t_prev, t_frame, n):
     ts = np.empty(n, np.float32)
     lib().v2e_oracle_ts(C.c_double(t_prev), C.c_double(t_frame), C.c_int32(n), _p(ts))

@@ -9,7 +9,7 @@ import re
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(R, "gpurun_out")
-EMU_KERNELS = ("k_ahead", "k_chain", "k_ctot", "k_cframe1", "k_cframe", "k_cemit", "k_coff", "k_zero_words")
+EMU_KERNELS = ("k_ahead", "k_chain", "k_ctot", "k_cframe1", "k_cframe", "k_cpull", "k_cemit", "k_coff", "k_zero_words")
 
 
 def rd(name):
@@ -71,7 +71,7 @@ def static_f64_share():
                 if op.startswith("v_") and not op.startswith(("v_readlane", "v_readfirstlane", "v_writelane")):
                     st[cur][0] += 1
                     st[cur][1] += "_f64" in op
-    for key, tag in (("k_chainIdhLb0ELb1E", "k_chain"), ("7k_aheadIh", "k_ahead"), ("6k_ctotE", "k_ctot"), ("7k_cemitE", "k_cemit"), ("9k_cframe1E", "k_cframe1")):
+    for key, tag in (("k_chainIdhLb0ELb1E", "k_chain"), ("7k_aheadIh", "k_ahead"), ("6k_ctotE", "k_ctot"), ("7k_cpullILb0E", "k_cpull"), ("7k_cemitE", "k_cemit"), ("9k_cframe1E", "k_cframe1")):
         for k, (v, f) in st.items():
             if key in k:
                 out[tag] = f / max(v, 1)
@@ -97,19 +97,19 @@ def per_kernel_lines(rows, frames):
 def emulator():
     kt, tl = rd("p5_kt.txt"), rd("p5_kt_timeline.txt")
     window = rd("p5_kt_step.txt")
-    wr("r05_emulator_chain_kernel_trace.txt", """# rocprofv3 kernel trace of the headline workload, round 5 (k_ahead | k_chain | k_ctot + k_cframe1 + k_cemit, one hipGraph per run)
+    wr("r05_emulator_chain_kernel_trace.txt", """# rocprofv3 kernel trace of the headline workload, round 5 (k_ahead | k_chain | k_ctot + k_cframe1 + k_cpull, one hipGraph per run; k_cpull: the event writer as a pull, a thread per output row)
 # command (on the MI355X box, cd /tmp; TMPDIR=/tmp):
 #   rocprofv3 --kernel-trace --stats -d out -- python bench.py --steps 4 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline
 # summarised by profiles/summarize_rocprof_db.py (top kernels) and scripts/kernel_timeline.py (k_chain launch timeline).
 # workload: BASELINE configs[1], 346x260, one clip, 300 frames per step, CLI-default DVS parameters, Philox.
 # one k_chain launch = 32 frames (10 per step + a tail launch validating the last speculation; a redo pass runs inside the launch
-# that finds the miss -- this round with a fence-free rendezvous); k_ahead / k_ctot / k_cframe1 / k_cemit: one launch per 64 frames.
+# that finds the miss -- this round with a fence-free rendezvous); k_ahead / k_ctot / k_cframe1 / k_cpull: one launch per 64 frames.
 # The three streams run side by side on the same CUs: every duration below is a duration UNDER CONTENTION.
 #
 """ + kt + "\n# k_chain launch timeline (same trace)\n" + tl + "\n# every kernel of the trace's last steps: start (us), duration (us), hardware queue, stream (scripts/dump_timeline.py)\n" + window)
     f, w = rd("p5_FETCH_SIZE.txt"), rd("p5_WRITE_SIZE.txt")
     rows = []
-    for k in ("k_chain<double, unsigned char, false", "k_ahead<unsigned char>", "k_cemit", "k_ctot", "k_cframe1"):
+    for k in ("k_chain<double, unsigned char, false", "k_ahead<unsigned char>", "k_cpull<false>", "k_cemit", "k_ctot", "k_cframe1"):
         n, fa = pmc_avg(f, k)
         n2, wa = pmc_avg(w, k)
         if n is None and n2 is None:
@@ -127,7 +127,8 @@ def emulator():
 """ + "\n".join(rows) + """
 #
 # algorithmic, per launch: k_chain (32 frames) 53 B x 89 960 px x 32 = 153 MB priced / what it touches: records 46 MB + state
-# once + count words 11.5 MB; k_cemit (64 frames) 64 x ~35 700 events x 16 B = 36.5 MB of rows (the keyed shuffle scatters them).
+# once + count words 11.5 MB; k_cpull (64 frames) 64 x ~35 700 events x 16 B = 36.5 MB of rows, written in row order (whole lines: the
+# push writer k_cemit of rounds 2-4 wrote 55.5 MB for them); k_ctot additionally writes the pull's pixel ballots (32 B per group and key).
 #
 # raw summaries:
 """ + f + w)

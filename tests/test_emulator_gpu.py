@@ -289,6 +289,49 @@ def test_chain_launch_lengths_and_ring_wrap(name, chain_k, monkeypatch):
             assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
 
 
+@pytest.mark.parametrize("variant", ["push", "pull_two_level"])
+@pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260", "philox_defaults_346x260"])
+def test_event_writer_variants_write_the_same_rows(name, variant, monkeypatch):
+    """The chain's event rows are written by k_cpull (a thread per output row: inverse bijection, prefix search, bit select; every
+    other test of this file runs it with the whole prefix row in LDS).  Its two-level search (what frames beyond 260 000 pixels
+    take) and the push writer k_cemit (the fallback when the pull's tables do not fit) must write the same bytes."""
+    if variant == "push":
+        monkeypatch.setenv("V2E_AMD_EMIT_PULL", "0")
+    else:
+        monkeypatch.setenv("V2E_AMD_PULL_TWO_LEVEL", "1")
+    fx = PhiloxFixture(name)
+    for use_graph in (256, 257):
+        emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+        ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph)
+        assert list(counts) == list(fx.n_events)
+        row = 0
+        for k, n in enumerate(counts):
+            if n:
+                assert sha(ev[row:row + n]) == fx.ev_sha[k], "frame %d event digest differs" % k
+            row += n
+        assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
+
+
+@pytest.mark.parametrize("variant", ["push", "pull_two_level"])
+def test_event_writer_variants_many_iterations(variant, oracle_lib, monkeypatch):
+    """> 64 events per pixel and frame (many keys and iterations with a handful of rows each, rule on): both writer variants."""
+    from v2e_amd import EventEmulator
+    if variant == "push":
+        monkeypatch.setenv("V2E_AMD_EMIT_PULL", "0")
+    else:
+        monkeypatch.setenv("V2E_AMD_PULL_TWO_LEVEL", "1")
+    kw = dict(pos_thres=0.03, neg_thres=0.04, sigma_thres=0.01, cutoff_hz=200, leak_rate_hz=0.2, shot_noise_rate_hz=30.0,
+              refractory_period_s=0.0004)
+    rng = np.random.Generator(np.random.PCG64(17))
+    frames = [rng.integers(0, 256, size=(37, 91)).astype(np.uint8) for _ in range(7)]
+    times = [0.01 * i for i in range(7)]
+    ora = oracle_lib.OracleEmulator(rng_mode="philox", seed=21, **kw)
+    ref = np.concatenate([e for e in (ora.generate_events(f, t) for f, t in zip(frames, times)) if e is not None])
+    hip = EventEmulator(device="cuda", rng_mode="philox", seed=21, max_iters=1024, **kw)
+    ev, counts = hip.generate_events_batch(np.stack(frames), times, use_graph=257, cap=6_000_000)
+    assert np.array_equal(ev, ref)
+
+
 @pytest.mark.parametrize("refr", [0.0005, 0.002])
 def test_pipelines_agree_on_benchmark_clip(refr, oracle_lib):
     """BASELINE configs[1] at full size (346x260, 300 frames, dt = 1/300 s): every device-resident pipeline gives the
@@ -515,7 +558,7 @@ def test_many_iterations_grow_scratch(oracle_lib):
 @pytest.mark.parametrize("use_graph", [257, 129, 17])
 @pytest.mark.parametrize("refr", [0.0, 0.0004])
 def test_device_resident_clip_many_iterations(use_graph, refr, oracle_lib):
-    """> 31 events per pixel per frame: several 64-key chunks in k_ctot / k_cemit, refractory on/off."""
+    """> 31 events per pixel per frame: several 64-key chunks in k_ctot, many iterations in k_cpull, refractory on/off."""
     from v2e_amd import EventEmulator
     kw = dict(pos_thres=0.03, neg_thres=0.04, sigma_thres=0.01, cutoff_hz=200, leak_rate_hz=0.2, shot_noise_rate_hz=30.0,
               refractory_period_s=refr)

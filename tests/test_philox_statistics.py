@@ -51,6 +51,25 @@ def test_keyed_bijection_is_a_uniform_shuffle(oracle_lib):
     assert abs(np.corrcoef(np.arange(30000), idx)[0, 1]) < 0.03
 
 
+def test_inverse_bijection_and_group_bit_select(oracle_lib):
+    """The event writer PULLS: output row j holds the event of canonical index v2e_perm_invert(j), found in its 256-pixel group by
+    v2e_nth_set_bit_256.  The inverse map against the forward one for every shape of domain split (n = 1, 2: no low part), and the
+    bit select against numpy on random and extreme masks."""
+    for n in (1, 2, 3, 4, 5, 7, 64, 100, 255, 256, 257, 1000, 4096, 4097, 35000, 131071):
+        for key in ((3, 0, 17, 2), (99, 5, 123456, 0)):
+            assert np.array_equal(oracle_lib.perm_inv_idx(*key, n), oracle_lib.perm_idx(*key, n)), (n, key)
+    rng = np.random.default_rng(5)
+    masks = [rng.integers(0, 2 ** 64, 4, dtype=np.uint64) for _ in range(40)]
+    masks += [rng.integers(0, 2 ** 64, 4, dtype=np.uint64) & rng.integers(0, 2 ** 64, 4, dtype=np.uint64) &
+              rng.integers(0, 2 ** 64, 4, dtype=np.uint64) for _ in range(40)]                       # sparse
+    masks += [np.array([0, 0, 0, 1 << 63], np.uint64), np.array([1, 0, 0, 0], np.uint64), np.array([0, 1 << 31, 1 << 32, 0], np.uint64),
+              np.full(4, 2 ** 64 - 1, np.uint64)]
+    for m in masks:
+        bits = np.flatnonzero(np.unpackbits(m.view(np.uint8), bitorder="little"))
+        for r in range(len(bits)):
+            assert oracle_lib.nth_set_bit_256(m, r) == bits[r], (m, r)
+
+
 @pytest.mark.gpu
 def test_philox_mode_emits_like_the_reference_stream():
     """BASELINE configs[1] pattern, 346x260, 10x slowdown, 80 frames, `noisy` preset (leak and 5 Hz shot noise: the

@@ -886,6 +886,8 @@ struct v2e_emu {
     CFrame *ch_cf = nullptr;        // [2][ch_E][n_clips]
     unsigned *ch_cdone = nullptr;   // [2][ch_E][n_clips] k_cframe's per-frame completion counters
     uint32_t *ch_cT = nullptr, *ch_ckbase = nullptr, *ch_cperm = nullptr, *ch_cpre = nullptr;
+    uint32_t *ch_cpre16 = nullptr; // every 16th entry of ch_cpre (CEmitArgs::cpre16)
+    uint32_t *ch_cmask = nullptr; // the pull's per-(group, key) pixel ballots (CEmitArgs::cmask), three sets like the other tables
     int ch_nkeys_cap = 0;           // nkeys_cap the chain scratch was sized for
     int occ_cache[24];              // workgroups of a k_chain instantiation a CU holds (-1: not queried yet)
 };
@@ -1042,7 +1044,7 @@ int v2e_emu_destroy(v2e_emu *h)
     if (h->tabs) hipStreamDestroy(h->tabs);
     if (h->side2) hipStreamDestroy(h->side2);
     hipFree(h->ch_base2); hipFree(h->ch_lp2); hipFree(h->ch_ts2); hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase);
-    hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_cdone);
+    hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_cdone); hipFree(h->ch_cmask); hipFree(h->ch_cpre16);
     if (h->ctl_host) hipHostFree(h->ctl_host);
     hipFree(h->off_dev);
     if (h->off_host) hipHostFree(h->off_host);
@@ -1743,6 +1745,18 @@ static std::vector<ChainLaunch> chain_plan(int n_frames, int K, int E, int nD, b
 }
 
 // scratch of the chain pipeline: everything a captured run must not allocate
+// The event writer: k_cpull (a thread per output row; round 5, the default) or k_cemit (a wave per pixel group pushing its rows through
+// the bijection).  The pull needs 32 bytes of pixel ballots per (frame of the three table sets, group, key) -- 281 MB at 346x260 with
+// the default max_iters = 64, 18 GB for 64 clips: when that would take more than a quarter of the free device memory the push writer
+// stays (same rows, bit for bit; V2E_AMD_EMIT_PULL=0 forces it: tests/test_emulator_gpu.py runs both).
+static bool emit_pull(size_t table_bytes)
+{
+    if (const char *e = getenv("V2E_AMD_EMIT_PULL")) { if (atoi(e) == 0) return false; } // (read when a handle's tables are allocated)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    return table_bytes <= free_b / 4;
+}
+
 static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_frames, int use_graph)
 {
     const bool has_refr = p->refractory_period_s > 0;
@@ -1760,11 +1774,11 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
     const int E = m * K;
     if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap || h->ch_fused != (int)fused) {
         hipFree(h->ch_cnt); hipFree(h->ch_ruleM); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck);
-        hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase); hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_gM);
+        hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase); hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_gM); hipFree(h->ch_cmask); hipFree(h->ch_cpre16);
         hipFree(h->ch_bar); hipFree(h->ch_rec); hipFree(h->ch_cdone);
         h->ch_rec = nullptr; h->ch_cdone = nullptr; h->ch_ruleM = nullptr;
         h->ch_cnt = nullptr; h->ch_wmax = nullptr; h->ch_wtot = nullptr; h->ch_tsold = nullptr; h->ch_ck = nullptr; h->ch_cf = nullptr; h->ch_cT = nullptr;
-        h->ch_ckbase = nullptr; h->ch_cperm = nullptr; h->ch_cpre = nullptr; h->ch_gM = nullptr; h->ch_bar = nullptr;
+        h->ch_ckbase = nullptr; h->ch_cperm = nullptr; h->ch_cpre = nullptr; h->ch_gM = nullptr; h->ch_bar = nullptr; h->ch_cmask = nullptr; h->ch_cpre16 = nullptr;
         h->ch_launch_cap = 0;
         h->ch_K = K;
         h->ch_E = E;
@@ -1796,6 +1810,12 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         V2E_HIP(hipMalloc(&h->ch_ckbase, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap));
         V2E_HIP(hipMalloc(&h->ch_cperm, 3 * sizeof(uint32_t) * E * nc * h->max_iters * 8));
         V2E_HIP(hipMalloc(&h->ch_cpre, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp));
+        // 32 bytes per (group, key): only the keys a group has events of are ever written or read (no clearing)
+        const size_t mask_bytes = 3 * sizeof(uint32_t) * 2 * GPX * E * nc * h->nkeys_cap * h->ch_nwp;
+        if (emit_pull(mask_bytes)) {
+            V2E_HIP(hipMalloc(&h->ch_cmask, mask_bytes));
+            V2E_HIP(hipMalloc(&h->ch_cpre16, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap * (h->ch_nwp / 16)));
+        }
         if (!fused) V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
         h->drop_graphs();
     }
@@ -1932,6 +1952,18 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ea.cf = h->ch_cf + set; ea.cT = h->ch_cT + set * h->nkeys_cap; ea.ckbase = h->ch_ckbase + set * h->nkeys_cap;
         ea.cperm = h->ch_cperm + set * h->max_iters * 8; ea.cpre = h->ch_cpre + set * h->nkeys_cap * h->ch_nwp;
         ea.cdone = h->ch_cdone + set;
+        const bool pull = h->ch_cmask != nullptr;
+        ea.cmask = pull ? h->ch_cmask + set * h->ch_nwp * h->nkeys_cap * 2 * GPX : nullptr;
+        // k_cpull: small frames search a whole prefix row in LDS (346x260: 1.4 KB per key), a workgroup per ~2048 pixels' worth of
+        // a frame's rows; large ones search every 16th entry there and one line from L2, and take more, smaller workgroups (their
+        // batches are few frames: the launch needs the parallelism)
+        bool two = h->ch_nwp > 1024;
+        if (const char *ev = getenv("V2E_AMD_PULL_TWO_LEVEL")) two = atoi(ev) != 0;
+        ea.cpre16 = pull && two ? h->ch_cpre16 + set * h->nkeys_cap * (h->ch_nwp / 16) : nullptr;
+        ea.wpf = std::max(4, std::min(two ? 128 : 64, h->npx / 2048)); // (1280x720 noisy, round 5: 450 workgroups per frame 9.28, 128: 9.68, push 9.41 Gev/s)
+        if (const char *ev = getenv("V2E_AMD_PULL_WPF")) { const int v = atoi(ev); if (v >= 1 && v <= 1024) ea.wpf = v; }
+        ea.p2 = two ? 16 : 64;
+        while (ea.p2 < (two ? h->ch_nwp / 16 : ea.nwaves)) ea.p2 *= 2;
         ea.events = (float4 *)events; ea.cap = cap;
         ea.off_in = h->run_off + (size_t)b * NC;
         ea.off_out = h->run_off + (size_t)(b + 1) * NC;
@@ -1975,7 +2007,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (sc.record(EV_TAB, b, tab_stream)) return V2E_EHIP;
         if (row_stream != tab_stream && sc.wait(row_stream, EV_TAB, b)) return V2E_EHIP;
         if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
-        if (!no_emit && sc.kernel(row_stream, (const void *)k_cemit, dim3(egx, NC, ea.nE), dim3(BLOCK), (size_t)std::max(REC_LDS, side_pad), args)) return V2E_EHIP;
+        if (pull) {
+            if (sc.kernel(row_stream, ea.cpre16 ? (const void *)k_cpull<true> : (const void *)k_cpull<false>, dim3(8 * ea.wpf * ((ea.nE + 7) / 8), NC), dim3(BLOCK), (size_t)(2 * ea.p2 * 4), args)) return V2E_EHIP;
+        } else if (!no_emit && sc.kernel(row_stream, (const void *)k_cemit, dim3(egx, NC, ea.nE), dim3(BLOCK), (size_t)std::max(REC_LDS, side_pad), args)) return V2E_EHIP;
         if (mark(ev_side, sc.st[row_stream])) return V2E_EHIP;
         return sc.record(EV_JOIN, b, row_stream);
     };

@@ -703,6 +703,10 @@ struct CEmitArgs {
     int capw, ich; // event records per wave in LDS; iterations per pass of k_cemit (64 * ich <= capw, 2 * ich <= 62)
     int zpw_tot, zpw_emit; // frames a workgroup of k_ctot / k_cemit walks (grid z = ceil(nE / that)); see enqueue_run_chain
     int coff_in_cemit;     // the next batch's event offset is written by k_cemit (one stream for tables and rows) instead of k_coff
+    uint32_t *cmask;       // [E][n_clips][nwp][nkeys_cap][2 GPX] per (group, key): which of the group's pixels have an event of that
+                           // (iteration, polarity), one 64-bit ballot per sub-group (k_ctot -> k_cpull); nullptr: k_cemit writes the rows
+    int wpf, p2;           // k_cpull: workgroups per frame; length of a prefix row in LDS (power of two >= nwaves; two-level: >= nwp / 16)
+    uint32_t *cpre16;      // [E][n_clips][nkeys_cap][nwp / 16] every 16th entry of cpre (k_cframe*): the coarse level of k_cpull<true>
 };
 
 // ---- Emission groups.  The event list is assembled per GROUP of 256 consecutive pixels, one wave per group (GPX = 4 pixels
@@ -762,6 +766,7 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
         unsigned long long negb[GPX]; // the sub-group's OFF lanes (a lane without events is neither)
         int mmax = 0;
         uint32_t son = 0, soff = 0;
+        unsigned long long sob[GPX], sfb[GPX];
 #pragma unroll
         for (int j = 0; j < GPX; ++j) {
             const uint32_t cw = cwq[q][j];
@@ -769,12 +774,27 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
             neg[j] = (cw & CNT_NEG) != 0;
             negb[j] = __ballot(neg[j]);
             mmax = max(mmax, magv[j]);
-            son += (uint32_t)__popcll(__ballot((cw & CNT_SHOT_ON) != 0));
-            soff += (uint32_t)__popcll(__ballot((cw & CNT_SHOT_OFF) != 0));
+            sob[j] = __ballot((cw & CNT_SHOT_ON) != 0);
+            sfb[j] = __ballot((cw & CNT_SHOT_OFF) != 0);
+            son += (uint32_t)__popcll(sob[j]);
+            soff += (uint32_t)__popcll(sfb[j]);
         }
         const int wm = wave_max_i32(mmax);
         if (lane == 0) ea.wmax[zc * ea.nwp + grp] = (uint16_t)min(wm, 65535);
         uint16_t *trow = ea.wtot + (zc * a.nkeys_cap) * ea.nwp + grp;
+        // the pull's masks: lanes 0 .. 4 GPX - 1 hold the words of an iteration's ON key (2 GPX of them) and OFF key
+        uint32_t *mrow = ea.cmask ? ea.cmask + ((zc * ea.nwp + grp) * a.nkeys_cap) * (2 * GPX) + lane : nullptr;
+        auto put_masks = [&](const int key_on, const unsigned long long (&on_m)[GPX], const unsigned long long (&off_m)[GPX]) __attribute__((always_inline)) {
+            uint32_t mw = 0u;
+#pragma unroll
+            for (int j = 0; j < GPX; ++j) { // (no writelane builtin in this compiler)
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(mw) : "s"((uint32_t)on_m[j]), "n"(2 * j));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(mw) : "s"((uint32_t)(on_m[j] >> 32)), "n"(2 * j + 1));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(mw) : "s"((uint32_t)off_m[j]), "n"(2 * GPX + 2 * j));
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(mw) : "s"((uint32_t)(off_m[j] >> 32)), "n"(2 * GPX + 2 * j + 1));
+            }
+            if (lane < 4 * GPX) mrow[(size_t)key_on * (2 * GPX)] = mw;
+        };
         const int wmc = min(wm, a.max_iters); // beyond max_iters the frame is flagged and not emitted
         const int nkw = 2 + 2 * wmc;
         bool ruled = false;
@@ -798,12 +818,13 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
             const int i_hi = min((kb + WAVE - 2) / 2, wmc);
             for (int i = i_lo; i < i_hi; ++i) {
                 uint32_t on = 0, off = 0;
+                unsigned long long on_m[GPX], off_m[GPX];
                 if (!ruled) { // the common case: one compare per sub-group, the polarity split on the scalar unit
 #pragma unroll
                     for (int j = 0; j < GPX; ++j) {
                         const unsigned long long cb = __ballot(magv[j] > i);
-                        on += (uint32_t)__popcll(cb & ~negb[j]);
-                        off += (uint32_t)__popcll(cb & negb[j]);
+                        on_m[j] = cb & ~negb[j];
+                        off_m[j] = cb & negb[j];
                     }
                 } else {
 #pragma unroll
@@ -815,10 +836,16 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
                             pass = pt > a.refr_f;
                             if (pass) tsm[j] = t;
                         }
-                        on += (uint32_t)__popcll(__ballot(pass && !neg[j]));
-                        off += (uint32_t)__popcll(__ballot(pass && neg[j]));
+                        on_m[j] = __ballot(pass && !neg[j]);
+                        off_m[j] = __ballot(pass && neg[j]);
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < GPX; ++j) {
+                    on += (uint32_t)__popcll(on_m[j]);
+                    off += (uint32_t)__popcll(off_m[j]);
+                }
+                if (mrow) put_masks(2 + 2 * i, on_m, off_m);
                 const int kl = 2 + 2 * i - kb;
                 if (lane == kl) mine = on;
                 if (lane == kl + 1) mine = off;
@@ -826,6 +853,7 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
             if (kb == 0) {
                 if (lane == 0) mine = son;
                 if (lane == 1) mine = soff;
+                if (mrow && (son | soff) != 0u) put_masks(0, sob, sfb);
             }
             if (kb + lane < nkw) trow[(size_t)(kb + lane) * ea.nwp] = (uint16_t)mine;
         }
@@ -898,6 +926,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe1(KArgs a, CEmitArgs e
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { o[j] = run; run += v[j]; }
                 uint4 *dst = (uint4 *)(pre + (size_t)k * ea.nwp + wi);
+                if (ea.cpre16) ea.cpre16[(((size_t)z * ea.n_clips + clip) * a.nkeys_cap + k) * (ea.nwp / 16) + wi / 16] = o[0];
                 dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
                 dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
                 dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
@@ -1023,6 +1052,7 @@ __global__ __launch_bounds__(CFRAME_THREADS) void k_cframe(KArgs a, CEmitArgs ea
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { o[j] = run; run += v[j]; }
                 uint4 *dst = (uint4 *)(pre + (size_t)k * ea.nwp + wi);
+                if (ea.cpre16) ea.cpre16[(((size_t)z * ea.n_clips + clip) * a.nkeys_cap + k) * (ea.nwp / 16) + wi / 16] = o[0];
                 dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
                 dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
                 dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
@@ -1326,6 +1356,152 @@ __global__ __launch_bounds__(BLOCK) void k_cemit(KArgs a, CEmitArgs ea)
                 son_off += (uint32_t)__popcll(so[j]);
                 soff_off += (uint32_t)__popcll(sf[j]);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the event writer as a PULL (round 5)
+// k_cemit pushes: a wave per 256-pixel group finds the group's events and scatters their 16-byte rows through the keyed bijection --
+// partial lines (1.5x the row bytes written), and a per-group control flow that is bound by the scalar unit.  k_cpull turns it
+// round: a thread per OUTPUT row.  Row j of iteration i holds the event of canonical index c = sigma_i^-1(j) (v2e_perm_invert;
+// emulator.py:861-870: the iteration's ON block then its OFF block, shuffled together); c falls into the group g with
+// pre[key][g] <= c' < pre[key][g + 1] (binary search over the key's exclusive prefix row, staged in LDS), and is that group's
+// r-th pixel of the (iteration, polarity) block = the r-th set bit of the four ballots k_ctot left (v2e_nth_set_bit_256).  Rows
+// are written in order: whole lines.  A frame's rows are split into `wpf` contiguous ranges, one workgroup each; the workgroups of
+// one frame share blockIdx.x mod 8, i.e. an XCD and its L2 (prefix rows and masks of the frame are read from HBM once).
+static_assert(GPX == 4, "k_cpull selects a pixel of a 256-pixel group (v2e_nth_set_bit_256)");
+// TWO (large frames: a prefix row of 1280x720 is 14 KB): two levels -- every 16th entry in LDS, then the 16 entries (one line,
+// from L2) searched in registers.
+template <bool TWO>
+__global__ __launch_bounds__(BLOCK) void k_cpull(KArgs a, CEmitArgs ea)
+{
+    extern __shared__ uint32_t s_pre[]; // [2][p2]: the ON and the OFF key's prefix row (TWO: its coarse level) of the iteration at hand
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int clip = blockIdx.y;
+    const int blk = (int)blockIdx.x >> 3;
+    const int z = (blk / ea.wpf) * 8 + ((int)blockIdx.x & 7), q = blk % ea.wpf;
+    if (z >= ea.nE) return;
+    const int fe = ea.f0 + z;
+    const size_t zc = (size_t)z * ea.n_clips + clip;
+    const CFrame *cf = ea.cf + zc;
+    v2e_frame_rec *rec = ea.recs + (size_t)fe * ea.n_clips;
+    const FrameCtl *c = ea.ctl + (size_t)fe * ea.n_clips + clip;
+    const uint32_t *cT = ea.cT + zc * a.nkeys_cap, *ckb = ea.ckbase + zc * a.nkeys_cap;
+    const uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp;
+    const uint32_t *perm = ea.cperm + zc * a.max_iters * 8;
+    const uint32_t *cmask = ea.cmask + zc * ea.nwp * a.nkeys_cap * (2 * GPX);
+    const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
+    const uint32_t off_lo = (uint32_t)ea.off_in[clip], off_hi = (uint32_t)(ea.off_in[clip] >> 32);
+    const uint32_t nj = lane < z ? ea.cf[(size_t)lane * ea.n_clips + clip].n_events : 0u; // lane j: frame j of the batch (E <= 64)
+    const int M = __builtin_amdgcn_readfirstlane(cf->M);
+    const uint32_t n_signal = (uint32_t)__builtin_amdgcn_readfirstlane((int)cf->n_signal);
+    const uint32_t n_events = (uint32_t)__builtin_amdgcn_readfirstlane((int)cf->n_events);
+    const uint32_t disc = (uint32_t)__builtin_amdgcn_readfirstlane((int)cf->discarded);
+    const FrameTab ftb(c, lane);
+    const unsigned long long ev0 = ((unsigned long long)off_hi << 32 | off_lo) + (unsigned long long)wave_sum_u32(nj & 0xFFFFFFu) +
+                                   ((unsigned long long)wave_sum_u32(nj >> 24) << 24); // + the events of the batch's earlier frames
+    if (q == 0 && tid == 0) {
+        rec[clip].ev_offset = ev0;
+        if (ea.coff_in_cemit && z == ea.nE - 1) ea.off_out[clip] = ev0 + n_events; // else k_coff's
+        if (ev0 + n_events > ea.cap || n_events > 0x7FFFFFFu) atomicOr(&rec[clip].flags, V2E_FLAG_EVENTS_DROPPED);
+    }
+    if (disc) return;
+    const int n = M > 0 ? M : 1;
+    bool use_refr;
+    const TsGen tg = frame_tsgen(a, c, ftb, n, use_refr); // (the refractory filter is in k_ctot's masks already)
+    const uint32_t ev0_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ev0), ev0_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ev0 >> 32));
+    const unsigned long long ev0u = ((unsigned long long)ev0_hi << 32) | ev0_lo;
+    const unsigned long long room = ev0u < ea.cap ? ea.cap - ev0u : 0ull;
+    unsigned long long frows64 = room < (unsigned long long)n_events ? room : (unsigned long long)n_events; // rows that fit below the capacity
+    if (frows64 > 0x7FFFFFFull) frows64 = 0x7FFFFFFull;
+    const uint32_t frows = (uint32_t)frows64;
+    const uint32_t per = ((frows + (uint32_t)ea.wpf - 1u) / (uint32_t)ea.wpf + (uint32_t)WAVE - 1u) & ~(uint32_t)(WAVE - 1);
+    const uint32_t lo = (uint32_t)q * per, hi = min(lo + per, frows);
+    if (lo >= hi) return;
+    const __amdgpu_buffer_rsrc_t ev_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(ea.events + (size_t)clip * ea.cap + ev0u), 0, (int)(frows * 16u), 0x00020000);
+    const float rcpW = 1.0f / (float)a.W;
+    const int P2 = ea.p2;
+    bool staged = false;
+    for (int i = 0; i <= M; ++i) { // i == M: the shot-noise rows (ON block, OFF block, unshuffled, ts[-1]) behind the signal rows
+        if (i == M && !a.do_shot) break;
+        const int key0 = i < M ? 2 + 2 * i : 0;
+        const uint32_t base = i < M ? ckb[key0] : n_signal;
+        const uint32_t T_on = cT[key0], T_off = cT[key0 + 1];
+        const uint32_t r_lo = max(lo, base), r_hi = min(hi, base + T_on + T_off);
+        if (r_lo >= r_hi) continue; // (uniform: none of this iteration's rows in the workgroup's range)
+        if (staged) __syncthreads(); // the readers of the rows staged before
+        if (TWO) {
+            const int nc16 = ea.nwp / 16;
+            const uint32_t *pre16 = ea.cpre16 + (zc * a.nkeys_cap + key0) * nc16;
+            for (int k = tid; k < 2 * P2; k += BLOCK) {
+                const int kk = k & (P2 - 1);
+                s_pre[k] = kk < nc16 ? pre16[(size_t)(k >= P2 ? nc16 : 0) + kk] : 0xFFFFFFFFu;
+            }
+        } else { // four entries per load (nwp is a multiple of 16; entries nwaves .. nwp - 1 hold the key's total: never <= cp)
+            for (int k = tid * 4; k < 2 * P2; k += BLOCK * 4) {
+                const int kk = k & (P2 - 1);
+                uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (kk < ea.nwp) v = *(const uint4 *)(pre + (size_t)(key0 + (k >= P2 ? 1 : 0)) * ea.nwp + kk);
+                *(uint4 *)(s_pre + k) = v;
+            }
+        }
+        __syncthreads();
+        staged = true;
+        v2e_perm_t pm;
+        const bool sh_i = shuf && i < M;
+        if (sh_i) {
+            const uint32_t *pp = perm + (size_t)i * 8;
+            pm.k[0] = pp[0]; pm.k[1] = pp[1]; pm.k[2] = pp[2]; pm.k[3] = pp[3];
+            pm.sh = pp[4]; pm.a = pp[5]; pm.amask = 0u; pm.n = pp[7];
+            pm.rmask = (1u << pm.sh) - 1u;
+        }
+        const float t = tg(i < M ? i : n - 1);
+        for (uint32_t row = r_lo + (uint32_t)tid; row < r_hi; row += BLOCK) {
+            const uint32_t jj = row - base;
+            const uint32_t ci = sh_i ? v2e_perm_invert(&pm, jj) : jj;
+            const bool eneg = ci >= T_on;
+            const uint32_t cp = eneg ? ci - T_on : ci;
+            const uint32_t *tab = s_pre + (eneg ? P2 : 0);
+            uint32_t g = 0, gbase = 0; // the last group whose prefix is <= cp (an empty group shares its prefix with the next one)
+            if (!TWO) {
+                for (int st = P2 >> 1; st >= 1; st >>= 1) {
+                    const uint32_t v = tab[g + st];
+                    if (v <= cp) { g += st; gbase = v; }
+                }
+            } else {
+                for (int st = P2 >> 1; st >= 1; st >>= 1) {
+                    const uint32_t v = tab[g + st];
+                    if (v <= cp) g += st;
+                }
+                // the line of 16 entries whose first one is <= cp: four halving steps in registers
+                const uint4 *lp = (const uint4 *)(pre + (size_t)(key0 + (eneg ? 1 : 0)) * ea.nwp + g * 16u);
+                const uint4 q0 = lp[0], q1 = lp[1], q2 = lp[2], q3 = lp[3];
+                const bool h8 = q2.x <= cp;
+                const uint4 a0 = h8 ? q2 : q0, a1 = h8 ? q3 : q1;
+                const bool h4 = a1.x <= cp;
+                const uint4 b = h4 ? a1 : a0;
+                const bool h2 = b.z <= cp;
+                const uint32_t c0 = h2 ? b.z : b.x, c1 = h2 ? b.w : b.y;
+                const bool h1 = c1 <= cp;
+                gbase = h1 ? c1 : c0;
+                g = g * 16u + (h8 ? 8u : 0u) + (h4 ? 4u : 0u) + (h2 ? 2u : 0u) + (h1 ? 1u : 0u);
+            }
+            const uint4 *mp = (const uint4 *)(cmask + ((size_t)g * a.nkeys_cap + key0 + (eneg ? 1 : 0)) * (2 * GPX));
+            const uint4 ma = mp[0], mb = mp[1];
+            const uint32_t bit = v2e_nth_set_bit_256((unsigned long long)ma.x | ((unsigned long long)ma.y << 32), (unsigned long long)ma.z | ((unsigned long long)ma.w << 32),
+                                                     (unsigned long long)mb.x | ((unsigned long long)mb.y << 32), (unsigned long long)mb.z | ((unsigned long long)mb.w << 32),
+                                                     cp - gbase);
+            const uint32_t p = g * (uint32_t)GROUP_PX + bit;
+            uint32_t qy; // y = p / W, x = p % W, exactly
+            if (a.npx < (1 << 24)) { // float32 holds p exactly: the quotient estimate is the true one or one off
+                qy = (uint32_t)((float)p * rcpW);
+                if (qy * (uint32_t)a.W > p) --qy;
+                else if ((qy + 1u) * (uint32_t)a.W <= p) ++qy;
+            } else {
+                qy = p / (uint32_t)a.W;
+            }
+            const v2e_f4 v = {t, (float)(p - qy * (uint32_t)a.W), (float)qy, eneg ? -1.0f : 1.0f};
+            __builtin_amdgcn_raw_buffer_store_b128(v, ev_rsrc, (int)(row * 16u), 0, 17); // sc0 sc1: written through (see store_event_wt)
         }
     }
 }
