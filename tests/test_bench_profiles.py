@@ -21,7 +21,7 @@ def test_emulator_profile_parsers_read_this_rounds_files():
     # float64 VALU instructions are priced at 4 cycles (round-4 review): the vector pipe's time is above the all-at-2-cycles figure by
     # each kernel's static float64 share, and the per-kernel lines add up to the headline totals
     pk = ii["per_kernel"]
-    assert {q["kernel"] for q in pk} >= {"k_chain", "k_ahead", "k_ctot", "k_cemit"}
+    assert {q["kernel"] for q in pk} >= {"k_chain", "k_ahead", "k_ctot", "k_cpull"}
     assert abs(sum(q["valu"] for q in pk) - ii["valu_per_frame"]) <= 0.01 * ii["valu_per_frame"]
     assert 0.2 < next(q for q in pk if q["kernel"] == "k_chain")["f64_share_static"] < 0.4
     all_two = ii["valu_per_frame"] / B.VALU_RATE * 1e6
