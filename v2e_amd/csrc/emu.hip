@@ -1961,7 +1961,6 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (const char *ev = getenv("V2E_AMD_PULL_TWO_LEVEL")) two = atoi(ev) != 0;
         ea.cpre16 = pull && two ? h->ch_cpre16 + set * h->nkeys_cap * (h->ch_nwp / 16) : nullptr;
         ea.wpf = std::max(4, std::min(two ? 128 : 64, h->npx / 2048)); // (1280x720 noisy, round 5: 450 workgroups per frame 9.28, 128: 9.68, push 9.41 Gev/s)
-        if (const char *ev = getenv("V2E_AMD_PULL_WPF")) { const int v = atoi(ev); if (v >= 1 && v <= 1024) ea.wpf = v; }
         ea.p2 = two ? 16 : 64;
         while (ea.p2 < (two ? h->ch_nwp / 16 : ea.nwaves)) ea.p2 *= 2;
         ea.events = (float4 *)events; ea.cap = cap;
@@ -1989,8 +1988,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (b >= NSET && tab_stream != ST_SIDE && sc.wait(tab_stream, EV_JOIN, b - NSET)) return V2E_EHIP;
         if (!no_emit) {
             if (sc.kernel(tab_stream, (const void *)k_ctot, dim3(egx, NC, (ea.nE + CTOT_ZF - 1) / CTOT_ZF), dim3(BLOCK), (size_t)side_pad, args)) return V2E_EHIP;
-            // a key row of a small grid is a couple of steps of one wave: one workgroup per frame; of a large grid (1280x720:
-            // 14 400 waves) a segmented scan by a workgroup of its own
+            // a key row of a small grid is a couple of steps of one wave: one workgroup per frame; of a large grid (beyond a million
+            // pixels) a segmented scan by a workgroup of its own.  (1280x720 has 3 600 groups since the groups are 256 pixels: k_cframe1,
+            // 45 us per 32 frames; round 5 measured k_cframe there: 9.74 / 9.51 -> 8.89 / 9.02 Gev/s.)
             if (h->ch_nwp <= 4096) {
                 if (sc.kernel(tab_stream, (const void *)k_cframe1, dim3(1, NC, ea.nE), dim3(CFRAME_THREADS), 0, args)) return V2E_EHIP;
             } else if (sc.kernel(tab_stream, (const void *)k_cframe, dim3(std::min(h->nkeys_cap, CFRAME_ROWS), NC, ea.nE), dim3(CFRAME_THREADS), 0, args)) {
