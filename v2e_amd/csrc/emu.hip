@@ -886,6 +886,7 @@ struct v2e_emu {
     CFrame *ch_cf = nullptr;        // [2][ch_E][n_clips]
     unsigned *ch_cdone = nullptr;   // [2][ch_E][n_clips] k_cframe's per-frame completion counters
     uint32_t *ch_cT = nullptr, *ch_ckbase = nullptr, *ch_cperm = nullptr, *ch_cpre = nullptr;
+    int ch_long_batches = -1;      // large grids: 64-frame emission batches (1) or max(K, 8) (0: the ring would not fit); -1: not decided yet
     uint32_t *ch_cpre16 = nullptr; // every 16th entry of ch_cpre (CEmitArgs::cpre16)
     uint32_t *ch_cmask = nullptr; // the pull's per-(group, key) pixel ballots (CEmitArgs::cmask), three sets like the other tables
     int ch_nkeys_cap = 0;           // nkeys_cap the chain scratch was sized for
@@ -1764,11 +1765,23 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
     const int inst = (p->f64_state ? 1 : 0) | ((dtype & 3) << 1) | (fused ? 8 : 0);
     const int max_blocks = chain_blocks_per_cu(h, p->f64_state != 0, dtype, fused) * h->n_cu;
     const int K = chain_frames_per_launch(h, has_refr, use_graph, max_blocks);
-    // frames per k_ahead launch and per emission batch: a multiple of K.  Small grids 64 frames (the emission kernels are
-    // bound by per-wave latency and by the launch gaps between them, and this runtime runs the captured graph's chain and
-    // emission kernels one after the other: fewer, larger batches -- 346x260, round 3: 64 frames 8.7 Gev/s, 32 frames 7.7);
-    // large ones max(K, 8) (their ring is what costs memory)
-    int m = std::max(1, (chain_small_grid(h) ? 64 : std::max(K, 8)) / K);
+    // frames per k_ahead launch and per emission batch: a multiple of K, 64 frames (the emission kernels are bound by per-wave latency
+    // and by the launch gaps between them, and this runtime runs the captured graph's chain and emission kernels one after the
+    // other: fewer, larger batches -- 346x260, round 3: 64 frames 8.7 Gev/s, 32 frames 7.7; 1280x720 noisy, round 5 with the pull
+    // writer: 32 frames 9.57 / 9.61, 64 frames 10.70 / 10.71 Gev/s -- until round 5 large grids took max(K, 8) for their ring's
+    // memory: 64 frames of 1280x720 are 0.7 GB of count words in a ring of three batches).  Grids whose ring would take more than an
+    // eighth of the free device memory, and multi-clip runs whose short batch holds 64 (frame, clip) pairs anyway, keep the short batches.
+    int m = std::max(1, 64 / K);
+    if (!chain_small_grid(h)) {
+        if (h->ch_long_batches < 0) { // decided once per handle (the answer must not change with what the handle itself allocates)
+            size_t free_b = 0, total_b = 0;
+            const size_t ring = (size_t)3 * 64 * h->n_clips * h->npx_pad * (sizeof(uint32_t) + sizeof(float) + sizeof(uint4));
+            h->ch_long_batches = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ring <= free_b / 8) ? 1 : 0;
+        }
+        // (64 clips of 346x260 have 2 048 (frame, clip) pairs in a 32-frame batch already: 11.64 Gev/s with 32 frames, 11.37 with 64)
+        const int m_short = std::max(1, std::max(K, 8) / K);
+        if (!h->ch_long_batches || (long long)m_short * K * h->n_clips >= 64) m = m_short;
+    }
     if (const char *ev = getenv("V2E_AMD_CHAIN_M")) { const int v = atoi(ev); if (v >= 1 && v <= 64) m = v; }
     m = std::max(1, std::min(m, 64 / K)); // k_cemit sums a batch's per-frame event counts one frame per lane
     const int E = m * K;
