@@ -703,7 +703,7 @@ struct CEmitArgs {
     int capw, ich; // event records per wave in LDS; iterations per pass of k_cemit (64 * ich <= capw, 2 * ich <= 62)
     int zpw_tot, zpw_emit; // frames a workgroup of k_ctot / k_cemit walks (grid z = ceil(nE / that)); see enqueue_run_chain
     int coff_in_cemit;     // the next batch's event offset is written by k_cemit (one stream for tables and rows) instead of k_coff
-    uint32_t *cmask;       // [E][n_clips][nwp][nkeys_cap][2 GPX] per (group, key): which of the group's pixels have an event of that
+    uint32_t *cmask;       // [E][n_clips][nkeys_cap][nwp][2 GPX] (key-major: a frame uses its low keys only, so what is touched is dense) per (key, group): which of the group's pixels have an event of that
                            // (iteration, polarity), one 64-bit ballot per sub-group (k_ctot -> k_cpull); nullptr: k_cemit writes the rows
     int wpf, p2;           // k_cpull: workgroups per frame; length of a prefix row in LDS (power of two >= nwaves; two-level: >= nwp / 16)
     uint32_t *cpre16;      // [E][n_clips][nkeys_cap][nwp / 16] every 16th entry of cpre (k_cframe*): the coarse level of k_cpull<true>
@@ -783,7 +783,8 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
         if (lane == 0) ea.wmax[zc * ea.nwp + grp] = (uint16_t)min(wm, 65535);
         uint16_t *trow = ea.wtot + (zc * a.nkeys_cap) * ea.nwp + grp;
         // the pull's masks: lanes 0 .. 4 GPX - 1 hold the words of an iteration's ON key (2 GPX of them) and OFF key
-        uint32_t *mrow = ea.cmask ? ea.cmask + ((zc * ea.nwp + grp) * a.nkeys_cap) * (2 * GPX) + lane : nullptr;
+        // (lanes 0 .. 2 GPX - 1: the ON key's row, the next 2 GPX: the OFF key's, one row further)
+        uint32_t *mrow = ea.cmask ? ea.cmask + ((zc * a.nkeys_cap + (lane >= 2 * GPX ? 1 : 0)) * ea.nwp + grp) * (2 * GPX) + (lane & (2 * GPX - 1)) : nullptr;
         auto put_masks = [&](const int key_on, const unsigned long long (&on_m)[GPX], const unsigned long long (&off_m)[GPX]) __attribute__((always_inline)) {
             uint32_t mw = 0u;
 #pragma unroll
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(BLOCK) void k_ctot(KArgs a, CEmitArgs ea)
                 asm("v_writelane_b32 %0, %1, %2" : "+v"(mw) : "s"((uint32_t)off_m[j]), "n"(2 * GPX + 2 * j));
                 asm("v_writelane_b32 %0, %1, %2" : "+v"(mw) : "s"((uint32_t)(off_m[j] >> 32)), "n"(2 * GPX + 2 * j + 1));
             }
-            if (lane < 4 * GPX) mrow[(size_t)key_on * (2 * GPX)] = mw;
+            if (lane < 4 * GPX) mrow[(size_t)key_on * ea.nwp * (2 * GPX)] = mw;
         };
         const int wmc = min(wm, a.max_iters); // beyond max_iters the frame is flagged and not emitted
         const int nkw = 2 + 2 * wmc;
@@ -1389,7 +1390,7 @@ __global__ __launch_bounds__(BLOCK) void k_cpull(KArgs a, CEmitArgs ea)
     const uint32_t *cT = ea.cT + zc * a.nkeys_cap, *ckb = ea.ckbase + zc * a.nkeys_cap;
     const uint32_t *pre = ea.cpre + zc * a.nkeys_cap * ea.nwp;
     const uint32_t *perm = ea.cperm + zc * a.max_iters * 8;
-    const uint32_t *cmask = ea.cmask + zc * ea.nwp * a.nkeys_cap * (2 * GPX);
+    const uint32_t *cmask = ea.cmask + zc * a.nkeys_cap * ea.nwp * (2 * GPX);
     const bool shuf = (a.rng_mode == V2E_RNG_PHILOX) && a.shuffle;
     const uint32_t off_lo = (uint32_t)ea.off_in[clip], off_hi = (uint32_t)(ea.off_in[clip] >> 32);
     const uint32_t nj = lane < z ? ea.cf[(size_t)lane * ea.n_clips + clip].n_events : 0u; // lane j: frame j of the batch (E <= 64)
@@ -1486,7 +1487,7 @@ __global__ __launch_bounds__(BLOCK) void k_cpull(KArgs a, CEmitArgs ea)
                 gbase = h1 ? c1 : c0;
                 g = g * 16u + (h8 ? 8u : 0u) + (h4 ? 4u : 0u) + (h2 ? 2u : 0u) + (h1 ? 1u : 0u);
             }
-            const uint4 *mp = (const uint4 *)(cmask + ((size_t)g * a.nkeys_cap + key0 + (eneg ? 1 : 0)) * (2 * GPX));
+            const uint4 *mp = (const uint4 *)(cmask + ((size_t)(key0 + (eneg ? 1 : 0)) * ea.nwp + g) * (2 * GPX));
             const uint4 ma = mp[0], mb = mp[1];
             const uint32_t bit = v2e_nth_set_bit_256((unsigned long long)ma.x | ((unsigned long long)ma.y << 32), (unsigned long long)ma.z | ((unsigned long long)ma.w << 32),
                                                      (unsigned long long)mb.x | ((unsigned long long)mb.y << 32), (unsigned long long)mb.z | ((unsigned long long)mb.w << 32),
