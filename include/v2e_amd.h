@@ -392,8 +392,9 @@ int v2e_f32_to_u8_trunc(const float *in, uint8_t *out, int U, int B, int hw, flo
  * the same for rows. */
 int v2e_resize_area_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, int dh, int dw, int cn, const int32_t *xofs,
                        const int32_t *xsi, const float *xalpha, const int32_t *yofs, const int32_t *ysi, const float *yalpha, void *stream);
-/* cv2.cvtColor(src, cv2.COLOR_BGR2GRAY) of npx interleaved BGR uint8 pixels */
-int v2e_bgr2gray_u8(const uint8_t *src_bgr, uint8_t *dst, int64_t npx, void *stream);
+/* cv2.cvtColor(src, cv2.COLOR_BGR2GRAY) of npx interleaved BGR uint8 pixels.  gray_shift 15: OpenCV 4.x's RGB2Gray<uchar>
+ * ((3735 B + 19235 G + 9798 R + 2^14) >> 15); 14: OpenCV 3.x's ((1868 B + 9617 G + 4899 R + 2^13) >> 14). */
+int v2e_bgr2gray_u8(const uint8_t *src_bgr, uint8_t *dst, int64_t npx, int gray_shift, void *stream);
 
 /* ----------------------------------------------------- event sinks */
 

@@ -15,12 +15,14 @@ restates OpenCV 4.x's published source as follows; it has NOT been compared with
       source rows in order: buf[dx] = 0; buf[di] += S[si] * alpha for the x table in order (float32); rows of one
       destination row: sum = beta * buf for the first, sum += beta * buf after; D = saturate_cast<uchar>(sum).
       Each product and each sum is rounded on its own (no fused multiply-add: resizeArea_ has no FMA dispatch variant).
-  modules/imgproc/src/color_yuv.simd.hpp, RGB2Gray<uchar> (BGR order: blueIdx 0): shift 14, B2Y 1868, G2Y 9617, R2Y 4899,
-      D = (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14.
-      (Round-4 advisor, also from memory: 4.x may use the 15-bit set BY15 3735 / GY15 19235 / RY15 9798 with (1 << 14) >> 15 here and
-      the 14-bit set only on the YUV path; the two forms differ by one grey level on ~1 % of random pixels.  Neither of us can open
-      color_rgb.simd.hpp here.  scripts/check_stage1_against_cv2.py prints which of the two equals cv2.cvtColor on a host that has
-      OpenCV -- until someone runs it this stage stays "parity unpinned".)
+  modules/imgproc/src/color_rgb.simd.hpp, RGB2Gray<uchar> (BGR order: blueIdx 0), the DEFAULT here since round 5: gray_shift 15,
+      BY15 3735, GY15 19235, RY15 9798 (color.simd_helpers.hpp), D = (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15.
+      Rounds 3-4 restated the 14-bit set (B2Y 1868, G2Y 9617, R2Y 4899, (1 << 13) >> 14): that is OpenCV 3.x's table form and 4.x's
+      YUV path; the round-4 advisor and the builder, both from memory and independently, place the 15-bit set in 4.x's RGB2Gray<uchar>,
+      and an unpinned `pip install opencv-python` has given v2e a 4.x for years -- so 15 is the default and 14 stays selectable
+      (`Stage1(gray_shift=14)`).  The two differ by one grey level on ~1 % of random pixels.  Neither of us can open the file here:
+      scripts/check_stage1_against_cv2.py prints which of the two equals cv2.cvtColor on a host that has OpenCV -- until someone
+      runs it this stage stays "parity unpinned".
   What CAN be checked without OpenCV is checked in tests/test_preproc.py: the integer-factor path equals the exact rational box mean
   (ties as OpenCV rounds them) and stays within one grey level of Pillow's independent Image.reduce.
 """
@@ -62,12 +64,15 @@ def resize_area(img, out_wh, area_tab, is_area_fast):
     return out if img.ndim == 3 else out[:, :, 0]
 
 
-def bgr2gray(img):
+def bgr2gray(img, gray_shift=15):
     b, g, r = (img[..., c].astype(np.int64) for c in range(3))
+    if gray_shift == 15:
+        return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+    assert gray_shift == 14
     return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
 
 
-def stage1(frame, out_wh, area_tab, is_area_fast, crop=None):
+def stage1(frame, out_wh, area_tab, is_area_fast, crop=None, gray_shift=15):
     """One frame through v2e.py:702-731: crop, resize if the uncropped size differs from the output size, grey."""
     ih, iw = frame.shape[:2]
     x = frame
@@ -77,5 +82,5 @@ def stage1(frame, out_wh, area_tab, is_area_fast, crop=None):
     if ih != out_wh[1] or iw != out_wh[0]:
         x = resize_area(np.ascontiguousarray(x), out_wh, area_tab, is_area_fast)
     if x.ndim == 3:
-        x = bgr2gray(x)
+        x = bgr2gray(x, gray_shift)
     return x

@@ -7,8 +7,9 @@ PARITY UNPINNED until somebody runs this.
   python scripts/check_stage1_against_cv2.py --hip      # the HIP kernels too (needs a GPU)
 
 Prints, per case, the fraction of pixels that differ and the largest difference, and for BGR2GRAY both candidate fixed-point
-forms: the 14-bit one that is built ((1868 B + 9617 G + 4899 R + 8192) >> 14: `RGB2Gray<uchar>` with yuv_shift as restated in the
-oracle's header) and the 15-bit one the round-4 advisor remembered ((3735 B + 19235 G + 9798 R + 16384) >> 15)."""
+forms: the 15-bit one that is the default since round 5 ((3735 B + 19235 G + 9798 R + 16384) >> 15: OpenCV 4.x's `RGB2Gray<uchar>`
+as the oracle's header restates it) and the 14-bit one of OpenCV 3.x ((1868 B + 9617 G + 4899 R + 8192) >> 14; `Stage1(gray_shift=14)`).
+Exactly one of the two BGR2GRAY lines is expected to say 0 differing pixels: that is the gray_shift to use with this cv2."""
 import os
 import sys
 
@@ -26,18 +27,22 @@ rng = np.random.default_rng(1)
 bad = 0
 
 
-def report(tag, a, b):
+def report(tag, a, b, count=True):
     global bad
     d = np.abs(a.astype(int) - b.astype(int))
-    bad += int(d.max() > 0)
+    if count:
+        bad += int(d.max() > 0)
     print("%-58s differing pixels %.6f  max |d| %d" % (tag, float((d > 0).mean()), int(d.max())))
+    return int(d.max()) == 0
 
 
 img = rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8)
 g = cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)
-b_, g_, r_ = (img[..., c].astype(np.int64) for c in range(3))
-report("BGR2GRAY 14-bit (built)", po.bgr2gray(img), g)
-report("BGR2GRAY 15-bit (candidate)", ((b_ * 3735 + g_ * 19235 + r_ * 9798 + (1 << 14)) >> 15).astype(np.uint8), g)
+ok15 = report("BGR2GRAY gray_shift = 15 (the default; OpenCV 4.x)", po.bgr2gray(img, 15), g, count=False)
+ok14 = report("BGR2GRAY gray_shift = 14 (OpenCV 3.x)", po.bgr2gray(img, 14), g, count=False)
+shift = 15 if ok15 else (14 if ok14 else None)
+bad += shift is None
+print("  -> this cv2 computes the %s form%s" % (("%d-bit" % shift) if shift else "NEITHER", "" if shift == 15 else ": construct Stage1(gray_shift=14)" if shift == 14 else ""))
 for (sw, sh), (ow, oh) in (((1280, 720), (346, 260)), ((1280, 720), (640, 360)), ((1038, 780), (346, 260)), ((1280, 720), (320, 240)),
                            ((700, 530), (346, 260)), ((347, 261), (346, 260))):
     for cn in (1, 3):
@@ -48,7 +53,7 @@ if "--hip" in sys.argv:
     import torch
     from v2e_amd import Stage1
     x = rng.integers(0, 256, (4, 720, 1280, 3), dtype=np.uint8)
-    st = Stage1((720, 1280), (346, 260), channels=3, device="cuda")
+    st = Stage1((720, 1280), (346, 260), channels=3, device="cuda", gray_shift=shift or 15)
     out = st(torch.from_numpy(x).cuda()).cpu().numpy()
     ref = np.stack([cv2.cvtColor(cv2.resize(f, (346, 260), interpolation=cv2.INTER_AREA), cv2.COLOR_BGR2GRAY) for f in x])
     report("HIP Stage1 1280x720 BGR -> 346x260 grey", out, ref)

@@ -50,10 +50,18 @@ def test_restatement_invariants():
     assert is_area_fast((1280, 720), (640, 360)) and not is_area_fast((1280, 720), (346, 260))
     bgr = np.zeros((2, 2, 3), np.uint8)
     bgr[0, 0] = (255, 255, 255); bgr[0, 1] = (255, 0, 0); bgr[1, 0] = (0, 255, 0); bgr[1, 1] = (0, 0, 255)
-    assert po.bgr2gray(bgr).tolist() == [[255, 29], [150, 76]]                           # 0.114 / 0.587 / 0.299 of 255
+    for shift in (15, 14):                                                               # both fixed-point forms: 0.114 / 0.587 / 0.299 of 255
+        assert po.bgr2gray(bgr, shift).tolist() == [[255, 29], [150, 76]]
+    px = rng.integers(0, 256, size=(1, 100000, 3), dtype=np.uint8)
+    d = po.bgr2gray(px, 15).astype(int) - po.bgr2gray(px, 14).astype(int)                 # ... which differ by one grey level on ~1 % of pixels
+    assert np.abs(d).max() == 1 and 0.002 < float((d != 0).mean()) < 0.03
+    exact = (px[..., 0] * 0.114 + px[..., 1] * 0.587 + px[..., 2] * 0.299)                # both within half a level (+ coefficient rounding) of the weights
+    for shift in (15, 14):
+        assert np.abs(po.bgr2gray(px, shift).astype(np.float64) - exact).max() < 0.52
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gray_shift", [15, 14])
 @pytest.mark.parametrize("case", [
     # (in_h, in_w, channels, out_w, out_h, crop)
     (720, 1280, 3, 346, 260, None),      # a 720p colour video to DAVIS346: the general path, both axes
@@ -64,7 +72,7 @@ def test_restatement_invariants():
     (260, 346, 3, 346, 260, None),       # no resize: grey conversion only
     (97, 131, 1, 17, 5, (0, 0, 2, 0)),
 ])
-def test_hip_stage1_equals_the_restatement(case):
+def test_hip_stage1_equals_the_restatement(case, gray_shift):
     import torch
     po = _oracle()
     from v2e_amd.preproc import Stage1, area_tab, is_area_fast
@@ -74,11 +82,13 @@ def test_hip_stage1_equals_the_restatement(case):
     fr = rng.integers(0, 256, size=shape, dtype=np.uint8)
     fr[0, : ih // 2] = 255  # saturated and black regions: ties and the clamp
     fr[1, :, : iw // 3] = 0
-    st = Stage1((ih, iw), (ow, oh), channels=cn, crop=crop, device="cuda")
+    if cn == 1 and gray_shift == 14:
+        pytest.skip("grey frames: no colour conversion")
+    st = Stage1((ih, iw), (ow, oh), channels=cn, crop=crop, device="cuda", gray_shift=gray_shift)
     got = st(torch.from_numpy(fr).cuda()).cpu().numpy()
     assert got.shape == (3, oh, ow) or (not st.resize and got.shape[0] == 3)
     for i in range(3):
-        ref = po.stage1(fr[i], (ow, oh), area_tab, is_area_fast, crop=crop)
+        ref = po.stage1(fr[i], (ow, oh), area_tab, is_area_fast, crop=crop, gray_shift=gray_shift)
         assert np.array_equal(got[i], ref), (case, i, int(np.abs(got[i].astype(int) - ref.astype(int)).max()))
 
 

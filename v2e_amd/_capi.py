@@ -116,7 +116,7 @@ SIGNATURES = {
     "v2e_slomo_prep": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "v2e_resample_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "v2e_resize_area_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "v2e_bgr2gray_u8": (_i, [_vp, _vp, _i64, _vp]),
+    "v2e_bgr2gray_u8": (_i, [_vp, _vp, _i64, _i, _vp]),
     "v2e_u8_to_f32_norm": (_i, [_vp, _vp, _i64, C.c_float, _vp]),
     "v2e_f32_to_u8_trunc": (_i, [_vp, _vp, _i, _i, _i, C.c_float, _i, _vp]),
     "v2e_events_pack_aedat2": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i64, _vp]),

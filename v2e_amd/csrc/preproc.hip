@@ -11,7 +11,10 @@
 //   * otherwise: per source row the horizontal weighted sums buf[dx] = sum_k S[si_k] * alpha_k (float32, in table order, each
 //     product and sum rounded), rows combined as sum[dx] = beta_0 buf_0 (+= beta_j buf_j ...), saturate_cast<uchar>(sum);
 //     the (source index, weight) tables are computed on the host exactly as computeResizeAreaTab does (v2e_amd/preproc.py);
-//   * BGR2GRAY: (B * 1868 + G * 9617 + R * 4899 + (1 << 13)) >> 14.
+//   * BGR2GRAY, gray_shift 15 (the default: RGB2Gray<uchar> of OpenCV 4.x, color_rgb.simd.hpp: BY15 3735, GY15 19235, RY15 9798):
+//     (B * 3735 + G * 19235 + R * 9798 + (1 << 14)) >> 15; gray_shift 14 (OpenCV 3.x's table form, and 4.x's YUV path):
+//     (B * 1868 + G * 9617 + R * 4899 + (1 << 13)) >> 14.  The two differ by one grey level on ~1 % of random pixels; which one a
+//     given cv2 computes is what scripts/check_stage1_against_cv2.py prints.
 // The HIP kernels are tested bit for bit against that restatement (tests/test_preproc.py); neither has been compared with
 // cv2 itself.
 #include "common.h"
@@ -71,12 +74,15 @@ __global__ __launch_bounds__(256) void k_area_fast(const uint8_t *__restrict__ s
     else dst[i] = sat_u8_rint(__fmul_rn((float)sum, 1.f / (float)(isx * isy)));
 }
 
+template <int SHIFT>
 __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, long long npx)
 {
+    constexpr int BY = SHIFT == 15 ? 3735 : 1868, GY = SHIFT == 15 ? 19235 : 9617, RY = SHIFT == 15 ? 9798 : 4899;
+    static_assert(BY + GY + RY == (1 << SHIFT), "the coefficients sum to one");
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= npx) return;
     const uint8_t *p = src + i * 3;
-    dst[i] = (uint8_t)(((int)p[0] * 1868 + (int)p[1] * 9617 + (int)p[2] * 4899 + (1 << 13)) >> 14);
+    dst[i] = (uint8_t)(((int)p[0] * BY + (int)p[1] * GY + (int)p[2] * RY + (1 << (SHIFT - 1))) >> SHIFT);
 }
 
 } // namespace
@@ -101,10 +107,12 @@ int v2e_resize_area_u8(const uint8_t *src, uint8_t *dst, int n, int sh, int sw, 
     return 0;
 }
 
-int v2e_bgr2gray_u8(const uint8_t *src_bgr, uint8_t *dst, int64_t npx, void *stream)
+int v2e_bgr2gray_u8(const uint8_t *src_bgr, uint8_t *dst, int64_t npx, int gray_shift, void *stream)
 {
     V2E_REQUIRE(src_bgr && dst && npx > 0, "bad args");
-    k_bgr2gray<<<v2e_cdiv(npx, 256), 256, 0, (hipStream_t)stream>>>(src_bgr, dst, npx);
+    V2E_REQUIRE(gray_shift == 14 || gray_shift == 15, "gray_shift is 15 (OpenCV 4.x RGB2Gray<uchar>) or 14 (OpenCV 3.x)");
+    if (gray_shift == 15) k_bgr2gray<15><<<v2e_cdiv(npx, 256), 256, 0, (hipStream_t)stream>>>(src_bgr, dst, npx);
+    else k_bgr2gray<14><<<v2e_cdiv(npx, 256), 256, 0, (hipStream_t)stream>>>(src_bgr, dst, npx);
     V2E_HIP(hipGetLastError());
     return 0;
 }

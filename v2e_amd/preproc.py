@@ -59,10 +59,14 @@ class Stage1:
     """v2e.py:687-738 for a batch of source frames already in HBM: uint8 [N, H, W] (grey) or [N, H, W, 3] (BGR, as cv2 reads
     a video) -> uint8 [N, out_h, out_w] grey.  crop = (left, right, top, bottom) pixels as --crop gives them."""
 
-    def __init__(self, in_hw, out_wh, channels=1, crop=None, device="cuda"):
+    def __init__(self, in_hw, out_wh, channels=1, crop=None, device="cuda", gray_shift=15):
         self.device = torch.device(device)
         self.lib = _capi.lib()
         self.cn = int(channels)
+        # BGR2GRAY fixed-point form: 15 = OpenCV 4.x (what `pip install opencv-python` gives v2e today), 14 = OpenCV 3.x (csrc/preproc.hip)
+        if gray_shift not in (14, 15):
+            raise ValueError("gray_shift is 15 (OpenCV 4.x) or 14 (OpenCV 3.x)")
+        self.gray_shift = int(gray_shift)
         if self.cn not in (1, 3):
             raise ValueError("frames have 1 (grey) or 3 (BGR) channels")
         self.crop = crop
@@ -111,6 +115,6 @@ class Stage1:
             x = y
         if self.cn == 3:
             g = torch.empty(tuple(x.shape[:3]), dtype=torch.uint8, device=self.device)
-            check(self.lib.v2e_bgr2gray_u8(_ptr(x), _ptr(g), n * int(x.shape[1]) * int(x.shape[2]), s), "v2e_bgr2gray_u8")
+            check(self.lib.v2e_bgr2gray_u8(_ptr(x), _ptr(g), n * int(x.shape[1]) * int(x.shape[2]), self.gray_shift, s), "v2e_bgr2gray_u8")
             x = g
         return x
