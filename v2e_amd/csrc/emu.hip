@@ -1825,7 +1825,8 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         V2E_HIP(hipMalloc(&h->ch_cpre, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp));
         // 32 bytes per (group, key): only the keys a group has events of are ever written or read (no clearing)
         const size_t mask_bytes = 3 * sizeof(uint32_t) * 2 * GPX * E * nc * h->nkeys_cap * h->ch_nwp;
-        if (emit_pull(mask_bytes)) {
+        // (beyond 2 M groups = 33 M pixels the two-level search's coarse rows would not fit the 64 KB of LDS a launch gets by default)
+        if (h->ch_nwp / 16 <= 8192 && emit_pull(mask_bytes)) {
             V2E_HIP(hipMalloc(&h->ch_cmask, mask_bytes));
             V2E_HIP(hipMalloc(&h->ch_cpre16, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap * (h->ch_nwp / 16)));
         }
