@@ -14,7 +14,7 @@ timeout 300 rocprofv3 --pmc $SQC --kernel-trace -d $O/p5_sqh -- python $R/script
 timeout 400 rocprofv3 --pmc $SQC --kernel-trace -d $O/p5_sq -- python $R/scripts/emu_workloads.py batched hd > $O/p5_sq.log 2>&1
 cd $R
 python profiles/summarize_rocprof_db.py $(ls $O/p5_kt/*/*.db | head -1) $O/p5_kt.txt > /dev/null
-for c in FETCH_SIZE WRITE_SIZE; do python profiles/summarize_rocprof_pmc.py $O/p5_$c $c > $O/p5_$c.txt 2>&1; done
+for c in FETCH_SIZE WRITE_SIZE; do python profiles/summarize_rocprof_pmc.py $O/p5_$c $c 24 > $O/p5_$c.txt 2>&1; done
 python profiles/summarize_rocprof_sq.py $O/p5_sqh k_ > $O/p5_sqh.txt 2>&1
 python profiles/summarize_rocprof_sq.py $O/p5_sq k_ > $O/p5_sq.txt 2>&1
 python scripts/kernel_timeline.py $O/p5_kt k_chain > $O/p5_kt_timeline.txt 2>&1
