@@ -1662,10 +1662,21 @@ struct Sched {
 static int chain_egroups(const v2e_emu *h) { return (h->npx + GROUP_PX - 1) / GROUP_PX; }
 static bool chain_small_grid(const v2e_emu *h) { return (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu; }
 
+// batches in the ring of frame slots (three; V2E_AMD_CHAIN_RING: the profiling scripts' deeper rings)
+static int chain_ring_batches()
+{
+    int nD = 3;
+    if (const char *ev = getenv("V2E_AMD_CHAIN_RING")) { const int v = atoi(ev); if (v >= 3 && v <= 16) nD = v; }
+    return nD;
+}
+
 // records built inside the chain (large grids) or by k_ahead (small grids); V2E_AMD_CHAIN_FUSED=0/1 overrides (dev / tests)
 static bool chain_fused_records(const v2e_emu *h, int dtype)
 {
     if (dtype != V2E_DT_U8) return true; // k_ahead's record path is instantiated for uint8 frames only
+    // k_chain reads k_ahead's records and writes the count words through buffer resources (32-bit offsets): the record ring of
+    // nD batches of up to 64 frames must stay below 4 GB (1280x720: 2.8 GB with three batches; beyond that the chain builds the records)
+    if ((size_t)chain_ring_batches() * 64 * h->n_clips * h->npx_pad * sizeof(uint4) >= (1ull << 32)) return true;
     const char *fe = getenv("V2E_AMD_CHAIN_FUSED"); // read per call: tests switch it per emulator instance
     const int fused_env = fe ? atoi(fe) : -1;
     return fused_env >= 0 ? fused_env != 0 : !chain_small_grid(h);
@@ -1800,8 +1811,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         // batch b + 1 and k_ahead fills batch b + 2); the chain then waits for k_cemit(b - 3) at batch boundaries.  Deeper
         // rings (V2E_AMD_CHAIN_RING) let it run further ahead and measured SLOWER: 8.5 Gev/s with 3 batches, 7.3 with 5 or 7
         // -- three batches of slots and records (174 MB at 346x260) stay in the 256 MB MALL, five do not.
-        int nD = 3;
-        if (const char *ev = getenv("V2E_AMD_CHAIN_RING")) { const int v = atoi(ev); if (v >= 3 && v <= 16) nD = v; }
+        const int nD = chain_ring_batches();
         h->ch_nD = nD;
         h->ch_D = nD * E;
         h->ch_nwp = (chain_egroups(h) + 15) / 16 * 16; // emission groups (one wave each), padded to the 16 a lane of k_cframe takes

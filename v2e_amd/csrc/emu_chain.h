@@ -120,6 +120,7 @@ __device__ __forceinline__ TsGen frame_tsgen(const KArgs &a, const FrameCtl *c, 
 // device reads back, and as dirty L2 lines they would be written back by the release at the end of every chain
 // launch that happens to run meanwhile.
 typedef float v2e_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int v2e_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_event_wt(float4 *ev_clip, unsigned long long row, float t, float x, float y, float pol)
 {
     if (row < 0x7000000ull) { // byte offset below 2^31
@@ -350,6 +351,18 @@ void k_chain(KArgs a_in, ChainArgs ca)
         // Every thread reads back only what it wrote: no barrier.
         // ring slot of a pass's frame k: the slot of its first frame (from the host: no division in the kernel) + k, wrapped (K <= D)
         auto wrap_slot = [&](const int sl) __attribute__((always_inline)) -> int { return sl >= ca.D ? sl - ca.D : sl; };
+        // !FUSED: the ring planes through buffer resources -- the ring slot goes into the instruction's SCALAR offset, the lane's pixel
+        // into its vector offset, computed once: an access at a sub-pass boundary is one scalar multiply and the memory instruction
+        // where a 64-bit `(slot * clips + clip) * pixels + p` per access was a quarter of the boundary's ~300 instructions (round-4
+        // review, item 2a).  The host guarantees the planes stay below 4 GB on this path (chain_fused_records).
+        const uint32_t lane_px = (uint32_t)((size_t)clip * a.npx_pad + p);
+        const uint32_t slot_px = (uint32_t)((size_t)ca.n_clips * a.npx_pad); // pixels of one ring slot
+        const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ca.rec, 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t cnt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ca.cnt, 0, -1, 0x00020000);
+        auto load_rec = [&](const int sl) __attribute__((always_inline)) -> uint4 {
+            const v2e_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (int)(lane_px * 16u), (int)((uint32_t)sl * slot_px * 16u), 0);
+            return make_uint4(v.x, v.y, v.z, v.w);
+        };
         auto stage = [&](const int sl0, const int fn) __attribute__((always_inline)) { // the first CHAIN_SUB frames of a pass (sl0: the first one's slot)
             if (FUSED || !valid) return;
             uint4 t[CHAIN_SUB];
@@ -357,7 +370,7 @@ void k_chain(KArgs a_in, ChainArgs ca)
 #pragma unroll
             for (int j = 0; j < CHAIN_SUB; ++j) {
                 t[j] = make_uint4(0u, 0u, 0u, 0u);
-                if (j < fn) t[j] = ca.rec[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p];
+                if (j < fn) t[j] = load_rec(sl);
                 if (++sl == ca.D) sl = 0;
             }
 #pragma unroll
@@ -603,7 +616,7 @@ void k_chain(KArgs a_in, ChainArgs ca)
 #pragma unroll
                 for (int j = 0; j < CHAIN_SUB; ++j) {
                     nx[j] = make_uint4(0u, 0u, 0u, 0u);
-                    if (!FUSED && valid && j < cn) nx[j] = ca.rec[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p];
+                    if (!FUSED && valid && j < cn) nx[j] = load_rec(sl);
                     if (++sl == ca.D) sl = 0;
                 }
             };
@@ -641,7 +654,8 @@ void k_chain(KArgs a_in, ChainArgs ca)
                     if (valid) {
                         int sl = slot0;
                         for (int k = k0; k < kend; ++k) { // the sub-pass's count words
-                            WT_STORE(&ca.cnt[((size_t)sl * ca.n_clips + clip) * a.npx_pad + p], s_cw[(size_t)((unsigned)k % CHAIN_SUB) * BLOCK + tid]);
+                            __builtin_amdgcn_raw_buffer_store_b32(s_cw[(size_t)((unsigned)k % CHAIN_SUB) * BLOCK + tid], cnt_rsrc, (int)(lane_px * 4u),
+                                                                  (int)((uint32_t)sl * slot_px * 4u), 17); // sc0 sc1: written through, as WT_STORE
                             if (++sl == ca.D) sl = 0;
                         }
                     }
