@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the V2E_AMD_PULL_WPF / V2E_AMD_PULL_NR / V2E_AMD_CFRAME1_MAX knobs this script sweeps existed only in the experiment builds of round 5
+# (profiles/r05_emulator_experiments.txt items 8-10); the committed library has the measured values as constants.
 # k_cpull rows per thread (V2E_AMD_PULL_NR = 1 / 2 / 4): parity, then headline / 1280x720 / 64 clips.  Every step bounded.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 cd $R

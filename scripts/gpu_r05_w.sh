@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the V2E_AMD_PULL_WPF / V2E_AMD_PULL_NR / V2E_AMD_CFRAME1_MAX knobs this script sweeps existed only in the experiment builds of round 5
+# (profiles/r05_emulator_experiments.txt items 8-10); the committed library has the measured values as constants.
 # 1280x720: the per-frame tables by k_cframe (a workgroup per key row) instead of k_cframe1 (one workgroup per frame)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 cd $R
