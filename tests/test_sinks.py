@@ -159,3 +159,73 @@ def test_emulator_writes_aedat2_while_generating(tmp_path):
     assert np.array_equal(words[:, 0], (x << 12) | (y << 22) | (p << 11))
     rows = [l for l in open(str(tmp_path / "ev.txt")).read().splitlines() if not l.startswith("#")]
     assert len(rows) == len(allev)
+
+
+class _FakeDv:
+    """A stand-in for the third-party `dv_processing` package (absent from this image and from the reference tree) that RECORDS what
+    a writer does with it: EventStore.push_back refuses a time stamp that goes backwards, as the real store does."""
+
+    class EventStore:
+        def __init__(self):
+            self.rows = []
+
+        def push_back(self, t, x, y, p):
+            assert all(type(v) is int for v in (t, x, y, p)), "the store takes Python ints"
+            if self.rows and t < self.rows[-1][0]:
+                raise RuntimeError("timestamp %d is lower than the last one" % t)
+            self.rows.append((t, x, y, p))
+
+    class io:
+        class MonoCameraWriter:
+            instances = []
+
+            @staticmethod
+            def EventOnlyConfig(name, resolution):
+                return ("event-only", name, tuple(resolution))
+
+            def __init__(self, path, config):
+                self.path, self.config, self.written = path, config, []
+                type(self).instances.append(self)
+
+            def writeEvents(self, store):
+                self.written.append(list(store.rows))
+
+
+def test_aedat4_sink_drives_dv_processing_like_the_reference_writer(tmp_path, monkeypatch):
+    """SURVEY 8(f-2), AEDAT-4 (aedat4_output.py:17-99): the file container is dv_processing's and that package is not here, so the sink
+    cannot be compared byte for byte; what CAN be pinned is everything the writer class itself does -- the conversions (microsecond
+    time stamps in the precision numpy gives `float32 * 1e6`, polarity 0 / 1, no flips), the events the store refuses (logged and
+    skipped, still counted), the counters, the writer configuration and the single write at close() -- by running the REFERENCE's
+    class and ours against the same recording stand-in for dv_processing."""
+    import sys
+    from golden import ref_harness as rh
+    if not rh.reference_available():
+        pytest.skip("reference tree not present")
+    rh.install_stubs()
+    import importlib
+    ref_mod = importlib.import_module("v2ecore.output.aedat4_output")
+    monkeypatch.setattr(ref_mod, "dv", _FakeDv)
+    monkeypatch.setitem(sys.modules, "dv_processing", _FakeDv)
+    from v2e_amd.sinks import HostAEDat4Output
+    rng = np.random.default_rng(11)
+    n = 5000
+    t = np.sort(rng.uniform(0.0, 3.0, n)).astype(np.float32)
+    t[100], t[2500], t[2501] = t[50], 0.0, t[2400]                   # time stamps that go backwards: refused by the store
+    ev = np.stack([t, rng.integers(0, 346, n).astype(np.float32), rng.integers(0, 260, n).astype(np.float32),
+                   rng.choice([-1.0, 1.0], n).astype(np.float32)], axis=1)
+    _FakeDv.io.MonoCameraWriter.instances.clear()
+    ref = ref_mod.AEDat4Output(str(tmp_path / "ref.aedat4"), output_width=346, output_height=260)
+    ours = HostAEDat4Output(str(tmp_path / "ours.aedat4"), output_width=346, output_height=260)
+    for lo in range(0, n, 1300):                                      # several packets, an empty one in between
+        ref.appendEvents(ev[lo:lo + 1300])
+        ours.appendEvents(ev[lo:lo + 1300])
+        ref.appendEvents(ev[:0])
+        ours.appendEvents(ev[:0])
+    assert len(ours.store.rows) == len(ref.store.rows) < n and ours.store.rows == ref.store.rows
+    assert (ours.numEventsWritten, ours.numOnEvents, ours.numOffEvents) == (ref.numEventsWritten, ref.numOnEvents, ref.numOffEvents) \
+        and ours.numEventsWritten == n
+    ref.close(); ours.close(); ours.close()                           # close() twice: one write
+    wr, wo = _FakeDv.io.MonoCameraWriter.instances
+    assert wo.config == wr.config and len(wo.written) == len(wr.written) == 1 and wo.written[0] == wr.written[0]
+    ours.appendEvents(ev[:10])                                        # after close(): ignored, as the reference does
+    assert ours.numEventsWritten == n
