@@ -105,6 +105,8 @@ def emulator():
 # one k_chain launch = 32 frames (10 per step + a tail launch validating the last speculation; a redo pass runs inside the launch
 # that finds the miss -- this round with a fence-free rendezvous); k_ahead / k_ctot / k_cframe1 / k_cpull: one launch per 64 frames.
 # The three streams run side by side on the same CUs: every duration below is a duration UNDER CONTENTION.
+# (Recorded with the build before profiles/r05_emulator_experiments.txt item 13 -- k_chain's ring accesses through buffer resources, the
+# round's last kernel change: 205 fewer static instructions in k_chain, a launch without a redo 29.6 -> 29.0 us; the GPU budget was spent.)
 #
 """ + kt + "\n# k_chain launch timeline (same trace)\n" + tl + "\n# every kernel of the trace's last steps: start (us), duration (us), hardware queue, stream (scripts/dump_timeline.py)\n" + window)
     f, w = rd("p5_FETCH_SIZE.txt"), rd("p5_WRITE_SIZE.txt")
@@ -138,6 +140,7 @@ def emulator():
     frames = int(m.group(2)) if m else 1200
     per_wave = (v + s) / frames / (346 * 260 / 64.0)
     wr("r05_emulator_sq.txt", """# SQ counters of the emulator kernels, round 5
+# (recorded with the build before profiles/r05_emulator_experiments.txt item 13: k_chain has 205 fewer static instructions since)
 # command: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU
 #          --kernel-trace -- python scripts/emu_workloads.py headline        (first table: the headline clip ALONE, %d frames)
 #          ... -- python scripts/emu_workloads.py batched hd                  (second table: 64 clips x 346x260; 1280x720 noisy)
