@@ -638,11 +638,16 @@ def main():
                     out["self_allgather"] = self_allgather_bench(device, frames_all)
                 except Exception as e:
                     out["self_allgather"] = {"error": repr(e)[:300]}
-    if dist is not None and not STUB and not args.no_extras:
-        # the SuperSloMo stage of ONE clip sharded over the ranks by source pairs (every rank takes part; rank 0 reports)
+    if dist is not None and not args.no_extras:
+        # the SuperSloMo stage of ONE clip sharded over the ranks by source pairs (every rank takes part; rank 0 reports); stub mode:
+        # the same collective sequence over gloo with a stand-in for the interpolator, a small clip
         try:
             from v2e_amd.benchutil import slomo_sharded_bench
-            r = slomo_sharded_bench(device, dist)
+            if STUB:
+                from tests.bench_stub import StubUpsampler
+                r = slomo_sharded_bench(device, dist, n_src=11, U=3, H=6, W=8, reps=2, pipe=StubUpsampler(3))
+            else:
+                r = slomo_sharded_bench(device, dist)
             if rank == 0:
                 out["slomo_sharded"] = r
         except Exception as e:

@@ -39,3 +39,27 @@ class StubEmulator:
         self.calls.append((float(times[0]), float(times[-1]), int(frames[0, 0, 0])))
         self.step += 1
         return StubPending(ev, counts)
+
+
+class StubUpsampler:
+    """Stands in for VideoToEvents' SuperSloMo stage in bench.py's `slomo_sharded` leg: upsample() is a deterministic blend of each
+    source pair; the sharding and the in-order gather are v2e_amd.pipeline's own code (pair_shard, gather_frames_in_order)."""
+
+    def __init__(self, U):
+        self.U = int(U)
+
+    def upsample(self, frames_u8):
+        n, U = int(frames_u8.shape[0]) - 1, self.U
+        a = frames_u8[:-1].to(torch.int32)[:, None]
+        b = frames_u8[1:].to(torch.int32)[:, None]
+        u = torch.arange(U, dtype=torch.int32).view(1, U, 1, 1)
+        return ((a * (U - u) + b * u) // U).to(torch.uint8).reshape((n * U,) + tuple(frames_u8.shape[1:]))
+
+    def upsample_sharded(self, frames_u8, group=None, owner=None):
+        import torch.distributed as dist
+        from v2e_amd.pipeline import gather_frames_in_order, pair_shard
+        G, r = dist.get_world_size(group), dist.get_rank(group)
+        N = int(frames_u8.shape[0])
+        lo, hi = pair_shard(N - 1, G, r)
+        mine = self.upsample(frames_u8[lo:hi + 1]) if hi > lo else frames_u8.new_empty((0,) + tuple(frames_u8.shape[1:]))
+        return gather_frames_in_order(mine, N - 1, self.U, group, owner)

@@ -36,6 +36,12 @@ def _check_line(d, n, steps, warmup):
     if n > 1:
         assert d["config"]["event_stream_allgather"] is True
         assert d["compute_only"]["value"] > 0 and d["with_allgather"]["bytes_gathered_per_rank_per_step"] > 0
+        # the SuperSloMo stage of one clip sharded over the ranks by source pairs: every rank went through the leg's collectives in
+        # the same order (no hang), and rank 0 assembled the unsharded clip (the stub interpolator's frames, compared in the leg)
+        sh = d["slomo_sharded"]
+        assert "error" not in sh, sh
+        assert sh["ranks"] == n and sh["scaling"] == "strong" and sh["frames_gathered_in_order"] is True and sh["value"] > 0
+        assert sh["bytes_gathered_per_clip"] == 10 * 3 * 6 * 8
     # the stub's event counts are a known function of (rank, step): SUM over ranks of the median block's steps
     from tests.bench_stub import stub_counts
     F = d["config"]["frames_per_step"]

@@ -341,37 +341,51 @@ def e2e_bench(device, n_src=31, U=10, H=260, W=346, batch=10, reps=3):
                       "quantise/resize on device -> emulator HIP, batch %d pairs, frames never leave HBM" % (n_src, U, batch)}
 
 
-def slomo_sharded_bench(device, dist, n_src=65, U=10, H=260, W=346, batch=8, reps=3):
+def slomo_sharded_bench(device, dist, n_src=65, U=10, H=260, W=346, batch=8, reps=3, pipe=None):
     """ONE clip's SuperSloMo stage sharded over the ranks of the job by source pairs (north_star: "frame batches shard across the
     GPUs"): every rank holds the same 346x260 source clip (seed 2), interpolates its contiguous block of the 64 pairs
     (VideoToEvents.upsample_sharded) and the uint8 frames are all-gathered in order to rank 0.  STRONG scaling: the clip is fixed,
     the ranks split it; value = interpolated frames of the whole clip / wall time (barrier + synchronise on both sides, max over
-    ranks by construction of the barrier).  At world size 1 it is the unsharded stage with a one-rank gather."""
-    from .pipeline import VideoToEvents
-    from .slomo import SloMoEngine
-    from .synth import portable_unet_state_dict
-    sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
-    eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
-                      {k: torch.from_numpy(v) for k, v in sd_i.items()}, device)
+    ranks by construction of the barrier).  At world size 1 it is the unsharded stage with a one-rank gather.
+    pipe: an object with upsample_sharded(frames, group, owner) and upsample(frames) in place of the HIP pipeline (bench.py's stub
+    mode on CPU: the collective sequence of this leg is then exercised by tests/test_bench_launch.py); the gathered clip is compared
+    with the unsharded one on rank 0 in that case."""
+    device = torch.device(device)
+    on_gpu = device.type == "cuda"
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(device)
+
+    stub = pipe is not None
+    if pipe is None:
+        from .pipeline import VideoToEvents
+        from .slomo import SloMoEngine
+        from .synth import portable_unet_state_dict
+        sd_f, sd_i = portable_unet_state_dict(2, 4, 101), portable_unet_state_dict(12, 5, 102)
+        eng = SloMoEngine({k: torch.from_numpy(v) for k, v in sd_f.items()},
+                          {k: torch.from_numpy(v) for k, v in sd_i.items()}, device)
+        pipe = VideoToEvents(eng, None, U, batch_size=batch)
     g = torch.Generator(device=device)
     g.manual_seed(2)
     src = torch.randint(0, 256, (n_src, H, W), dtype=torch.uint8, device=device, generator=g)
-    pipe = VideoToEvents(eng, None, U, batch_size=batch)
     world = dist.get_world_size()
     out = pipe.upsample_sharded(src, dist.group.WORLD, 0)  # warm-up: allocations, RCCL channels
-    torch.cuda.synchronize(device)
+    sync()
     dist.barrier()
-    torch.cuda.synchronize(device)
+    sync()
     t0 = time.perf_counter()
     for _ in range(reps):
         out = pipe.upsample_sharded(src, dist.group.WORLD, 0)
-    torch.cuda.synchronize(device)
+    sync()
     dist.barrier()
-    torch.cuda.synchronize(device)
+    sync()
     sec = (time.perf_counter() - t0) / reps
     n = (n_src - 1) * U
     ok = out is None or tuple(out.shape) == (n, H, W)
+    if stub and out is not None:  # the gathered clip IS the unsharded one
+        ok = ok and bool(torch.equal(out, pipe.upsample(src)))
     return {"value": round(n / sec, 1), "unit": "interpolated frames/s", "scaling": "strong", "ranks": world, "ms_per_clip": round(sec * 1e3, 2),
             "frames_gathered_in_order": bool(ok), "bytes_gathered_per_clip": int(n * H * W),
-            "config": "one 346x260 clip, %d source pairs, U = %d, pairs [r P / G, (r + 1) P / G) per rank, uint8 frames all-gathered in order "
-                      "to rank 0 (v2e_amd.pipeline.VideoToEvents.upsample_sharded)" % (n_src - 1, U)}
+            "config": "one %dx%d clip, %d source pairs, U = %d, pairs [r P / G, (r + 1) P / G) per rank, uint8 frames all-gathered in order "
+                      "to rank 0 (v2e_amd.pipeline.VideoToEvents.upsample_sharded)" % (W, H, n_src - 1, U)}
