@@ -255,10 +255,26 @@ int v2e_emu_frame_host_rows(v2e_emu *h, float *pinned_rows, uint64_t cap_rows);
  * reads a pinned staging set (no copy-engine transfer), and the k_chain pipeline's kernels read the frames through that device
  * variable: with use_graph & 1 a cached graph is replayed over whatever `frames` buffer a call names (events / recs_dev are still
  * baked in: callers alternate between fixed buffer sets), so a caller need not copy frames into one fixed buffer per run.
+ * Round 6, PIPELINED RUNS (use_graph = 0 | 1024; the k_chain pipeline with a refractory period): plain launches on three streams, no
+ * graph and no join at the run's end.  `stream` carries the chain's launches and nothing else, so consecutive runs' chains follow one
+ * another in one hardware queue; the run's upload, zero fills and k_ahead records go to a stream of the handle that runs ahead of the
+ * chain (beside the run before), the emission to another that finishes beside the run after; everything two runs in flight would share
+ * exists twice.  `stream` then orders the PIXEL STATE only: the run's event rows and records are complete behind v2e_emu_run_wait
+ * (host) / v2e_emu_run_join (a stream), which the caller must call before reading them; every other entry point of the handle joins by
+ * itself.  Callers alternate two sets of `events` / `recs_dev` buffers (a run that names the buffers of the run before it waits for that
+ * run).  | 2048: the caller vouches that `frames` are resident (nothing enqueued on `stream` still writes them): the run's head then
+ * does not wait for `stream`, i.e. for the chain of the run before.  Results are identical to every other mode.
  */
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames,
                 const double *t_prev, const double *t_frame, uint32_t frame_idx0, float *events,
                 uint64_t cap, v2e_frame_rec *recs_dev, int use_graph, void *stream);
+/* `stream` waits (device side, no host block) for every piece of every pipelined run enqueued on the handle so far. */
+int v2e_emu_run_join(v2e_emu *h, void *stream);
+/* The scratch set (0 / 1) the run enqueued last took if the library enqueued it in pieces (the ticket of that run, valid until the
+ * second-next such run), or -1: that run is whole on its stream. */
+int v2e_emu_run_ticket(v2e_emu *h);
+/* Host-blocking: every piece of the last overlapped run with that ticket has completed (its rows and records can be read). */
+int v2e_emu_run_wait(v2e_emu *h, int ticket);
 
 /* After an instrumented v2e_emu_run (blocking): summed milliseconds per kernel class and frames.
  * k_chain pipeline (a HIP event before and after every chain launch, on its stream): ms_count = first
@@ -282,6 +298,15 @@ int v2e_emu_last_profile_pipe(v2e_emu *h, int *emit_batches, int *frames_per_bat
 /* The chain launches of the last instrumented run one by one, in launch order (microseconds; the last one is the tail launch
  * that only validates): *n = how many there were, the first min(cap, *n) written to us (may be NULL). */
 int v2e_emu_last_profile_launches(v2e_emu *h, float *us, int cap, int *n);
+
+/* Device time stamps of the chain kernel, per launch, in the configuration that is actually timed (graph replay, side streams running):
+ * every k_chain launch of the runs enqueued after v2e_emu_launch_stamps(h, runs > 0, NULL, 0, NULL, NULL) leaves the wall-clock time
+ * of its first workgroup's start and of its last workgroup's end (two atomics per workgroup; s_memrealtime, 100 MHz) in a ring of
+ * `runs` runs.  With out_ns != NULL or n_runs != NULL the call first synchronises the device and copies the last min(cap_runs, runs
+ * stamped) runs out, oldest first: out_ns[run][launch][2] = {start, end} in nanoseconds of the device clock, *launches_per_run
+ * entries per run (0 / 0: the run had no such launch); then `runs` takes effect (0 switches the stamps off; a changed value
+ * re-allocates the ring and forgets what it held).  What bench.py's roofline object divides the chain's algorithmic bytes by. */
+int v2e_emu_launch_stamps(v2e_emu *h, int runs, uint64_t *out_ns, int cap_runs, int *n_runs, int *launches_per_run);
 
 /* Which pipeline the last v2e_emu_run on this handle used: kind 0 = unfused count/rank/scan/emit, 3 = k_chain (K frames
  * per launch, state in registers; records from k_ahead), 4 = k_chain with the per-frame records built inside the chain;

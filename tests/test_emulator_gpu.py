@@ -264,7 +264,7 @@ def test_scidvs_float32_state_philox_matches_reference_and_oracle(api, oracle_li
     assert np.array_equal(hp, ora.scidvs_highpass) and np.array_equal(emu.base_log_frame.cpu().numpy(), ora.base_log_frame)
 
 
-@pytest.mark.parametrize("chain_k", [1, 2, 3, 5, 8, 11, 16, 32])
+@pytest.mark.parametrize("chain_k", [1, 2, 3, 5, 8, 11, 16, 32, 40, 64])
 @pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260", "philox_defaults_346x260"])
 def test_chain_launch_lengths_and_ring_wrap(name, chain_k, monkeypatch):
     """k_chain with few frames per launch: the ring of 3 K frame slots wraps several times within the fixture clip,
@@ -769,3 +769,73 @@ def test_model_state_planes_are_readable_without_a_display():
     assert emu.diff_frame is not None and tuple(emu.diff_frame.shape) == tuple(fx.frames[0].shape)
     assert emu.log_new_frame.dtype == torch.float32 and emu.c_minus_s_frame is None
     emu.cleanup()
+
+
+@pytest.mark.parametrize("chunk", [24, 9, 5])
+@pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260", "philox_defaults_346x260"])
+def test_pipelined_runs_equal_whole_clip(name, chunk):
+    """Pipelined runs (v2e_emu_run 0 | 1024: plain launches on three streams, the next run's upload and records beside this run's chain,
+    this run's last emission batches beside the next run's chain, two scratch sets alternating): a clip fed in runs of `chunk` frames,
+    every run enqueued before the result of the run before it is read, with and without the caller's word that the frames are
+    resident -- the reference's events, frame by frame, and its final state."""
+    fx = PhiloxFixture(name)
+    for resident in (True, False):
+        emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+        frames = torch.from_numpy(np.ascontiguousarray(fx.frames)).cuda()
+        torch.cuda.synchronize()
+        pend, evs, cnts = [], [], []
+        for lo in range(0, len(fx.frames), chunk):
+            pend.append(emu.generate_events_batch_async(frames[lo:lo + chunk], fx.times[lo:lo + chunk], use_graph=0, return_device=True,
+                                                        frames_resident=resident))
+            if len(pend) > 1:
+                ev, c = pend.pop(0).result()
+                evs.append(ev.cpu().numpy()); cnts += list(c)
+        ev, c = pend.pop(0).result()
+        evs.append(ev.cpu().numpy()); cnts += list(c)
+        assert cnts == list(fx.n_events)
+        ev = np.concatenate(evs)
+        row = 0
+        for k, n in enumerate(cnts):
+            if n:
+                assert sha(ev[row:row + n]) == fx.ev_sha[k], "frame %d event digest differs" % k
+            row += n
+        st = _state(emu)
+        assert sha(st["base_log_frame"]) == fx.base_sha
+        assert sha(st["lp_log_frame"]) == fx.lp_sha
+        if fx.ts_mem_sha:
+            assert sha(st["timestamp_mem"]) == fx.ts_mem_sha
+        # ... and the frame-at-a-time API right behind a pipelined run sees its state (every other entry point joins by itself)
+        emu2 = _mk(fx, seed=fx.seed, rng_mode="philox")
+        half = len(fx.frames) // 2
+        p = emu2.generate_events_batch_async(frames[:half], fx.times[:half], use_graph=0, frames_resident=resident)
+        e1 = emu2.generate_events(fx.frames[half], float(fx.times[half]))
+        assert (0 if e1 is None else len(e1)) == fx.n_events[half]
+        if e1 is not None:
+            assert sha(e1) == fx.ev_sha[half]
+        assert list(p.result()[1]) == list(fx.n_events[:half])
+
+
+def test_pipelined_runs_at_1280x720():
+    """The same at 1280x720 with a refractory period (records built in the chain, K = 8, the two-level pull writer): runs of 9 frames."""
+    fx = PhiloxFixture("philox_refractory_1280x720")
+    emu = _mk(fx, seed=fx.seed, rng_mode="philox")
+    emu.generate_events(fx.frames[0], float(fx.times[0]))
+    frames = torch.from_numpy(np.ascontiguousarray(fx.frames)).cuda()
+    torch.cuda.synchronize()
+    pend, evs, cnts = [], [], [0]
+    for lo in range(1, len(fx.frames), 9):
+        pend.append(emu.generate_events_batch_async(frames[lo:lo + 9], fx.times[lo:lo + 9], use_graph=0, return_device=True, cap=8_000_000,
+                                                    frames_resident=True))
+        if len(pend) > 1:
+            ev, c = pend.pop(0).result()
+            evs.append(ev.cpu().numpy()); cnts += list(c)
+    ev, c = pend.pop(0).result()
+    evs.append(ev.cpu().numpy()); cnts += list(c)
+    assert cnts == list(fx.n_events)
+    ev = np.concatenate(evs)
+    row = 0
+    for k, n in enumerate(cnts):
+        if n:
+            assert sha(ev[row:row + n]) == fx.ev_sha[k], "frame %d event digest differs" % k
+        row += n
+    assert sha(_state(emu)["base_log_frame"]) == fx.base_sha

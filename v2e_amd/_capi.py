@@ -99,12 +99,16 @@ SIGNATURES = {
     "v2e_emu_frame": (_i, [_vp, _PP, _vp, _i, _i, _d, _d, _u32, _vp, _u64, C.POINTER(_u32), C.POINTER(C.POINTER(C.c_float)), _vp]),
     "v2e_emu_run": (_i, [_vp, _PP, _vp, _i, _i, C.POINTER(_d), C.POINTER(_d), _u32, _vp, _u64,
                          _vp, _i, _vp]),
+    "v2e_emu_run_join": (_i, [_vp, _vp]),
+    "v2e_emu_run_ticket": (_i, [_vp]),
+    "v2e_emu_run_wait": (_i, [_vp, _i]),
     "v2e_emu_last_profile": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),
                                   C.POINTER(_i)]),
     "v2e_emu_chain_plan": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i]),
     "v2e_emu_last_profile_pipe": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "v2e_emu_last_profile_launches": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "v2e_emu_last_pipeline": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "v2e_emu_launch_stamps": (_i, [_vp, _i, _vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "v2e_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_pack_conv_weight_s3": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "v2e_pack_conv_weight_h2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -27,6 +27,14 @@ def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device, first
     gc.collect()
     gc.freeze()
     nclip = max((int(frames_all.shape[0]) - 1) // F, 1)
+    import inspect
+    # The loop's mode: pipelined runs (plain launches on three streams, consecutive runs overlapping: v2e_emu_run 0 | 1024; the clip was
+    # generated and synchronised before the loop, so the frames are resident).  V2E_AMD_BENCH_UG=1: one hipGraph per run, run after
+    # run on one stream (rounds 2-5), for A/B.  (The CPU tests' stand-ins have no such switch.)
+    ug = int(os.environ.get("V2E_AMD_BENCH_UG", "0"))
+    kw = {}
+    if "pipelined" in inspect.signature(emu.generate_events_batch_async).parameters:
+        kw = dict(pipelined=os.environ.get("V2E_AMD_BENCH_PIPELINED", "1") != "0", frames_resident=True)
 
     def enqueue(s):
         lo = 1 + (s % nclip) * F  # the synthetic clip is cycled through; time keeps running
@@ -35,7 +43,7 @@ def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device, first
         # and began every step with a 27 MB device-to-device copy into one fixed buffer)
         src = frames_all[lo:lo + F]
         return emu.generate_events_batch_async(src, [(1 + s * F + i) * dt for i in range(F)], return_device=True,
-                                               use_graph=int(os.environ.get("V2E_AMD_BENCH_UG", "1")))
+                                               use_graph=ug, **kw)
 
     def finish(pend):
         ev, counts = pend.result()

@@ -34,6 +34,7 @@ constexpr int BLOCK = 256;
 constexpr int WAVE = 64;
 constexpr int RING = 64;        // record / control ring for the frame-at-a-time API
 constexpr int SCAN_BLOCKS = 64; // workgroups of k_scan per clip
+constexpr int STAMP_LAUNCHES = 128; // chain launches of one run that v2e_emu_launch_stamps keeps
 
 // packed per-pixel scratch word written by k_count
 constexpr uint32_t CNT_MASK = 0x00FFFFFFu;
@@ -844,6 +845,12 @@ struct v2e_emu {
     uint32_t *run_fidx_host = nullptr; // pinned
     const void **run_frames = nullptr;      // device: the current run's frames (k_ahead / k_chain read the pointer from here)
     const void **run_frames_host = nullptr; // pinned, two slots
+    // per-launch device time stamps of the chain kernel (v2e_emu_launch_stamps): [runs_cap][STAMP_LAUNCHES][2] wall-clock words
+    unsigned long long *stamps = nullptr;
+    int stamps_runs = 0;                       // runs the buffer holds (0: off)
+    unsigned long long stamp_seq = 0;          // runs stamped so far
+    unsigned long long **stamp_slot = nullptr;      // device: the current run's slot (nullptr: off), read by k_chain
+    unsigned long long **stamp_slot_host = nullptr; // pinned, two slots
     // captured runs, keyed by everything baked into them (buffers, sizes, parameters): a caller that alternates between two
     // sets of frame / event / record buffers (the asynchronous API) replays two graphs
     struct CachedGraph { std::vector<unsigned char> key; hipGraphExec_t exec; unsigned long long used; };
@@ -871,7 +878,7 @@ struct v2e_emu {
     uint16_t *ch_wmax = nullptr;    // [2][ch_E][n_clips][ch_nwp]
     uint16_t *ch_wtot = nullptr;    // [3][ch_E][n_clips][nkeys_cap][ch_nwp]
     float *ch_tsold = nullptr;      // [ch_D][n_clips][npx_pad] (refractory runs)
-    void *ch_ck = nullptr;          // refractory runs: 2 launch parities x 3 checkpoints x (base 8 B, lp 8 B, ts 4 B) planes
+    void *ch_ck = nullptr;          // refractory runs: 2 launch parities x (K / 8 - 1) checkpoints x (base 8 B, lp 8 B, ts 4 B) planes
     uint4 *ch_rec = nullptr;        // [ch_D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
     hipStream_t ahead = nullptr;    // k_ahead runs beside the chain and the emission
     hipStream_t tabs = nullptr;     // the emission tables (k_ctot, k_cframe, k_coff) of batch b + 1 beside the event writer on batch b
@@ -890,6 +897,63 @@ struct v2e_emu {
     uint32_t *ch_cpre16 = nullptr; // every 16th entry of ch_cpre (CEmitArgs::cpre16)
     uint32_t *ch_cmask = nullptr; // the pull's per-(group, key) pixel ballots (CEmitArgs::cmask), three sets like the other tables
     int ch_nkeys_cap = 0;           // nkeys_cap the chain scratch was sized for
+    int ch_pull = 0;                // the event writer of this configuration: k_cpull (1) or k_cemit
+    // ---- two scratch sets for OVERLAPPED runs (v2e_emu_run, use_graph | 1024): everything a run's head (uploads, zero fills, first
+    // records), its chain and its last emission batches touch while the run before / after it is still in flight exists twice; the
+    // fields above / below name the CURRENT set, `alt` holds the other one, swap_scratch() exchanges them before a run is enqueued.
+    // (Not doubled: the pixel state and its ping-pong set, the checkpoints: only the chain touches them, and chains never overlap.)
+    static constexpr int NPF = 21;
+    void *alt[NPF] = {};
+    void **pf(int i)
+    {
+        void **t[NPF] = {(void **)&run_ctl, (void **)&run_fidx, (void **)&run_frames, (void **)&stamp_slot, (void **)&run_off,
+                         (void **)&ch_gM, (void **)&ch_bar, (void **)&ch_rec, (void **)&ch_cnt, (void **)&ch_ruleM, (void **)&ch_tsold,
+                         (void **)&ch_wmax, (void **)&ch_wtot, (void **)&ch_cf, (void **)&ch_cdone, (void **)&ch_cT, (void **)&ch_ckbase,
+                         (void **)&ch_cperm, (void **)&ch_cpre, (void **)&ch_cmask, (void **)&ch_cpre16};
+        return t[i];
+    }
+    void *&alt_of(void **field)
+    {
+        for (int i = 0; i < NPF; ++i) if (pf(i) == field) return alt[i];
+        static void *none = nullptr;
+        return none;
+    }
+    int scratch_par = 0;
+    void swap_scratch()
+    {
+        for (int i = 0; i < NPF; ++i) std::swap(*pf(i), alt[i]);
+        scratch_par ^= 1;
+    }
+    // what is sized by the chain configuration (K, E, keys), in both sets
+    void free_chain_scratch()
+    {
+        for (int i = 5; i < NPF; ++i) { // from ch_gM on (run_ctl / run_fidx / run_frames / stamp_slot / run_off have their own sizes)
+            hipFree(*pf(i)); hipFree(alt[i]);
+            *pf(i) = nullptr; alt[i] = nullptr;
+        }
+        hipFree(ch_ck); ch_ck = nullptr;
+    }
+    // overlapped runs in flight: events of the pieces
+    hipEvent_t ev_main_done2[2] = {nullptr, nullptr}, ev_tail_done2[2] = {nullptr, nullptr};
+    bool piece_pending[2] = {false, false}; // set `par` has a run whose pieces may still be executing
+    const void *last_events = nullptr, *last_recs = nullptr; // buffers of the overlapped run enqueued last
+    hipEvent_t ev_user = nullptr;
+    int last_ticket = -1; // the scratch set of the run enqueued last if it went out in pieces, else -1 (v2e_emu_run_ticket)
+    // every piece of every overlapped run has completed (host-blocking; before scratch is freed or re-sized)
+    void sync_runs()
+    {
+        for (int q = 0; q < 2; ++q)
+            if (piece_pending[q]) { if (ev_tail_done2[q]) hipEventSynchronize(ev_tail_done2[q]); if (ev_main_done2[q]) hipEventSynchronize(ev_main_done2[q]); piece_pending[q] = false; }
+    }
+    // `s` waits for every piece of every overlapped run enqueued so far (no host block)
+    int join_runs(hipStream_t s)
+    {
+        for (int q = 0; q < 2; ++q)
+            if (piece_pending[q]) {
+                if (hipStreamWaitEvent(s, ev_main_done2[q], 0) != hipSuccess || hipStreamWaitEvent(s, ev_tail_done2[q], 0) != hipSuccess) return -1;
+            }
+        return 0;
+    }
     int occ_cache[24];              // workgroups of a k_chain instantiation a CU holds (-1: not queried yet)
 };
 
@@ -906,10 +970,15 @@ void v2e_set_error(const char *fmt, ...)
 // pinned host staging -> device (v2e_emu_run): frame scalars of a run and its first frame index
 static __global__ __launch_bounds__(BLOCK) void k_upload_ctl(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
                                                       const uint32_t *__restrict__ fsrc, uint32_t *__restrict__ fdst,
-                                                      const void *const *__restrict__ psrc, const void **__restrict__ pdst)
+                                                      const void *const *__restrict__ psrc, const void **__restrict__ pdst,
+                                                      unsigned long long *const *__restrict__ ssrc, unsigned long long **__restrict__ sdst)
 {
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *fdst = *fsrc; *pdst = *psrc; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *fdst = *fsrc; *pdst = *psrc; *sdst = *ssrc; }
+    // the run's slot of per-launch time stamps (v2e_emu_launch_stamps; nullptr: off) starts out zero
+    unsigned long long *slot = *ssrc;
+    if (slot && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 2 * STAMP_LAUNCHES; i += BLOCK) slot[i] = 0ull;
 }
 
 static KArgs make_kargs(const v2e_emu *h, const v2e_emu_params *p)
@@ -1022,6 +1091,15 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
     V2E_HIP(hipHostMalloc(&h->run_fidx_host, 2 * sizeof(uint32_t)));
     V2E_HIP(hipMalloc(&h->run_frames, sizeof(void *)));
     V2E_HIP(hipHostMalloc(&h->run_frames_host, 2 * sizeof(void *)));
+    V2E_HIP(hipMalloc(&h->stamp_slot, sizeof(void *)));
+    V2E_HIP(hipMemset(h->stamp_slot, 0, sizeof(void *)));
+    V2E_HIP(hipHostMalloc(&h->stamp_slot_host, 2 * sizeof(void *)));
+    h->stamp_slot_host[0] = h->stamp_slot_host[1] = nullptr;
+    // the second scratch set's copies of the run's device variables (overlapped runs)
+    V2E_HIP(hipMalloc(&h->alt_of((void **)&h->run_fidx), sizeof(uint32_t)));
+    V2E_HIP(hipMalloc(&h->alt_of((void **)&h->run_frames), sizeof(void *)));
+    V2E_HIP(hipMalloc(&h->alt_of((void **)&h->stamp_slot), sizeof(void *)));
+    V2E_HIP(hipMemset(h->alt_of((void **)&h->stamp_slot), 0, sizeof(void *)));
     *out = h;
     return 0;
 }
@@ -1030,7 +1108,16 @@ int v2e_emu_destroy(v2e_emu *h)
 {
     if (!h) return 0;
     hipSetDevice(h->device);
+    h->sync_runs();
+    hipDeviceSynchronize();
     h->drop_graphs();
+    for (int i = 0; i < v2e_emu::NPF; ++i) hipFree(h->alt[i]);
+    if (h->ev_user) hipEventDestroy(h->ev_user);
+    for (int q = 0; q < 2; ++q) {
+        if (h->ev_main_done2[q]) hipEventDestroy(h->ev_main_done2[q]);
+        if (h->ev_tail_done2[q]) hipEventDestroy(h->ev_tail_done2[q]);
+    }
+
     hipFree(h->cnt); hipFree(h->hist); hipFree(h->tot); hipFree(h->rec_ring); hipFree(h->ctl_ring);
     hipFree(h->lut_L); hipFree(h->lut_I); hipFree(h->run_off);
     for (hipEvent_t e : h->ev_fork) hipEventDestroy(e);
@@ -1055,6 +1142,8 @@ int v2e_emu_destroy(v2e_emu *h)
     if (h->run_fidx_host) hipHostFree(h->run_fidx_host);
     hipFree(h->run_frames);
     if (h->run_frames_host) hipHostFree(h->run_frames_host);
+    hipFree(h->stamp_slot); hipFree(h->stamps);
+    if (h->stamp_slot_host) hipHostFree(h->stamp_slot_host);
     hipFree(h->fr_dev); hipFree(h->off_zero);
     if (h->fr_stage) hipHostFree(h->fr_stage);
     if (h->fr_par) hipHostFree(h->fr_par);
@@ -1085,6 +1174,7 @@ int v2e_emu_bind_state(v2e_emu *h, void *lp, void *base, float *ts_mem, float *p
 int v2e_emu_init_state(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, double t_frame,
                        const float *thres_pos, const float *thres_neg, const float *noise_rate, void *stream)
 {
+    if (h && (h->piece_pending[0] || h->piece_pending[1]) && h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(frame, "null frame");
@@ -1146,6 +1236,7 @@ int v2e_emu_set_csdvs(v2e_emu *h, const void *surround)
 int v2e_emu_lp_preview(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, const double *t_prev, const double *t_frame,
                        uint32_t frame_idx, void *lp_out, void *stream)
 {
+    if (h && (h->piece_pending[0] || h->piece_pending[1]) && h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(frame && t_prev && t_frame && lp_out, "null");
@@ -1211,6 +1302,7 @@ int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dt
                   const double *t_frame, uint32_t frame_idx, const float *leak_randn, const float *shot_rand,
                   void *stream)
 {
+    if (h && (h->piece_pending[0] || h->piece_pending[1]) && h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(frame && t_prev && t_frame, "null frame/time");
@@ -1238,6 +1330,7 @@ int v2e_emu_count(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dt
 int v2e_emu_shot(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dtype, uint32_t frame_idx,
                  const float *shot_rand, void *stream)
 {
+    if (h && (h->piece_pending[0] || h->piece_pending[1]) && h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(frame && shot_rand, "null frame/shot_rand");
@@ -1253,6 +1346,7 @@ int v2e_emu_shot(v2e_emu *h, const v2e_emu_params *p, const void *frame, int dty
 
 int v2e_emu_read_rec(v2e_emu *h, uint32_t frame_idx, v2e_frame_rec *recs_host, void *stream)
 {
+    if (h && (h->piece_pending[0] || h->piece_pending[1]) && h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
     V2E_REQUIRE(h && recs_host, "null");
     V2E_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1277,6 +1371,7 @@ int v2e_emu_reserve_iters(v2e_emu *h, int max_events, void *stream)
 int v2e_emu_rank(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, const float *ts_table, int n_ts,
                  void *stream)
 {
+    if (h && (h->piece_pending[0] || h->piece_pending[1]) && h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_HIP(hipSetDevice(h->device));
@@ -1295,6 +1390,7 @@ int v2e_emu_rank(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, const 
 int v2e_emu_emit(v2e_emu *h, const v2e_emu_params *p, uint32_t frame_idx, const float *ts_table, int n_ts,
                  float *events, uint64_t cap, const uint64_t *ev_offset0, void *stream)
 {
+    if (h && (h->piece_pending[0] || h->piece_pending[1]) && h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(events || cap == 0, "null events");
@@ -1354,6 +1450,7 @@ int v2e_emu_permute(v2e_emu *h, const float *events_in, float *events_out, const
 int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int frame_on_host, int dtype, double t_prev, double t_frame,
                   uint32_t frame_idx, float *events_dev, uint64_t cap, uint32_t *out8, const float **events_host, void *stream)
 {
+    if (h && (h->piece_pending[0] || h->piece_pending[1]) && h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
     int rc = check_params(h, p);
     if (rc) return rc;
     V2E_REQUIRE(frame && out8 && events_host && events_dev, "null");
@@ -1579,12 +1676,6 @@ enum { ST_MAIN = 0, ST_AHEAD = 1, ST_SIDE = 2, ST_TAB = 3, ST_SIDE2 = 4, ST_COUN
 enum { EV_FORK = 0, EV_JOIN = 1, EV_AHEAD = 2, EV_CHAIN = 3, EV_TAB = 4, EV_KINDS = 5 };
 
 // dev tool (scripts/step_stamps.py): sequence-numbered device time stamps from inside a run's graph: buf[0] counts, buf[1 + i] = time
-__global__ void k_dbg_stamp(unsigned long long *buf)
-{
-    const unsigned long long i = atomicAdd(buf, 1ull);
-    buf[1 + i] = wall_clock64();
-}
-
 struct Sched {
     v2e_emu *h;
     hipStream_t st[ST_COUNT];
@@ -1730,7 +1821,6 @@ static int chain_frames_per_launch(const v2e_emu *h, bool has_refr, int use_grap
 // [f0, f0 + nf) and validates [pf0, pf0 + pnf), the emission batch whose completion frees the ring slots it overwrites,
 // the k_ahead batch it needs, the k_ahead batch enqueued behind it, the emission batch that is final once it is enqueued.
 struct ChainLaunch { int f0, nf, pf0, pnf, wait_join, wait_ahead, ahead_next, emit_batch; };
-
 static std::vector<ChainLaunch> chain_plan(int n_frames, int K, int E, int nD, bool has_refr, bool fused)
 {
     const int m = E / K;
@@ -1797,12 +1887,10 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
     m = std::max(1, std::min(m, 64 / K)); // k_cemit sums a batch's per-frame event counts one frame per lane
     const int E = m * K;
     if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap || h->ch_fused != (int)fused) {
-        hipFree(h->ch_cnt); hipFree(h->ch_ruleM); hipFree(h->ch_wmax); hipFree(h->ch_wtot); hipFree(h->ch_tsold); hipFree(h->ch_ck);
-        hipFree(h->ch_cf); hipFree(h->ch_cT); hipFree(h->ch_ckbase); hipFree(h->ch_cperm); hipFree(h->ch_cpre); hipFree(h->ch_gM); hipFree(h->ch_cmask); hipFree(h->ch_cpre16);
-        hipFree(h->ch_bar); hipFree(h->ch_rec); hipFree(h->ch_cdone);
-        h->ch_rec = nullptr; h->ch_cdone = nullptr; h->ch_ruleM = nullptr;
-        h->ch_cnt = nullptr; h->ch_wmax = nullptr; h->ch_wtot = nullptr; h->ch_tsold = nullptr; h->ch_ck = nullptr; h->ch_cf = nullptr; h->ch_cT = nullptr;
-        h->ch_ckbase = nullptr; h->ch_cperm = nullptr; h->ch_cpre = nullptr; h->ch_gM = nullptr; h->ch_bar = nullptr; h->ch_cmask = nullptr; h->ch_cpre16 = nullptr;
+        // a new configuration: everything sized by it goes, in BOTH scratch sets (overlapped runs alternate between two, see
+        // v2e_emu::swap_scratch); what the run needs is allocated below, for the set that is current
+        h->sync_runs();
+        h->free_chain_scratch();
         h->ch_launch_cap = 0;
         h->ch_K = K;
         h->ch_E = E;
@@ -1816,7 +1904,15 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         h->ch_D = nD * E;
         h->ch_nwp = (chain_egroups(h) + 15) / 16 * 16; // emission groups (one wave each), padded to the 16 a lane of k_cframe takes
         h->ch_nkeys_cap = h->nkeys_cap;
-        const size_t nc = (size_t)h->n_clips;
+        // The event writer (decided once per configuration, for both scratch sets): the pull needs 32 bytes per (group, key) of the
+        // three table sets -- only the keys a group has events of are ever written or read (no clearing)
+        const size_t mask_bytes = 3 * sizeof(uint32_t) * 2 * GPX * E * (size_t)h->n_clips * h->nkeys_cap * h->ch_nwp;
+        // (beyond 2 M groups = 33 M pixels the two-level search's coarse rows would not fit the 64 KB of LDS a launch gets by default)
+        h->ch_pull = (h->ch_nwp / 16 <= 8192 && emit_pull(mask_bytes)) ? 1 : 0;
+        h->drop_graphs();
+    }
+    const size_t nc = (size_t)h->n_clips;
+    if (!h->ch_cnt) {
         V2E_HIP(hipMalloc(&h->ch_cnt, sizeof(uint32_t) * h->ch_D * nc * h->npx_pad));
         V2E_HIP(hipMalloc(&h->ch_ruleM, sizeof(uint32_t) * h->ch_D * nc));
         V2E_HIP(hipMemset(h->ch_ruleM, 0, sizeof(uint32_t) * h->ch_D * nc));
@@ -1833,11 +1929,8 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         V2E_HIP(hipMalloc(&h->ch_ckbase, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap));
         V2E_HIP(hipMalloc(&h->ch_cperm, 3 * sizeof(uint32_t) * E * nc * h->max_iters * 8));
         V2E_HIP(hipMalloc(&h->ch_cpre, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap * h->ch_nwp));
-        // 32 bytes per (group, key): only the keys a group has events of are ever written or read (no clearing)
-        const size_t mask_bytes = 3 * sizeof(uint32_t) * 2 * GPX * E * nc * h->nkeys_cap * h->ch_nwp;
-        // (beyond 2 M groups = 33 M pixels the two-level search's coarse rows would not fit the 64 KB of LDS a launch gets by default)
-        if (h->ch_nwp / 16 <= 8192 && emit_pull(mask_bytes)) {
-            V2E_HIP(hipMalloc(&h->ch_cmask, mask_bytes));
+        if (h->ch_pull) {
+            V2E_HIP(hipMalloc(&h->ch_cmask, 3 * sizeof(uint32_t) * 2 * GPX * E * nc * h->nkeys_cap * h->ch_nwp));
             V2E_HIP(hipMalloc(&h->ch_cpre16, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap * (h->ch_nwp / 16)));
         }
         if (!fused) V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
@@ -1847,11 +1940,13 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
     h->ch_inst = inst;
     const int n_launch = (n_frames + K - 1) / K + 1;
     if (n_launch + 2 > h->run_off_cap) {
-        hipFree(h->run_off);
+        h->sync_runs();
+        hipFree(h->run_off); hipFree(h->alt_of((void **)&h->run_off));
+        h->run_off = nullptr; h->alt_of((void **)&h->run_off) = nullptr;
         h->run_off_cap = n_launch + 2;
-        V2E_HIP(hipMalloc(&h->run_off, sizeof(unsigned long long) * (size_t)h->run_off_cap * h->n_clips));
         h->drop_graphs();
     }
+    if (!h->run_off) V2E_HIP(hipMalloc(&h->run_off, sizeof(unsigned long long) * (size_t)h->run_off_cap * h->n_clips));
     if (!h->ahead) V2E_HIP(hipStreamCreateWithFlags(&h->ahead, hipStreamNonBlocking));
     if (!h->tabs) V2E_HIP(hipStreamCreateWithFlags(&h->tabs, hipStreamNonBlocking));
     if (!h->side2) V2E_HIP(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
@@ -1867,7 +1962,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         grow(h->ev_join, n_launch + 1) || grow(h->ev_tab, n_launch + 1)) return V2E_EHIP;
     if (has_refr) {
         if (!h->ch_tsold) V2E_HIP(hipMalloc(&h->ch_tsold, sizeof(float) * (size_t)h->ch_D * h->n_clips * h->npx_pad));
-        if (!h->ch_ck) V2E_HIP(hipMalloc(&h->ch_ck, (size_t)2 * 3 * 20 * h->n_clips * h->npx_pad)); // see ChainArgs::ckc_base
+        if (!h->ch_ck && K > CHAIN_SUB) V2E_HIP(hipMalloc(&h->ch_ck, (size_t)2 * (K / CHAIN_SUB - 1 + (K % CHAIN_SUB ? 1 : 0)) * 20 * h->n_clips * h->npx_pad)); // see ChainArgs::ckc_base
         if (!h->ch_base2) {
             const size_t n = (size_t)h->n_clips * h->npx_pad;
             V2E_HIP(hipMalloc(&h->ch_base2, sizeof(double) * n));
@@ -1878,10 +1973,15 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
             V2E_HIP(hipMemset(h->ch_ts2, 0, sizeof(float) * n));
         }
         if (n_launch > h->ch_launch_cap) {
-            hipFree(h->ch_gM); hipFree(h->ch_bar);
+            h->sync_runs();
+            hipFree(h->ch_gM); hipFree(h->ch_bar); hipFree(h->alt_of((void **)&h->ch_gM)); hipFree(h->alt_of((void **)&h->ch_bar));
+            h->ch_gM = nullptr; h->ch_bar = nullptr; h->alt_of((void **)&h->ch_gM) = nullptr; h->alt_of((void **)&h->ch_bar) = nullptr;
             h->ch_launch_cap = n_launch;
-            V2E_HIP(hipMalloc(&h->ch_gM, sizeof(uint32_t) * (size_t)n_launch * (K + 1) * h->n_clips * K));
-            V2E_HIP(hipMalloc(&h->ch_bar, sizeof(unsigned) * (size_t)n_launch * 2 * K * h->n_clips));
+            h->drop_graphs();
+        }
+        if (!h->ch_gM) {
+            V2E_HIP(hipMalloc(&h->ch_gM, sizeof(uint32_t) * (size_t)h->ch_launch_cap * (K + 1) * h->n_clips * K));
+            V2E_HIP(hipMalloc(&h->ch_bar, sizeof(unsigned) * (size_t)h->ch_launch_cap * 2 * K * h->n_clips));
             h->drop_graphs();
         }
     }
@@ -1902,7 +2002,7 @@ static bool chain_eligible(const v2e_emu *h, const v2e_emu_params *p, int dtype)
 static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a_in, const void *frames, int dtype, int n_frames,
                              float *events, uint64_t cap, v2e_frame_rec *recs, hipStream_t s, hipGraph_t graph = nullptr,
                              std::vector<hipEvent_t> *ev_main = nullptr, std::vector<hipEvent_t> *ev_side = nullptr,
-                             bool capturing = false)
+                             bool capturing = false, bool pipelined = false)
 {
     // Three logical streams: the chain (k_chain, K frames per launch); k_ahead and the emission tables (k_ctot, k_cframe);
     // the event writer k_cemit; the last two in batches of E = m K frames (batch b = frames [b E, (b + 1) E) = chain
@@ -1957,7 +2057,8 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // streams crash hipStreamEndCapture on this runtime): tables and rows then share the side stream.
     constexpr int tab_env = ST_TAB; // plain streams: tables on a stream of their own
     constexpr bool tabs_on_main = false;
-    const int tab_stream = capturing ? (tabs_on_main ? ST_MAIN : ST_SIDE) : tab_env;
+    // pipelined plain launches (v2e_emu_run, mode 0 | 1024): three streams in all -- the chain's, k_ahead's, the emission's
+    const int tab_stream = (capturing || pipelined) ? (tabs_on_main ? ST_MAIN : ST_SIDE) : tab_env;
     constexpr int NSET = 3; // emission table sets (chain_alloc sizes them)
     constexpr bool one_row_stream = false;
     // b: the emission's slot (event indices, table set b % NSET, event offsets run_off[b] -> run_off[b + 1]); frames [ef0, ef0 + enE).
@@ -2070,9 +2171,6 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     float *xt[2] = {h->ts_mem, has_refr ? h->ch_ts2 : h->ts_mem};
     // the run's uploads (frame times, first frame index) and the zero fills precede everything
     static const bool no_side_fork = getenv("V2E_AMD_INITIAL_SIDE_FORK") == nullptr; // under capture the side stream joins at its first batch
-    static const char *stamp_env = getenv("V2E_AMD_DBG_STAMP_PTR"); // dev: a device buffer of uint64 (scripts/step_stamps.py)
-    unsigned long long *stamp_buf = stamp_env ? (unsigned long long *)strtoull(stamp_env, nullptr, 0) : nullptr;
-    if (stamp_buf) { void *sargs[] = {(void *)&stamp_buf}; if (sc.kernel(ST_MAIN, (const void *)k_dbg_stamp, dim3(1), dim3(1), 0, sargs)) return V2E_EHIP; }
     // The zero fill precedes the fork.  (Round 5 tried the fork first -- k_ahead touches nothing the fill clears -- and lost 10 %:
     // 12.0 -> 10.8 Gev/s, A/B x 3 in one session; the enqueue order of a capture decides which branches this runtime overlaps,
     // profiles/r03_graph_scheduling.txt.)
@@ -2080,19 +2178,27 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         void *const zp[4] = {recs, h->run_off, has_refr ? (void *)h->ch_gM : nullptr, has_refr ? (void *)h->ch_bar : nullptr};
         const size_t zb[4] = {sizeof(v2e_frame_rec) * (size_t)n_frames * NC, sizeof(unsigned long long) * NC,
                               sizeof(uint32_t) * (size_t)nL * (K + 1) * NC * K, sizeof(unsigned) * (size_t)nL * 2 * K * NC};
-        if (sc.zero4(ST_MAIN, zp, zb)) return V2E_EHIP;
+        if (sc.zero4(pipelined ? ST_AHEAD : ST_MAIN, zp, zb)) return V2E_EHIP;
     }
+    // (pipelined: no forks -- the k_ahead stream carries the run's upload and zero fills itself and runs ahead of the chain, the
+    // emission stream waits for the chain batch by batch)
+    if (!pipelined) {
     if (sc.record(EV_FORK, nL, ST_MAIN)) return V2E_EHIP;
     if (!(capturing && no_side_fork) && sc.wait(ST_SIDE, EV_FORK, nL)) return V2E_EHIP;
     if (!fused_rec && sc.wait(ST_AHEAD, EV_FORK, nL)) return V2E_EHIP;
     if (!capturing && (sc.wait(ST_TAB, EV_FORK, nL) || sc.wait(ST_SIDE2, EV_FORK, nL))) return V2E_EHIP;
-    for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b)
+    }
+    int last_ahead = -1; // the last k_ahead batch this piece enqueued (joined at the end)
+    if (pipelined && (sc.record(EV_FORK, nL, ST_AHEAD) || sc.wait(ST_MAIN, EV_FORK, nL))) return V2E_EHIP; // the upload and the zero fills, for the chain
+    for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b) {
         if (launch_ahead(b)) return V2E_EHIP;
+        last_ahead = b;
+    }
     // last batch in two pieces: only where the last launch is not the first of its batch (else there is nothing to emit early)
     constexpr bool split_tail_env = true;
     const int tail_f0 = (nB - 1) * K;                          // first frame of the last chain launch with frames
     const bool split_tail = split_tail_env && has_refr && m > 1 && nB >= 2 && (nB - 1) % m != 0 && !no_emit_run;
-    const int last_slot = (split_tail && tail_f0 > (nEB - 1) * E) ? nEB : nEB - 1;
+    int last_emitted = -1; // the last emission slot this piece enqueued (joined at the end)
     constexpr int allon_env = 1;
     const bool allon = allon_env && a_in.has_cutoff && a_in.do_leak && a_in.do_shot && a_in.has_refr;
     const void *kfn = chain_fn(p->f64_state != 0, dtype, fused_rec, allon);
@@ -2120,7 +2226,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.base_pin = xb[pin]; ca.lp_pin = xl[pin]; ca.ts_pin = xt[pin];
         constexpr bool no_ckpt = false;
         if (has_refr && K > CHAIN_SUB && h->ch_ck && !no_ckpt) {
-            const size_t plane = (size_t)3 * NC * h->npx_pad; // elements per (parity, quantity)
+            const size_t plane = (size_t)(K / CHAIN_SUB - 1 + (K % CHAIN_SUB ? 1 : 0)) * NC * h->npx_pad; // elements per (parity, quantity): a checkpoint before frames 8, 16, ...
             auto ck = [&](int par, char *&bp, char *&lpp, float *&tp) {
                 char *q = (char *)h->ch_ck + (size_t)par * plane * 20;
                 bp = q; lpp = q + plane * 8; tp = (float *)(q + plane * 16);
@@ -2137,7 +2243,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.bar_light = bar_light;
         ca.lockstep = lockstep;
         ca.dbg = (h->dbg && L == nB / 2) ? h->dbg : nullptr;
+        ca.stamp_pp = h->stamp_slot; ca.lidx = std::min(L, STAMP_LAUNCHES - 1);
         if (pl.wait_join >= 0 && sc.wait(ST_MAIN, EV_JOIN, pl.wait_join)) return V2E_EHIP; // ring slots: read by k_cemit of that batch
+        // (records of batches 0 and 1 without the head piece in this enqueue: the caller ordered this piece behind the head's stream)
         if (pl.wait_ahead >= 0 && sc.wait(ST_MAIN, EV_AHEAD, pl.wait_ahead)) return V2E_EHIP;
         if (split0 && !fused_rec && !tail && L >= 1 && L < m && sc.wait(ST_MAIN, EV_AHEAD, nL)) return V2E_EHIP; // the rest of batch 0
         if (mark(ev_main, s)) return V2E_EHIP; // instrumented runs: an event before and after every chain launch
@@ -2149,30 +2257,29 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         // with the emission enqueued first the chain's next launch runs BEHIND the emission kernels (measured, profiles/
         // r03_graph_scheduling.txt), with k_ahead first it runs beside them.
         static const bool ahead_first = getenv("V2E_AMD_ORDER_EMISSION_FIRST") == nullptr;
-        if (ahead_first && pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
-        // The run's last batch in two pieces (refractory runs, several launches per batch): the frames of its launches before
-        // the last one are final one launch earlier -- emitted then, beside the chain, instead of behind the tail launch with the
-        // rest (the chain idled ~50 us at the end of every 300-frame step while 44 frames were emitted; now 12).
+        if (ahead_first && pl.ahead_next >= 0) { if (launch_ahead(pl.ahead_next)) return V2E_EHIP; last_ahead = pl.ahead_next; }
         if (split_tail && L == nB - 1 && tail_f0 > (nEB - 1) * E) {
             if (sc.record(EV_FORK, nEB - 1, ST_MAIN)) return V2E_EHIP;
             if (launch_emission(nEB - 1, (nEB - 1) * E, tail_f0 - (nEB - 1) * E)) return V2E_EHIP;
+            last_emitted = nEB - 1;
         }
         if (pl.emit_batch >= 0 && split_tail && pl.emit_batch == nEB - 1 && tail_f0 > (nEB - 1) * E) {
             if (sc.record(EV_FORK, nEB, ST_MAIN)) return V2E_EHIP;
             if (launch_emission(nEB, tail_f0, n_frames - tail_f0)) return V2E_EHIP;
+            last_emitted = nEB;
         } else if (pl.emit_batch >= 0) {
             if (sc.record(EV_FORK, pl.emit_batch, ST_MAIN)) return V2E_EHIP;
             if (launch_emission(pl.emit_batch, pl.emit_batch * E, std::min((pl.emit_batch + 1) * E, n_frames) - pl.emit_batch * E)) return V2E_EHIP;
+            last_emitted = pl.emit_batch;
         }
-        if (!ahead_first && pl.ahead_next >= 0 && launch_ahead(pl.ahead_next)) return V2E_EHIP;
+        if (!ahead_first && pl.ahead_next >= 0) { if (launch_ahead(pl.ahead_next)) return V2E_EHIP; last_ahead = pl.ahead_next; }
     }
-    if (!graph) { // join: the run is complete on `s` (a graph is complete when all its nodes are)
-        if (sc.wait(ST_MAIN, EV_JOIN, last_slot)) return V2E_EHIP;
-        if (!capturing && sc.wait(ST_MAIN, EV_TAB, last_slot)) return V2E_EHIP;
-        if (!capturing && last_slot >= 1 && sc.wait(ST_MAIN, EV_JOIN, last_slot - 1)) return V2E_EHIP;
-        if (!fused_rec && sc.wait(ST_MAIN, EV_AHEAD, nEB - 1)) return V2E_EHIP;
+    if (!graph && !pipelined) { // join: the piece is complete on `s` (a graph is complete when all its nodes are)
+        if (last_emitted >= 0 && sc.wait(ST_MAIN, EV_JOIN, last_emitted)) return V2E_EHIP;
+        if (!capturing && last_emitted >= 0 && sc.wait(ST_MAIN, EV_TAB, last_emitted)) return V2E_EHIP;
+        if (!capturing && last_emitted >= 1 && sc.wait(ST_MAIN, EV_JOIN, last_emitted - 1)) return V2E_EHIP;
+        if (!fused_rec && last_ahead >= 0 && sc.wait(ST_MAIN, EV_AHEAD, last_ahead)) return V2E_EHIP;
     }
-    if (stamp_buf) { void *sargs[] = {(void *)&stamp_buf}; if (sc.kernel(ST_MAIN, (const void *)k_dbg_stamp, dim3(1), dim3(1), 0, sargs)) return V2E_EHIP; }
     V2E_HIP(hipGetLastError());
     return 0;
 }
@@ -2191,13 +2298,68 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     V2E_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (n_frames > h->run_cap) {
+        h->sync_runs();
         V2E_HIP(hipStreamSynchronize(s));
         if (h->run_ctl) V2E_HIP(hipFree(h->run_ctl));
+        hipFree(h->alt_of((void **)&h->run_ctl));
+        h->run_ctl = nullptr; h->alt_of((void **)&h->run_ctl) = nullptr;
         for (int q = 0; q < 2; ++q) if (h->run_ctl_host2[q]) V2E_HIP(hipHostFree(h->run_ctl_host2[q]));
         h->run_cap = n_frames;
-        V2E_HIP(hipMalloc(&h->run_ctl, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
         for (int q = 0; q < 2; ++q) V2E_HIP(hipHostMalloc(&h->run_ctl_host2[q], sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips));
         h->drop_graphs();
+    }
+    KArgs a = make_kargs(h, p);
+    const int mode = use_graph & 3;          // 0 plain launches, 1 hipGraph, 2 instrumented
+    // K frames per launch with the state in registers (emu_chain.h) wherever it can run: |256 insists on it; |16 selects the
+    // count / rank / scan / emit kernels one frame at a time (kept for A/B; also what carries the photoreceptor-noise plane,
+    // emulator.py:694-703, float64 log-encoded frames and more than CHAIN_MAX_ITERS events per pixel and frame)
+    const bool chain_ok = chain_eligible(h, p, dtype);
+    V2E_REQUIRE(!(use_graph & 256) || chain_ok, "k_chain cannot run this configuration (max_iters, photoreceptor noise or float64 log frames)");
+    const bool chain = chain_ok && ((use_graph & 256) != 0 || !(use_graph & 16));
+    const bool legacy = !chain;
+    // mode 0 | 1024: PIPELINED runs (round 6) -- plain launches on three streams, no graph, no join at the run's end.  The chain of run
+    // n + 1 needs the chain of run n and nothing else of it, but a run begins with an upload, zero fills and its first records (k_ahead)
+    // and ends with the emission of its last frames: measured with the device stamps (v2e_emu_launch_stamps), 145-165 us of every
+    // 820 us step of the benchmark passed between the last chain launch of one run and the first of the next (a graph's end and start
+    // cost two cross-queue hops of 20-50 us each on this runtime, and everything of a graph must be complete before the next one
+    // starts).  Pipelined: the caller's stream carries the chain's launches and nothing else, run after run in one hardware queue
+    // (33 us between two runs' chains); the handle's k_ahead stream carries the run's upload, zero fills and records and runs AHEAD of
+    // the chain, beside the run before; the handle's emission stream follows the chain batch by batch and finishes beside the run
+    // after.  What two runs in flight would share exists twice (v2e_emu::swap_scratch): such a run takes the set the run before it did not.
+    const bool pipelined = (use_graph & 1024) != 0 && mode == 0 && chain && p->refractory_period_s > 0;
+    if (pipelined) h->swap_scratch();
+    h->last_ticket = pipelined ? h->scratch_par : -1;
+    if (!h->run_ctl) { V2E_HIP(hipMalloc(&h->run_ctl, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips)); h->drop_graphs(); }
+    if (chain) {
+        rc = chain_alloc(h, p, dtype, n_frames, use_graph);
+        if (rc) return rc;
+    }
+    const int par = h->scratch_par;
+    hipStream_t s_up = s; // the stream of the run's upload
+    if (pipelined) {
+        for (int q = 0; q < 2; ++q) {
+            if (!h->ev_main_done2[q]) V2E_HIP(hipEventCreateWithFlags(&h->ev_main_done2[q], hipEventDisableTiming));
+            if (!h->ev_tail_done2[q]) V2E_HIP(hipEventCreateWithFlags(&h->ev_tail_done2[q], hipEventDisableTiming));
+        }
+        s_up = h->ahead; // (created by chain_alloc)
+        // the k_ahead stream reads the frames: it is ordered behind what the caller's stream holds now -- unless the caller vouches
+        // that the frames are resident (|2048: nothing enqueued on `stream` still writes them); otherwise it would wait for the chain
+        // of the run before, which is on that stream, and the run's head would not overlap it
+        if (!(use_graph & 2048)) {
+            if (!h->ev_user) V2E_HIP(hipEventCreateWithFlags(&h->ev_user, hipEventDisableTiming));
+            V2E_HIP(hipEventRecord(h->ev_user, s));
+            V2E_HIP(hipStreamWaitEvent(s_up, h->ev_user, 0));
+        }
+        // this scratch set's last user (two runs ago): its chain and its emission have finished
+        if (h->piece_pending[par]) {
+            V2E_HIP(hipStreamWaitEvent(s_up, h->ev_main_done2[par], 0));
+            V2E_HIP(hipStreamWaitEvent(s_up, h->ev_tail_done2[par], 0));
+        }
+        if (h->piece_pending[par ^ 1] && (events == h->last_events || (const void *)recs_dev == h->last_recs))
+            V2E_HIP(hipStreamWaitEvent(s_up, h->ev_tail_done2[par ^ 1], 0));
+    } else if (h->join_runs(s)) { // everything else runs whole on the caller's stream, behind every piece still in flight
+        v2e_set_error("hipStreamWaitEvent failed");
+        return V2E_EHIP;
     }
     // two pinned staging sets, each guarded by the event of the upload that last read it: the host prepares run n + 1
     // while run n executes
@@ -2217,30 +2379,26 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     {
         static_assert(sizeof(FrameCtl) % 16 == 0, "FrameCtl is copied in 16-byte pieces");
         const size_t n16 = sizeof(FrameCtl) * nct / 16;
-        k_upload_ctl<<<(unsigned)std::min<size_t>((n16 + BLOCK - 1) / BLOCK, 1024), BLOCK, 0, s>>>((const uint4 *)ctl_host, (uint4 *)h->run_ctl, n16, fidx_host, h->run_fidx,
-                                                                                                   frames_host, h->run_frames);
+        unsigned long long **slot_host = h->stamp_slot_host + sq;
+        *slot_host = h->stamps_runs > 0 ? h->stamps + (size_t)(h->stamp_seq++ % (unsigned long long)h->stamps_runs) * 2 * STAMP_LAUNCHES : nullptr;
+        k_upload_ctl<<<(unsigned)std::min<size_t>((n16 + BLOCK - 1) / BLOCK, 1024), BLOCK, 0, s_up>>>((const uint4 *)ctl_host, (uint4 *)h->run_ctl, n16, fidx_host, h->run_fidx,
+                                                                                                   frames_host, h->run_frames, slot_host, h->stamp_slot);
         V2E_HIP(hipGetLastError());
     }
-    V2E_HIP(hipEventRecord(h->ev_stage[sq], s));
-    KArgs a = make_kargs(h, p);
-    const int mode = use_graph & 3;          // 0 plain launches, 1 hipGraph, 2 instrumented
-    // K frames per launch with the state in registers (emu_chain.h) wherever it can run: |256 insists on it; |16 selects the
-    // count / rank / scan / emit kernels one frame at a time (kept for A/B; also what carries the photoreceptor-noise plane,
-    // emulator.py:694-703, float64 log-encoded frames and more than CHAIN_MAX_ITERS events per pixel and frame)
-    const bool chain_ok = chain_eligible(h, p, dtype);
-    V2E_REQUIRE(!(use_graph & 256) || chain_ok, "k_chain cannot run this configuration (max_iters, photoreceptor noise or float64 log frames)");
-    const bool chain = chain_ok && ((use_graph & 256) != 0 || !(use_graph & 16));
-    const bool legacy = !chain;
-    if (chain) {
-        rc = chain_alloc(h, p, dtype, n_frames, use_graph);
-        if (rc) return rc;
-    }
+    V2E_HIP(hipEventRecord(h->ev_stage[sq], s_up));
     h->last_kind = legacy ? 0 : (h->ch_fused ? 4 : 3);
     h->last_fpl = chain ? h->ch_K : 1;
     h->last_fpb = chain ? h->ch_E : 1;
     if (mode == 0) {
         if (legacy) return enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, nullptr);
-        return enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s);
+        if (!pipelined) return enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s);
+        rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, nullptr, nullptr, nullptr, false, true);
+        if (rc) return rc;
+        V2E_HIP(hipEventRecord(h->ev_main_done2[par], s));          // the run's chain (the pixel state)
+        V2E_HIP(hipEventRecord(h->ev_tail_done2[par], h->side));    // its last event rows
+        h->piece_pending[par] = true;
+        h->last_events = events; h->last_recs = recs_dev;
+        return 0;
     }
     if (mode == 2 && chain) { // instrumented: chain time from events on `s`, emission batches from events on the side stream
         std::vector<hipEvent_t> em, es;
@@ -2298,6 +2456,8 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     push(&events, sizeof(events)); push(&cap, sizeof(cap)); push(&recs_dev, sizeof(recs_dev));
     int f64 = p->f64_state; push(&f64, sizeof(f64));
     int lg = legacy ? 1 : 3; push(&lg, sizeof(lg)); push(&h->dbg, sizeof(h->dbg));
+    push(&h->run_ctl, sizeof(h->run_ctl)); push(&h->run_fidx, sizeof(h->run_fidx)); push(&h->run_off, sizeof(h->run_off)); // (per scratch set)
+    { const int mk = h->stamps_runs > 0 ? 1 : 0; push(&mk, sizeof(mk)); }
     if (h->cs_sur) { // everything the diffuser's launches bake in
         push(&h->cs_sur, sizeof(h->cs_sur)); push(&h->csr_scratch, sizeof(void *)); push(&h->csr_lp, sizeof(void *));
         push(&h->csr_steps_dev, sizeof(void *)); push(&h->csr_slots, sizeof(void *)); push(&h->csr_thr, sizeof(double));
@@ -2309,45 +2469,113 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         push(&h->ch_max_blocks, sizeof(h->ch_max_blocks));
         push(&h->ch_gM, sizeof(h->ch_gM)); push(&h->ch_tsold, sizeof(h->ch_tsold)); push(&h->ch_ck, sizeof(h->ch_ck)); push(&h->ch_cnt, sizeof(h->ch_cnt));
     }
-    hipGraphExec_t exec = nullptr;
-    for (auto &cg : h->graphs)
-        if (cg.key == key) { exec = cg.exec; cg.used = ++h->graph_clock; break; }
-    if (!exec) {
-        if (h->graphs.size() >= 4) { // drop the least recently used one
+    auto get_exec = [&](int phase, hipGraphExec_t *out) -> int { // the cached graph of the run
+        std::vector<unsigned char> k2 = key;
+        k2.push_back((unsigned char)phase);
+        for (auto &cg : h->graphs)
+            if (cg.key == k2) { *out = cg.exec; cg.used = ++h->graph_clock; return 0; }
+        if (h->graphs.size() >= 24) { // drop the least recently used one (two scratch sets x the caller's buffer sets x the pieces of a run)
             size_t lru = 0;
             for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
             hipGraphExecDestroy(h->graphs[lru].exec);
             h->graphs.erase(h->graphs.begin() + lru);
         }
         hipGraph_t g = nullptr;
+        int rc2 = 0;
         if (legacy) { // one stream: plain stream capture
             hipStream_t cs;
             V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs, nullptr);
+            rc2 = enqueue_run(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs, nullptr);
             hipError_t e = hipStreamEndCapture(cs, &g);
             hipStreamDestroy(cs);
-            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            if (rc2) { if (g) hipGraphDestroy(g); return rc2; }
             V2E_HIP(e);
         } else if (getenv("V2E_AMD_GRAPH_EXPLICIT")) { // dev: the graph node by node (see Sched); this runtime then runs it serially
             V2E_HIP(hipGraphCreate(&g, 0));
-            rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, g);
-            if (rc) { hipGraphDestroy(g); return rc; }
+            rc2 = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, g);
+            if (rc2) { hipGraphDestroy(g); return rc2; }
         } else { // stream capture, with edges between the origin and the forked streams only
             hipStream_t cs;
             V2E_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             V2E_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs, nullptr, nullptr, nullptr, true);
+            rc2 = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, cs, nullptr, nullptr, nullptr, true);
             hipError_t e = hipStreamEndCapture(cs, &g);
             hipStreamDestroy(cs);
-            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            if (rc2) { if (g) hipGraphDestroy(g); return rc2; }
             V2E_HIP(e);
         }
+        hipGraphExec_t exec = nullptr;
         V2E_HIP(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
         V2E_HIP(hipGraphDestroy(g));
-        h->graphs.push_back({key, exec, ++h->graph_clock});
-    }
+        h->graphs.push_back({k2, exec, ++h->graph_clock});
+        *out = exec;
+        return 0;
+    };
+    hipGraphExec_t exec = nullptr;
+    rc = get_exec(0, &exec);
+    if (rc) return rc;
     V2E_HIP(hipGraphLaunch(exec, s));
+    return 0;
+}
+
+// host-blocking: every piece of the LAST overlapped run that used scratch set `ticket` (v2e_emu_run_ticket right after that run) is complete
+int v2e_emu_run_wait(v2e_emu *h, int ticket)
+{
+    V2E_REQUIRE(h && (ticket == 0 || ticket == 1), "bad ticket");
+    if (h->piece_pending[ticket]) {
+        V2E_HIP(hipEventSynchronize(h->ev_main_done2[ticket]));
+        V2E_HIP(hipEventSynchronize(h->ev_tail_done2[ticket]));
+    }
+    return 0;
+}
+int v2e_emu_run_ticket(v2e_emu *h) { return h ? h->last_ticket : -1; }
+
+// `stream` waits for every piece of every overlapped run (v2e_emu_run, |1024) enqueued on this handle so far
+int v2e_emu_run_join(v2e_emu *h, void *stream)
+{
+    V2E_REQUIRE(h, "null");
+    V2E_HIP(hipSetDevice(h->device));
+    if (h->join_runs((hipStream_t)stream)) { v2e_set_error("hipStreamWaitEvent failed"); return V2E_EHIP; }
+    return 0;
+}
+
+int v2e_emu_launch_stamps(v2e_emu *h, int runs, uint64_t *out_ns, int cap_runs, int *n_runs, int *launches_per_run)
+{
+    V2E_REQUIRE(h && runs >= 0, "bad args");
+    V2E_HIP(hipSetDevice(h->device));
+    if (out_ns || n_runs) { // read back (blocking): the last min(stamp_seq, stamps_runs) runs, oldest first
+        V2E_HIP(hipDeviceSynchronize());
+        const unsigned long long have = std::min<unsigned long long>(h->stamp_seq, (unsigned long long)h->stamps_runs);
+        const int n = (int)std::min<unsigned long long>(have, (unsigned long long)std::max(cap_runs, 0));
+        if (n_runs) *n_runs = n;
+        if (launches_per_run) *launches_per_run = STAMP_LAUNCHES;
+        if (out_ns && n > 0) {
+            std::vector<unsigned long long> tmp((size_t)h->stamps_runs * 2 * STAMP_LAUNCHES);
+            V2E_HIP(hipMemcpy(tmp.data(), h->stamps, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (int r = 0; r < n; ++r) {
+                const unsigned long long seq = h->stamp_seq - (unsigned long long)n + (unsigned long long)r;
+                const unsigned long long *src = tmp.data() + (size_t)(seq % (unsigned long long)h->stamps_runs) * 2 * STAMP_LAUNCHES;
+                for (int l = 0; l < STAMP_LAUNCHES; ++l) { // wall clock: 100 MHz (s_memrealtime); the start is kept complemented
+                    const unsigned long long a = src[2 * l], b = src[2 * l + 1];
+                    out_ns[((size_t)r * STAMP_LAUNCHES + l) * 2] = a ? (~a) * 10ull : 0ull;
+                    out_ns[((size_t)r * STAMP_LAUNCHES + l) * 2 + 1] = b * 10ull;
+                }
+            }
+        }
+    }
+    if (runs != h->stamps_runs) {
+        V2E_HIP(hipDeviceSynchronize());
+        hipFree(h->stamps);
+        h->stamps = nullptr;
+        h->stamps_runs = 0;
+        h->stamp_seq = 0;
+        if (runs > 0) {
+            V2E_HIP(hipMalloc(&h->stamps, sizeof(unsigned long long) * (size_t)runs * 2 * STAMP_LAUNCHES));
+            V2E_HIP(hipMemset(h->stamps, 0, sizeof(unsigned long long) * (size_t)runs * 2 * STAMP_LAUNCHES));
+            h->stamps_runs = runs;
+        }
+    }
     return 0;
 }
 

@@ -42,7 +42,7 @@
 #define V2E_CHAIN_STAMPS 0
 #endif
 
-constexpr int CHAIN_K_MAX = 32;
+constexpr int CHAIN_K_MAX = 64; // (a lane per frame of a launch: rule thresholds, maxima, predictions)
 constexpr int CFRAME_THREADS = 1024;
 constexpr int CHAIN_SUB = 8; // frames whose records are in LDS at a time (4 KB per frame and workgroup)
 constexpr int CHAIN_MAX_ITERS = 1024; // k_cframe keeps one total per key in LDS
@@ -168,6 +168,8 @@ struct ChainArgs {
     int bar_light;                    // the redo rendezvous without release / acquire fences (the maxima rows are atomics)
     int lockstep;                     // redo passes take the frame(s) right behind a rule-on frame in lock-step (see k_chain)
     unsigned long long *dbg;          // dev tool: [ngroups][16] wall-clock stamps of one launch, or nullptr
+    unsigned long long *const *stamp_pp; // *stamp_pp: the run's [launch][2] time stamps (v2e_emu_launch_stamps) or nullptr
+    int lidx;                         // this launch's index in the run
 };
 
 // Per-frame outputs of the chain are written through to memory: as dirty L2 lines they would all be written back by the
@@ -331,6 +333,10 @@ void k_chain(KArgs a_in, ChainArgs ca)
     uint32_t *const s_cw = (uint32_t *)(s_arec + (size_t)CHAIN_SUB * BLOCK);
     if (ca.prio) __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
     V2E_STAMP_C(0);
+    // measurement (v2e_emu_launch_stamps; off: one scalar load and branch per launch): the launch's first workgroup start and last
+    // workgroup end on the device's 100 MHz wall clock -- its duration as it runs in the TIMED configuration (graph replay, side streams)
+    unsigned long long *const stamp = *ca.stamp_pp;
+    if (stamp && tid == 0) atomicMax(stamp + 2 * ca.lidx, ~wall_clock64());
     uint32_t fbase = 0u;
     const char *frames = nullptr;
     if (FUSED) {
@@ -685,6 +691,7 @@ void k_chain(KArgs a_in, ChainArgs ca)
         }
         V2E_STAMP_C(15);
     }
+    if (stamp && tid == 0) atomicMax(stamp + 2 * ca.lidx + 1, wall_clock64());
 }
 
 // ------------------------------------------------------------------ emission side of the chain

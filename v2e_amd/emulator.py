@@ -134,10 +134,18 @@ def _as_f32_tensor(a):
 class _PendingRun:
     """Handle of an enqueued device-resident run (EventEmulator.generate_events_batch_async)."""
 
-    def __init__(self, emu, ev, recs, done, counts, start, return_device, empty, dts=None):
-        self.emu, self.ev, self.recs, self.done = emu, ev, recs, done
+    def __init__(self, emu, ev, recs, done, counts, start, return_device, empty, dts=None, ticket=None):
+        self.emu, self.ev, self.recs, self._done = emu, ev, recs, done
         self.counts, self.start, self.return_device, self.empty, self.dts = counts, start, return_device, empty, dts
+        self.ticket = ticket  # overlapped runs (v2e_emu_run | 1024): what result() waits for on the host (v2e_emu_run_wait)
         self._res = None
+
+    @property
+    def done(self):
+        """A torch event behind which the run's rows and records are final (for callers that order their own streams behind it)."""
+        if self._done is None and self.recs is not None:
+            self._done = self.emu._engine.run_done_event()
+        return self._done
 
     def result(self):
         if self._res is None:
@@ -906,12 +914,18 @@ class EventEmulator(object):
                                                 cap=cap, _single_buffer=True).result()
 
     def generate_events_batch_async(self, frames, t_frames, return_device=False, use_graph=True, cap=None,
-                                    _single_buffer=False):
+                                    _single_buffer=False, pipelined=None, frames_resident=False):
         """generate_events_batch without waiting for the device: enqueues the run and returns a handle whose
         result() gives (events, counts).  The host can prepare and enqueue the next run (it executes behind this one
         on the same stream) before reading this one's result: two sets of event / record buffers alternate, so a
         result stays valid until the second-next call.  Pixel state, frame counter and t_previous advance at enqueue
         time; the event counters (num_events_*) when result() is called; errors (capacity, max_iters) are raised there.
+        use_graph: True / 1 one hipGraph per run (what the blocking call uses: lowest latency of a single run), 0 plain launches.
+        pipelined (default: on where use_graph is 0): consecutive runs overlap -- the run's upload and first records go out beside the run
+        before, its last emission batches finish beside the run after, the current stream carries the chain's launches only
+        (v2e_emu_run, 0 | 1024): the throughput mode of a loop that keeps one run enqueued ahead (bench.py).  The current stream then
+        orders the pixel state only; result() waits for the rows.  frames_resident=True: the caller vouches that nothing enqueued on
+        the current stream still writes `frames`; the run's head then need not wait for the chain of the run before.
         """
         if getattr(self, "_failed", None):
             raise _capi.V2EAmdError("a previous device-resident run failed (%s); call reset()" % self._failed)
@@ -1014,13 +1028,22 @@ class EventEmulator(object):
         ug = int(use_graph)
         if getattr(self, "_refr_mostly_on", False):
             ug |= 128  # one frame per launch: the speculating chain would redo most of its launches
+        if (ug & 3) == 0 and (pipelined or pipelined is None) and not _single_buffer:
+            ug |= 1024 | (2048 if frames_resident else 0)
         eng.run(P, frames_dev[start:], t_prev, t_frames[start:], self.frame_counter, ev, recs, use_graph=ug)
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(eng.device))
+        ticket = None
+        if ug & 1024:
+            # the library may have enqueued the run in pieces on streams of its own: result() waits for them on the host; a device-side
+            # event (the `done` property) is only built for a caller that asks for one
+            done, ticket = None, eng.run_ticket()
+        if ticket is None or ticket < 0:
+            ticket = None
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(eng.device))
         self.frame_counter += nrun
         self.t_previous = t_frames[-1]
         dts = np.asarray(t_frames[start:]) - np.asarray(t_prev)
-        pend = _PendingRun(self, ev, recs, done, counts, start, return_device, None, dts)
+        pend = _PendingRun(self, ev, recs, done, counts, start, return_device, None, dts, ticket)
         pend.cs_steps_dev = cs_steps_dev
         return pend
 
@@ -1029,7 +1052,11 @@ class EventEmulator(object):
         if getattr(self, "_failed", None):  # an earlier pending run failed: the state this run started from is not the clip's
             raise _capi.V2EAmdError("a previous device-resident run failed (%s); this run started from its state: call reset()"
                                     % self._failed)
-        r = eng.read_recs_after(pend.recs, pend.done)[:, 0]
+        if pend.ticket is not None:
+            eng.run_wait(pend.ticket)  # (host-blocking; no device-side wait is put into any stream's queue)
+            r = eng.read_recs_after(pend.recs, None)[:, 0]
+        else:
+            r = eng.read_recs_after(pend.recs, pend.done)[:, 0]
         if self.refractory_period_s > 0:  # emulator.py:830 on the frames just run: how often was the rule active?
             m = np.maximum(r["max_events"], 1)
             self._refr_mostly_on = bool(np.mean(self.refractory_period_s > pend.dts / m) > 0.05)

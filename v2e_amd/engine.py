@@ -333,6 +333,36 @@ class EmuEngine:
                                    int(events.shape[1]), _ptr(recs_dev), int(use_graph), self.stream),
               "v2e_emu_run")
 
+    def run_done_event(self):
+        """A torch event behind every piece of every overlapped run (use_graph | 1024) enqueued so far: recorded on a stream of the
+        engine that waits for them (v2e_emu_run_join), never on the caller's stream -- which carries the next run's chain."""
+        js = self.__dict__.get("_join_stream")
+        if js is None:
+            js = self._join_stream = torch.cuda.Stream(self.device)
+        e0 = torch.cuda.Event()  # what the caller's stream holds (the run's chain; the whole run where the library did not overlap it)
+        e0.record(torch.cuda.current_stream(self.device))
+        js.wait_event(e0)
+        check(self.lib.v2e_emu_run_join(self._h, js.cuda_stream), "v2e_emu_run_join")
+        ev = torch.cuda.Event()
+        ev.record(js)
+        return ev
+
+    def launch_stamps(self, runs, read=0):
+        """Device time stamps of the chain kernel's launches (v2e_emu_launch_stamps): keep `runs` runs from now on (0: off); with
+        read > 0 first return the last `read` runs as an array [run][launch][2] of nanoseconds {first workgroup's start, last
+        workgroup's end} (zeros: no such launch)."""
+        out = None
+        if read > 0:
+            n, lpr = C.c_int(), C.c_int()
+            buf = np.zeros((read, 128, 2), dtype=np.uint64)
+            check(self.lib.v2e_emu_launch_stamps(self._h, int(runs), buf.ctypes.data_as(C.c_void_p), int(read), C.byref(n), C.byref(lpr)),
+                  "v2e_emu_launch_stamps")
+            assert lpr.value == 128
+            out = buf[:n.value]
+        else:
+            check(self.lib.v2e_emu_launch_stamps(self._h, int(runs), None, 0, None, None), "v2e_emu_launch_stamps")
+        return out
+
     def last_profile(self):
         """Kernel-class times (ms) of the last run(use_graph=2); see v2e_emu_last_profile[_pipe]."""
         v = [C.c_double() for _ in range(4)]
@@ -366,6 +396,12 @@ class EmuEngine:
                                      device=self.device)
         return cache[key]
 
+    def run_ticket(self):
+        return int(self.lib.v2e_emu_run_ticket(self._h))
+
+    def run_wait(self, ticket):
+        check(self.lib.v2e_emu_run_wait(self._h, int(ticket)), "v2e_emu_run_wait")
+
     def read_recs_after(self, recs_dev, done_event):
         """Records of a run as a structured numpy array, copied on a side stream once `done_event` (recorded behind the run)
         has completed: later runs already enqueued on the main stream are not waited for."""
@@ -377,7 +413,8 @@ class EmuEngine:
         if key not in host:
             host[key] = torch.empty(recs_dev.shape, dtype=torch.uint8).pin_memory()
         with torch.cuda.stream(cs):
-            cs.wait_event(done_event)
+            if done_event is not None:
+                cs.wait_event(done_event)
             host[key].copy_(recs_dev, non_blocking=True)
             cs.synchronize()
         dt = np.dtype([("max_events", "<i4"), ("flags", "<u4"), ("n_signal", "<u4"), ("n_events", "<u4"),
