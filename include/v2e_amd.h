@@ -255,7 +255,7 @@ int v2e_emu_frame_host_rows(v2e_emu *h, float *pinned_rows, uint64_t cap_rows);
  * reads a pinned staging set (no copy-engine transfer), and the k_chain pipeline's kernels read the frames through that device
  * variable: with use_graph & 1 a cached graph is replayed over whatever `frames` buffer a call names (events / recs_dev are still
  * baked in: callers alternate between fixed buffer sets), so a caller need not copy frames into one fixed buffer per run.
- * Round 6, PIPELINED RUNS (use_graph = 0 | 1024; the k_chain pipeline with a refractory period): plain launches on three streams, no
+ * Round 6, PIPELINED RUNS (use_graph = 0 | 1024; wherever the k_chain pipeline runs): plain launches on three streams, no
  * graph and no join at the run's end.  `stream` carries the chain's launches and nothing else, so consecutive runs' chains follow one
  * another in one hardware queue; the run's upload, zero fills and k_ahead records go to a stream of the handle that runs ahead of the
  * chain (beside the run before), the emission to another that finishes beside the run after; everything two runs in flight would share

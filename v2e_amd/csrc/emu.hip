@@ -2326,7 +2326,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     // (33 us between two runs' chains); the handle's k_ahead stream carries the run's upload, zero fills and records and runs AHEAD of
     // the chain, beside the run before; the handle's emission stream follows the chain batch by batch and finishes beside the run
     // after.  What two runs in flight would share exists twice (v2e_emu::swap_scratch): such a run takes the set the run before it did not.
-    const bool pipelined = (use_graph & 1024) != 0 && mode == 0 && chain && p->refractory_period_s > 0;
+    const bool pipelined = (use_graph & 1024) != 0 && mode == 0 && chain;
     if (pipelined) h->swap_scratch();
     h->last_ticket = pipelined ? h->scratch_par : -1;
     if (!h->run_ctl) { V2E_HIP(hipMalloc(&h->run_ctl, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips)); h->drop_graphs(); }
