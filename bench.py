@@ -44,9 +44,10 @@ DEFAULT_KW = dict(pos_thres=.2, neg_thres=.2, sigma_thres=.03, cutoff_hz=300, le
 HBM_PEAK = 8.0e12        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_RATE = 256 * 4 * 2.4e9 / 2  # wave64 VALU instructions per second: a SIMD-32 takes one in 2 cycles (MI355X_MICROARCH.md)
 SALU_RATE = 256 * 2.4e9          # one scalar unit per CU
-PMC_FILES = ("r05_emulator_pmc_hbm.txt", "r04_emulator_pmc_hbm.txt")
-TRACE_FILES = ("r05_emulator_chain_kernel_trace.txt", "r04_emulator_chain_kernel_trace.txt")
-SQ_FILES = ("r05_emulator_sq.txt", "r04_emulator_sq.txt")
+PMC_FILES = ("r06_emulator_pmc_hbm.txt", "r05_emulator_pmc_hbm.txt")
+TRACE_FILES = ("r06_emulator_chain_kernel_trace.txt",)
+SQ_FILES = ("r06_emulator_sq.txt", "r05_emulator_sq.txt")
+STAMP_STEPS = 20          # steps of the timed loop repeated with the chain's launches stamped on the device (roofline.frac)
 F32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: f32-input MFMA peak
 INSTR_STEPS = 6           # steps re-run instrumented for the live per-launch kernel times of the roofline object
 CLIP_STEPS = 24           # distinct seconds of synthetic video generated; longer runs cycle through them
@@ -519,6 +520,17 @@ def main():
         eng = emu._engine
         P = emu._params()
         buf = torch.empty((F, H, W), dtype=torch.uint8, device=device)
+        # ---- the kernel AS IT RUNS IN THE TIMED CONFIGURATION: the timed loop once more (same run_steps, same pipelined runs, k_ahead and
+        # the emission on their streams beside the chain), every chain launch leaving the device wall-clock time of its first workgroup's
+        # start and its last workgroup's end (v2e_emu_launch_stamps: two atomics per workgroup, nothing else changes)
+        eng.launch_stamps(STAMP_STEPS)
+        el_st, ne_st = run_steps(emu, frames_all, F, DT, STAMP_STEPS, 0, None, None, device, first_step=Wm + nblocks * K)
+        st = eng.launch_stamps(0, read=STAMP_STEPS).astype(np.int64)
+        nl_st = int((st[0, :, 1] > 0).sum())
+        st_us = st[:, :nl_st] / 1e3
+        st_dur = st_us[:, :, 1] - st_us[:, :, 0]
+        st_gap = st_us[:, 1:, 0] - st_us[:, :-1, 1]
+        st_bound = st_us[1:, 0, 0] - st_us[:-1, -1, 1]
         # re-run the frames of INSTR_STEPS steps instrumented (state keeps advancing; timing only).  Several steps, because the
         # launches that first redo their predecessor are few and uneven (one step of the clip holds a 245 us launch, others
         # none above 70): the average over one step says little
@@ -567,24 +579,38 @@ def main():
         whole = (bpp * npx + 16 * ev_per_frame)
         traffic, prof_file = pmc_traffic_per_launch(kname.split("(")[0])
         rp_us, rp_file = rocprof_kernel_us(kname.split("(")[0])
-        this_round = rp_file is not None and "/r05_" in rp_file
         live = {"avg_kernel_us": round(kernel_us, 3), "achieved_GBps": round(ach / 1e9, 2), "frac": round(ach / HBM_PEAK, 5),
                 "launches_timed": n_step, "launch_us": [round(u, 1) for u in per_launch],
                 "note": "HIP events before and after every chain launch of an instrumented re-run of %d steps' frames with ALL kernels "
                         "of the run on ONE stream: each kernel running alone (no contention with k_ahead / the emission kernels)" % INSTR_STEPS}
-        timed = None if rp_us is None else {
-            "avg_kernel_us": rp_us, "source": rp_file, "achieved_GBps": round(step_bytes / (rp_us * 1e-6) / 1e9, 2),
-            "frac": round(step_bytes / (rp_us * 1e-6) / HBM_PEAK, 5),
-            "note": "the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this same command: the "
-                    "TIMED configuration (three streams side by side, every duration under contention, redo passes included)"}
-        # what the line's frac is (round-4 review: "report the roofline that follows from profiles/"): the timed configuration's figure
-        # when this round's trace is committed, else the live one (each kernel alone), and it says which
-        head = timed if (timed and this_round) else live
+        st_full = np.sort(st_dur[:, :F // fpl].ravel())   # the launches that advance fpl frames
+        st_mean = float(st_dur.mean())
+        timed = {
+            "avg_kernel_us": round(st_mean, 3), "achieved_GBps": round(step_bytes / (st_mean * 1e-6) / 1e9, 2),
+            "frac": round(step_bytes / (st_mean * 1e-6) / HBM_PEAK, 5),
+            "launches_timed": int(st_dur.size), "launches_per_step": nl_st, "steps": int(st_dur.shape[0]),
+            "Mevents_per_s_of_the_stamped_steps": round(ne_st / el_st / 1e6, 1),
+            "full_launch_us": {"p10": round(float(st_full[len(st_full) // 10]), 2), "p50": round(float(st_full[len(st_full) // 2]), 2),
+                               "p90": round(float(st_full[len(st_full) * 9 // 10]), 2)},
+            "per_step_us": {"sum_of_launch_durations": round(float(st_dur.sum(1).mean()), 1),
+                            "gaps_between_launches": round(float(st_gap.sum(1).mean()), 1),
+                            "last_launch_end_to_next_steps_first_start": round(float(st_bound.mean()), 1)},
+            "note": "LIVE, this process, this binary: %d more steps of the timed loop (pipelined runs: k_ahead and the emission kernels on "
+                    "their streams beside the chain) with every chain launch stamped on the device (first workgroup's start to last "
+                    "workgroup's end, s_memrealtime); the mean covers every launch of a step -- the full ones, the partial one, the tail "
+                    "launch that only validates, redo passes included" % STAMP_STEPS}
+        recorded = None if rp_us is None else {
+            "avg_kernel_us": rp_us, "source": rp_file, "frac": round(step_bytes / (rp_us * 1e-6) / HBM_PEAK, 5),
+            "note": "the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of `bench.py --no-roofline-rerun` "
+                    "(the timed configuration's launches only): the cross-check of `timed_configuration` (the profiler's duration runs from "
+                    "dispatch to completion, the stamps from first workgroup to last)"}
+        head = timed
         out["roofline"] = {
             "bound": "hbm", "kernel": kname.split("(")[0],
             "achieved": head["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": head["frac"],
-            "frac_is": ("algorithmic bytes / the kernel's average duration in the TIMED configuration (profiles/, rocprofv3)" if head is timed
-                        else "algorithmic bytes / the kernel's average duration running ALONE (live HIP events): no rocprofv3 trace of this round is committed"),
+            "frac_is": "algorithmic bytes per launch / the kernel's average launch duration in the TIMED configuration, measured live on the "
+                       "device in this process (timed_configuration); alone_hip_events / median_full_launch: every kernel alone; "
+                       "as_delivered / whole_step: against the driver-timed region",
             "traffic": traffic,
             "traffic_source": str(prof_file) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; counters cannot be read "
                                           "from inside the process)",
@@ -592,6 +618,7 @@ def main():
             "algorithmic_bytes_per_launch": int(step_bytes), "frames_per_launch": fpl,
             "frames_per_launch_avg": round(F / n_per_step, 2),
             "timed_configuration": timed,
+            "rocprof_recorded": recorded,
             "alone_hip_events": live,
             "median_full_launch": None if p50 is None else {
                 "us": round(p50, 3), "bytes": int(full_bytes), "achieved_GBps": round(full_bytes / (p50 * 1e-6) / 1e9, 2),
@@ -609,8 +636,8 @@ def main():
                            "achieved_GBps": round(whole * K * F / elapsed / 1e9, 2),
                            "frac": round(whole * K * F / elapsed / HBM_PEAK, 5)},
             "note": "algorithmic bytes = 53 B x pixels x the step's frames / the step's chain launches (what a launch advances on average; "
-                    "SURVEY.md 8(d)).  Three durations divide them: timed_configuration (what `frac` is when this round's trace is "
-                    "committed), alone_hip_events (live, each kernel alone), as_delivered (the driver-timed region per launch).  The "
+                    "SURVEY.md 8(d)).  Three durations divide them: timed_configuration (what `frac` is: live device stamps of the timed "
+                    "loop), alone_hip_events (live HIP events, each kernel alone), as_delivered (the driver-timed region per launch).  The "
                     "per-pixel state (2.9 MB at 346x260) stays in registers for a launch's 32 frames and the PMC traffic is below the "
                     "algorithmic bytes: HBM is not what binds this kernel -- instruction_issue states the fraction of the resource that "
                     "does, and whole_step prices the complete frame (state + event rows) against the driver-timed region",
