@@ -273,8 +273,11 @@ int v2e_emu_run_join(v2e_emu *h, void *stream);
 /* The scratch set (0 / 1) the run enqueued last took if the library enqueued it in pieces (the ticket of that run, valid until the
  * second-next such run), or -1: that run is whole on its stream. */
 int v2e_emu_run_ticket(v2e_emu *h);
-/* Host-blocking: every piece of the last overlapped run with that ticket has completed (its rows and records can be read). */
+/* Host-blocking: every piece of the last pipelined run with that ticket has completed (its rows and records can be read). */
 int v2e_emu_run_wait(v2e_emu *h, int ticket);
+/* The records [n_frames][n_clips] of the last pipelined run with that ticket in pinned host memory of the handle (copied there behind
+ * the run's last rows; valid behind v2e_emu_run_wait, until the second-next pipelined run); *n_recs = how many. */
+const v2e_frame_rec *v2e_emu_run_recs(v2e_emu *h, int ticket, uint64_t *n_recs);
 
 /* After an instrumented v2e_emu_run (blocking): summed milliseconds per kernel class and frames.
  * k_chain pipeline (a HIP event before and after every chain launch, on its stream): ms_count = first

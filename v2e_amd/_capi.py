@@ -102,6 +102,7 @@ SIGNATURES = {
     "v2e_emu_run_join": (_i, [_vp, _vp]),
     "v2e_emu_run_ticket": (_i, [_vp]),
     "v2e_emu_run_wait": (_i, [_vp, _i]),
+    "v2e_emu_run_recs": (_vp, [_vp, _i, C.POINTER(_u64)]),
     "v2e_emu_last_profile": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),
                                   C.POINTER(_i)]),
     "v2e_emu_chain_plan": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i]),

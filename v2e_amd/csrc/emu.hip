@@ -57,7 +57,7 @@ struct FrameCtl {
     uint32_t pad_;
 };
 
-__host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_hz, double shot_rate_hz, double refr_s)
+__host__ __device__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_hz, double shot_rate_hz, double refr_s)
 {
     FrameCtl c;
     c.t_prev = t_prev; c.t_frame = t_frame;
@@ -80,7 +80,7 @@ __host__ inline FrameCtl make_ctl(double t_prev, double t_frame, double cutoff_h
     if (refr_s > 0) { // emulator.py:830 `refractory_period_s > ts_step`, ts_step = delta_time / n: first n that satisfies it
         const double g = dt / refr_s;
         if (!(g > 4.0e9)) {
-            long long n0 = (long long)std::floor(g) - 2;
+            long long n0 = (long long)floor(g) - 2;
             if (n0 < 1) n0 = 1;
             while (!(refr_s > dt / (double)n0) && n0 < 0xFFFFFFFEll) ++n0;
             while (n0 > 1 && refr_s > dt / (double)(n0 - 1)) --n0;
@@ -938,6 +938,8 @@ struct v2e_emu {
     bool piece_pending[2] = {false, false}; // set `par` has a run whose pieces may still be executing
     const void *last_events = nullptr, *last_recs = nullptr; // buffers of the overlapped run enqueued last
     hipEvent_t ev_user = nullptr;
+    void *recs_host[2] = {nullptr, nullptr}; // pinned: the records of the last pipelined run per scratch set (v2e_emu_run_recs)
+    size_t recs_host_cap[2] = {0, 0}, recs_host_n[2] = {0, 0};
     int last_ticket = -1; // the scratch set of the run enqueued last if it went out in pieces, else -1 (v2e_emu_run_ticket)
     // every piece of every overlapped run has completed (host-blocking; before scratch is freed or re-sized)
     void sync_runs()
@@ -967,13 +969,18 @@ void v2e_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-// pinned host staging -> device (v2e_emu_run): frame scalars of a run and its first frame index
-static __global__ __launch_bounds__(BLOCK) void k_upload_ctl(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+// pinned host staging -> device (v2e_emu_run): the run's frame times, from which the frame scalars (FrameCtl: the reference's Python
+// doubles, the per-iteration-count timestamp tables, the refractory switch) are computed HERE, one thread per frame -- the same IEEE
+// operations as on the host (make_ctl is one function for both; device float64 / float32 division is correctly rounded, and
+// -ffp-contract=off holds for this file): 64 divisions per frame were ~100 us of host time per 300-frame run, on the path that
+// bounds the pipelined loop -- and its first frame index, frames' address and stamp slot
+static __global__ __launch_bounds__(BLOCK) void k_upload_ctl(const double *__restrict__ tp, const double *__restrict__ tf, FrameCtl *__restrict__ dst, size_t nct,
+                                                      double cutoff_hz, double shot_rate_hz, double refr_s,
                                                       const uint32_t *__restrict__ fsrc, uint32_t *__restrict__ fdst,
                                                       const void *const *__restrict__ psrc, const void **__restrict__ pdst,
                                                       unsigned long long *const *__restrict__ ssrc, unsigned long long **__restrict__ sdst)
 {
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < nct; i += (size_t)gridDim.x * BLOCK) dst[i] = make_ctl(tp[i], tf[i], cutoff_hz, shot_rate_hz, refr_s);
     if (blockIdx.x == 0 && threadIdx.x == 0) { *fdst = *fsrc; *pdst = *psrc; *sdst = *ssrc; }
     // the run's slot of per-launch time stamps (v2e_emu_launch_stamps; nullptr: off) starts out zero
     unsigned long long *slot = *ssrc;
@@ -1113,6 +1120,7 @@ int v2e_emu_destroy(v2e_emu *h)
     h->drop_graphs();
     for (int i = 0; i < v2e_emu::NPF; ++i) hipFree(h->alt[i]);
     if (h->ev_user) hipEventDestroy(h->ev_user);
+    for (int q = 0; q < 2; ++q) if (h->recs_host[q]) hipHostFree(h->recs_host[q]);
     for (int q = 0; q < 2; ++q) {
         if (h->ev_main_done2[q]) hipEventDestroy(h->ev_main_done2[q]);
         if (h->ev_tail_done2[q]) hipEventDestroy(h->ev_tail_done2[q]);
@@ -1773,7 +1781,7 @@ static bool chain_fused_records(const v2e_emu *h, int dtype)
     return fused_env >= 0 ? fused_env != 0 : !chain_small_grid(h);
 }
 
-static size_t chain_dyn_lds(bool fused) { return fused ? 0 : (size_t)CHAIN_SUB * BLOCK * (sizeof(uint4) + sizeof(uint32_t)); }
+static size_t chain_dyn_lds(bool fused) { return fused ? 0 : (size_t)CHAIN_SUB * BLOCK * sizeof(uint4); }
 
 // allon: every run-time feature switch of the frame loop is on (cutoff, leak, shot noise, refractory period: the v2e CLI
 // defaults) -> the instantiation without those tests; built for float64 state and uint8 frames (what that configuration has)
@@ -2057,8 +2065,14 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // streams crash hipStreamEndCapture on this runtime): tables and rows then share the side stream.
     constexpr int tab_env = ST_TAB; // plain streams: tables on a stream of their own
     constexpr bool tabs_on_main = false;
-    // pipelined plain launches (v2e_emu_run, mode 0 | 1024): three streams in all -- the chain's, k_ahead's, the emission's
-    const int tab_stream = (capturing || pipelined) ? (tabs_on_main ? ST_MAIN : ST_SIDE) : tab_env;
+    // pipelined plain launches (v2e_emu_run, mode 0 | 1024): four streams in all
+    // -- the caller's (the chain), k_ahead's, the emission tables' (h->side) and the event rows' (h->side2): with tables and rows on one
+    // stream that stream was busy ~500 of a step's 720 us and the chain waited for it where the ring of frame slots wraps (device
+    // stamps: 57 us before the first launch of batch 3; with the rows on their own stream 19, 717-732 -> 699-713 us per step).
+    // (The tables on the k_ahead stream instead: the next run's head queues behind this run's last tables, 290 us between two runs'
+    // chains.)  V2E_AMD_PIPE_ROWS=one: tables and rows on one stream (A/B)
+    static const bool pipe_rows_own = !(getenv("V2E_AMD_PIPE_ROWS") && !strcmp(getenv("V2E_AMD_PIPE_ROWS"), "one"));
+    const int tab_stream = capturing ? (tabs_on_main ? ST_MAIN : ST_SIDE) : (pipelined ? ST_SIDE : tab_env);
     constexpr int NSET = 3; // emission table sets (chain_alloc sizes them)
     constexpr bool one_row_stream = false;
     // b: the emission's slot (event indices, table set b % NSET, event offsets run_off[b] -> run_off[b + 1]); frames [ef0, ef0 + enE).
@@ -2096,7 +2110,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         constexpr int ich_env = 0;
         ea.ich = (ich_env >= 1 && ich_env <= 31) ? ich_env : 4;
         ea.capw = GROUP_PX * ea.ich;
-        ea.coff_in_cemit = (tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream) ? 1 : 0;
+        const bool rows_own = pipelined && pipe_rows_own;
+        // (one row stream: the rows carry the running event offset forward themselves -- no k_coff launch)
+        ea.coff_in_cemit = (tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream || rows_own) ? 1 : 0;
         // frames per workgroup (measured at 346x260, 32-frame batches: k_ctot 4 frames 13 us, 32 frames 37 us; k_cemit 1 frame
         // 34 us, 8 frames 45 us -- these kernels are bound by the latency of a wave's dependent loads, not by wave dispatch:
         // more, shorter waves win)
@@ -2110,7 +2126,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         // tables on a stream of their own (NSET table sets rotate: tables(b + 1) are built while k_cemit(b) reads those of b;
         // k_cemit(b - NSET), which read this set last, is waited for), rows on the side stream
         if (tab_stream != ST_MAIN && sc.wait(tab_stream, EV_FORK, b)) return V2E_EHIP;
-        if (b >= NSET && tab_stream != ST_SIDE && sc.wait(tab_stream, EV_JOIN, b - NSET)) return V2E_EHIP;
+        if (b >= NSET && (tab_stream != ST_SIDE || rows_own) && sc.wait(tab_stream, EV_JOIN, b - NSET)) return V2E_EHIP;
         if (!no_emit) {
             if (sc.kernel(tab_stream, (const void *)k_ctot, dim3(egx, NC, (ea.nE + CTOT_ZF - 1) / CTOT_ZF), dim3(BLOCK), (size_t)side_pad, args)) return V2E_EHIP;
             // a key row of a small grid is a couple of steps of one wave: one workgroup per frame; of a large grid (beyond a million
@@ -2124,7 +2140,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         }
         // rows: two batches side by side on two streams (the rows of a batch depend on nothing but its tables; the batch's
         // event offset then comes from k_coff behind the tables); on one stream with the tables the rows carry it forward
-        const int row_stream = (tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream) ? ST_SIDE : ((b & 1) ? ST_SIDE2 : ST_SIDE);
+        const int row_stream = rows_own ? ST_SIDE2 : ((tab_stream == ST_SIDE || tab_stream == ST_MAIN || one_row_stream || pipelined) ? ST_SIDE : ((b & 1) ? ST_SIDE2 : ST_SIDE));
         if (!no_emit && !ea.coff_in_cemit) {
             void *oargs[] = {(void *)&ea};
             if (sc.kernel(tab_stream, (const void *)k_coff, dim3(NC), dim3(WAVE), 0, oargs)) return V2E_EHIP;
@@ -2197,7 +2213,8 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // last batch in two pieces: only where the last launch is not the first of its batch (else there is nothing to emit early)
     constexpr bool split_tail_env = true;
     const int tail_f0 = (nB - 1) * K;                          // first frame of the last chain launch with frames
-    const bool split_tail = split_tail_env && has_refr && m > 1 && nB >= 2 && (nB - 1) % m != 0 && !no_emit_run;
+    // (pipelined runs: the last emission finishes beside the next run's chain -- one piece, six API calls fewer)
+    const bool split_tail = split_tail_env && has_refr && m > 1 && nB >= 2 && (nB - 1) % m != 0 && !no_emit_run && !pipelined;
     int last_emitted = -1; // the last emission slot this piece enqueued (joined at the end)
     constexpr int allon_env = 1;
     const bool allon = allon_env && a_in.has_cutoff && a_in.do_leak && a_in.do_shot && a_in.has_refr;
@@ -2369,7 +2386,9 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     FrameCtl *ctl_host = h->run_ctl_host2[sq];
     uint32_t *fidx_host = h->run_fidx_host + sq;
     const size_t nct = (size_t)n_frames * h->n_clips;
-    for (size_t i = 0; i < nct; ++i) ctl_host[i] = make_ctl(t_prev[i], t_frame[i], p->cutoff_hz, p->shot_noise_rate_hz, p->refractory_period_s);
+    double *const tp_host = (double *)ctl_host, *const tf_host = tp_host + nct; // (the staging set holds the frame times)
+    memcpy(tp_host, t_prev, sizeof(double) * nct);
+    memcpy(tf_host, t_frame, sizeof(double) * nct);
     *fidx_host = frame_idx0;
     const void **frames_host = h->run_frames_host + sq; // the chain pipeline reads the frames' address from a device variable:
     *frames_host = frames;                              // runs over different frame buffers replay the same captured graph
@@ -2377,12 +2396,12 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     // (round 5; before: three hipMemcpyAsync).  A/B x 3 in one session on the benchmark loop: 11.9 -> 12.15 Gev/s -- in the rocprofv3
     // timeline the copy-engine upload started 40-90 us behind the command before it, the kernel 10 us.
     {
-        static_assert(sizeof(FrameCtl) % 16 == 0, "FrameCtl is copied in 16-byte pieces");
-        const size_t n16 = sizeof(FrameCtl) * nct / 16;
+        static_assert(sizeof(FrameCtl) >= 2 * sizeof(double), "the staging set holds two doubles per frame");
         unsigned long long **slot_host = h->stamp_slot_host + sq;
         *slot_host = h->stamps_runs > 0 ? h->stamps + (size_t)(h->stamp_seq++ % (unsigned long long)h->stamps_runs) * 2 * STAMP_LAUNCHES : nullptr;
-        k_upload_ctl<<<(unsigned)std::min<size_t>((n16 + BLOCK - 1) / BLOCK, 1024), BLOCK, 0, s_up>>>((const uint4 *)ctl_host, (uint4 *)h->run_ctl, n16, fidx_host, h->run_fidx,
-                                                                                                   frames_host, h->run_frames, slot_host, h->stamp_slot);
+        k_upload_ctl<<<(unsigned)std::min<size_t>((nct + BLOCK - 1) / BLOCK, 1024), BLOCK, 0, s_up>>>(tp_host, tf_host, h->run_ctl, nct, p->cutoff_hz, p->shot_noise_rate_hz,
+                                                                                                   p->refractory_period_s, fidx_host, h->run_fidx, frames_host, h->run_frames,
+                                                                                                   slot_host, h->stamp_slot);
         V2E_HIP(hipGetLastError());
     }
     V2E_HIP(hipEventRecord(h->ev_stage[sq], s_up));
@@ -2395,7 +2414,19 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, nullptr, nullptr, nullptr, false, true);
         if (rc) return rc;
         V2E_HIP(hipEventRecord(h->ev_main_done2[par], s));          // the run's chain (the pixel state)
-        V2E_HIP(hipEventRecord(h->ev_tail_done2[par], h->side));    // its last event rows
+        hipStream_t rows_stream = (getenv("V2E_AMD_PIPE_ROWS") && !strcmp(getenv("V2E_AMD_PIPE_ROWS"), "one")) ? h->side : h->side2;
+        // the run's records to pinned host memory behind its last rows (v2e_emu_run_recs): what result() reads -- no copy of the
+        // caller's own, no stream of the caller's to synchronise
+        const size_t rbytes = sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips;
+        if (rbytes > h->recs_host_cap[par]) {
+            if (h->recs_host[par]) V2E_HIP(hipHostFree(h->recs_host[par]));
+            h->recs_host[par] = nullptr;
+            V2E_HIP(hipHostMalloc(&h->recs_host[par], rbytes));
+            h->recs_host_cap[par] = rbytes;
+        }
+        V2E_HIP(hipMemcpyAsync(h->recs_host[par], recs_dev, rbytes, hipMemcpyDeviceToHost, rows_stream));
+        h->recs_host_n[par] = (size_t)n_frames * h->n_clips;
+        V2E_HIP(hipEventRecord(h->ev_tail_done2[par], rows_stream)); // its last event rows (and the records' copy)
         h->piece_pending[par] = true;
         h->last_events = events; h->last_recs = recs_dev;
         return 0;
@@ -2530,6 +2561,12 @@ int v2e_emu_run_wait(v2e_emu *h, int ticket)
     return 0;
 }
 int v2e_emu_run_ticket(v2e_emu *h) { return h ? h->last_ticket : -1; }
+const v2e_frame_rec *v2e_emu_run_recs(v2e_emu *h, int ticket, uint64_t *n_recs)
+{
+    if (!h || (ticket != 0 && ticket != 1)) return nullptr;
+    if (n_recs) *n_recs = h->recs_host_n[ticket];
+    return (const v2e_frame_rec *)h->recs_host[ticket];
+}
 
 // `stream` waits for every piece of every overlapped run (v2e_emu_run, |1024) enqueued on this handle so far
 int v2e_emu_run_join(v2e_emu *h, void *stream)

@@ -304,7 +304,7 @@ template <typename R> __device__ __forceinline__ R floor_div_rcp(R a, R b, R rb)
 // FUSED = false: the frames' records come from k_ahead through LDS (small grids: the chain is one wave per SIMD and every
 // instruction in it is latency).  FUSED = true: the chain builds each record itself (large grids: the occupancy hides
 // latencies, and the records' 32 B per pixel and frame of extra HBM traffic would be what bounds the run).
-// Dynamic LDS (FUSED = false): [CHAIN_SUB][BLOCK] uint4 records + [CHAIN_SUB][BLOCK] count words.
+// Dynamic LDS (FUSED = false): [CHAIN_SUB][BLOCK] uint4 records.
 // ALLON: instantiation for runs with a photoreceptor cutoff, leak, shot noise AND a refractory period (the v2e CLI defaults,
 // i.e. the benchmark): the per-frame tests of those run-time switches -- a scalar compare and a branch each, in a loop whose
 // every instruction is exposed latency -- are compiled out.  ALLON = false reads the switches from KArgs.
@@ -317,7 +317,7 @@ void k_chain(KArgs a_in, ChainArgs ca)
 {
     KArgs a = a_in;
     if (ALLON) { a.has_cutoff = 1; a.do_leak = 1; a.do_shot = 1; a.has_refr = 1; a.use_inten = 1; }
-    extern __shared__ uint4 s_arec[];         // [CHAIN_SUB][BLOCK] k_ahead's records of the frames in flight, then s_cw
+    extern __shared__ uint4 s_arec[];         // [CHAIN_SUB][BLOCK] k_ahead's records of the frames in flight
     __shared__ float s_lutL[FUSED ? 256 : 1]; // FUSED: lin-log tables and the pass's frame scalars
     __shared__ double s_lutI[FUSED ? 256 : 1];
     __shared__ double s_dtau[FUSED ? CHAIN_K_MAX : 1], s_shot[FUSED ? CHAIN_K_MAX : 1];
@@ -327,10 +327,6 @@ void k_chain(KArgs a_in, ChainArgs ca)
     const int g = blockIdx.x;
     const int p = g * BLOCK + tid;
     const bool valid = p < a.npx;
-    // the count words of a sub-pass wait in LDS and go out together behind it: vector memory operations retire in order
-    // and the counter covers stores too, so a store inside the frame loop would stand between the loop and the arrival
-    // of the next sub-pass's records
-    uint32_t *const s_cw = (uint32_t *)(s_arec + (size_t)CHAIN_SUB * BLOCK);
     if (ca.prio) __builtin_amdgcn_s_setprio(3); // the dependency chain outranks the emission waves sharing the SIMD
     V2E_STAMP_C(0);
     // measurement (v2e_emu_launch_stamps; off: one scalar load and branch per launch): the launch's first workgroup start and last
@@ -370,13 +366,15 @@ void k_chain(KArgs a_in, ChainArgs ca)
             return make_uint4(v.x, v.y, v.z, v.w);
         };
         auto stage = [&](const int sl0, const int fn) __attribute__((always_inline)) { // the first CHAIN_SUB frames of a pass (sl0: the first one's slot)
-            if (FUSED || !valid) return;
+            if (FUSED) return;
+            // (a lane beyond the frame stages ZERO records: with its zero state they give no events -- the frame loop carries no
+            // per-lane validity test)
             uint4 t[CHAIN_SUB];
             int sl = sl0;
 #pragma unroll
             for (int j = 0; j < CHAIN_SUB; ++j) {
                 t[j] = make_uint4(0u, 0u, 0u, 0u);
-                if (j < fn) t[j] = load_rec(sl);
+                if (j < fn && valid) t[j] = load_rec(sl);
                 if (++sl == ca.D) sl = 0;
             }
 #pragma unroll
@@ -517,13 +515,20 @@ void k_chain(KArgs a_in, ChainArgs ca)
             if (own) V2E_STAMP_C(2);
             float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f; // FUSED: the draws of the current frame pair
             bool have_pair = false;
-            int slot = 0; // ring slot of the frame in hand: (fs + k) % D, advanced without a division per frame
-            auto frame_body = [&](const int k, const uint4 rc_in) __attribute__((always_inline)) {
+            // lane k: M of frame k where this pass finalised it by the rule, else 0 -- written to the frames' ruleM slots behind the
+            // pass (a store per frame and workgroup cost the common path three scalar instructions and a branch)
+            uint32_t rule_v = 0u;
+            // guard of the reciprocal floor division (below): a threshold that is not positive takes the generic path
+            const bool thr_bad = !(tpd > (R)0) || !(tnd > (R)0);
+            constexpr double QMAX = sizeof(R) == 8 ? 1.0e9 : 1.0e6; // quotients beyond it (and NaN) take the generic path
+            // One frame of one pixel.  k: frame of the pass; js: its slot among the CHAIN_SUB frames staged in LDS (k % CHAIN_SUB; a
+            // compile-time constant in the unrolled sub-pass); returns the frame's count word.
+            auto frame_body = [&](const int k, const int js) __attribute__((always_inline)) -> uint32_t {
                 const int f = fs + k;
                 const uint32_t Mon = (uint32_t)__builtin_amdgcn_readlane((int)mon_v, k);
                 uint32_t exM = own ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)exact_v, k);
                 // the frame's record: eps (+ shot decisions in its two free bits), lin-log value, leak step
-                uint4 rc = rc_in;
+                uint4 rc = make_uint4(0u, 0u, 0u, 0u);
                 if (FUSED) {
                     FT px = (FT)0;
                     if (valid) px = ((const FT *)(frames + (size_t)f * ca.frame_stride))[(size_t)clip * a.npx + p];
@@ -536,6 +541,8 @@ void k_chain(KArgs a_in, ChainArgs ca)
                     const bool even = v2e_frame_half(gf) != 0u;
                     rc = make_frame_record<FT>(a, px, s_lutL, s_lutI, s_dtau[k], s_shot[k], s_dtime[k], lk, thp, ppre, npre,
                                                even ? r_even : r_odd, even ? u_even : u_odd);
+                } else {
+                    rc = s_arec[(size_t)js * BLOCK + tid];
                 }
                 const double eps = __longlong_as_double((long long)(((unsigned long long)(rc.y & 0x3FFFFFFFu) << 32) | rc.x));
                 const double L = (double)__uint_as_float(rc.z);
@@ -543,22 +550,37 @@ void k_chain(KArgs a_in, ChainArgs ca)
                 if (a.has_cutoff) lpn = (R)((1.0 - eps) * (double)lp + eps * L);
                 else lpn = (R)L;
                 if (a.do_leak) b = b - (R)__uint_as_float(rc.w); // emulator_utils.py:131
-                // counts (emulator_utils.py:137-173): diff has one sign, one exact floor division
+                // counts (emulator_utils.py:137-173): diff has one sign, one exact floor division.  floor(|diff| / theta) from the
+                // reciprocal computed once per launch: |diff| * (1 / theta) is within a few ulp of the quotient, so its floor q0 is the
+                // true floor or one off, and the remainder |diff| - q0 theta -- EXACT in one fma for such a q0 -- says which (the value
+                // floor_div_pos returns, which equals c10::div_floor_floating for these operands).  The fix-up is applied to the
+                // integer; anything unusual (NaN, a quotient beyond QMAX, a threshold <= 0) takes floor_div_pos on the operands the
+                // reference's relu leaves.
                 const R diff = (lpn + (R)0.0f) - b;
                 const bool is_pos = diff > (R)0;
-                const R mg = is_pos ? diff : ((-diff) > (R)0 ? -diff : (R)0);
-                const int q = (int)floor_div_rcp<R>(mg, is_pos ? tpd : tnd, is_pos ? rtp : rtn);
-                const int mag = q > 0 ? q : 0;
                 const bool neg = !is_pos;
-                uint32_t cw = mag > 0 ? (((uint32_t)mag & CNT_MASK) | (neg ? CNT_NEG : 0u)) : 0u;
-                if (a.do_shot) cw |= (rc.y >> 30) << 25; // CNT_SHOT_ON / CNT_SHOT_OFF
-                if (!valid) cw = 0u;
-                if (FUSED) {
-                    if (valid) WT_STORE(&ca.cnt[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p], cw);
-                } else {
-                    s_cw[(size_t)((unsigned)k % CHAIN_SUB) * BLOCK + tid] = cw;
+                const R bt = is_pos ? tpd : tnd, rbt = is_pos ? rtp : rtn;
+                const R am = sizeof(R) == 8 ? (R)__builtin_fabs((double)diff) : (R)__builtin_fabsf((float)diff);
+                const R q0 = floor(am * rbt);
+                const R r0 = fma(-q0, bt, am);
+                int mag = (int)q0;
+                mag -= (r0 < (R)0) ? 1 : 0;
+                mag += (r0 >= bt) ? 1 : 0;
+                asm volatile("" : "+v"(mag)); // (every lane takes the arithmetic above; the compiler otherwise sinks it under the guard's mask)
+                if (__builtin_expect(!(q0 <= (R)QMAX) || thr_bad, 0)) {
+                    const R mg = is_pos ? diff : ((-diff) > (R)0 ? -diff : (R)0);
+                    const int q = (int)floor_div_pos<R>(mg, bt);
+                    mag = q > 0 ? q : 0;
                 }
-                const int magv = valid ? mag : 0;
+                if (FUSED && !valid) mag = 0; // (k_ahead's records of a pixel beyond the frame are zero: no events by themselves)
+                // count word: count | sign (events only) | the record's shot decisions
+                uint32_t cw = ((uint32_t)mag & CNT_MASK) | ((mag > 0 && neg) ? CNT_NEG : 0u);
+                if (a.do_shot) cw |= (rc.y >> 5) & (CNT_SHOT_ON | CNT_SHOT_OFF);
+                if (FUSED && !valid) cw = 0u;
+                if (FUSED) {
+                    if (valid) WT_STORE(&ca.cnt[((size_t)wrap_slot(fs_slot + k) * ca.n_clips + clip) * a.npx_pad + p], cw);
+                }
+                const int magv = mag;
                 // speculation check: only a wave with a lane that reaches the rule threshold says so
                 if (a.has_refr && k > (own ? -1 : last_exact) && __ballot((uint32_t)magv >= Mon) != 0ull) {
                     const int wm = wave_max_i32(magv);
@@ -582,37 +604,38 @@ void k_chain(KArgs a_in, ChainArgs ca)
                 // The rule-on walk is its own branch: nothing it loads (timestamp tables) may be live in the common path,
                 // or the common path inherits a wait for every outstanding store.
                 int fcount = magv;
-                uint32_t rule_m = 0u;
                 if (exM != 0u) {
                     const FrameCtl *c = ca.ctl + (size_t)f * ca.n_clips + clip;
                     const FrameTab ftb(c, lane);
                     bool ruled = false;
                     const TsGen tg = frame_tsgen(a, c, ftb, (int)exM, ruled);
                     if (ruled) {
-                        rule_m = exM;
-                        if (valid) ca.tsold[((size_t)slot * ca.n_clips + clip) * a.npx_pad + p] = tsm; // ts_mem as it was
+                        if (lane == k) rule_v = exM;
+                        if (valid) ca.tsold[((size_t)wrap_slot(fs_slot + k) * ca.n_clips + clip) * a.npx_pad + p] = tsm; // ts_mem as it was
                         fcount = 0;
-                        for (int i = 0; i < magv; ++i) { // emulator.py:836-842, this pixel's iterations
+                        // (bounded: beyond max_iters <= 1024 events the frame is flagged and the run fails anyway; a wild count must not
+                        // turn into minutes of spinning)
+                        const int nit = min(magv, 1 << 16);
+                        for (int i = 0; i < nit; ++i) { // emulator.py:836-842, this pixel's iterations
                             const float t = tg(i);
                             const float pt = 1.0f * t - tsm;
                             if (pt > a.refr_f) { tsm = t; ++fcount; }
                         }
                     }
                 }
-                if (a.has_refr && g == 0 && tid == 0) WT_STORE(&ca.ruleM[(size_t)slot * ca.n_clips + clip], rule_m);
-                if (valid) {
-                    const bool shot = (cw & (CNT_SHOT_ON | CNT_SHOT_OFF)) != 0u;
-                    if (fcount > 0 || shot) {
-                        const float dp = (float)(neg ? 0 : fcount) * thp;
-                        const float dn = (float)(neg ? fcount : 0) * thn;
-                        b = b + (R)dp;
-                        b = b - (R)dn;
-                        if (shot) b = lpn;
-                    }
+                // base += pos_events * pos_thres; base -= neg_events * neg_thres (one of the two products is +0 and leaves the sum as it
+                // is; x - y == x + (-y) bit for bit), then the shot-noise reset -- unconditionally: a masked branch around it cost more
+                // scalar instructions than the arithmetic has vector ones
+                {
+                    float d = (float)fcount * (neg ? thn : thp);
+                    d = neg ? -d : d;
+                    const R bn = b + (R)d;
+                    const bool shot = a.do_shot && (rc.y >> 30) != 0u;
+                    b = shot ? lpn : bn;
                 }
                 lp = lpn;
-                if (++slot == ca.D) slot = 0;
                 if (V2E_CHAIN_STAMPS && own && k < 12) V2E_STAMP_C(3 + k);
+                return cw;
             };
             // records of the pass's frames [kn, kn + CHAIN_SUB) into registers (in flight while the frames before them compute)
             uint4 nx[CHAIN_SUB];
@@ -637,35 +660,43 @@ void k_chain(KArgs a_in, ChainArgs ca)
                 __builtin_amdgcn_sched_barrier(0);
                 const int kend = min(k0 + CHAIN_SUB, fn);
                 const int slot0 = wrap_slot(fs_slot + k0);
-                slot = slot0;
-                // the record of frame k + 1 is read from LDS while frame k computes
-                uint4 rc_cur = make_uint4(0u, 0u, 0u, 0u);
-                if (!FUSED) rc_cur = s_arec[(size_t)((unsigned)k0 % CHAIN_SUB) * BLOCK + tid];
-                for (int k = k0; k < kend; ++k) {
-                    uint4 rc_nxt = make_uint4(0u, 0u, 0u, 0u);
-                    if (!FUSED && k + 1 < kend) rc_nxt = s_arec[(size_t)((unsigned)(k + 1) % CHAIN_SUB) * BLOCK + tid];
-                    frame_body(k, rc_cur);
-                    rc_cur = rc_nxt;
+                // the sub-pass's count words stay in registers and go out together behind it (a store inside the frame loop would
+                // stand between the loop and the arrival of the next sub-pass's records: vector memory operations retire in order)
+                uint32_t cwq[CHAIN_SUB];
+#pragma unroll
+                for (int j = 0; j < CHAIN_SUB; ++j) cwq[j] = 0u;
+                if (kend - k0 == CHAIN_SUB) { // a full sub-pass, unrolled: LDS offsets, ring slots and lane indices fold
+#pragma unroll
+                    for (int j = 0; j < CHAIN_SUB; ++j) cwq[j] = frame_body(k0 + j, j);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < CHAIN_SUB; ++j)
+                        if (k0 + j < kend) cwq[j] = frame_body(k0 + j, j);
                 }
                 if (!FUSED) {
                     const int nnext = min(CHAIN_SUB, fn - k0 - CHAIN_SUB); // frames of the next sub-pass (<= 0: none)
-                    if (valid) {
 #pragma unroll
-                        for (int j = 0; j < CHAIN_SUB; ++j)
-                            if (j < nnext) s_arec[(size_t)j * BLOCK + tid] = nx[j];
-                    }
+                    for (int j = 0; j < CHAIN_SUB; ++j) // (every lane: a lane beyond the frame keeps zero records in LDS)
+                        if (j < nnext) s_arec[(size_t)j * BLOCK + tid] = nx[j];
                     // the sub-pass after the next: its loads go out BEFORE this sub-pass's count words (vector memory operations
                     // retire in order; the wait above then only ever covers operations a whole sub-pass old)
                     fetch_next(k0 + 2 * CHAIN_SUB);
                     if (valid) {
                         int sl = slot0;
-                        for (int k = k0; k < kend; ++k) { // the sub-pass's count words
-                            __builtin_amdgcn_raw_buffer_store_b32(s_cw[(size_t)((unsigned)k % CHAIN_SUB) * BLOCK + tid], cnt_rsrc, (int)(lane_px * 4u),
-                                                                  (int)((uint32_t)sl * slot_px * 4u), 17); // sc0 sc1: written through, as WT_STORE
+#pragma unroll
+                        for (int j = 0; j < CHAIN_SUB; ++j) { // the sub-pass's count words
+                            if (k0 + j < kend)
+                                __builtin_amdgcn_raw_buffer_store_b32(cwq[j], cnt_rsrc, (int)(lane_px * 4u), (int)((uint32_t)sl * slot_px * 4u), 17); // sc0 sc1: written through, as WT_STORE
                             if (++sl == ca.D) sl = 0;
                         }
                     }
                 }
+            }
+            // the pass's ruleM slots: M where the rule finalised the frame, 0 elsewhere (the emission reads them; one wave writes them)
+            if (a.has_refr && g == 0 && tid < WAVE) {
+                int sl = fs_slot + lane;
+                if (sl >= ca.D) sl -= ca.D;
+                if (lane >= c0 && lane < fn) WT_STORE(&ca.ruleM[(size_t)sl * ca.n_clips + clip], rule_v);
             }
             if (own) break;
             // a redo pass: leave the corrected state where the next launch's own redo would look for it, and let every

@@ -1054,7 +1054,7 @@ class EventEmulator(object):
                                     % self._failed)
         if pend.ticket is not None:
             eng.run_wait(pend.ticket)  # (host-blocking; no device-side wait is put into any stream's queue)
-            r = eng.read_recs_after(pend.recs, None)[:, 0]
+            r = eng.run_recs(pend.ticket)[:, 0]
         else:
             r = eng.read_recs_after(pend.recs, pend.done)[:, 0]
         if self.refractory_period_s > 0:  # emulator.py:830 on the frames just run: how often was the rule active?

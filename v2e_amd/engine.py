@@ -94,6 +94,10 @@ def _dbl_array(vals):
     return arr
 
 
+_REC_DT = np.dtype([("max_events", "<i4"), ("flags", "<u4"), ("n_signal", "<u4"), ("n_events", "<u4"),
+                    ("n_on", "<u4"), ("n_off", "<u4"), ("ev_offset", "<u8")])
+
+
 class EmuEngine:
     """Device state + kernels of `n_clips` DVS pixel arrays of size H x W."""
 
@@ -402,6 +406,16 @@ class EmuEngine:
     def run_wait(self, ticket):
         check(self.lib.v2e_emu_run_wait(self._h, int(ticket)), "v2e_emu_run_wait")
 
+    def run_recs(self, ticket):
+        """Records of the pipelined run with that ticket (behind run_wait) as a structured array [n_frames][n_clips], copied out of the
+        handle's pinned buffer."""
+        n = C.c_uint64()
+        ptr = self.lib.v2e_emu_run_recs(self._h, int(ticket), C.byref(n))
+        if not ptr:
+            raise _capi.V2EAmdError("no records for that ticket")
+        raw = np.frombuffer(C.string_at(ptr, int(n.value) * C.sizeof(FrameRec)), dtype=_REC_DT)
+        return raw.reshape(-1, self.n_clips)
+
     def read_recs_after(self, recs_dev, done_event):
         """Records of a run as a structured numpy array, copied on a side stream once `done_event` (recorded behind the run)
         has completed: later runs already enqueued on the main stream are not waited for."""
@@ -417,10 +431,8 @@ class EmuEngine:
                 cs.wait_event(done_event)
             host[key].copy_(recs_dev, non_blocking=True)
             cs.synchronize()
-        dt = np.dtype([("max_events", "<i4"), ("flags", "<u4"), ("n_signal", "<u4"), ("n_events", "<u4"),
-                       ("n_on", "<u4"), ("n_off", "<u4"), ("ev_offset", "<u8")])
         a = host[key].numpy().copy()
-        return a.view(dt).reshape(a.shape[0], a.shape[1])
+        return a.view(_REC_DT).reshape(a.shape[0], a.shape[1])
 
     @staticmethod
     def recs_to_numpy(recs_dev):
