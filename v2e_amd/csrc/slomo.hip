@@ -440,60 +440,96 @@ __global__ __launch_bounds__(256) void k_upsample2_scalar(const float *__restric
     y[i] = hy * (hx * p[y0 * sw + x0] + lx * p[y0 * sw + x1]) + ly * (hx * p[y1 * sw + x0] + lx * p[y1 * sw + x1]);
 }
 
-// Final UNet layer (32 -> 4/5 channels, 3x3): too few output channels for a 32-wide MFMA tile
-// (84 % of it would be padding), so one thread computes one pixel for all COUT channels on the
-// VALU from an LDS-staged input patch; weights are wave-uniform scalar loads.
+// Final UNet layer (32 -> 4/5 channels, 3x3): too few output channels for a 32-wide MFMA tile (84 % of it would be padding: at the
+// ~190 TF/s the 32-channel full-resolution layers reach, a padded tile would take longer than this), so it runs on the VALU from an
+// LDS-staged input patch with wave-uniform scalar weight loads.  Round 6: FOUR pixels along x per thread -- a row of the patch is read
+// as 6 floats (one 16-byte and one 8-byte LDS read) for 3 taps x 4 pixels x COUT = 60 multiply-adds, where one pixel per thread read
+// 9 floats for 45 (the kernel was bound by its LDS reads: 33 TF/s); same accumulation order (ci, ky, kx) per output.
 template <int COUT>
 __global__ __launch_bounds__(256) void k_conv3x3_small(const float *__restrict__ x, const float *__restrict__ wp /* [cin][3][3][COUT] */,
                                                        const float *__restrict__ bias, float *__restrict__ y, int n_img, int cin,
                                                        int h, int w, int tiles_x, int tiles_y)
 {
-    constexpr int TW = 32, TH = 8, PH = TH + 2, PW = TW + 2, CI_T = 8;
-    __shared__ float sp[CI_T * PH * PW];
+    constexpr int PXT = 4, TW = 64, TH = 16, PH = TH + 2, PW = 68 /* 66 padded: rows start 16-byte aligned */, CI_T = 8;
+    __shared__ __attribute__((aligned(16))) float sp[CI_T * PH * PW];
     const int tid = threadIdx.x;
     int bx = blockIdx.x;
     const int tx_i = bx % tiles_x; bx /= tiles_x;
     const int ty_i = bx % tiles_y;
     const int n = bx / tiles_y;
     const int oy0 = ty_i * TH, ox0 = tx_i * TW;
-    const int ty = tid / TW, tx = tid % TW;
+    const int ty = tid / (TW / PXT), tx = (tid % (TW / PXT)) * PXT; // this thread's row and first column inside the tile
     const int hw = h * w;
-    float acc[COUT];
+    float acc[PXT][COUT];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int q = 0; q < PXT; ++q)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[q][co] = 0.f;
     for (int cb = 0; cb < cin; cb += CI_T) {
-        __syncthreads();
-        for (int idx = tid; idx < CI_T * PH * PW; idx += 256) {
-            const int ci = idx / (PH * PW);
-            const int r = idx - ci * (PH * PW);
-            const int py = r / PW, px = r - py * PW;
+        // the chunk's patch: every load of a thread in flight before the first LDS store (a rolled loop waits for each load in turn)
+        constexpr int NPATCH = CI_T * PH * (TW + 2), NLD = (NPATCH + 255) / 256;
+        float stg[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + j * 256;
+            const int ci = idx / (PH * (TW + 2));
+            const int r = idx - ci * (PH * (TW + 2));
+            const int py = r / (TW + 2), px = r - py * (TW + 2);
             const int gy = oy0 + py - 1, gx = ox0 + px - 1;
-            float v = 0.f;
-            if (cb + ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w) v = x[((size_t)n * cin + cb + ci) * hw + gy * w + gx];
-            sp[idx] = v;
+            stg[j] = 0.f;
+            if (idx < NPATCH && cb + ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w) stg[j] = x[((size_t)n * cin + cb + ci) * hw + gy * w + gx];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + j * 256;
+            const int ci = idx / (PH * (TW + 2));
+            const int r = idx - ci * (PH * (TW + 2));
+            const int py = r / (TW + 2), px = r - py * (TW + 2);
+            if (idx < NPATCH) sp[(ci * PH + py) * PW + px] = stg[j];
         }
         __syncthreads();
 #pragma unroll
         for (int ci = 0; ci < CI_T; ++ci) {
             if (cb + ci >= cin) break;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky) {
+                const float *row = sp + (ci * PH + ty + ky) * PW + tx;
+                const float4 va = *(const float4 *)row;
+                const float2 vb = *(const float2 *)(row + 4);
+                const float v[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const float v = sp[(ci * PH + ty + ky) * PW + tx + kx];
                     const float *wr = wp + ((size_t)(cb + ci) * 9 + ky * 3 + kx) * COUT;
 #pragma unroll
-                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wr[co], v, acc[co]);
+                    for (int co = 0; co < COUT; ++co) {
+                        const float wv = wr[co];
+#pragma unroll
+                        for (int q = 0; q < PXT; ++q) acc[q][co] = fmaf(wv, v[q + kx], acc[q][co]);
+                    }
                 }
+            }
         }
     }
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy < h && ox < w) {
+    const int oy = oy0 + ty;
+    if (oy < h) {
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
-            float v = acc[co] + bias[co];
-            v = v > 0.f ? v : v * 0.1f;
-            y[((size_t)n * COUT + co) * hw + oy * w + ox] = v;
+            const float bv = bias[co];
+            float o[PXT];
+#pragma unroll
+            for (int q = 0; q < PXT; ++q) {
+                const float t = acc[q][co] + bv;
+                o[q] = t > 0.f ? t : t * 0.1f;
+            }
+            float *dst = y + ((size_t)n * COUT + co) * hw + oy * w + ox0 + tx;
+            if (ox0 + tx + PXT <= w && (w & 3) == 0) {
+                *(float4 *)dst = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < PXT; ++q)
+                    if (ox0 + tx + q < w) dst[q] = o[q];
+            }
         }
     }
 }
@@ -752,6 +788,14 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
             // (the 20-wide level's 5-wave tiles with 64 channels: measured slower, 18.39 against 17.95 ms per forward)
         }
         if (ks == 3) {
+            // (dev, round 6: 32 channels x 128 pixels per wave on the 32-channel full-resolution layers -- one weight operand read feeds
+            // four multiplies; variants 31 / 32)
+            // 32-channel layers (up5.*: 64 -> 32 at full resolution): 32 channels x 128 pixels per wave with one kernel row of weights
+            // resident at a time -- a weight operand read from LDS feeds four multiplies instead of two: 1262 / 1242 -> 1149 / 1134 us per
+            // layer at 80 samples (profiles/r06_slomo_per_layer.txt; variant 33: the 32 x 64 tile of rounds 3-5; all weights resident
+            // with this tile, variant 31, measured slower than either)
+            if (a.w_ % 32 == 0 && a.h % 16 == 0 && variant == 31) return launch_conv_s3<3, 1, 4, 4, 32, 1, 0, 0, 2>(a, s);
+            if (a.w_ % 32 == 0 && a.h % 16 == 0 && variant != 33) return launch_conv_s3<3, 1, 4, 4, 32, 1, 0, 1, 2>(a, s);
             if (a.w_ % 32 == 0) return launch_conv_s3<3, 1, 2, 4, 32, 1, 0, 0, 2>(a, s);
             if (a.w_ % 16 == 0) return launch_conv_s3<3, 1, 2, 4, 16, 1, 0, 0, 2>(a, s);
             if (a.w_ % 8 == 0) return launch_conv_s3<3, 1, 2, 4, 8, 1, 0, 0, 2>(a, s);
@@ -765,6 +809,8 @@ static int conv_dispatch_s3(const ConvArgs &a, int ks, hipStream_t s)
         }
         if (ks == 5 && a.w_ % 32 == 0 && a.cout % 64 == 0 && variant != 18) return launch_conv_s3<5, 2, 2, 4, 32, 1, 0, 1, 2>(a, s); // 64 x 64 tiles: 1.5 % more
         if (ks == 5 && a.w_ % 32 == 0) return launch_conv_s3<5, 1, 2, 4, 32, 1, 0, 0, 2>(a, s);
+        // (dev, round 6: 32 channels x 128 pixels per wave on the 7x7 layers too; variant 34)
+        if (ks == 7 && a.w_ % 32 == 0 && a.h % 16 == 0 && variant == 34) return a.cin % 16 == 0 ? launch_conv_s3<7, 1, 4, 4, 32, 1, 0, 0, 2>(a, s) : launch_conv_s3<7, 1, 4, 4, 32, 1, 1, 0, 2>(a, s);
         if (ks == 7 && a.w_ % 32 == 0) return a.cin % 16 == 0 ? launch_conv_s3<7, 1, 2, 4, 32, 1, 0, 0, 2>(a, s) : launch_conv_s3<7, 1, 2, 4, 32, 1, 1, 0, 2>(a, s);
         return 1;
     }
@@ -897,7 +943,7 @@ int v2e_conv2d_lrelu(const float *x0, int c0, const float *x1, int c1, int pre, 
     a.tl_on = 0;
     a.am_in0 = g_am_in0; a.am_in1 = g_am_in1; a.am_out = g_am_out; a.ypool = nullptr;
     if (conv->ksize == 3 && pre == 0 && c1 == 0 && (conv->cout == 4 || conv->cout == 5)) {
-        const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;
+        const int tiles_x = (w + 63) / 64, tiles_y = (h + 15) / 16;
         dim3 grid((unsigned)(n * tiles_x * tiles_y));
         if (conv->cout == 4) k_conv3x3_small<4><<<grid, 256, 0, (hipStream_t)stream>>>(x0, conv->weight, conv->bias, y, n, conv->cin, h, w, tiles_x, tiles_y);
         else k_conv3x3_small<5><<<grid, 256, 0, (hipStream_t)stream>>>(x0, conv->weight, conv->bias, y, n, conv->cin, h, w, tiles_x, tiles_y);
