@@ -41,7 +41,7 @@ def _check_line(d, n, steps, warmup):
         sh = d["slomo_sharded"]
         assert "error" not in sh, sh
         assert sh["ranks"] == n and sh["scaling"] == "strong" and sh["frames_gathered_in_order"] is True and sh["value"] > 0
-        assert sh["bytes_gathered_per_clip"] == 10 * 3 * 6 * 8
+        assert sh["max_abs_diff_vs_unsharded"] == 0 and sh["bytes_received_by_owner_per_clip"] == 10 * 3 * 6 * 8 * (n - 1) // n
     # the stub's event counts are a known function of (rank, step): SUM over ranks of the median block's steps
     from tests.bench_stub import stub_counts
     F = d["config"]["frames_per_step"]

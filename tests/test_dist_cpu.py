@@ -299,7 +299,11 @@ class _StubSloMoPipeline:
 
                 class Emu:
                     def generate_events_batch(self, frames, times, return_device=False):
-                        outer.seen = (frames.clone(), np.asarray(times).copy())
+                        # (every call's frames and times, concatenated: a chunked run feeds the emulator chunk by chunk)
+                        if outer.seen is None:
+                            outer.seen = (frames.clone(), np.asarray(times).copy())
+                        else:
+                            outer.seen = (torch.cat((outer.seen[0], frames)), np.concatenate((outer.seen[1], np.asarray(times))))
                         return torch.zeros((int(frames.sum()) % 7, 4)), np.asarray([int(f.sum()) % 5 for f in frames])
                 self.emu = Emu()
 
@@ -331,6 +335,16 @@ def _slomo_shard_worker(rank, world, port, q, n_src, U):
         ok &= ev2 is None and c2 is None and sharded.seen is None
     every = sharded.upsample_sharded(frames, dist.group.WORLD, None)  # owner=None: the clip on every rank
     ok &= torch.equal(every, single.seen[0])
+    # in chunks of 3 and of 1 source pairs (the owner's DVS stage on chunk c while chunk c + 1 is interpolated; ragged last chunk, chunks
+    # with fewer pairs than ranks): the same frames in the same order with the same times, the same per-frame counts
+    for cp in (3, 1):
+        chunked = _StubSloMoPipeline(U, 2)
+        ev3, c3, n3 = chunked.run(frames, 1 / 30, group=dist.group.WORLD, owner=world - 1, chunk_pairs=cp)
+        ok &= n3 == n1
+        if rank == world - 1:
+            ok &= torch.equal(chunked.seen[0], single.seen[0]) and np.array_equal(chunked.seen[1], single.seen[1]) and np.array_equal(c3, c1)
+        else:
+            ok &= ev3 is None and c3 is None and chunked.seen is None
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -355,7 +355,7 @@ def e2e_bench(device, n_src=31, U=10, H=260, W=346, batch=10, reps=3):
 def slomo_sharded_bench(device, dist, n_src=65, U=10, H=260, W=346, batch=8, reps=3, pipe=None):
     """ONE clip's SuperSloMo stage sharded over the ranks of the job by source pairs (north_star: "frame batches shard across the
     GPUs"): every rank holds the same 346x260 source clip (seed 2), interpolates its contiguous block of the 64 pairs
-    (VideoToEvents.upsample_sharded) and the uint8 frames are all-gathered in order to rank 0.  STRONG scaling: the clip is fixed,
+    (VideoToEvents.upsample_sharded) and the uint8 frames are sent in order to rank 0 (point to point, exact sizes).  STRONG scaling: the clip is fixed,
     the ranks split it; value = interpolated frames of the whole clip / wall time (barrier + synchronise on both sides, max over
     ranks by construction of the barrier).  At world size 1 it is the unsharded stage with a one-rank gather.
     pipe: an object with upsample_sharded(frames, group, owner) and upsample(frames) in place of the HIP pipeline (bench.py's stub
@@ -381,22 +381,43 @@ def slomo_sharded_bench(device, dist, n_src=65, U=10, H=260, W=346, batch=8, rep
     g.manual_seed(2)
     src = torch.randint(0, 256, (n_src, H, W), dtype=torch.uint8, device=device, generator=g)
     world = dist.get_world_size()
-    out = pipe.upsample_sharded(src, dist.group.WORLD, 0)  # warm-up: allocations, RCCL channels
+
+    def agreed(fn):
+        """fn() on every rank; an exception on ANY rank is agreed on (an all-reduce of the error flags) before anybody enters the next
+        collective -- a rank that raised would otherwise leave its peers waiting in it."""
+        err = None
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001
+            res, err = None, repr(e)[:200]
+        flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag)
+        if int(flag.item()):
+            raise RuntimeError("slomo_sharded: %d rank(s) failed%s" % (int(flag.item()), (": " + err) if err else ""))
+        return res
+
+    out = agreed(lambda: pipe.upsample_sharded(src, dist.group.WORLD, 0))  # warm-up: allocations, RCCL channels
     sync()
     dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(reps):
-        out = pipe.upsample_sharded(src, dist.group.WORLD, 0)
+        out = agreed(lambda: pipe.upsample_sharded(src, dist.group.WORLD, 0))
     sync()
     dist.barrier()
     sync()
     sec = (time.perf_counter() - t0) / reps
     n = (n_src - 1) * U
-    ok = out is None or tuple(out.shape) == (n, H, W)
-    if stub and out is not None:  # the gathered clip IS the unsharded one
-        ok = ok and bool(torch.equal(out, pipe.upsample(src)))
+    # rank 0: the gathered clip against the unsharded stage on the same source (the shards move the interpolation's batch boundaries:
+    # with the default conv math the activation scale is per batch tensor, so the uint8 frames may differ by a grey level here and there)
+    maxdiff = frac_diff = None
+    if out is not None:
+        ref = pipe.upsample(src)
+        d = (out.to(torch.int16) - ref.to(torch.int16)).abs()
+        maxdiff, frac_diff = int(d.max().item()), float((d > 0).float().mean().item())
+    ok = out is None or (tuple(out.shape) == (n, H, W) and maxdiff <= (0 if stub else 1))
     return {"value": round(n / sec, 1), "unit": "interpolated frames/s", "scaling": "strong", "ranks": world, "ms_per_clip": round(sec * 1e3, 2),
-            "frames_gathered_in_order": bool(ok), "bytes_gathered_per_clip": int(n * H * W),
-            "config": "one %dx%d clip, %d source pairs, U = %d, pairs [r P / G, (r + 1) P / G) per rank, uint8 frames all-gathered in order "
-                      "to rank 0 (v2e_amd.pipeline.VideoToEvents.upsample_sharded)" % (W, H, n_src - 1, U)}
+            "frames_gathered_in_order": bool(ok), "max_abs_diff_vs_unsharded": maxdiff, "fraction_of_pixels_differing": frac_diff,
+            "bytes_received_by_owner_per_clip": int(n * H * W * (world - 1) / max(world, 1)),
+            "config": "one %dx%d clip, %d source pairs, U = %d, pairs [r P / G, (r + 1) P / G) per rank, uint8 frames sent in order "
+                      "to rank 0, point to point (v2e_amd.pipeline.VideoToEvents.upsample_sharded)" % (W, H, n_src - 1, U)}

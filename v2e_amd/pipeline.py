@@ -124,8 +124,8 @@ class VideoToEvents:
         """SuperSloMo of ONE clip over the ranks of `group` (BASELINE north_star: "frame batches shard across the
         GPUs"): the P = N - 1 source pairs are independent (slomo.py:330-466: every batch is computed from its own frames), so rank r
         interpolates pairs [r P / G, (r + 1) P / G) -- it needs source frames r P / G .. (r + 1) P / G only -- and the uint8 output
-        frames are gathered IN ORDER (one all-gather of the ranks' frame blocks, padded to the largest block: 90 KB per frame at
-        346x260, 27 MB for a second of video at 10x; `owner`: only that rank assembles the clip, None: every rank does).
+        frames are gathered IN ORDER: to rank `owner` point to point with exact sizes (90 KB per frame at 346x260, 27 MB for a second
+        of video at 10x), or, owner = None, to every rank by one all-gather of padded blocks (gather_frames_in_order).
         Returns uint8 [(N - 1) U, H, W] on the assembling rank(s), None elsewhere.  Every rank must hold the same frames_u8 (or at
         least its own slice of it: only frames lo .. hi are read)."""
         import torch.distributed as dist
@@ -137,11 +137,17 @@ class VideoToEvents:
         mine = self.upsample(frames_u8[lo:hi + 1]) if hi > lo else frames_u8.new_empty((0,) + tuple(frames_u8.shape[1:]))
         return gather_frames_in_order(mine, N - 1, self.U, group, owner)
 
-    def run(self, frames_u8, src_frame_interval_s, return_device=False, group=None, owner=0):
+    def run(self, frames_u8, src_frame_interval_s, return_device=False, group=None, owner=0, chunk_pairs=None):
         """Full pipeline; returns (events, counts_per_interpolated_frame, n_interpolated_frames).
         group: a torch.distributed process group -- the SuperSloMo stage is sharded over its ranks by source pairs
         (`upsample_sharded`), the frames are funnelled in order to rank `owner` (rank within the group), which holds the emulator
-        state and runs the DVS model; the other ranks return (None, None, n)."""
+        state and runs the DVS model; the other ranks return (None, None, n).
+        chunk_pairs (with a group): the clip goes through in CHUNKS of that many source pairs -- every chunk sharded over the ranks
+        and sent to the owner (point to point, exact sizes), the owner's DVS stage taking chunk c (enqueued, not waited for) while
+        the ranks, the owner included, interpolate chunk c + 1: for a long clip the owner no longer idles through the whole
+        interpolation and holds one chunk of frames, not the clip.  Same frames, order, times and events as one rank."""
+        if group is not None and chunk_pairs:
+            return self._run_chunked(frames_u8, src_frame_interval_s, return_device, group, owner, int(chunk_pairs))
         if group is not None:
             import torch.distributed as dist
             up = self.upsample_sharded(frames_u8, group, owner)
@@ -155,6 +161,65 @@ class VideoToEvents:
         ev, counts = self.emu.generate_events_batch(up, times, return_device=return_device)
         return ev, counts, n
 
+    def _run_chunked(self, frames_u8, src_frame_interval_s, return_device, group, owner, chunk_pairs):
+        import torch.distributed as dist
+        G, r = dist.get_world_size(group), dist.get_rank(group)
+        N = int(frames_u8.shape[0])
+        P, U = N - 1, self.U
+        times = interp_frame_times(N, U, float(src_frame_interval_s), self.batch_size)
+        shape = tuple(frames_u8.shape[1:])
+        evs, counts, pending = [], [], None   # pending: (receive requests, the chunk's frames, its times) -- the chunk the owner takes next
+        asynchronous = hasattr(self.emu, "generate_events_batch_async")
+        runs = []
+
+        def dvs(chunk, t):
+            if asynchronous:  # enqueue; the result is read at the end (the emulator alternates two buffer sets: at most two in flight)
+                runs.append(self.emu.generate_events_batch_async(chunk, t, return_device=return_device))
+                while len(runs) > 1:
+                    e, c = runs.pop(0).result()
+                    evs.append(e if return_device or e is None else e)
+                    counts.append(c)
+            else:
+                e, c = self.emu.generate_events_batch(chunk, t, return_device=return_device)
+                evs.append(e)
+                counts.append(c)
+
+        for p0 in range(0, P, chunk_pairs):
+            p1 = min(p0 + chunk_pairs, P)
+            lo, hi = pair_shard(p1 - p0, G, r)
+            # (the owner posts its receives BEFORE its own share of the interpolation: the other ranks' sends then complete as they finish)
+            reqs, chunk = send_frames_to_owner_begin(p1 - p0, U, shape, frames_u8, group, owner)
+            mine = self.upsample(frames_u8[p0 + lo:p0 + hi + 1]) if hi > lo else frames_u8.new_empty((0,) + shape)
+            if r == owner and pending is not None:  # the DVS stage of the chunk BEFORE, while this chunk's frames arrive
+                for q in pending[0]:
+                    q.wait()
+                dvs(pending[1], pending[2])
+            reqs = send_frames_to_owner_finish(reqs, chunk, mine, p1 - p0, U, group, owner)
+            if r == owner:
+                pending = (reqs, chunk, times[p0 * U:p1 * U])
+            else:
+                for q in reqs:
+                    q.wait()
+        n = P * U
+        if r != owner:
+            return None, None, n
+        for q in pending[0]:
+            q.wait()
+        dvs(pending[1], pending[2])
+        for run in runs:
+            e, c = run.result()
+            evs.append(e)
+            counts.append(c)
+        import numpy as np
+        evs = [e for e in evs if e is not None and len(e)]
+        if not evs:
+            ev = None
+        elif torch.is_tensor(evs[0]):
+            ev = torch.cat(evs)
+        else:
+            ev = np.concatenate(evs)
+        return ev, np.concatenate([np.asarray(c) for c in counts]), n
+
 
 def pair_shard(n_pairs, world, rank):
     """Source pairs [lo, hi) of rank `rank`: contiguous blocks r P / G .. (r + 1) P / G; empty when P < G leaves none."""
@@ -162,17 +227,55 @@ def pair_shard(n_pairs, world, rank):
 
 
 def gather_frames_in_order(mine, n_pairs, U, group=None, owner=None):
-    """All-gather of the ranks' interpolated-frame blocks (uint8 [pairs_r U, H, W], pairs_r from pair_shard) into the clip's frame
-    order.  The blocks are padded to the largest one (ncclAllGather / gloo all_gather want equal sizes); block sizes follow from
-    (n_pairs, world) alone, so no size exchange is needed."""
+    """The ranks' interpolated-frame blocks (uint8 [pairs_r U, H, W], pairs_r from pair_shard) in the clip's frame order.
+    owner = a rank of the group: POINT TO POINT to that rank, exact sizes, received straight into the clip's tensor (round 6; an
+    all-gather hands every rank the whole clip -- G - 1 times the receive volume anybody needs -- and wants the blocks padded to the
+    largest); the other ranks return None.  owner = None: every rank assembles the clip (one all-gather of padded blocks).  Block
+    sizes follow from (n_pairs, world) alone, so no size exchange is needed."""
     import torch.distributed as dist
     G, r = dist.get_world_size(group), dist.get_rank(group)
     cnt = [(pair_shard(n_pairs, G, q)[1] - pair_shard(n_pairs, G, q)[0]) * U for q in range(G)]
     assert int(mine.shape[0]) == cnt[r], "this rank interpolated %d frames, its shard has %d" % (int(mine.shape[0]), cnt[r])
+    if owner is not None:
+        reqs, clip = send_frames_to_owner_begin(n_pairs, U, tuple(mine.shape[1:]), mine, group, owner)
+        for q in send_frames_to_owner_finish(reqs, clip, mine, n_pairs, U, group, owner):
+            q.wait()
+        return clip if r == owner else None
     m = max(cnt)
     pad = mine if cnt[r] == m else torch.cat((mine, mine.new_zeros((m - cnt[r],) + tuple(mine.shape[1:]))))
     parts = [torch.empty_like(pad) for _ in range(G)]
     dist.all_gather(parts, pad.contiguous(), group=group)
-    if owner is not None and r != owner:
-        return None
     return torch.cat([parts[q][:cnt[q]] for q in range(G)])
+
+
+def _global_rank(group, q):
+    import torch.distributed as dist
+    return q if group is None or group is dist.group.WORLD else dist.get_global_rank(group, q)
+
+
+def send_frames_to_owner_begin(n_pairs, U, frame_shape, like, group, owner):
+    """Owner: the tensor of the n_pairs * U frames and one posted receive per other rank's block, straight into its slice (posted
+    before the owner's own interpolation, so that a sender never waits for the receiver).  Other ranks: ([], None)."""
+    import torch.distributed as dist
+    G, r = dist.get_world_size(group), dist.get_rank(group)
+    if r != owner:
+        return [], None
+    clip = like.new_empty((n_pairs * U,) + tuple(frame_shape))
+    reqs = []
+    for q in range(G):
+        lo, hi = pair_shard(n_pairs, G, q)
+        if q != owner and hi > lo:
+            reqs.append(dist.irecv(clip[lo * U:hi * U], src=_global_rank(group, q), group=group))
+    return reqs, clip
+
+
+def send_frames_to_owner_finish(reqs, clip, mine, n_pairs, U, group, owner):
+    """Owner: its own block copied into place, the receive requests handed back.  Other ranks: their block sent (a request to wait for)."""
+    import torch.distributed as dist
+    G, r = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = pair_shard(n_pairs, G, r)
+    if r == owner:
+        if hi > lo:
+            clip[lo * U:hi * U] = mine
+        return reqs
+    return [dist.isend(mine.contiguous(), dst=_global_rank(group, owner), group=group)] if hi > lo else []
