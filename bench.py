@@ -162,7 +162,11 @@ def recorded_reference():
     """The unmodified reference timed on the build container's CPU (scripts/cpu_reference_baseline.py): recorded,
     because /root/reference does not exist on the GPU box."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_reference.json")))
+        for name in ("r06_cpu_reference.json", "r02_cpu_reference.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                return json.load(open(path))
+        return None
     except Exception:
         return None
 

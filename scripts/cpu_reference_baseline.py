@@ -9,7 +9,7 @@ tests/golden/ref_harness.py, which stubs only imports that the hot path never ca
 
 each at torch.set_num_threads(1) and at all cores; warm-up, then median of 3 repeats; only the reference calls are
 inside the timed region (no frame synthesis, no PNG/disk).  The reference cannot travel to the GPU box
-(/root/reference exists only in the build container), so the result is RECORDED: profiles/r02_cpu_reference.json,
+(/root/reference exists only in the build container), so the result is RECORDED: profiles/r06_cpu_reference.json (host, time and repository commit stamped),
 which bench.py attaches to its JSON line as cpu_baseline.reference (host named).
 
 usage: python scripts/cpu_reference_baseline.py [--frames 120] [--quick]
@@ -117,7 +117,14 @@ def main():
         r = time_slomo(B, 10, th, reps=rp)
         print("slomo", r, flush=True)
         out["slomo"]["runs"].append(r)
-    path = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
+    import subprocess
+    try:
+        out["host"]["repo_commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        out["host"]["repo_commit"] = None
+    out["host"]["recorded"] = time.strftime("%Y-%m-%d %H:%M:%S")
+    out["host"]["hostname"] = platform.node()
+    path = os.path.join(ROOT, "profiles", "r06_cpu_reference.json")
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
 

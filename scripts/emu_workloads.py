@@ -14,17 +14,13 @@ from v2e_amd.benchutil import batched_emulator_bench, hd_noisy_emulator_bench  #
 which = sys.argv[1:] or ["headline", "batched", "hd"]
 dev = torch.device("cuda")
 if "headline" in which:
-    F, steps = B.FRAMES_PER_STEP, 4
+    # the TIMED configuration: bench.py's loop (run_steps: pipelined runs, the next run enqueued while this one executes)
+    from v2e_amd.benchutil import run_steps  # noqa: E402
+    F, steps = B.FRAMES_PER_STEP, 8
     frames = B.gen_frames_device(steps * F + 1, 1, dev)
     emu = EventEmulator(device=dev, seed=1, rng_mode="philox", **B.DEFAULT_KW)
     emu.generate_events(frames[0], 0.0)
-    n = 0
-    for s in range(steps):
-        lo = 1 + s * F
-        ev, c = emu.generate_events_batch(frames[lo:lo + F].contiguous(), [(lo + i) * B.DT for i in range(F)],
-                                          return_device=True, use_graph=True)
-        n += int(c.sum())
-    torch.cuda.synchronize()
+    el, n = run_steps(emu, frames, F, B.DT, steps, 0, None, None, dev)
     print("headline: %d events in %d frames" % (n, steps * F))
 if "batched" in which:
     print("batched:", batched_emulator_bench(dev))

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""Assemble the committed round-5 profile artefacts (profiles/r05_*.txt) from what scripts/gpu_r05_profiles.sh left under
+"""Assemble the committed round-6 profile artefacts (profiles/r06_*.txt) from what scripts/gpu_r06_profiles.sh left under
 gpurun_out/ (rocprofv3 summaries made on the MI355X box).  bench.py / benchutil.py read the machine-readable lines:
-  r05_emulator_pmc_hbm.txt   '# k_chain<...>  <launches> <FETCH KiB> <WRITE KiB>'
-  r05_emulator_sq.txt        '# headline_instr_per_frame <VALU> <SALU> <frames>'
-  r05_slomo_counters.txt     '# unet_forward_bytes <conv_math> <fetch bytes> <write bytes>'"""
+  r06_emulator_pmc_hbm.txt   '# k_chain<...>  <launches> <FETCH KiB> <WRITE KiB>'
+  r06_emulator_sq.txt        '# headline_instr_per_frame <VALU> <SALU> <frames>'
+  r06_slomo_counters.txt     '# unet_forward_bytes <conv_math> <fetch bytes> <write bytes>'"""
 import os
 import re
 
@@ -95,21 +95,25 @@ def per_kernel_lines(rows, frames):
 
 
 def emulator():
-    kt, tl = rd("p5_kt.txt"), rd("p5_kt_timeline.txt")
-    window = rd("p5_kt_step.txt")
-    wr("r05_emulator_chain_kernel_trace.txt", """# rocprofv3 kernel trace of the headline workload, round 5 (k_ahead | k_chain | k_ctot + k_cframe1 + k_cpull, one hipGraph per run; k_cpull: the event writer as a pull, a thread per output row)
+    kt, tl = rd("p6_kt.txt"), rd("p6_kt_timeline.txt")
+    window = rd("p6_kt_step.txt")
+    wr("r06_emulator_chain_kernel_trace.txt", """# rocprofv3 kernel trace of the headline workload, round 6: PIPELINED runs (plain launches on four streams: the chain | k_ahead |
+# the emission tables k_ctot + k_cframe1 | the event rows k_cpull; no graph, no join at a run's end: DESIGN.md section 3)
 # command (on the MI355X box, cd /tmp; TMPDIR=/tmp):
-#   rocprofv3 --kernel-trace --stats -d out -- python bench.py --steps 4 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline
+#   rocprofv3 --kernel-trace --stats -d out -- python bench.py --steps 12 --warmup 3 --blocks 1 --no-extras --no-cpu-baseline --no-roofline-rerun
+# (--no-roofline-rerun: no instrumented re-run behind the timed steps, so EVERY k_chain launch below is one of the timed configuration,
+#  under contention with the other streams; the round-5 review found 66 alone-run launches blended into that round's 121.)
 # summarised by profiles/summarize_rocprof_db.py (top kernels) and scripts/kernel_timeline.py (k_chain launch timeline).
 # workload: BASELINE configs[1], 346x260, one clip, 300 frames per step, CLI-default DVS parameters, Philox.
-# one k_chain launch = 32 frames (10 per step + a tail launch validating the last speculation; a redo pass runs inside the launch
-# that finds the miss -- this round with a fence-free rendezvous); k_ahead / k_ctot / k_cframe1 / k_cpull: one launch per 64 frames.
-# The three streams run side by side on the same CUs: every duration below is a duration UNDER CONTENTION.
-# (Recorded with the build before profiles/r05_emulator_experiments.txt item 13 -- k_chain's ring accesses through buffer resources, the
-# round's last kernel change: 205 fewer static instructions in k_chain, a launch without a redo 29.6 -> 29.0 us; the GPU budget was spent.)
+# one k_chain launch = 32 frames (10 per step: nine full ones, one of 12 frames, + a tail launch validating the last speculation; a
+# redo pass runs inside the launch that finds the miss); k_ahead / k_ctot / k_cframe1 / k_cpull: one launch per 64 frames.
+# UNDER THE PROFILER the host's ~100 API calls per run take several times as long and the loop becomes host-bound (the steps of this
+# trace take ~2x the unprofiled 0.69 ms): the kernels' DURATIONS are what this file is for -- bench.py's live figure
+# (roofline.timed_configuration: device time stamps of the same launches in the unprofiled loop) is the one `frac` uses, and this
+# trace's k_chain average is its cross-check (roofline.rocprof_recorded).
 #
 """ + kt + "\n# k_chain launch timeline (same trace)\n" + tl + "\n# every kernel of the trace's last steps: start (us), duration (us), hardware queue, stream (scripts/dump_timeline.py)\n" + window)
-    f, w = rd("p5_FETCH_SIZE.txt"), rd("p5_WRITE_SIZE.txt")
+    f, w = rd("p6_FETCH_SIZE.txt"), rd("p6_WRITE_SIZE.txt")
     rows = []
     for k in ("k_chain<double, unsigned char, false", "k_ahead<unsigned char>", "k_cpull<false>", "k_cemit", "k_ctot", "k_cframe1"):
         n, fa = pmc_avg(f, k)
@@ -117,10 +121,11 @@ def emulator():
         if n is None and n2 is None:
             continue
         rows.append("# %-38s %4d  %9.1f  %9.1f" % (k + (", true>" if k.startswith("k_chain") else ""), n or n2, fa or 0.0, wa or 0.0))
-    wr("r05_emulator_pmc_hbm.txt", """# HBM traffic of the emulator kernels, round 5
+    wr("r06_emulator_pmc_hbm.txt", """# HBM traffic of the emulator kernels, round 6
 # commands (separate passes, as the MI355X guide prescribes; summary by profiles/summarize_rocprof_pmc.py):
-#   rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 4 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline
-#   rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 4 --warmup 1 --blocks 1 --no-extras --no-cpu-baseline
+#   rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py ...
+#   rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python bench.py ...
+# (the same command as the kernel trace: ... bench.py --steps 12 --warmup 3 --blocks 1 --no-extras --no-cpu-baseline --no-roofline-rerun)
 # workload: 346x260, one clip, 300 frames/step, CLI-default DVS parameters; a k_chain launch covers 32 frames, the others 64.
 # units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB (summed over XCDs); no x2 correction applied (the guide calibrates it for
 # wide coalesced streams; these kernels load 1-16 B per lane).  A kernel missing from one pass's top list shows 0.0.
@@ -134,29 +139,36 @@ def emulator():
 #
 # raw summaries:
 """ + f + w)
-    sqh, sqa = rd("p5_sqh.txt"), rd("p5_sq.txt")
+    sqh, sqa = rd("p6_sqh.txt"), rd("p6_sq.txt")
     v, s, rows = sq_totals(sqh)
-    m = re.search(r"headline: (\d+) events in (\d+) frames", rd("p5_sqh_frames.txt"))
+    m = re.search(r"headline: (\d+) events in (\d+) frames", rd("p6_sqh_frames.txt"))
     frames = int(m.group(2)) if m else 1200
     per_wave = (v + s) / frames / (346 * 260 / 64.0)
-    wr("r05_emulator_sq.txt", """# SQ counters of the emulator kernels, round 5
-# (recorded with the build before profiles/r05_emulator_experiments.txt item 13: k_chain has 205 fewer static instructions since)
+    wr("r06_emulator_sq.txt", """# SQ counters of the emulator kernels, round 6
 # command: rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU
-#          --kernel-trace -- python scripts/emu_workloads.py headline        (first table: the headline clip ALONE, %d frames)
+#          --kernel-trace -- python scripts/emu_workloads.py headline        (first table: the headline clip, the timed loop of bench.py: pipelined runs, %d frames)
 #          ... -- python scripts/emu_workloads.py batched hd                  (second table: 64 clips x 346x260; 1280x720 noisy)
 # summary: profiles/summarize_rocprof_sq.py; *_w = per wave and launch.
 # Instructions per frame of the headline pipeline = sum over its kernels of calls x waves x (VALU_w, SALU_w) / frames:
 # headline_instr_per_frame %.0f %.0f %d
-#   = %.0f VALU + %.0f SALU = %.0f instructions per 64-pixel wave and frame over the WHOLE pipeline (round 3: ~840 on the batched
-#   path by the same accounting; the review's target: <= 600)
+#   = %.0f VALU + %.0f SALU = %.0f instructions per 64-pixel wave and frame over the WHOLE pipeline (round 5: 700, round 4: 784; the round-5 review's target: <= 600)
 #
 """ % (frames, v / frames, s / frames, frames, v / frames / (346 * 260 / 64.0), s / frames / (346 * 260 / 64.0), per_wave) +
        "\n".join("#   %-44s calls %4d waves %8d  VALU_w %8.1f SALU_w %8.1f" % r for r in rows) + "\n#\n" + per_kernel_lines(rows, frames) + sqh +
        "\n# ---- batched (64 clips) and 1280x720 noisy\n" + sqa)
 
 
+def hd():
+    wr("r06_emulator_hd_kernel_trace.txt", """# rocprofv3 kernel trace of the 1280x720 `noisy` workload (BASELINE configs[3]; bench.py's hd_noisy leg), round 6
+# (one hipGraph per run, as in round 5: at this size the chain and the emission each fill the chip and pipelined runs measured
+#  11.3-11.4 against 11.5-12.0 Gev/s; pull event writer k_cpull<true>, emission batches of 64 frames)
+# command (on the MI355X box, cd /tmp; TMPDIR=/tmp): rocprofv3 --kernel-trace --stats -d out -- python scripts/emu_workloads.py hd
+#
+""" + rd("p6_hd.txt"))
+
+
 def slomo():
-    out = ["""# HBM traffic of ONE interpolation-UNet forward (12 -> 5 channels; 80 samples at 320x256, and 2 samples at 1280x704), round 5, per conv math
+    out = ["""# HBM traffic of ONE interpolation-UNet forward (12 -> 5 channels; 80 samples at 320x256, and 2 samples at 1280x704), round 6, per conv math
 # commands (separate passes): V2E_AMD_CONV_MATH=<m> rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace -- python scripts/slomo_layers.py 80
 # (three forwards per process; profiles/summarize_rocprof_pmc.py lists the per-launch average per kernel and the process total).
 # FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; total / 3 forwards = bytes per forward below (the weight packing and the
@@ -165,7 +177,7 @@ def slomo():
     for m, shape in (("fp16x2", None), ("bf16x3", None), ("f32", None), ("hd", "2x704x1280")):
         tot = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            t = rd("p5_slomo_%s_%s.txt" % (m, c))
+            t = rd("p6_slomo_%s_%s.txt" % (m, c))
             mm = re.search(r"total over the whole process: ([0-9.]+)", t)
             tot[c] = float(mm.group(1)) * 1024 / 3 if mm else 0.0
         out.append("# unet_forward_bytes %s %.0f %.0f %s" % ("fp16x2" if m == "hd" else m, tot["FETCH_SIZE"], tot["WRITE_SIZE"], shape or "80x256x320"))
@@ -173,18 +185,19 @@ def slomo():
                "(v2e_amd.benchutil.unet_algorithmic_bytes);\n# avg_pool2d / bilinear x2 run as their own passes and add their reads and writes.\n")
     for m in ("fp16x2", "bf16x3", "f32", "hd"):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            out.append("# ---- %s %s\n" % ("fp16x2 at 2 x 1280x704 (slomo_layers.py 2 704 1280)" if m == "hd" else m, c) + rd("p5_slomo_%s_%s.txt" % (m, c)))
-    wr("r05_slomo_counters.txt", "\n".join(out))
-    wr("r05_slomo_per_layer.txt", """# Interpolation UNet (12 -> 5 channels) forward at 320x256, 80 samples (B = 8 pairs x U = 10: what bench.py's slomo leg and the
-# 320x256 parity test run), per conv launch of the last of 3 forwards, round 5
+            out.append("# ---- %s %s\n" % ("fp16x2 at 2 x 1280x704 (slomo_layers.py 2 704 1280)" if m == "hd" else m, c) + rd("p6_slomo_%s_%s.txt" % (m, c)))
+    wr("r06_slomo_counters.txt", "\n".join(out))
+    wr("r06_slomo_per_layer.txt", """# Interpolation UNet (12 -> 5 channels) forward at 320x256, 80 samples (B = 8 pairs x U = 10: what bench.py's slomo leg and the
+# 320x256 parity test run), per conv launch of the last of 3 forwards, round 6
 # command: V2E_AMD_CONV_MATH=<m> rocprofv3 --kernel-trace --stats -- python scripts/slomo_layers.py 80   (parsed by scripts/parse_layers.py)
 # TF = algorithmic f32 FLOPs of the layer / its launch duration (f32-equivalent).  First table: fp16x2 (what the default "auto"
 # runs: two float16 pieces, operands staged times a power of two from the producers' range slots); second: bf16x3 (exact split).
 #
-""" + rd("p5_slomo_fp16x2_layers.txt") + "\n# ---- conv_math bf16x3\n" + rd("p5_slomo_bf16x3_layers.txt") +
-       "\n# ---- conv_math f32 (v_mfma_f32_32x32x2_f32: the reference's own arithmetic type)\n" + rd("p5_slomo_f32_layers.txt"))
+""" + rd("p6_slomo_fp16x2_layers.txt") + "\n# ---- conv_math bf16x3\n" + rd("p6_slomo_bf16x3_layers.txt") +
+       "\n# ---- conv_math f32 (v_mfma_f32_32x32x2_f32: the reference's own arithmetic type)\n" + rd("p6_slomo_f32_layers.txt"))
 
 
 if __name__ == "__main__":
     emulator()
+    hd()
     slomo()
