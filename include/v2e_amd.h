@@ -311,6 +311,12 @@ int v2e_emu_last_profile_launches(v2e_emu *h, float *us, int cap, int *n);
  * re-allocates the ring and forgets what it held).  What bench.py's roofline object divides the chain's algorithmic bytes by. */
 int v2e_emu_launch_stamps(v2e_emu *h, int runs, uint64_t *out_ns, int cap_runs, int *n_runs, int *launches_per_run);
 
+/* The event writer of the handle's k_chain pipeline: 1 = k_cpull (a thread per output row; needs 32 bytes of pixel ballots per frame
+ * of the table sets, group and key: 281 MB at 346x260 with max_iters = 64), 0 = k_cemit (the push writer: same rows, 1.5x the bytes
+ * written), -1 = no such run yet.  Chosen when the pipeline's scratch is allocated: the pull where its tables fit a quarter of the free
+ * device memory AND an absolute budget (24 GB per scratch set; V2E_AMD_PULL_BUDGET_MB), V2E_AMD_EMIT_PULL=0 forces the push writer. */
+int v2e_emu_event_writer(v2e_emu *h);
+
 /* Which pipeline the last v2e_emu_run on this handle used: kind 0 = unfused count/rank/scan/emit, 3 = k_chain (K frames
  * per launch, state in registers; records from k_ahead), 4 = k_chain with the per-frame records built inside the chain;
  * frames_per_launch of the dependency chain and frames per emission batch. */

@@ -101,6 +101,7 @@ SIGNATURES = {
                          _vp, _i, _vp]),
     "v2e_emu_run_join": (_i, [_vp, _vp]),
     "v2e_emu_run_ticket": (_i, [_vp]),
+    "v2e_emu_event_writer": (_i, [_vp]),
     "v2e_emu_run_wait": (_i, [_vp, _i]),
     "v2e_emu_run_recs": (_vp, [_vp, _i, C.POINTER(_u64)]),
     "v2e_emu_last_profile": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),

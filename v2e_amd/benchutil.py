@@ -268,7 +268,7 @@ def batched_emulator_bench(device, n_clips=64, frames=60, H=260, W=346):
     byts = bpp * H * W * n_clips * frames * reps + 16 * n_ev
     return {"value": round(n_ev / sec / 1e6, 1), "unit": "Mevents/s", "clips_per_launch": n_clips,
             "frames_per_s_all_clips": round(n_clips * frames * reps / sec, 1),
-            "algorithmic_GBps": round(byts / sec / 1e9, 1), "hbm_frac": round(byts / sec / HBM_PEAK, 4),
+            "algorithmic_GBps": round(byts / sec / 1e9, 1), "hbm_frac": round(byts / sec / HBM_PEAK, 4), "event_writer": eng.event_writer(),
             "note": "same kernels as the headline run, %d clips advanced per launch" % n_clips}
 
 
@@ -310,6 +310,7 @@ def hd_noisy_emulator_bench(device, frames=64, H=720, W=1280, reps=6):
     return {"value": round(n_ev / sec / 1e6, 1), "unit": "Mevents/s", "frames_per_s": round(frames * reps / sec, 1),
             "events_per_frame": round(n_ev / (frames * reps), 1), "algorithmic_GBps": round(byts / sec / 1e9, 1),
             "hbm_frac": round(byts / sec / HBM_PEAK, 4), "pipeline": "%s, %d frames per launch" % (kind, fpl),
+            "event_writer": emu._engine.event_writer(),
             "config": "BASELINE configs[3]: 1280x720, dvs_params noisy, dt=1/600 s, one clip, Philox"}
 
 

@@ -1862,9 +1862,14 @@ static std::vector<ChainLaunch> chain_plan(int n_frames, int K, int E, int nD, b
 static bool emit_pull(size_t table_bytes)
 {
     if (const char *e = getenv("V2E_AMD_EMIT_PULL")) { if (atoi(e) == 0) return false; } // (read when a handle's tables are allocated)
+    // an absolute budget as well as a share of what is free NOW (round-5 advisor: a quarter of momentarily free memory alone let the
+    // choice depend on who allocated first, and 18 GB of tables for 64 clips could starve a SloMo engine built later): 24 GB per
+    // scratch set by default, V2E_AMD_PULL_BUDGET_MB overrides; v2e_emu_event_writer says which writer a handle got
+    size_t budget = (size_t)24 << 30;
+    if (const char *e = getenv("V2E_AMD_PULL_BUDGET_MB")) { const long long v = atoll(e); if (v >= 0) budget = (size_t)v << 20; }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-    return table_bytes <= free_b / 4;
+    return table_bytes <= free_b / 4 && table_bytes <= budget;
 }
 
 static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_frames, int use_graph)
@@ -2561,6 +2566,7 @@ int v2e_emu_run_wait(v2e_emu *h, int ticket)
     return 0;
 }
 int v2e_emu_run_ticket(v2e_emu *h) { return h ? h->last_ticket : -1; }
+int v2e_emu_event_writer(v2e_emu *h) { return (h && h->ch_K > 0) ? (h->ch_pull ? 1 : 0) : -1; }
 const v2e_frame_rec *v2e_emu_run_recs(v2e_emu *h, int ticket, uint64_t *n_recs)
 {
     if (!h || (ticket != 0 && ticket != 1)) return nullptr;

@@ -381,6 +381,10 @@ class EmuEngine:
                     emit_batches=nb.value, frames_per_batch=fpb.value, step_launches=nsl.value,
                     chain_launch_us=[float(us[i]) for i in range(min(nl.value, 4096))])
 
+    def event_writer(self):
+        """'k_cpull' / 'k_cemit' / None: the event writer the handle's k_chain pipeline was given (v2e_emu_event_writer)."""
+        return {1: "k_cpull", 0: "k_cemit"}.get(int(self.lib.v2e_emu_event_writer(self._h)))
+
     def last_pipeline(self):
         """(kind, frames per chain launch, frames per emission batch) of the last run(); see v2e_emu_last_pipeline."""
         k, a, b = C.c_int(), C.c_int(), C.c_int()
