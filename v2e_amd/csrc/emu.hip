@@ -1946,7 +1946,10 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
             V2E_HIP(hipMalloc(&h->ch_cmask, 3 * sizeof(uint32_t) * 2 * GPX * E * nc * h->nkeys_cap * h->ch_nwp));
             V2E_HIP(hipMalloc(&h->ch_cpre16, 3 * sizeof(uint32_t) * E * nc * h->nkeys_cap * (h->ch_nwp / 16)));
         }
-        if (!fused) V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
+        if (!fused) { // (zero once: k_ahead never writes a slot's padding [npx, npx_pad), and k_chain's lanes beyond the frame read it)
+            V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
+            V2E_HIP(hipMemset(h->ch_rec, 0, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
+        }
         h->drop_graphs();
     }
     h->ch_max_blocks = max_blocks;

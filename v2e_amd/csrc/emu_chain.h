@@ -674,7 +674,11 @@ void k_chain(KArgs a_in, ChainArgs ca)
                         if (k0 + j < kend) cwq[j] = frame_body(k0 + j, j);
                 }
                 if (!FUSED) {
-                    const int nnext = min(CHAIN_SUB, fn - k0 - CHAIN_SUB); // frames of the next sub-pass (<= 0: none)
+                    const int rem = fn - k0 - CHAIN_SUB; // frames of the pass behind this sub-pass
+                    // (A straight-line form of this boundary for full sub-passes whose slots do not wrap -- 8 LDS writes, 8 loads, 8 stores, no
+                    // per-record test -- was built in round 6 and measured 1-2 us per launch SLOWER, A/B x 3 in one session: the tests are
+                    // scalar instructions beside vector work; profiles/r06_emulator_experiments.txt item 11.)
+                    const int nnext = min(CHAIN_SUB, rem); // frames of the next sub-pass (<= 0: none)
 #pragma unroll
                     for (int j = 0; j < CHAIN_SUB; ++j) // (every lane: a lane beyond the frame keeps zero records in LDS)
                         if (j < nnext) s_arec[(size_t)j * BLOCK + tid] = nx[j];
