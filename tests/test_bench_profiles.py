@@ -11,20 +11,19 @@ sys.path.insert(0, ROOT)
 def test_emulator_profile_parsers_read_this_rounds_files():
     import bench as B
     traffic, src = B.pmc_traffic_per_launch("k_chain")
-    assert src in ["profiles/" + f for f in B.PMC_FILES] and ("r06" in src or "r05" in src)
+    assert src == "profiles/" + B.PMC_FILES[0] and "r06" in src
     assert 20e6 < traffic < 153e6                      # FETCH + WRITE per 32-frame launch: below the 153 MB priced (state in registers)
     us, src = B.rocprof_kernel_us("k_chain")
-    if os.path.exists(os.path.join(ROOT, "profiles", B.TRACE_FILES[0])):   # (the cross-check of the live figure: this round's trace only)
-        assert src == "profiles/" + B.TRACE_FILES[0] and 20.0 < us < 120.0
+    assert src == "profiles/" + B.TRACE_FILES[0] and "r06" in src and 20.0 < us < 120.0   # (the cross-check of the live figure)
     ii = B.instruction_issue(3.0e-3)                   # 3 us per frame
-    assert ii["source"] in ["profiles/" + f for f in B.SQ_FILES]
+    assert ii["source"] == "profiles/" + B.SQ_FILES[0] and "r06" in ii["source"]
     assert 500 < ii["per_64px_wave_frame"] < 1200 and 0.05 < ii["frac"] < 1.0
     # float64 VALU instructions are priced at 4 cycles (round-4 review): the vector pipe's time is above the all-at-2-cycles figure by
     # each kernel's static float64 share, and the per-kernel lines add up to the headline totals
     pk = ii["per_kernel"]
     assert {q["kernel"] for q in pk} >= {"k_chain", "k_ahead", "k_ctot", "k_cpull"}
     assert abs(sum(q["valu"] for q in pk) - ii["valu_per_frame"]) <= 0.01 * ii["valu_per_frame"]
-    assert 0.2 < next(q for q in pk if q["kernel"] == "k_chain")["f64_share_static"] < 0.4
+    assert 0.2 < next(q for q in pk if q["kernel"] == "k_chain")["f64_share_static"] < 0.6
     all_two = ii["valu_per_frame"] / B.VALU_RATE * 1e6
     assert all_two < ii["valu_us_per_frame"] < 1.5 * all_two
     assert ii["bound_us_per_frame"] == max(ii["valu_us_per_frame"], ii["salu_us_per_frame"])
@@ -33,10 +32,10 @@ def test_emulator_profile_parsers_read_this_rounds_files():
 def test_slomo_traffic_reads_this_rounds_counters_per_conv_math():
     from v2e_amd.benchutil import slomo_pmc_traffic, unet_algorithmic_bytes
     alg = unet_algorithmic_bytes(80, 12, 5, 256, 320)
-    for math in ("fp16x2", "bf16x3", "f32"):              # round 5: the float32 kernels have their pass too
+    for math in ("fp16x2", "bf16x3", "f32"):
         total, detail = slomo_pmc_traffic(math, alg)
         assert 0.8 * alg < total < 4 * alg, (math, total, alg)   # measured 2 - 2.9x the algorithmic bytes
-        assert "r05" in str(detail)
+        assert "r06" in str(detail)
     hd = unet_algorithmic_bytes(2, 12, 5, 704, 1280)
     total, detail = slomo_pmc_traffic("fp16x2", hd, "2x704x1280")   # the HD shape bench.py's slomo_hd leg runs
     assert 0.8 * hd < total < 4 * hd and detail["shape"] == "2x704x1280"
