@@ -1950,6 +1950,11 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
             V2E_HIP(hipMalloc(&h->ch_rec, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
             V2E_HIP(hipMemset(h->ch_rec, 0, sizeof(uint4) * (size_t)h->ch_D * nc * h->npx_pad));
         }
+        // The fills above are ordered on the DEFAULT stream only, and a pipelined run's head (its k_ahead records, its tables) goes out on
+        // streams of the handle that do not wait for it: enqueued behind a run still executing on the default stream, the record ring's
+        // fill once ran AFTER the next run's k_ahead had written its records (round 6: wrong events in the first run on a freshly
+        // allocated scratch set, only with another run in flight).  Allocation is rare: wait for the device.
+        V2E_HIP(hipDeviceSynchronize());
         h->drop_graphs();
     }
     h->ch_max_blocks = max_blocks;
@@ -1987,6 +1992,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
             V2E_HIP(hipMemset(h->ch_base2, 0, sizeof(double) * n));
             V2E_HIP(hipMemset(h->ch_lp2, 0, sizeof(double) * n));
             V2E_HIP(hipMemset(h->ch_ts2, 0, sizeof(float) * n));
+            V2E_HIP(hipDeviceSynchronize()); // (as above)
         }
         if (n_launch > h->ch_launch_cap) {
             h->sync_runs();
