@@ -10,6 +10,7 @@
   `_refr_mostly_on` switch -- and the hd_noisy enqueue loop, step by step against the CPU oracle.
 
 Everything is bit-exact (event rows incl. order, state planes, counters)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -232,3 +233,38 @@ def test_chain_carries_lp_without_cutoff_or_shot(shape, nframes, oracle_lib):
     assert np.array_equal(emu.lp_log_frame.cpu().numpy(), ora.lp_log_frame)
     assert np.array_equal(emu.base_log_frame.cpu().numpy(), ora.base_log_frame)
     assert np.array_equal(emu.timestamp_mem.cpu().numpy(), ora.timestamp_mem)
+
+
+def test_pipelined_loop_on_recycled_device_memory_equals_graph_runs():
+    """Round 6 regression: the first pipelined run on a freshly allocated scratch set, with another run still in flight, read a
+    record ring that an allocation-time fill (ordered on the default stream only) wiped AFTER k_ahead had written it -- only on
+    recycled (non-zero) device memory and only where the pipeline re-allocates mid-loop (refr = 4 ms: `_refr_mostly_on` switches to
+    one frame per launch after the first step).  The loop of bench.py on three emulators in a row, with other allocations on the
+    device, against one hipGraph per run on one stream."""
+    import bench as B
+    from v2e_amd import EventEmulator
+    from v2e_amd.benchutil import run_steps
+    dev = torch.device("cuda")
+    kw = dict(B.DEFAULT_KW)
+    kw["refractory_period_s"] = 0.004
+    F = B.FRAMES_PER_STEP
+    frames = B.gen_frames_device(2 * F + 1, 1, dev)
+    junk = [torch.full((1 << 27,), 0xA5, dtype=torch.uint8, device=dev) for _ in range(4)]  # noqa: F841 (recycled memory is not zero)
+    del junk
+    ref = None
+    for rep in range(4):
+        if rep == 0:
+            os.environ["V2E_AMD_BENCH_UG"] = "1"
+        else:
+            os.environ.pop("V2E_AMD_BENCH_UG", None)
+        try:
+            emu = EventEmulator(device=dev, seed=1, rng_mode="philox", **kw)
+            emu.generate_events(frames[0], 0.0)
+            sink = _DigestSink()
+            run_steps(emu, frames, F, B.DT, 4, 1, sink, None, dev)
+        finally:
+            os.environ.pop("V2E_AMD_BENCH_UG", None)
+        if ref is None:
+            ref = sink.steps
+        else:
+            assert sink.steps == ref, "pipelined repetition %d: %s, graph runs %s" % (rep, [n for n, _ in sink.steps], [n for n, _ in ref])
