@@ -956,7 +956,7 @@ struct v2e_emu {
             }
         return 0;
     }
-    int occ_cache[24];              // workgroups of a k_chain instantiation a CU holds (-1: not queried yet)
+    int occ_cache[32];              // workgroups of a k_chain instantiation a CU holds (-1: not queried yet)
 };
 
 static thread_local char g_err[512] = "";
@@ -1800,12 +1800,16 @@ static const void *chain_fn(bool f64, int dtype, bool fused, bool allon = false)
 // workgroups of the k_chain instantiation that will run which a CU holds (the redo rendezvous needs a clip's workgroups
 // co-resident); the occupancy API can over-report by one per CU (MI355X guide), hence the margin.  Queried once per
 // (handle = device, instantiation).
-static int chain_blocks_per_cu(v2e_emu *h, bool f64, int dtype, bool fused)
+static int chain_blocks_per_cu(v2e_emu *h, bool f64, int dtype, bool fused, bool allon = false)
 {
-    const int key = (f64 ? 1 : 0) | ((dtype & 3) << 1) | (fused ? 8 : 0);
+    // (the instantiation that will be launched: the ALLON one -- every feature switch on, the v2e CLI defaults -- needs half the
+    // registers of the general fused one, so twice the clips of a multi-clip run fit beside one another)
+    allon = allon && f64 && dtype == V2E_DT_U8;
+    const int key = (f64 ? 1 : 0) | ((dtype & 3) << 1) | (fused ? 8 : 0) | (allon ? 16 : 0);
     if (h->occ_cache[key] >= 0) return h->occ_cache[key];
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_fn(f64, dtype, fused), BLOCK, chain_dyn_lds(fused)) != hipSuccess) per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_fn(f64, dtype, fused, allon), BLOCK, chain_dyn_lds(fused)) != hipSuccess) per_cu = 0;
+    if (const char *ev = getenv("V2E_AMD_CHAIN_OCC")) { const int v = atoi(ev); if (v >= 1 && v <= 8) per_cu = v + 1; } // dev: A/B
     if (per_cu > 2) per_cu = std::min(per_cu - 1, 6); // LDS-bound counts (<= 2) are exact
     h->occ_cache[key] = per_cu;
     return per_cu;
@@ -1877,7 +1881,8 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
     const bool has_refr = p->refractory_period_s > 0;
     const bool fused = chain_fused_records(h, dtype);
     const int inst = (p->f64_state ? 1 : 0) | ((dtype & 3) << 1) | (fused ? 8 : 0);
-    const int max_blocks = chain_blocks_per_cu(h, p->f64_state != 0, dtype, fused) * h->n_cu;
+    const bool allon_p = p->cutoff_hz > 0 && p->leak_rate_hz > 0 && p->shot_noise_rate_hz > 0 && has_refr;
+    const int max_blocks = chain_blocks_per_cu(h, p->f64_state != 0, dtype, fused, allon_p) * h->n_cu;
     const int K = chain_frames_per_launch(h, has_refr, use_graph, max_blocks);
     // frames per k_ahead launch and per emission batch: a multiple of K, 64 frames (the emission kernels are bound by per-wave latency
     // and by the launch gaps between them, and this runtime runs the captured graph's chain and emission kernels one after the
@@ -2172,7 +2177,10 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // (its first launch idled through the whole first k_ahead: ~15 us of every 300-frame step); the rest of the batch follows on
     // the same stream and is waited for by the batch's other launches (event slot nL of EV_AHEAD: the batches use 0 .. nEB - 1).
     constexpr bool split_first_ahead = true;
-    const bool split0 = split_first_ahead && m > 1 && n_frames > K;
+    // (pipelined runs: the head runs beside the run before, the chain never waits for it -- one k_ahead launch, one event and one wait fewer;
+    // V2E_AMD_PIPE_SPLIT0=1: A/B)
+    static const bool pipe_split0 = getenv("V2E_AMD_PIPE_SPLIT0") && atoi(getenv("V2E_AMD_PIPE_SPLIT0")) != 0;
+    const bool split0 = split_first_ahead && m > 1 && n_frames > K && (!pipelined || pipe_split0);
     auto launch_ahead = [&](int b) -> int {
         if (b >= nD && sc.wait(ST_AHEAD, EV_CHAIN, (b - nD + 1) * m)) return V2E_EHIP; // records of batch b - nD: last read by that launch's redo
         // frame pairs touched by a launch: at most nf / 2 + 1 (the device knows the run's first frame index, the host
