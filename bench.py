@@ -114,7 +114,7 @@ def rocprof_kernel_us(kernel):
 
 def instruction_issue(ms_per_frame):
     """The resource that binds this pipeline (round-3 review): vector and scalar instructions issued per frame over ALL its
-    kernels, from the committed SQ-counter pass of the headline workload (profiles/r05_emulator_sq.txt: SQ_INSTS_VALU / SQ_INSTS_SALU
+    kernels, from the committed SQ-counter pass of the headline workload (profiles/r06_emulator_sq.txt: SQ_INSTS_VALU / SQ_INSTS_SALU
     of k_ahead, k_chain, k_ctot, k_cframe1, k_cpull divided by the frames run), against the chip's issue rates
     (MI355X_MICROARCH.md: a wave64 float32 VALU instruction occupies its SIMD-32 for 2 cycles, a float64 one for 4 -> every
     kernel's VALU count is priced at 2 + 2 x its float64 share, the share being a static count over the kernel's disassembly
@@ -165,7 +165,9 @@ def recorded_reference():
         for name in ("r06_cpu_reference.json", "r02_cpu_reference.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
-                return json.load(open(path))
+                ref = json.load(open(path))
+                ref["file"] = "profiles/" + name
+                return ref
         return None
     except Exception:
         return None
@@ -219,7 +221,7 @@ def cpu_baseline(frames_host, budget_s=8.0):
         out["same_host_reference_note"] = ("no same-host reference baseline exists: the reference tree cannot travel to the GPU box; `value` "
                                             "is the C port on THIS host, `reference` the unmodified reference on the build container")
         out["reference"] = {"kind": "reference, recorded on a DIFFERENT host (the build container: the reference tree does not exist on the GPU box)",
-                            "host": ref["host"], "script": "scripts/cpu_reference_baseline.py -> profiles/r02_cpu_reference.json",
+                            "host": ref["host"], "script": "scripts/cpu_reference_baseline.py -> " + ref["file"],
                             "runs": [{"cores": r["threads"], "value": r["Mevents_per_s"], "unit": "Mevents/s",
                                       "frames_per_s": r["frames_per_s"]} for r in runs]}
     return out

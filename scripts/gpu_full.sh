@@ -1,7 +1,7 @@
 #!/bin/bash
 # the round-end checks as the driver runs them: GPU parity tests, smoke(), the default bench line
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/full_pytest.log 2>&1; echo "pytest rc $?" >> $O/full_pytest.log
+timeout 1500 python -m pytest tests -m gpu -x -q --timeout 240 --timeout-method=thread > $O/full_pytest.log 2>&1; echo "pytest rc $?" >> $O/full_pytest.log
 tail -4 $O/full_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 900 python bench.py > $O/full_bench.log 2>&1; echo "bench rc $?"

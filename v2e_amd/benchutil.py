@@ -181,8 +181,7 @@ def slomo_bench(device, B=8, U=10, H=256, W=320, iters=5, conv_math=None):
 def slomo_pmc_traffic(conv_math, algorithmic=None, shape="80x256x320"):
     """HBM bytes per interpolation-UNet forward of the conv math that ran, from the committed rocprofv3 PMC passes of THIS round's
     kernels (profiles/r06_slomo_counters.txt, lines '# unet_forward_bytes <conv_math> <fetch> <write> <samples>x<H>x<W>', made by
-    scripts/gpu_r05_profiles.sh + scripts/make_profiles_r05.py; the round-4 file, whose lines carry no shape and are 80x256x320, is the
-    fall-back).  Returns (bytes or None, detail dict)."""
+    scripts/gpu_r06_profiles.sh + scripts/make_profiles_r06.py; round 5's file is the fall-back).  Returns (bytes or None, detail dict)."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for name in ("r06_slomo_counters.txt", "r05_slomo_counters.txt"):
