@@ -1107,6 +1107,7 @@ int v2e_emu_create(int H, int W, int n_clips, int max_iters, int device, v2e_emu
     V2E_HIP(hipMalloc(&h->alt_of((void **)&h->run_frames), sizeof(void *)));
     V2E_HIP(hipMalloc(&h->alt_of((void **)&h->stamp_slot), sizeof(void *)));
     V2E_HIP(hipMemset(h->alt_of((void **)&h->stamp_slot), 0, sizeof(void *)));
+    V2E_HIP(hipDeviceSynchronize()); // the fills above are ordered on the default stream only; the caller's stream may be any
     *out = h;
     return 0;
 }
@@ -1481,6 +1482,7 @@ int v2e_emu_frame(v2e_emu *h, const v2e_emu_params *p, const void *frame, int fr
     if (!h->fr_dev) {
         V2E_HIP(hipMalloc((void **)&h->fr_dev, sizeof(FrameScratch)));
         V2E_HIP(hipMemset(h->fr_dev, 0, sizeof(FrameScratch))); // both records zero: the first frame counts into a clean one
+        V2E_HIP(hipDeviceSynchronize());                        // (ordered on the default stream only; once per handle)
         V2E_HIP(hipHostMalloc((void **)&h->fr_par, sizeof(FrameCtl), hipHostMallocMapped));
         V2E_HIP(hipHostGetDevicePointer((void **)&h->fr_par_dev, h->fr_par, 0));
         h->fr_flip = 0;
@@ -2633,6 +2635,7 @@ int v2e_emu_launch_stamps(v2e_emu *h, int runs, uint64_t *out_ns, int cap_runs, 
         if (runs > 0) {
             V2E_HIP(hipMalloc(&h->stamps, sizeof(unsigned long long) * (size_t)runs * 2 * STAMP_LAUNCHES));
             V2E_HIP(hipMemset(h->stamps, 0, sizeof(unsigned long long) * (size_t)runs * 2 * STAMP_LAUNCHES));
+            V2E_HIP(hipDeviceSynchronize()); // (the fill is ordered on the default stream only: see chain_alloc)
             h->stamps_runs = runs;
         }
     }
