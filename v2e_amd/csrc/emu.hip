@@ -1811,7 +1811,6 @@ static int chain_blocks_per_cu(v2e_emu *h, bool f64, int dtype, bool fused, bool
     if (h->occ_cache[key] >= 0) return h->occ_cache[key];
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_fn(f64, dtype, fused, allon), BLOCK, chain_dyn_lds(fused)) != hipSuccess) per_cu = 0;
-    if (const char *ev = getenv("V2E_AMD_CHAIN_OCC")) { const int v = atoi(ev); if (v >= 1 && v <= 8) per_cu = v + 1; } // dev: A/B
     if (per_cu > 2) per_cu = std::min(per_cu - 1, 6); // LDS-bound counts (<= 2) are exact
     h->occ_cache[key] = per_cu;
     return per_cu;
@@ -2091,8 +2090,8 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // stream that stream was busy ~500 of a step's 720 us and the chain waited for it where the ring of frame slots wraps (device
     // stamps: 57 us before the first launch of batch 3; with the rows on their own stream 19, 717-732 -> 699-713 us per step).
     // (The tables on the k_ahead stream instead: the next run's head queues behind this run's last tables, 290 us between two runs'
-    // chains.)  V2E_AMD_PIPE_ROWS=one: tables and rows on one stream (A/B)
-    static const bool pipe_rows_own = !(getenv("V2E_AMD_PIPE_ROWS") && !strcmp(getenv("V2E_AMD_PIPE_ROWS"), "one"));
+    // chains.)
+    constexpr bool pipe_rows_own = true;
     const int tab_stream = capturing ? (tabs_on_main ? ST_MAIN : ST_SIDE) : (pipelined ? ST_SIDE : tab_env);
     constexpr int NSET = 3; // emission table sets (chain_alloc sizes them)
     constexpr bool one_row_stream = false;
@@ -2179,10 +2178,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // (its first launch idled through the whole first k_ahead: ~15 us of every 300-frame step); the rest of the batch follows on
     // the same stream and is waited for by the batch's other launches (event slot nL of EV_AHEAD: the batches use 0 .. nEB - 1).
     constexpr bool split_first_ahead = true;
-    // (pipelined runs: the head runs beside the run before, the chain never waits for it -- one k_ahead launch, one event and one wait fewer;
-    // V2E_AMD_PIPE_SPLIT0=1: A/B)
-    static const bool pipe_split0 = getenv("V2E_AMD_PIPE_SPLIT0") && atoi(getenv("V2E_AMD_PIPE_SPLIT0")) != 0;
-    const bool split0 = split_first_ahead && m > 1 && n_frames > K && (!pipelined || pipe_split0);
+    // (pipelined runs: the head runs beside the run before, the chain never waits for it -- one k_ahead launch, one event and one wait
+    // fewer: profiles/r06_emulator_experiments.txt item 14)
+    const bool split0 = split_first_ahead && m > 1 && n_frames > K && !pipelined;
     auto launch_ahead = [&](int b) -> int {
         if (b >= nD && sc.wait(ST_AHEAD, EV_CHAIN, (b - nD + 1) * m)) return V2E_EHIP; // records of batch b - nD: last read by that launch's redo
         // frame pairs touched by a launch: at most nf / 2 + 1 (the device knows the run's first frame index, the host
@@ -2210,7 +2208,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     void *xb[2] = {h->base, has_refr ? h->ch_base2 : h->base}, *xl[2] = {h->lp, has_refr ? h->ch_lp2 : h->lp};
     float *xt[2] = {h->ts_mem, has_refr ? h->ch_ts2 : h->ts_mem};
     // the run's uploads (frame times, first frame index) and the zero fills precede everything
-    static const bool no_side_fork = getenv("V2E_AMD_INITIAL_SIDE_FORK") == nullptr; // under capture the side stream joins at its first batch
+    constexpr bool no_side_fork = true; // under capture the side stream joins at its first batch
     // The zero fill precedes the fork.  (Round 5 tried the fork first -- k_ahead touches nothing the fill clears -- and lost 10 %:
     // 12.0 -> 10.8 Gev/s, A/B x 3 in one session; the enqueue order of a capture decides which branches this runtime overlaps,
     // profiles/r03_graph_scheduling.txt.)
@@ -2297,7 +2295,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         // Enqueue order of the two side branches: k_ahead first.  It decides how this runtime executes the captured graph:
         // with the emission enqueued first the chain's next launch runs BEHIND the emission kernels (measured, profiles/
         // r03_graph_scheduling.txt), with k_ahead first it runs beside them.
-        static const bool ahead_first = getenv("V2E_AMD_ORDER_EMISSION_FIRST") == nullptr;
+        constexpr bool ahead_first = true;
         if (ahead_first && pl.ahead_next >= 0) { if (launch_ahead(pl.ahead_next)) return V2E_EHIP; last_ahead = pl.ahead_next; }
         if (split_tail && L == nB - 1 && tail_f0 > (nEB - 1) * E) {
             if (sc.record(EV_FORK, nEB - 1, ST_MAIN)) return V2E_EHIP;
@@ -2438,7 +2436,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
         rc = enqueue_run_chain(h, p, a, frames, dtype, n_frames, events, cap, recs_dev, s, nullptr, nullptr, nullptr, false, true);
         if (rc) return rc;
         V2E_HIP(hipEventRecord(h->ev_main_done2[par], s));          // the run's chain (the pixel state)
-        hipStream_t rows_stream = (getenv("V2E_AMD_PIPE_ROWS") && !strcmp(getenv("V2E_AMD_PIPE_ROWS"), "one")) ? h->side : h->side2;
+        hipStream_t rows_stream = h->side2;
         // the run's records to pinned host memory behind its last rows (v2e_emu_run_recs): what result() reads -- no copy of the
         // caller's own, no stream of the caller's to synchronise
         const size_t rbytes = sizeof(v2e_frame_rec) * (size_t)n_frames * h->n_clips;

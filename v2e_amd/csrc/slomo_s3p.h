@@ -25,7 +25,8 @@
 // pair so that every buffer and register-set index is a compile-time constant), plain f32 NCHW input (one or two concat
 // sources with channel counts that are multiples of 16).  Everything else stays on k_conv_s3.
 
-// DBG (dev, scripts/conv_s3_check with V2E_AMD_S3P_DBG, 16-wide tiles; results are wrong by construction): 1 = no side work
+// DBG (the ablation of round 3: instantiate launch_conv_s3p<16, DBG> in conv_dispatch_s3p to repeat it -- the environment switch that
+// selected it is gone; results are wrong by construction): 1 = no side work
 // (what the multiplies, their operand reads and the barriers cost alone), bit 2 (4) = no global reloads, bit 3 (8) = no LDS
 // stores, 16 = no splitting arithmetic, 32 = no operand reads of the next tap, 64 / 128 = no patch / weight reloads; 2 = no
 // multiplies.  The per-step timeline below works in every mode.  Measured (profiles/r03_slomo_s3p_ablation.txt): the kernel is
@@ -357,10 +358,6 @@ static int conv_dispatch_s3p(const ConvArgs &a, int ks, hipStream_t s)
 {
     if (ks != 3 || a.cout % 64 != 0 || a.cin % 32 != 0 || a.c0 % 16 != 0 || (a.x1 && a.c1 % 16 != 0)) return 1;
     if (a.w_ % 32 == 0) return launch_conv_s3p<32>(a, s);
-    static const int dbg = getenv("V2E_AMD_S3P_DBG") ? atoi(getenv("V2E_AMD_S3P_DBG")) : 0; // dev, 16-wide tiles only
-    if (a.w_ % 16 == 0 && dbg == 1) return launch_conv_s3p<16, 1>(a, s);  // multiplies, operand reads, barriers only
-    if (a.w_ % 16 == 0 && dbg == 4) return launch_conv_s3p<16, 4>(a, s);  // no global reloads
-    if (a.w_ % 16 == 0 && dbg == 8) return launch_conv_s3p<16, 8>(a, s);  // no LDS stores (the loads die with them)
     if (a.w_ % 16 == 0) return launch_conv_s3p<16>(a, s);
     if (a.w_ % 8 == 0) return launch_conv_s3p<8>(a, s);
     return 1;
