@@ -268,3 +268,34 @@ def test_pipelined_loop_on_recycled_device_memory_equals_graph_runs():
             ref = sink.steps
         else:
             assert sink.steps == ref, "pipelined repetition %d: %s, graph runs %s" % (rep, [n for n, _ in sink.steps], [n for n, _ in ref])
+
+
+@pytest.mark.parametrize("use_graph,return_device", [(0, True), (0, False), (1, True)])
+def test_three_runs_enqueued_before_any_result_is_read(use_graph, return_device):
+    """Two buffer sets (and, for pipelined runs, two scratch sets with their pinned records) alternate between asynchronous runs:
+    the third enqueue reuses the first run's.  A handle still unread at that point is collected by the enqueue itself -- reading
+    it afterwards must give ITS events, not the third run's."""
+    import bench as B
+    from v2e_amd import EventEmulator
+    dev = torch.device("cuda")
+    F = 40
+    frames = B.gen_frames_device(4 * F + 1, 1, dev)
+    ts = lambda s: [(1 + s * F + i) * B.DT for i in range(F)]  # noqa: E731
+
+    ref = EventEmulator(device=dev, seed=1, rng_mode="philox", **B.DEFAULT_KW)
+    ref.generate_events(frames[0], 0.0)
+    want = []
+    for s in range(4):
+        ev, counts = ref.generate_events_batch(frames[1 + s * F:1 + (s + 1) * F], ts(s), return_device=True)
+        want.append((ev.cpu().numpy().copy(), counts.copy()))
+
+    emu = EventEmulator(device=dev, seed=1, rng_mode="philox", **B.DEFAULT_KW)
+    emu.generate_events(frames[0], 0.0)
+    pend = [emu.generate_events_batch_async(frames[1 + s * F:1 + (s + 1) * F], ts(s), return_device=return_device, use_graph=use_graph)
+            for s in range(4)]
+    for s in (3, 0, 2, 1):  # any order
+        ev, counts = pend[s].result()
+        got = ev.cpu().numpy() if return_device else ev
+        assert np.array_equal(counts, want[s][1]), s
+        assert got.shape == want[s][0].shape and np.array_equal(got, want[s][0]), s
+    assert emu.num_events_total == ref.num_events_total

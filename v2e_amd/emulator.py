@@ -415,6 +415,7 @@ class EventEmulator(object):
 
     def reset(self):  # emulator.py:558-578
         self._failed = None
+        self._async_slots = {}  # handles of runs enqueued before the reset are no longer collected on the caller's behalf
         self.num_events_total = 0
         self.num_events_on = 0
         self.num_events_off = 0
@@ -918,7 +919,8 @@ class EventEmulator(object):
         """generate_events_batch without waiting for the device: enqueues the run and returns a handle whose
         result() gives (events, counts).  The host can prepare and enqueue the next run (it executes behind this one
         on the same stream) before reading this one's result: two sets of event / record buffers alternate, so a
-        result stays valid until the second-next call.  Pixel state, frame counter and t_previous advance at enqueue
+        result stays valid until the second-next call (a handle still unread at that point is collected by that call, device rows
+        copied aside).  Pixel state, frame counter and t_previous advance at enqueue
         time; the event counters (num_events_*) when result() is called; errors (capacity, max_iters) are raised there.
         use_graph: True / 1 one hipGraph per run (what the blocking call uses: lowest latency of a single run), 0 plain launches.
         pipelined (default: on where use_graph is 0): consecutive runs overlap -- the run's upload and first records go out beside the run
@@ -1023,6 +1025,14 @@ class EventEmulator(object):
         which = 2 if _single_buffer else self.__dict__.setdefault("_async_flip", 0)
         if not _single_buffer:
             self._async_flip = which ^ 1
+        # the run that last used this buffer set and has not been read yet: collect it now -- its rows and records (and, for pipelined
+        # runs, its scratch set's pinned records) are about to be reused, and a later result() would hand back this run's data instead
+        slots = self.__dict__.setdefault("_async_slots", {})
+        old = slots.get(which)
+        if old is not None and old._res is None and old.recs is not None:
+            ev_old, counts_old = old.result()
+            if old.return_device and ev_old is not None:
+                old._res = (ev_old.clone(), counts_old)
         ev = eng.event_buffer(cap, which)
         recs = eng.alloc_recs(nrun, which)
         ug = int(use_graph)
@@ -1045,6 +1055,7 @@ class EventEmulator(object):
         dts = np.asarray(t_frames[start:]) - np.asarray(t_prev)
         pend = _PendingRun(self, ev, recs, done, counts, start, return_device, None, dts, ticket)
         pend.cs_steps_dev = cs_steps_dev
+        slots[which] = pend
         return pend
 
     def _finish_run(self, pend):
