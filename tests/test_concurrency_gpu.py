@@ -123,6 +123,14 @@ def test_slomo_pair_sharding_over_an_rccl_group_of_one():
             res.append((np.asarray(ev), np.asarray(counts), n))
         assert res[0][2] == res[1][2] == 20 and np.array_equal(res[0][1], res[1][1])
         assert res[0][0].shape == res[1][0].shape and np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+        # in chunks (five chunks of one pair: the emulator's two event buffers are reused twice while earlier chunks' rows are held),
+        # rows on the host and on the device
+        for rd in (False, True):
+            pipe = VideoToEvents(_slomo("auto"), EventEmulator(device="cuda", seed=3, rng_mode="philox", **kw), 4, batch_size=2)
+            ev, counts, n = pipe.run(frames, 1 / 30, group=dist.group.WORLD, owner=0, chunk_pairs=1, return_device=rd)
+            ev = ev.cpu().numpy() if rd else np.asarray(ev)
+            assert n == 20 and np.array_equal(np.asarray(counts), res[0][1]), rd
+            assert ev.shape == res[0][0].shape and np.array_equal(ev.view(np.uint32), res[0][0].view(np.uint32)), rd
     finally:
         if created:
             dist.destroy_process_group()

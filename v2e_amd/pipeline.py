@@ -177,7 +177,8 @@ class VideoToEvents:
                 runs.append(self.emu.generate_events_batch_async(chunk, t, return_device=return_device))
                 while len(runs) > 1:
                     e, c = runs.pop(0).result()
-                    evs.append(e if return_device or e is None else e)
+                    # (device rows are a view of one of the emulator's two alternating buffers: the chunk after next overwrites it)
+                    evs.append(e.clone() if return_device and e is not None else e)
                     counts.append(c)
             else:
                 e, c = self.emu.generate_events_batch(chunk, t, return_device=return_device)
