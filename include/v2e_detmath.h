@@ -32,7 +32,36 @@
 #define V2E_PHILOX_W0 0x9E3779B9u
 #define V2E_PHILOX_W1 0xBB67AE85u
 
-/* Philox4x32-10 (Salmon et al., SC'11).  ctr[4] in, out[4] out. */
+/* The ten round keys of a Philox4x32-10 call (key bumped by the Weyl constants per round).  They depend on the key alone, so a
+ * kernel that makes many calls under one key computes them once (k_ahead: they are scalar registers there). */
+typedef struct { uint32_t k0[10], k1[10]; } v2e_philox_keys;
+V2E_HD void v2e_philox_key_schedule(uint32_t k0, uint32_t k1, v2e_philox_keys *ks)
+{
+    for (int r = 0; r < 10; ++r) {
+        ks->k0[r] = k0 + (uint32_t)r * V2E_PHILOX_W0;
+        ks->k1[r] = k1 + (uint32_t)r * V2E_PHILOX_W1;
+    }
+}
+
+/* Philox4x32-10 (Salmon et al., SC'11) under a precomputed key schedule.  ctr[4] in, out[4] out. */
+V2E_HD void v2e_philox4x32_ks(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const v2e_philox_keys *ks, uint32_t out[4])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)V2E_PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)V2E_PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ ks->k0[r];
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ ks->k1[r];
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Philox4x32-10.  ctr[4] in, out[4] out. */
 V2E_HD void v2e_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                            uint32_t k0, uint32_t k1, uint32_t out[4])
 {
@@ -106,12 +135,12 @@ V2E_HD void v2e_det_sincos2pi(float u, float *sn, float *cs)
     cp = fmaf(cp, t2, -1.388731625493765e-3f);
     cp = fmaf(cp, t2, 4.166664568298827e-2f);
     float c0 = fmaf(cp, t2 * t2, fmaf(-0.5f, t2, 1.0f));
+    /* quadrant k: (s, c) = (s0, c0), (c0, -s0), (-s0, -c0), (-c0, s0) -- as selects and sign flips (exact, -0 included): no branch */
     int k = ((int)kf) & 3;
-    float s, c;
-    if (k == 0)      { s = s0;  c = c0; }
-    else if (k == 1) { s = c0;  c = -s0; }
-    else if (k == 2) { s = -s0; c = -c0; }
-    else             { s = -c0; c = s0; }
+    float s = (k & 1) ? c0 : s0;
+    float c = (k & 1) ? s0 : c0;
+    s = (k & 2) ? -s : s;
+    c = ((k + 1) & 2) ? -c : c;
     *sn = s; *cs = c;
 }
 
@@ -174,6 +203,19 @@ V2E_HD void v2e_draw_pair(uint64_t seed, uint32_t clip, uint32_t pair, uint32_t 
 {
     uint32_t o[4];
     v2e_philox4x32(pixel, pair, V2E_STREAM_FRAME, clip, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    *randn_odd = 0.0f;
+    *randn_even = 0.0f;
+    if (want_normal) v2e_normal2(o[0], o[1], randn_odd, randn_even);
+    *u_odd = v2e_u01(o[2]);
+    *u_even = v2e_u01(o[3]);
+}
+
+/* The same draws under a precomputed key schedule of the seed (v2e_philox_key_schedule((uint32_t)seed, (uint32_t)(seed >> 32), ..)). */
+V2E_HD void v2e_draw_pair_ks(const v2e_philox_keys *ks, uint32_t clip, uint32_t pair, uint32_t pixel, int want_normal,
+                             float *randn_odd, float *u_odd, float *randn_even, float *u_even)
+{
+    uint32_t o[4];
+    v2e_philox4x32_ks(pixel, pair, V2E_STREAM_FRAME, clip, ks, o);
     *randn_odd = 0.0f;
     *randn_even = 0.0f;
     if (want_normal) v2e_normal2(o[0], o[1], randn_odd, randn_even);

@@ -2185,7 +2185,6 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         if (b >= nD && sc.wait(ST_AHEAD, EV_CHAIN, (b - nD + 1) * m)) return V2E_EHIP; // records of batch b - nD: last read by that launch's redo
         // frame pairs touched by a launch: at most nf / 2 + 1 (the device knows the run's first frame index, the host
         // does not when it builds a graph: one extra pair covers either alignment; threads of a pair outside the range return)
-        constexpr int ppt_env = 0;
         const int b0 = b * E, b1 = std::min((b + 1) * E, n_frames);
         const int cut = (b == 0 && split0) ? std::min(K, b1) : b1;
         for (int part = 0; part < 2; ++part) {
@@ -2197,7 +2196,16 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
             aa.ctl = h->run_ctl; aa.fidx_base = h->run_fidx;
             aa.f0 = f0; aa.nf = f1 - f0; aa.D = D; aa.n_clips = NC; aa.slot0 = f0 % D;
             aa.rec = h->ch_rec;
-            aa.ppt = ppt_env > 0 ? ppt_env : 1;
+            // frame pairs per thread: a thread's set-up (thresholds, two divisions, the seed's ten Philox round keys) is paid once per
+            // thread, so a thread takes several pairs -- as many as leave ~4 workgroups per CU (346x260, 64 frames: 3 z-blocks of 11 pairs;
+            // round 6, A/B x 3 in one session: 1 pair 683-689 us per step, 4: 668-676, 11: 665-670, 16: 663-671; k_ahead's instructions
+            // per 64-pixel wave-frame 133 + 81 -> 108 + 43), at most 16
+            {
+                const int pairs = aa.nf / 2 + 1;
+                const long long wg_xy = (long long)h->ngroups * NC;
+                int zb = (int)std::min<long long>(pairs, std::max<long long>((4ll * h->n_cu + wg_xy - 1) / wg_xy, (pairs + 15) / 16));
+                aa.ppt = (pairs + zb - 1) / zb;
+            }
             void *args[] = {(void *)&a, (void *)&aa};
             if (sc.kernel(ST_AHEAD, (const void *)k_ahead<uint8_t>, dim3(h->ngroups, NC, (aa.nf / 2 + 1 + aa.ppt - 1) / aa.ppt), dim3(BLOCK), (size_t)side_pad, args)) return V2E_EHIP;
             if (sc.record(EV_AHEAD, part == 0 ? b : nL, ST_AHEAD)) return V2E_EHIP;

@@ -261,6 +261,8 @@ __global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
     const float lk = a.do_leak ? a.leak_hz_f * a.noise_rate[sp] : 0.f;
     const float ppre = a.scalar_thres ? a.pos_pre_scalar : a.pos_nom_f / thp; // emulator.py:475-478
     const float npre = a.scalar_thres ? a.neg_pre_scalar : a.neg_nom_f / thn;
+    v2e_philox_keys ks; // the seed's ten round keys: scalar registers, computed once per thread (not per call: 35 scalar instructions a pair)
+    v2e_philox_key_schedule((uint32_t)a.seed, (uint32_t)(a.seed >> 32), &ks);
     for (int zz = 0; zz < aa.ppt; ++zz) {
         // pair z of the launch: global frames 2q-1 (odd) and 2q (even), q = pair of the launch's first frame + z
         const uint32_t q = v2e_frame_pair(fbase + (uint32_t)aa.f0) + blockIdx.z * (uint32_t)aa.ppt + (uint32_t)zz;
@@ -268,18 +270,20 @@ __global__ __launch_bounds__(BLOCK) void k_ahead(KArgs a, AheadArgs aa)
         const bool in0 = f_odd >= aa.f0 && f_odd < aa.f0 + aa.nf, in1 = f_odd + 1 >= aa.f0 && f_odd + 1 < aa.f0 + aa.nf;
         if (!in0 && !in1) continue;
         float r_odd = 0.f, u_odd = 0.f, r_even = 0.f, u_even = 0.f;
-        if (need_r || a.do_shot) v2e_draw_pair(a.seed, (uint32_t)clip, q, (uint32_t)p, need_r, &r_odd, &u_odd, &r_even, &u_even);
+        if (need_r || a.do_shot) v2e_draw_pair_ks(&ks, (uint32_t)clip, q, (uint32_t)p, need_r, &r_odd, &u_odd, &r_even, &u_even);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (!(half ? in1 : in0)) continue;
             const int f = f_odd + half;
             int sl = aa.slot0 + (f - aa.f0); // ring slot f % D (nf <= D)
             if (sl >= aa.D) sl -= aa.D;
-            const FrameCtl *c = aa.ctl + (size_t)f * aa.n_clips + clip;
+            // (32-bit indices: the record ring is below 4 GB -- chain_fused_records -- and a run has fewer than 2^31 / n_clips frames;
+            //  64-bit products of uniform values are four scalar instructions each)
+            const FrameCtl *c = aa.ctl + (f * aa.n_clips + clip);
             const FT px = ((const FT *)(frames + (size_t)f * aa.frame_stride))[(size_t)clip * a.npx + p];
             const uint4 r = make_frame_record<FT>(a, px, s_lutL, s_lutI, c->dt_over_tau, c->shot_base, (float)(c->t_frame - c->t_prev), lk, thp,
                                                   ppre, npre, half ? r_even : r_odd, half ? u_even : u_odd);
-            aa.rec[((size_t)sl * aa.n_clips + clip) * a.npx_pad + p] = r;
+            aa.rec[((uint32_t)sl * (uint32_t)aa.n_clips + (uint32_t)clip) * (uint32_t)a.npx_pad + (uint32_t)p] = r;
         }
     }
 }
@@ -344,6 +348,8 @@ void k_chain(KArgs a_in, ChainArgs ca)
         }
     }
     const bool need_r = a.do_leak && a.jit_f != 0.f;
+    // (the seed's Philox round keys precomputed for the FUSED calls, as k_ahead does: 20 more live scalar registers in a kernel that
+    //  already spills them -- 64 clips 14.4-14.6 -> 13.7-13.8 Gev/s, 1280x720 unchanged; round 6, A/B of two builds in one session)
 
     for (int clip = blockIdx.y; clip < ca.n_clips; clip += (int)gridDim.y) {
         if (clip != (int)blockIdx.y) __syncthreads(); // the LDS tables of the previous clip are no longer read
