@@ -872,6 +872,7 @@ struct v2e_emu {
     hipStream_t side = nullptr;        // the event writer of the chain: k_cemit
     std::vector<hipEvent_t> ev_fork, ev_join;
     // K-frames-per-launch chain (emu_chain.h); allocated on first use by v2e_emu_run
+    int ch_ring_pref = 0; // ring depth in batches, chosen by the handle's first device-resident run (chain_ring_batches)
     int ch_K = 0, ch_D = 0, ch_nD = 3, ch_nwp = 0, ch_launch_cap = 0, ch_max_blocks = 0, ch_fused = -1, ch_inst = -1;
     uint32_t *ch_cnt = nullptr;     // [ch_D][n_clips][npx_pad]
     uint32_t *ch_ruleM = nullptr;   // [ch_D][n_clips]
@@ -1763,21 +1764,27 @@ struct Sched {
 static int chain_egroups(const v2e_emu *h) { return (h->npx + GROUP_PX - 1) / GROUP_PX; }
 static bool chain_small_grid(const v2e_emu *h) { return (long long)h->ngroups * h->n_clips <= 2ll * h->n_cu; }
 
-// batches in the ring of frame slots (three; V2E_AMD_CHAIN_RING: the profiling scripts' deeper rings)
-static int chain_ring_batches()
+// Batches in the ring of frame slots.  Three is the minimum (batch b is read by its emission while the chain is in batch b + 1 and
+// k_ahead fills batch b + 2); the chain then waits for the emission of batch b - 3 where the ring wraps.  One hipGraph per run runs
+// SLOWER with a deeper ring (round 3: 8.5 Gev/s with 3 batches, 7.3 with 5 or 7; round 6: 787 -> 904 us per step with 5), 64 clips
+// and 1280x720 do not care (14.5-14.6 / 11.9-12.1 Gev/s either way) -- but PIPELINED runs of a small grid, whose k_ahead runs a whole
+// run ahead and whose event rows have a stream of their own, gain from never waiting inside a 300-frame run: ring 3 681-685 us per
+// step, 4 668-671, 5 662-664, 6 657-673, 8 671 (profiles/r06_emulator_experiments.txt item 21).  A handle keeps the depth its FIRST
+// device-resident run chose (no re-allocation when a caller mixes modes); V2E_AMD_CHAIN_RING overrides.
+static int chain_ring_batches(v2e_emu *h, bool pipelined)
 {
-    int nD = 3;
-    if (const char *ev = getenv("V2E_AMD_CHAIN_RING")) { const int v = atoi(ev); if (v >= 3 && v <= 16) nD = v; }
-    return nD;
+    if (const char *ev = getenv("V2E_AMD_CHAIN_RING")) { const int v = atoi(ev); if (v >= 3 && v <= 16) return v; }
+    if (h->ch_ring_pref == 0) h->ch_ring_pref = (pipelined && chain_small_grid(h) && h->n_clips == 1) ? 5 : 3;
+    return h->ch_ring_pref;
 }
 
 // records built inside the chain (large grids) or by k_ahead (small grids); V2E_AMD_CHAIN_FUSED=0/1 overrides (dev / tests)
-static bool chain_fused_records(const v2e_emu *h, int dtype)
+static bool chain_fused_records(const v2e_emu *h, int dtype, int nD)
 {
     if (dtype != V2E_DT_U8) return true; // k_ahead's record path is instantiated for uint8 frames only
     // k_chain reads k_ahead's records and writes the count words through buffer resources (32-bit offsets): the record ring of
     // nD batches of up to 64 frames must stay below 4 GB (1280x720: 2.8 GB with three batches; beyond that the chain builds the records)
-    if ((size_t)chain_ring_batches() * 64 * h->n_clips * h->npx_pad * sizeof(uint4) >= (1ull << 32)) return true;
+    if ((size_t)nD * 64 * h->n_clips * h->npx_pad * sizeof(uint4) >= (1ull << 32)) return true;
     const char *fe = getenv("V2E_AMD_CHAIN_FUSED"); // read per call: tests switch it per emulator instance
     const int fused_env = fe ? atoi(fe) : -1;
     return fused_env >= 0 ? fused_env != 0 : !chain_small_grid(h);
@@ -1880,7 +1887,8 @@ static bool emit_pull(size_t table_bytes)
 static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_frames, int use_graph)
 {
     const bool has_refr = p->refractory_period_s > 0;
-    const bool fused = chain_fused_records(h, dtype);
+    const int nD = chain_ring_batches(h, (use_graph & 1024) != 0 && (use_graph & 3) == 0);
+    const bool fused = chain_fused_records(h, dtype, nD);
     const int inst = (p->f64_state ? 1 : 0) | ((dtype & 3) << 1) | (fused ? 8 : 0);
     const bool allon_p = p->cutoff_hz > 0 && p->leak_rate_hz > 0 && p->shot_noise_rate_hz > 0 && has_refr;
     const int max_blocks = chain_blocks_per_cu(h, p->f64_state != 0, dtype, fused, allon_p) * h->n_cu;
@@ -1905,7 +1913,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
     if (const char *ev = getenv("V2E_AMD_CHAIN_M")) { const int v = atoi(ev); if (v >= 1 && v <= 64) m = v; }
     m = std::max(1, std::min(m, 64 / K)); // k_cemit sums a batch's per-frame event counts one frame per lane
     const int E = m * K;
-    if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap || h->ch_fused != (int)fused) {
+    if (h->ch_K != K || h->ch_E != E || h->ch_nkeys_cap != h->nkeys_cap || h->ch_fused != (int)fused || h->ch_nD != nD) {
         // a new configuration: everything sized by it goes, in BOTH scratch sets (overlapped runs alternate between two, see
         // v2e_emu::swap_scratch); what the run needs is allocated below, for the set that is current
         h->sync_runs();
@@ -1914,11 +1922,7 @@ static int chain_alloc(v2e_emu *h, const v2e_emu_params *p, int dtype, int n_fra
         h->ch_K = K;
         h->ch_E = E;
         h->ch_fused = fused;
-        // Ring of frame slots, nD batches deep.  Three is the minimum (batch b is read by its emission while the chain is in
-        // batch b + 1 and k_ahead fills batch b + 2); the chain then waits for k_cemit(b - 3) at batch boundaries.  Deeper
-        // rings (V2E_AMD_CHAIN_RING) let it run further ahead and measured SLOWER: 8.5 Gev/s with 3 batches, 7.3 with 5 or 7
-        // -- three batches of slots and records (174 MB at 346x260) stay in the 256 MB MALL, five do not.
-        const int nD = chain_ring_batches();
+        // (ring of frame slots: chain_ring_batches)
         h->ch_nD = nD;
         h->ch_D = nD * E;
         h->ch_nwp = (chain_egroups(h) + 15) / 16 * 16; // emission groups (one wave each), padded to the 16 a lane of k_cframe takes
