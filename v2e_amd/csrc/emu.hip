@@ -2185,11 +2185,16 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     // (pipelined runs: the head runs beside the run before, the chain never waits for it -- one k_ahead launch, one event and one wait
     // fewer: profiles/r06_emulator_experiments.txt item 14)
     const bool split0 = split_first_ahead && m > 1 && n_frames > K && !pipelined;
+    // Pipelined runs whose ring holds the whole run (n_frames <= D: 300 frames in five batches of 64): ONE k_ahead launch for the run, right
+    // behind its upload and zero fills, and ONE wait of the chain for all of it -- in steady state it ran beside the run before.  Every
+    // wait and every record on the chain's stream costs its next launch ~7 us even when the event has long completed (gap before a
+    // batch's first launch 13-16 us, before its second 6-7: profiles/r06_emulator_experiments.txt item 23).
+    const bool ahead_whole = pipelined && !fused_rec && n_frames <= D;
     auto launch_ahead = [&](int b) -> int {
-        if (b >= nD && sc.wait(ST_AHEAD, EV_CHAIN, (b - nD + 1) * m)) return V2E_EHIP; // records of batch b - nD: last read by that launch's redo
+        if (!ahead_whole && b >= nD && sc.wait(ST_AHEAD, EV_CHAIN, (b - nD + 1) * m)) return V2E_EHIP; // records of batch b - nD: last read by that launch's redo
         // frame pairs touched by a launch: at most nf / 2 + 1 (the device knows the run's first frame index, the host
         // does not when it builds a graph: one extra pair covers either alignment; threads of a pair outside the range return)
-        const int b0 = b * E, b1 = std::min((b + 1) * E, n_frames);
+        const int b0 = ahead_whole ? 0 : b * E, b1 = ahead_whole ? n_frames : std::min((b + 1) * E, n_frames);
         const int cut = (b == 0 && split0) ? std::min(K, b1) : b1;
         for (int part = 0; part < 2; ++part) {
             const int f0 = part == 0 ? b0 : cut, f1 = part == 0 ? cut : b1;
@@ -2239,8 +2244,9 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     if (!capturing && (sc.wait(ST_TAB, EV_FORK, nL) || sc.wait(ST_SIDE2, EV_FORK, nL))) return V2E_EHIP;
     }
     int last_ahead = -1; // the last k_ahead batch this piece enqueued (joined at the end)
+    if (ahead_whole && launch_ahead(0)) return V2E_EHIP; // (all of the run's records: before the one event the chain waits for)
     if (pipelined && (sc.record(EV_FORK, nL, ST_AHEAD) || sc.wait(ST_MAIN, EV_FORK, nL))) return V2E_EHIP; // the upload and the zero fills, for the chain
-    for (int b = 0; b < std::min(nEB, 2) && !fused_rec; ++b) {
+    for (int b = 0; b < std::min(nEB, 2) && !fused_rec && !ahead_whole; ++b) {
         if (launch_ahead(b)) return V2E_EHIP;
         last_ahead = b;
     }
@@ -2297,18 +2303,18 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         ca.stamp_pp = h->stamp_slot; ca.lidx = std::min(L, STAMP_LAUNCHES - 1);
         if (pl.wait_join >= 0 && sc.wait(ST_MAIN, EV_JOIN, pl.wait_join)) return V2E_EHIP; // ring slots: read by k_cemit of that batch
         // (records of batches 0 and 1 without the head piece in this enqueue: the caller ordered this piece behind the head's stream)
-        if (pl.wait_ahead >= 0 && sc.wait(ST_MAIN, EV_AHEAD, pl.wait_ahead)) return V2E_EHIP;
+        if (!ahead_whole && pl.wait_ahead >= 0 && sc.wait(ST_MAIN, EV_AHEAD, pl.wait_ahead)) return V2E_EHIP;
         if (split0 && !fused_rec && !tail && L >= 1 && L < m && sc.wait(ST_MAIN, EV_AHEAD, nL)) return V2E_EHIP; // the rest of batch 0
         if (mark(ev_main, s)) return V2E_EHIP; // instrumented runs: an event before and after every chain launch
         void *args[] = {(void *)&a, (void *)&ca};
         if (sc.kernel(ST_MAIN, kfn, grid, dim3(BLOCK), chain_dyn_lds(fused_rec), args)) return V2E_EHIP;
         if (mark(ev_main, s)) return V2E_EHIP;
-        if (L % m == 0 && sc.record(EV_CHAIN, L, ST_MAIN)) return V2E_EHIP;
+        if (!ahead_whole && L % m == 0 && sc.record(EV_CHAIN, L, ST_MAIN)) return V2E_EHIP; // (what a later k_ahead batch waits for where the ring wraps)
         // Enqueue order of the two side branches: k_ahead first.  It decides how this runtime executes the captured graph:
         // with the emission enqueued first the chain's next launch runs BEHIND the emission kernels (measured, profiles/
         // r03_graph_scheduling.txt), with k_ahead first it runs beside them.
         constexpr bool ahead_first = true;
-        if (ahead_first && pl.ahead_next >= 0) { if (launch_ahead(pl.ahead_next)) return V2E_EHIP; last_ahead = pl.ahead_next; }
+        if (ahead_first && !ahead_whole && pl.ahead_next >= 0) { if (launch_ahead(pl.ahead_next)) return V2E_EHIP; last_ahead = pl.ahead_next; }
         if (split_tail && L == nB - 1 && tail_f0 > (nEB - 1) * E) {
             if (sc.record(EV_FORK, nEB - 1, ST_MAIN)) return V2E_EHIP;
             if (launch_emission(nEB - 1, (nEB - 1) * E, tail_f0 - (nEB - 1) * E)) return V2E_EHIP;
@@ -2319,11 +2325,13 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
             if (launch_emission(nEB, tail_f0, n_frames - tail_f0)) return V2E_EHIP;
             last_emitted = nEB;
         } else if (pl.emit_batch >= 0) {
+            // (emitting the batches in PAIRS -- one record on the chain's stream per 128 frames -- was measured in round 6: gaps inside a run
+            //  54 -> 46 us, but the bunched emission costs the chain's launches more than that: 614-633 -> 628-641 us per step)
             if (sc.record(EV_FORK, pl.emit_batch, ST_MAIN)) return V2E_EHIP;
             if (launch_emission(pl.emit_batch, pl.emit_batch * E, std::min((pl.emit_batch + 1) * E, n_frames) - pl.emit_batch * E)) return V2E_EHIP;
             last_emitted = pl.emit_batch;
         }
-        if (!ahead_first && pl.ahead_next >= 0) { if (launch_ahead(pl.ahead_next)) return V2E_EHIP; last_ahead = pl.ahead_next; }
+        if (!ahead_first && !ahead_whole && pl.ahead_next >= 0) { if (launch_ahead(pl.ahead_next)) return V2E_EHIP; last_ahead = pl.ahead_next; }
     }
     if (!graph && !pipelined) { // join: the piece is complete on `s` (a graph is complete when all its nodes are)
         if (last_emitted >= 0 && sc.wait(ST_MAIN, EV_JOIN, last_emitted)) return V2E_EHIP;
