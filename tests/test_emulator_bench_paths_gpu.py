@@ -168,6 +168,35 @@ def test_bench_step_loop_matches_oracle(refr, oracle_lib):
     assert emu.num_events_total == ora.num_events_total and emu.num_events_on == ora.num_events_on
 
 
+def test_pipelined_runs_longer_than_the_ring_match_oracle(oracle_lib):
+    """Pipelined runs of a small single-clip grid take a ring of five 64-frame batches: a 300-frame run fits (one k_ahead launch, one
+    wait), a 400-frame run does NOT -- k_ahead goes batch by batch again and waits for the chain where the ring wraps (batches 5, 6 reuse
+    the slots of 0, 1).  Three runs of 400 frames through bench.py's loop, every run's event stream and the final planes against the
+    oracle."""
+    import bench as B
+    from v2e_amd import EventEmulator
+    from v2e_amd.benchutil import run_steps
+    dev = torch.device("cuda")
+    F, steps, warm = 400, 2, 1
+    frames_all = B.gen_frames_device(2 * F + 1, 1, dev)
+    emu = EventEmulator(device=dev, seed=1, rng_mode="philox", **B.DEFAULT_KW)
+    emu.generate_events(frames_all[0], 0.0)
+    sink = _DigestSink()
+    run_steps(emu, frames_all, F, B.DT, steps, warm, sink, None, dev)
+    assert len(sink.steps) == steps + warm
+    host = frames_all.cpu().numpy()
+    ora = oracle_lib.OracleEmulator(seed=1, rng_mode="philox", **B.DEFAULT_KW)
+    ora.generate_events(host[0], 0.0)
+    for s in range(steps + warm):
+        lo = 1 + (s % 2) * F
+        evs = [ora.generate_events(host[lo + i], (1 + s * F + i) * B.DT) for i in range(F)]
+        ref = np.concatenate([e for e in evs if e is not None])
+        assert sink.steps[s][0] == len(ref), "run %d: %d events, oracle %d" % (s, sink.steps[s][0], len(ref))
+        assert sink.steps[s][1] == sha(ref), "run %d event stream differs from the oracle" % s
+    assert np.array_equal(emu.base_log_frame.cpu().numpy(), ora.base_log_frame)
+    assert np.array_equal(emu.timestamp_mem.cpu().numpy(), ora.timestamp_mem)
+
+
 def test_hd_noisy_enqueue_loop_matches_oracle(oracle_lib):
     """The loop of benchutil.hd_noisy_emulator_bench (BASELINE configs[3]: 1280x720, noisy preset, dt = 1/600 s): runs of
     64 frames over one fixed frame buffer, run n + 1 enqueued before run n's result is read -- three runs, each run's
