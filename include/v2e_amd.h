@@ -255,11 +255,11 @@ int v2e_emu_frame_host_rows(v2e_emu *h, float *pinned_rows, uint64_t cap_rows);
  * reads a pinned staging set (no copy-engine transfer), and the k_chain pipeline's kernels read the frames through that device
  * variable: with use_graph & 1 a cached graph is replayed over whatever `frames` buffer a call names (events / recs_dev are still
  * baked in: callers alternate between fixed buffer sets), so a caller need not copy frames into one fixed buffer per run.
- * Round 6, PIPELINED RUNS (use_graph = 0 | 1024; wherever the k_chain pipeline runs): plain launches on three streams, no
+ * Round 6, PIPELINED RUNS (use_graph = 0 | 1024; wherever the k_chain pipeline runs): plain launches on four streams, no
  * graph and no join at the run's end.  `stream` carries the chain's launches and nothing else, so consecutive runs' chains follow one
  * another in one hardware queue; the run's upload, zero fills and k_ahead records go to a stream of the handle that runs ahead of the
- * chain (beside the run before), the emission to another that finishes beside the run after; everything two runs in flight would share
- * exists twice.  `stream` then orders the PIXEL STATE only: the run's event rows and records are complete behind v2e_emu_run_wait
+ * chain (beside the run before; one k_ahead launch and one wait per run where the handle's ring of frame slots holds the whole run), the
+ * emission's tables and rows to two more that finish beside the run after; everything two runs in flight would share exists twice.  `stream` then orders the PIXEL STATE only: the run's event rows and records are complete behind v2e_emu_run_wait
  * (host) / v2e_emu_run_join (a stream), which the caller must call before reading them; every other entry point of the handle joins by
  * itself.  Callers alternate two sets of `events` / `recs_dev` buffers (a run that names the buffers of the run before it waits for that
  * run).  | 2048: the caller vouches that `frames` are resident (nothing enqueued on `stream` still writes them): the run's head then

@@ -774,7 +774,7 @@ def test_model_state_planes_are_readable_without_a_display():
 @pytest.mark.parametrize("chunk", [24, 9, 5])
 @pytest.mark.parametrize("name", ["philox_refractory_346x260", "philox_noisy_346x260", "philox_defaults_346x260"])
 def test_pipelined_runs_equal_whole_clip(name, chunk):
-    """Pipelined runs (v2e_emu_run 0 | 1024: plain launches on three streams, the next run's upload and records beside this run's chain,
+    """Pipelined runs (v2e_emu_run 0 | 1024: plain launches on four streams, the next run's upload and records beside this run's chain,
     this run's last emission batches beside the next run's chain, two scratch sets alternating): a clip fed in runs of `chunk` frames,
     every run enqueued before the result of the run before it is read, with and without the caller's word that the frames are
     resident -- the reference's events, frame by frame, and its final state."""

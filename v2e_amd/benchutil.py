@@ -28,7 +28,7 @@ def run_steps(emu, frames_all, F, dt, steps, warmup, gather, dist, device, first
     gc.freeze()
     nclip = max((int(frames_all.shape[0]) - 1) // F, 1)
     import inspect
-    # The loop's mode: pipelined runs (plain launches on three streams, consecutive runs overlapping: v2e_emu_run 0 | 1024; the clip was
+    # The loop's mode: pipelined runs (plain launches on four streams, consecutive runs overlapping: v2e_emu_run 0 | 1024; the clip was
     # generated and synchronised before the loop, so the frames are resident).  V2E_AMD_BENCH_UG=1: one hipGraph per run, run after
     # run on one stream (rounds 2-5), for A/B.  (The CPU tests' stand-ins have no such switch.)
     ug = int(os.environ.get("V2E_AMD_BENCH_UG", "0"))

@@ -2376,7 +2376,7 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     V2E_REQUIRE(!(use_graph & 256) || chain_ok, "k_chain cannot run this configuration (max_iters, photoreceptor noise or float64 log frames)");
     const bool chain = chain_ok && ((use_graph & 256) != 0 || !(use_graph & 16));
     const bool legacy = !chain;
-    // mode 0 | 1024: PIPELINED runs (round 6) -- plain launches on three streams, no graph, no join at the run's end.  The chain of run
+    // mode 0 | 1024: PIPELINED runs (round 6) -- plain launches on four streams, no graph, no join at the run's end.  The chain of run
     // n + 1 needs the chain of run n and nothing else of it, but a run begins with an upload, zero fills and its first records (k_ahead)
     // and ends with the emission of its last frames: measured with the device stamps (v2e_emu_launch_stamps), 145-165 us of every
     // 820 us step of the benchmark passed between the last chain launch of one run and the first of the next (a graph's end and start
