@@ -1564,7 +1564,7 @@ __global__ __launch_bounds__(BLOCK) void k_cpull(KArgs a, CEmitArgs ea)
                 qy = p / (uint32_t)a.W;
             }
             const v2e_f4 v = {t, (float)(p - qy * (uint32_t)a.W), (float)qy, eneg ? -1.0f : 1.0f};
-            __builtin_amdgcn_raw_buffer_store_b128(v, ev_rsrc, (int)(row * 16u), 0, 17); // sc0 sc1: written through (see store_event_wt)
+            __builtin_amdgcn_raw_buffer_store_b128(v, ev_rsrc, (int)(row * 16u), 0, 19); // sc0 nt sc1: written through, non-temporal (see store_event_wt)
         }
     }
 }
