@@ -328,3 +328,34 @@ def test_three_runs_enqueued_before_any_result_is_read(use_graph, return_device)
         assert np.array_equal(counts, want[s][1]), s
         assert got.shape == want[s][0].shape and np.array_equal(got, want[s][0]), s
     assert emu.num_events_total == ref.num_events_total
+
+
+def test_one_handle_mixing_pipelined_and_graph_runs():
+    """A handle keeps the ring depth its first device-resident run chose (five batches when that run is pipelined on a small single-clip
+    grid): later graph runs and blocking calls on the same handle run on that ring.  Pipelined, graph, blocking, pipelined again -- runs of
+    300, 100, 37 and 300 frames -- against one-graph-per-run on a fresh emulator."""
+    import bench as B
+    from v2e_amd import EventEmulator
+    dev = torch.device("cuda")
+    lens = [300, 100, 37, 300]
+    frames = B.gen_frames_device(sum(lens) + 1, 1, dev)
+    times = [(1 + i) * B.DT for i in range(sum(lens))]
+
+    def feed(modes):
+        emu = EventEmulator(device=dev, seed=1, rng_mode="philox", **B.DEFAULT_KW)
+        emu.generate_events(frames[0], 0.0)
+        out, lo = [], 0
+        for n, mode in zip(lens, modes):
+            fr, ts = frames[1 + lo:1 + lo + n], times[lo:lo + n]
+            if mode == "blocking":
+                ev, counts = emu.generate_events_batch(fr, ts, return_device=True)
+            else:
+                ev, counts = emu.generate_events_batch_async(fr, ts, return_device=True, use_graph=0 if mode == "pipelined" else 1).result()
+            out.append((sha(ev.cpu().numpy()), list(counts)))
+            lo += n
+        return out, sha(emu.base_log_frame.cpu().numpy()), sha(emu.timestamp_mem.cpu().numpy())
+
+    want = feed(["graph"] * 4)
+    got = feed(["pipelined", "graph", "blocking", "pipelined"])
+    assert got == want
+    assert feed(["graph", "pipelined", "pipelined", "blocking"]) == want
