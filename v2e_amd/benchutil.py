@@ -242,25 +242,36 @@ def batched_emulator_bench(device, n_clips=64, frames=60, H=260, W=346):
     del f
     eng.init_state(P, fr[0].contiguous(), 0.0)
     cap = 80000 * frames
-    ev = eng.event_buffer(cap)
-    recs = eng.alloc_recs(frames)
+    evs = [eng.event_buffer(cap, 0), eng.event_buffer(cap, 1)]   # two buffer sets alternate: run k + 1 is enqueued before run k is read,
+    recs = [eng.alloc_recs(frames, 0), eng.alloc_recs(frames, 1)]  # as in the headline loop and the 1280x720 leg
     dt = 1.0 / 300.0
     frames_run = fr[1:].contiguous()
+    ug = int(os.environ.get("V2E_AMD_BATCHED_UG", "1"))
 
-    def run(k):
+    def enqueue(k):
         t_prev = np.array([[(k * frames + j) * dt] * n_clips for j in range(frames)])
         t_frame = t_prev + dt
-        eng.run(P, frames_run, t_prev, t_frame, 1 + k * frames, ev, recs, use_graph=int(os.environ.get("V2E_AMD_BATCHED_UG", "1")))
+        eng.run(P, frames_run, t_prev, t_frame, 1 + k * frames, evs[k & 1], recs[k & 1], use_graph=ug)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(device))
+        return k & 1, done
 
-    run(0)
+    def collect(pend):
+        which, done = pend
+        return int(eng.read_recs_after(recs[which], done)["n_events"].sum())
+
+    for k in range(2):
+        collect(enqueue(k))
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    reps = 3
-    n_ev = 0
-    for k in range(1, 1 + reps):
-        run(k)
-        r = eng.recs_to_numpy(recs)
-        n_ev += int(r["n_events"].sum())
+    reps = 6
+    n_ev, pend = 0, None
+    for k in range(2, 2 + reps):
+        nxt = enqueue(k)
+        if pend is not None:
+            n_ev += collect(pend)
+        pend = nxt
+    n_ev += collect(pend)
     torch.cuda.synchronize(device)
     sec = time.perf_counter() - t0
     bpp = 53
