@@ -160,8 +160,8 @@ def emulator():
 
 def hd():
     wr("r06_emulator_hd_kernel_trace.txt", """# rocprofv3 kernel trace of the 1280x720 `noisy` workload (BASELINE configs[3]; bench.py's hd_noisy leg), round 6
-# (one hipGraph per run, as in round 5: at this size the chain and the emission each fill the chip and pipelined runs measured
-#  11.3-11.4 against 11.5-12.0 Gev/s; pull event writer k_cpull<true>, emission batches of 64 frames)
+# (pipelined runs, as the headline loop: 13.1-13.65 Gev/s against 11.5-12.4 with one hipGraph per run -- experiment 30;
+#  pull event writer k_cpull<true>, emission batches of 64 frames)
 # command (on the MI355X box, cd /tmp; TMPDIR=/tmp): rocprofv3 --kernel-trace --stats -d out -- python scripts/emu_workloads.py hd
 #
 """ + rd("p6_hd.txt"))

@@ -197,7 +197,8 @@ def test_pipelined_runs_longer_than_the_ring_match_oracle(oracle_lib):
     assert np.array_equal(emu.timestamp_mem.cpu().numpy(), ora.timestamp_mem)
 
 
-def test_hd_noisy_enqueue_loop_matches_oracle(oracle_lib):
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_hd_noisy_enqueue_loop_matches_oracle(use_graph, oracle_lib):
     """The loop of benchutil.hd_noisy_emulator_bench (BASELINE configs[3]: 1280x720, noisy preset, dt = 1/600 s): runs of
     64 frames over one fixed frame buffer, run n + 1 enqueued before run n's result is read -- three runs, each run's
     stream against the oracle."""
@@ -214,7 +215,9 @@ def test_hd_noisy_enqueue_loop_matches_oracle(oracle_lib):
     cap = 400_000 * frames
 
     def enqueue(k):
-        return emu.generate_events_batch_async(buf, [(1 + k * frames + i) * dt for i in range(frames)], return_device=True, cap=cap)
+        # (use_graph 0: pipelined runs, what the bench leg runs since round 6; 1: one hipGraph per run)
+        return emu.generate_events_batch_async(buf, [(1 + k * frames + i) * dt for i in range(frames)], return_device=True, cap=cap,
+                                               use_graph=use_graph, frames_resident=True)
 
     got, pend = [], None
     for k in range(3):

@@ -252,12 +252,18 @@ def batched_emulator_bench(device, n_clips=64, frames=60, H=260, W=346):
         t_prev = np.array([[(k * frames + j) * dt] * n_clips for j in range(frames)])
         t_frame = t_prev + dt
         eng.run(P, frames_run, t_prev, t_frame, 1 + k * frames, evs[k & 1], recs[k & 1], use_graph=ug)
+        ticket = eng.run_ticket() if (ug & 1024) else -1
+        if ticket >= 0:  # pipelined: the library hands the records over itself (v2e_emu_run_wait / _run_recs)
+            return k & 1, ticket
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(device))
         return k & 1, done
 
     def collect(pend):
         which, done = pend
+        if isinstance(done, int):
+            eng.run_wait(done)
+            return int(eng.run_recs(done)["n_events"].sum())
         return int(eng.read_recs_after(recs[which], done)["n_events"].sum())
 
     for k in range(2):
@@ -296,10 +302,10 @@ def hd_noisy_emulator_bench(device, frames=64, H=720, W=1280, reps=6):
     cap = 400_000 * frames
 
     def enqueue(k):
-        # (one graph per run: at this size the chain and the emission each fill the chip and pipelined runs -- V2E_AMD_HD_UG=0, the
-        # headline loop's mode -- measured 11.3-11.4 against 11.5-12.0 Gev/s)
+        # (pipelined runs, the headline loop's mode: with the packets the chain's stream no longer carries -- round 6, experiments 23 and 30 --
+        # 13.1-13.65 Gev/s against 11.5-12.4 with one hipGraph per run, V2E_AMD_HD_UG=1; earlier in the round it was 11.3-11.4 against 11.5-12.0)
         return emu.generate_events_batch_async(buf, [(1 + k * frames + i) * dt for i in range(frames)], return_device=True, cap=cap,
-                                               use_graph=int(os.environ.get("V2E_AMD_HD_UG", "1")), frames_resident=True)
+                                               use_graph=int(os.environ.get("V2E_AMD_HD_UG", "0")), frames_resident=True)
 
     for k in range(2):
         enqueue(k).result()

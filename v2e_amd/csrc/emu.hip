@@ -2309,7 +2309,7 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
         void *args[] = {(void *)&a, (void *)&ca};
         if (sc.kernel(ST_MAIN, kfn, grid, dim3(BLOCK), chain_dyn_lds(fused_rec), args)) return V2E_EHIP;
         if (mark(ev_main, s)) return V2E_EHIP;
-        if (!ahead_whole && L % m == 0 && sc.record(EV_CHAIN, L, ST_MAIN)) return V2E_EHIP; // (what a later k_ahead batch waits for where the ring wraps)
+        if (!ahead_whole && !fused_rec && L % m == 0 && sc.record(EV_CHAIN, L, ST_MAIN)) return V2E_EHIP; // (what a later k_ahead batch waits for where the ring wraps)
         // Enqueue order of the two side branches: k_ahead first.  It decides how this runtime executes the captured graph:
         // with the emission enqueued first the chain's next launch runs BEHIND the emission kernels (measured, profiles/
         // r03_graph_scheduling.txt), with k_ahead first it runs beside them.
