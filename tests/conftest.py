@@ -39,3 +39,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory_between_gpu_tests(request):
+    """A 1280x720 emulator holds several GB of device scratch: whatever a test left unreachable is collected before the next test
+    starts (an emulator caught in a reference cycle would otherwise keep its memory until the cyclic GC happens to run)."""
+    yield
+    if "gpu" in request.keywords:
+        import gc
+        gc.collect()

@@ -42,18 +42,21 @@ def _check_clip(fx, emu, ev, counts):
     assert [emu.num_events_total, emu.num_events_on, emu.num_events_off] == list(fx.counters)
 
 
+@pytest.mark.parametrize("chain_k", [None, 32])
 @pytest.mark.parametrize("use_graph", [0, 1])
 @pytest.mark.parametrize("name", PHILOX_HD_FIXTURES)
-def test_hd_long_clips_match_reference(name, use_graph):
-    """1280x720 through the default pipeline selection, 40 MB of events per run handed back as one array."""
+def test_hd_long_clips_match_reference(name, use_graph, chain_k, monkeypatch):
+    """1280x720 through the default pipeline selection (and with 32 frames per launch), 40 MB of events per run handed back as one array."""
+    if chain_k is not None:
+        monkeypatch.setenv("V2E_AMD_CHAIN_K", str(chain_k))
     fx = PhiloxFixture(name)
     emu = _mk(fx, seed=fx.seed, rng_mode="philox")
     ev, counts = emu.generate_events_batch(fx.frames, fx.times, use_graph=use_graph, cap=12_000_000)
     _check_clip(fx, emu, ev, counts)
     kind, fpl, fpb = emu._engine.last_pipeline()
     assert kind.startswith("k_chain"), kind
-    if "noisy" in name:
-        assert fpl == 32  # full launches, a partial one, ring of 96 slots wrapped (104 frames)
+    if "noisy" in name:  # no refractory period: the longest launch by default (a full launch and a partial one over 104 frames);
+        assert fpl == (chain_k or 64)  # with 32: three full launches and a partial one
 
 
 def test_hd_long_clip_in_two_async_runs():
@@ -228,7 +231,7 @@ def test_hd_noisy_enqueue_loop_matches_oracle(use_graph, oracle_lib):
         pend = nxt
     ev, c = pend.result()
     got.append((int(c.sum()), sha(ev.cpu().numpy())))
-    assert emu._engine.last_pipeline()[:2] == ("k_chain(fused records)", 32)
+    assert emu._engine.last_pipeline()[:2] == ("k_chain(fused records)", 64)  # no refractory period: the longest launch
     host = fr.cpu().numpy()
     ora = oracle_lib.OracleEmulator(seed=4, rng_mode="philox", **B.DEFAULT_KW)
     ora.set_dvs_params("noisy")

@@ -1831,7 +1831,9 @@ static int chain_blocks_per_cu(v2e_emu *h, bool f64, int dtype, bool fused, bool
 // rule is active on most frames would redo most launches).
 static int chain_frames_per_launch(const v2e_emu *h, bool has_refr, int use_graph, int max_blocks)
 {
-    int K = chain_small_grid(h) ? 32 : (has_refr ? 8 : 32);
+    // (without a refractory period nothing is speculated and nothing redone: the longest launch the kernel supports -- 1280x720 noisy,
+    //  pipelined, round 6: 64 frames 13.6-14.1 Gev/s, 32 13.0-13.5, 16 12.6-13.0)
+    int K = !has_refr ? CHAIN_K_MAX : (chain_small_grid(h) ? 32 : 8);
     if (const char *ev = getenv("V2E_AMD_CHAIN_K")) { const int v = atoi(ev); if (v >= 1 && v <= CHAIN_K_MAX) K = v; }
     if (has_refr && ((use_graph & 128) || h->ngroups > max_blocks)) K = 1;
     return K;

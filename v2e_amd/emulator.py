@@ -36,6 +36,8 @@ import os
 import random
 from typing import Optional
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -129,6 +131,12 @@ def _limit_host_threads(n):
 
 def _as_f32_tensor(a):
     return a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def _cleanup_at_exit(ref):
+    emu = ref()
+    if emu is not None:
+        emu.cleanup()
 
 
 class _PendingRun:
@@ -309,7 +317,10 @@ class EventEmulator(object):
 
         self._engine: Optional[EmuEngine] = None
         self._thres_scalar = None
-        atexit.register(self.cleanup)
+        # emulator.py:296 registers cleanup with atexit.  Through a weak reference here: a bound method would keep every emulator -- and
+        # the gigabytes of device scratch a 1280x720 one holds -- alive until the process ends; one that is dropped is cleaned up then
+        # (__del__), one that is still alive at exit by the hook
+        atexit.register(_cleanup_at_exit, weakref.ref(self))
 
     # ------------------------------------------------------------- plumbing
     def _open_writers(self, dvs_h5, dvs_aedat2, dvs_aedat4, dvs_text):
@@ -361,6 +372,12 @@ class EventEmulator(object):
                 name="frame_idx", shape=(n_frames,), dtype="uint64", compression="gzip")
         else:
             self.frame_h5_dataset = self.frame_ts_dataset = self.frame_ev_idx_dataset = None
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
 
     def cleanup(self):  # emulator.py:402-429
         if len(getattr(self, "cs_steps_taken", ())) > 1:
@@ -1029,6 +1046,8 @@ class EventEmulator(object):
         # runs, its scratch set's pinned records) are about to be reused, and a later result() would hand back this run's data instead
         slots = self.__dict__.setdefault("_async_slots", {})
         old = slots.get(which)
+        old = old() if old is not None else None  # (weak: a handle the caller has dropped needs no collecting, and a strong reference
+        #                                            here would tie the emulator and its device memory into a cycle only the GC breaks)
         if old is not None and old._res is None and old.recs is not None:
             ev_old, counts_old = old.result()
             if old.return_device and ev_old is not None:
@@ -1055,7 +1074,7 @@ class EventEmulator(object):
         dts = np.asarray(t_frames[start:]) - np.asarray(t_prev)
         pend = _PendingRun(self, ev, recs, done, counts, start, return_device, None, dts, ticket)
         pend.cs_steps_dev = cs_steps_dev
-        slots[which] = pend
+        slots[which] = weakref.ref(pend)
         return pend
 
     def _finish_run(self, pend):
