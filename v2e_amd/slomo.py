@@ -16,6 +16,7 @@ Differences from the reference, all at the edges of the hot path:
   * host-side pre/post-processing (PIL LANCZOS / BILINEAR resize, PNG files) is kept as is.
 """
 import atexit
+import weakref
 import glob
 import logging
 import math
@@ -413,6 +414,12 @@ class SloMoEngine:
         return out.view(nt, B, 1, H, W)
 
 
+def _cleanup_at_exit(ref):
+    obj = ref()
+    if obj is not None:
+        obj.cleanup()
+
+
 class SuperSloMo(object):
     """Super SloMo class (MI355X implementation of v2ecore.slomo.SuperSloMo)."""
 
@@ -444,7 +451,15 @@ class SuperSloMo(object):
         self.model_loaded = False
         self.engine = None
         self.mean = 0.428  # slomo.py:148: Normalize(mean=[0.428], std=[1]) on the GPU path only
-        atexit.register(self.cleanup)
+        # (slomo.py:124 registers cleanup with atexit; through a weak reference: a bound method would keep the instance, its engine and
+        #  their device memory alive until the process ends)
+        atexit.register(_cleanup_at_exit, weakref.ref(self))
+
+    def __del__(self):
+        try:
+            self.cleanup()
+        except Exception:
+            pass
 
     def cleanup(self):  # slomo.py:126-138
         for attr, name, n in (("ori_writer", "vid_orig", "numOrigVideoFramesWritten"),
