@@ -653,13 +653,22 @@ def main():
         if not args.no_extras and world == 1:
             try:
                 from v2e_amd.benchutil import batched_emulator_bench, e2e_bench, hd_noisy_emulator_bench, slomo_bench
-                out["frame_api"] = frame_api_bench(frames_all)
-                out["delivered_to_host"] = delivered_to_host_bench(device, frames_all)
-                out["batched"] = batched_emulator_bench(device)
-                out["hd_noisy"] = hd_noisy_emulator_bench(device)
-                out["slomo"] = slomo_bench(device)
-                out["slomo_f32"] = slomo_bench(device, conv_math="f32")
-                out["slomo_bf16x3"] = slomo_bench(device, conv_math="bf16x3")  # the exact three-piece split (what the range guard falls back to)
+
+                def leg(fn, *a, **k):
+                    # what the leg before left unreachable (an emulator and its GB of device scratch) is released HERE, not by a
+                    # garbage collection in the middle of this leg's timed loop (freeing device memory synchronises the device)
+                    import gc
+                    gc.collect()
+                    torch.cuda.synchronize(device)
+                    return fn(*a, **k)
+
+                out["frame_api"] = leg(frame_api_bench, frames_all)
+                out["delivered_to_host"] = leg(delivered_to_host_bench, device, frames_all)
+                out["batched"] = leg(batched_emulator_bench, device)
+                out["hd_noisy"] = leg(hd_noisy_emulator_bench, device)
+                out["slomo"] = leg(slomo_bench, device)
+                out["slomo_f32"] = leg(slomo_bench, device, conv_math="f32")
+                out["slomo_bf16x3"] = leg(slomo_bench, device, conv_math="bf16x3")  # the exact three-piece split (what the range guard falls back to)
                 ref = recorded_reference()
                 if ref:
                     out["slomo"]["cpu_baseline"] = {
@@ -667,7 +676,7 @@ def main():
                         "same_host_reference": False,
                         "runs": [{"cores": q["threads"], "batch_pairs": q["batch_pairs"], "value": q["interpolated_frames_per_s"],
                                   "unit": "frames/s"} for q in ref["slomo"]["runs"]]}
-                out["end_to_end"] = e2e_bench(device)
+                out["end_to_end"] = leg(e2e_bench, device)
             except Exception as e:  # side measurements must never hide the headline number
                 out["extras_error"] = repr(e)[:300]
             try:  # SURVEY 8(a)'s other size (round-3 review): one pair of a 1280x720 source, U = 2, as the 1280x704 parity fixture runs it

@@ -882,6 +882,9 @@ struct v2e_emu {
     void *ch_ck = nullptr;          // refractory runs: 2 launch parities x (K / 8 - 1) checkpoints x (base 8 B, lp 8 B, ts 4 B) planes
     uint4 *ch_rec = nullptr;        // [ch_D][n_clips][npx_pad] k_ahead's per-(frame, pixel) records
     hipStream_t ahead = nullptr;    // k_ahead runs beside the chain and the emission
+    std::vector<hipStream_t> spare_streams; // candidates the queue probe did not give a role (destroyed with the handle)
+    hipStream_t probed_for = nullptr;       // the caller's stream the pipelined roles were last probed against
+    bool probed = false;
     hipStream_t tabs = nullptr;     // the emission tables (k_ctot, k_cframe, k_coff) of batch b + 1 beside the event writer on batch b
     hipStream_t side2 = nullptr;    // the event writer of the odd batches (two batches' rows are written side by side)
     std::vector<hipEvent_t> ev_ahead, ev_chain, ev_tab;
@@ -1138,6 +1141,7 @@ int v2e_emu_destroy(v2e_emu *h)
     for (hipEvent_t e : h->ev_ahead) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_chain) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_tab) hipEventDestroy(e);
+    for (hipStream_t q : h->spare_streams) hipStreamDestroy(q);
     if (h->ahead) hipStreamDestroy(h->ahead);
     if (h->tabs) hipStreamDestroy(h->tabs);
     if (h->side2) hipStreamDestroy(h->side2);
@@ -2345,6 +2349,101 @@ static int enqueue_run_chain(v2e_emu *h, const v2e_emu_params *p, const KArgs &a
     return 0;
 }
 
+// ---- which of the handle's streams share a HARDWARE queue with the caller's (pipelined runs)
+// This runtime serves every stream of a process from four in-order hardware queues (more make every cross-queue dependency cost
+// 20-50 us: profiles/r06_emulator_experiments.txt item 5), so of the five streams a pipelined run uses at least two share one -- which
+// two is decided by how many streams the process happened to have when the handle created its own.  When the chain's stream shares
+// its queue with the rows' or the tables' stream, their kernels take turns with the chain's: 1280x720 noisy 10.3 instead of 13.7 Gev/s
+// (experiment 32: the same leg behind 0 .. 6 other live streams).  So the roles are given out by MEASUREMENT, once per handle and
+// caller's stream: a kernel that spins for 100 us on one stream and a kernel that reads the clock on the other -- on one hardware queue
+// the second starts when the first has ended, on two it starts at once.  Roles: k_ahead, tables, rows on three queues that are not the
+// chain's; the stream left over (`tabs`, idle in pipelined runs) takes whatever remains.
+namespace {
+__global__ void k_probe_spin(unsigned long long *out, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16); // (bounded by the clock: 100 MHz ticks)
+    out[0] = wall_clock64();
+}
+__global__ void k_probe_stamp(unsigned long long *out) { out[1] = wall_clock64(); }
+} // namespace
+
+// 1: b's kernel waited for a's (one hardware queue, or a == b); 0: it ran beside it; < 0: HIP error
+static int streams_share_queue(hipStream_t a, hipStream_t b, unsigned long long *dev)
+{
+    if (a == b) return 1;
+    int shared = 1;
+    for (int trial = 0; trial < 2 && shared; ++trial) { // (a late enqueue of the second kernel looks like sharing: one clean trial decides)
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+        k_probe_spin<<<1, 64, 0, a>>>(dev, 10000ull);
+        k_probe_stamp<<<1, 64, 0, b>>>(dev);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+        unsigned long long t[2] = {0, 0};
+        if (hipMemcpy(t, dev, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        shared = t[1] >= t[0] ? 1 : 0;
+    }
+    return shared;
+}
+
+static int assign_pipelined_streams(v2e_emu *h, hipStream_t s)
+{
+    if (getenv("V2E_AMD_NO_QUEUE_PROBE")) return 0;
+    h->sync_runs();
+    V2E_HIP(hipDeviceSynchronize());
+    unsigned long long *dev = nullptr;
+    V2E_HIP(hipMalloc(&dev, 2 * sizeof(unsigned long long)));
+    std::vector<hipStream_t> cand = {h->ahead, h->side, h->side2, h->tabs};
+    for (hipStream_t q : h->spare_streams) cand.push_back(q);
+    h->spare_streams.clear();
+    while (cand.size() < 8) { // (streams take the least-loaded hardware queue when they are created: eight cover all four)
+        hipStream_t q = nullptr;
+        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) break;
+        cand.push_back(q);
+    }
+    std::vector<char> used(cand.size(), 0);
+    bool failed = false;
+    auto pick = [&](std::initializer_list<hipStream_t> avoid) -> int {
+        for (size_t i = 0; i < cand.size(); ++i) {
+            if (used[i]) continue;
+            bool ok = true;
+            for (hipStream_t a : avoid) {
+                const int sh = streams_share_queue(a, cand[i], dev);
+                if (sh < 0) failed = true;
+                if (sh != 0) { ok = false; break; }
+            }
+            if (ok) { used[i] = 1; return (int)i; }
+        }
+        return -1;
+    };
+    int ia = pick({s});
+    int it = ia >= 0 ? pick({s, cand[ia]}) : -1;
+    int ir = it >= 0 ? pick({s, cand[ia], cand[it]}) : -1;
+    if (it >= 0 && ir < 0) ir = pick({s, cand[ia]}); // (three free queues were not found: the rows share the tables' rather than the chain's)
+    if (getenv("V2E_AMD_PROBE_DEBUG")) { // dev: the candidates' relation to the caller's stream and to each other
+        fprintf(stderr, "queue probe: ahead %d tables %d rows %d failed %d | shares caller:", ia, it, ir, (int)failed);
+        for (size_t i = 0; i < cand.size(); ++i) fprintf(stderr, " %d", streams_share_queue(s, cand[i], dev));
+        fprintf(stderr, " | with candidate 0:");
+        for (size_t i = 0; i < cand.size(); ++i) fprintf(stderr, " %d", streams_share_queue(cand[0], cand[i], dev));
+        fprintf(stderr, "\n");
+    }
+    hipFree(dev);
+    if (!failed && ia >= 0 && it >= 0 && ir >= 0) {
+        h->ahead = cand[ia]; h->side = cand[it]; h->side2 = cand[ir];
+        bool have_tabs = false;
+        for (size_t i = 0; i < cand.size(); ++i) {
+            if (used[i]) continue;
+            if (!have_tabs) { h->tabs = cand[i]; have_tabs = true; }
+            else h->spare_streams.push_back(cand[i]);
+        }
+        h->drop_graphs(); // (captured with the old roles)
+    } else { // leave the roles as they were; the new candidates are kept for the handle's destruction
+        for (size_t i = 4; i < cand.size(); ++i) h->spare_streams.push_back(cand[i]);
+    }
+    h->probed = true;
+    h->probed_for = s;
+    return 0;
+}
+
 int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dtype, int n_frames, const double *t_prev,
                 const double *t_frame, uint32_t frame_idx0, float *events, uint64_t cap, v2e_frame_rec *recs_dev,
                 int use_graph, void *stream)
@@ -2393,6 +2492,10 @@ int v2e_emu_run(v2e_emu *h, const v2e_emu_params *p, const void *frames, int dty
     if (!h->run_ctl) { V2E_HIP(hipMalloc(&h->run_ctl, sizeof(FrameCtl) * (size_t)h->run_cap * h->n_clips)); h->drop_graphs(); }
     if (chain) {
         rc = chain_alloc(h, p, dtype, n_frames, use_graph);
+        if (rc) return rc;
+    }
+    if (pipelined && (!h->probed || h->probed_for != s)) {
+        rc = assign_pipelined_streams(h, s);
         if (rc) return rc;
     }
     const int par = h->scratch_par;
