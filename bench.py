@@ -250,7 +250,7 @@ def frame_api_bench(frames_all, budget_frames=600):
     return out
 
 
-def delivered_to_host_bench(device, frames_all, steps=6):
+def delivered_to_host_bench(device, frames_all, steps=10):
     """The device-resident run with its event rows delivered to pinned host memory: the D2H copy of step s on a side
     stream overlaps step s + 1 (two event buffers alternate)."""
     from v2e_amd import EventEmulator
@@ -277,7 +277,10 @@ def delivered_to_host_bench(device, frames_all, steps=6):
         return n
 
     pend = enqueue(0)
-    deliver(pend, 0)
+    n0 = deliver(pend, 0)
+    # (both pinned buffers exist before the clock starts: page-locking 200 MB takes tens of milliseconds, a multiple of a step -- the
+    #  second one used to be allocated inside the timed loop and the figure swung between 0.6 and 2.0 Gev/s with it)
+    host[1] = torch.empty((int(n0 * 1.2) + 1024, 4), dtype=torch.float32).pin_memory()
     copy_stream.synchronize()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
