@@ -651,8 +651,6 @@ def main():
                     "algorithmic bytes: HBM is not what binds this kernel -- instruction_issue states the fraction of the resource that "
                     "does, and whole_step prices the complete frame (state + event rows) against the driver-timed region",
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())
         if not args.no_extras and world == 1:
             try:
                 from v2e_amd.benchutil import batched_emulator_bench, e2e_bench, hd_noisy_emulator_bench, slomo_bench
@@ -691,6 +689,10 @@ def main():
                     out["self_allgather"] = self_allgather_bench(device, frames_all)
                 except Exception as e:
                     out["self_allgather"] = {"error": repr(e)[:300]}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        # (behind the GPU legs: its 64 host threads leave the main thread on whatever NUMA node the scheduler likes, and pinned host
+        #  buffers allocated from there cost the PCIe legs half their rate -- delivered_to_host 1.0 instead of 3.1 Gev/s, round 6)
+        out["cpu_baseline"] = cpu_baseline(frames_all[:1501].cpu().numpy())
     if dist is not None and not args.no_extras:
         # the SuperSloMo stage of ONE clip sharded over the ranks by source pairs (every rank takes part; rank 0 reports); stub mode:
         # the same collective sequence over gloo with a stand-in for the interpolator, a small clip
