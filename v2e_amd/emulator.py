@@ -928,8 +928,17 @@ class EventEmulator(object):
         an [N,4] float32 array (or device tensor) of all frames' events concatenated,
         counts[f] the number of events of frame f (0 for the very first frame).
         """
+        pipelined = None
+        if use_graph is True:
+            # the default: one hipGraph per run -- from the SECOND run of a length on.  Capturing and instantiating the graph costs ~2.3 ms,
+            # more than it saves a run that is never repeated (an emulator per clip, BASELINE configs[2]: 88.3 -> 86.0 ms per clip)
+            seen = self.__dict__.setdefault("_blocking_lengths", {})
+            n = int(frames.shape[0])
+            if seen.get(n, 0) == 0:
+                use_graph, pipelined = 0, False
+            seen[n] = seen.get(n, 0) + 1
         return self.generate_events_batch_async(frames, t_frames, return_device=return_device, use_graph=use_graph,
-                                                cap=cap, _single_buffer=True).result()
+                                                cap=cap, _single_buffer=True, pipelined=pipelined).result()
 
     def generate_events_batch_async(self, frames, t_frames, return_device=False, use_graph=True, cap=None,
                                     _single_buffer=False, pipelined=None, frames_resident=False):
